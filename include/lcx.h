@@ -1,0 +1,224 @@
+/*
+ * lcx.h -- C ABI of the MI355X-native super-droplet ("lgrngn") backend.
+ *
+ * This is the drop-in boundary: plain C, opaque handle, raw pointers + sizes,
+ * no C++ / torch types.  Every entry point replaces one virtual of the
+ * reference's particles_proto_t<real_t>
+ * (reference: include/libcloudph++/lgrngn/particles.hpp:17-134) or one of the
+ * structs passed to it (opts_init.hpp:29-253, opts.hpp:20-50, arrinfo.hpp:11-49).
+ * The C++ mirror in include/libcloudphxx_amd/lgrngn/ and the ctypes mirror in
+ * libcloudphxx_amd/lgrngn.py are thin shims over these functions.
+ *
+ * Error convention: every function returns 0 on success, non-zero on failure;
+ * lcx_last_error() then returns the message ("libcloudph++: ..." texts follow
+ * the reference's std::runtime_error strings, e.g. src/particles_step.ipp:44-78)
+ * and the C++ shim re-throws it as std::runtime_error.
+ *
+ * real_t: a handle is created for float (real_kind=4) or double (real_kind=8);
+ * all `void *` array arguments are arrays of that type.
+ */
+#ifndef LCX_H
+#define LCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum values follow the declaration order of the reference enums
+ * (kernel.hpp:8, terminal_velocity.hpp:8, advection_scheme.hpp:8, RH_formula.hpp:8) */
+enum lcx_kernel {
+  LCX_KERNEL_UNDEFINED = 0, LCX_KERNEL_GEOMETRIC, LCX_KERNEL_GOLOVIN, LCX_KERNEL_HALL,
+  LCX_KERNEL_HALL_DAVIS_NO_WAALS, LCX_KERNEL_LONG, LCX_KERNEL_ONISHI_HALL,
+  LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS, LCX_KERNEL_HALL_PINSKY_1000MB_GRAV,
+  LCX_KERNEL_HALL_PINSKY_CUMULONIMBUS, LCX_KERNEL_HALL_PINSKY_STRATOCUMULUS,
+  LCX_KERNEL_VOHL_DAVIS_NO_WAALS
+};
+enum lcx_vt {
+  LCX_VT_UNDEFINED = 0, LCX_VT_BEARD76, LCX_VT_BEARD77, LCX_VT_BEARD77FAST,
+  LCX_VT_KHVOROSTYANOV_SPHERICAL, LCX_VT_KHVOROSTYANOV_NONSPHERICAL
+};
+enum lcx_adve { LCX_ADVE_UNDEFINED = 0, LCX_ADVE_IMPLICIT, LCX_ADVE_EULER, LCX_ADVE_PRED_CORR };
+enum lcx_rh   { LCX_RH_PV_CC = 0, LCX_RH_RV_CC, LCX_RH_PV_TET, LCX_RH_RV_TET };
+
+/* indices of lcx_diag_puddle() output, = common::output_t (common/output.hpp:8-24) */
+enum lcx_puddle {
+  LCX_OUT_HNO3 = 0, LCX_OUT_NH3, LCX_OUT_CO2, LCX_OUT_SO2, LCX_OUT_H2O2, LCX_OUT_O3,
+  LCX_OUT_S_VI, LCX_OUT_H, LCX_OUT_LIQ_VOL, LCX_OUT_DRY_VOL, LCX_OUT_PRTCL_NUM,
+  LCX_OUT_ICE_MASS, LCX_OUT_LIQ_NUM, LCX_OUT_ICE_NUM, LCX_OUT_COUNT
+};
+
+/* n(ln rd) at STP of one dry-aerosol mode; evaluated ON THE HOST exactly like the
+ * reference evaluates unary_function::funval (init_n.ipp:56-84, init_dist_analysis.ipp:62-64) */
+typedef double (*lcx_distro_fn)(double lnrd, void *user);
+
+typedef struct {
+  double kappa, rd_insol;        /* key of dry_distros_t (distro_t.hpp:10-36) */
+  lcx_distro_fn fn;              /* used when fn != NULL */
+  void *user;
+  /* built-in alternative (fn == NULL): sum of n_modes lognormal modes
+   * n_stp/ (sqrt(2pi) ln sdev) exp(-(lnrd-ln mean_rd)^2 / (2 ln^2 sdev)), common/lognormal.hpp:25-37 */
+  int n_modes;
+  double mean_rd[4], sdev[4], n_stp[4];
+} lcx_distro_t;
+
+/* one (kappa, radius) -> (STP concentration, SD count) entry of dry_sizes_t (distro_t.hpp:39-46) */
+typedef struct { double kappa, rd_insol, radius, conc; int sd_count; } lcx_dry_size_t;
+
+/* POD mirror of opts_init_t<real_t> (opts_init.hpp:29-253); same field names and defaults.
+ * Fields of sub-systems that are out of scope (chemistry, ice, sources, relaxation, SGS
+ * turbulence) are kept so that a caller's settings are checked, not silently dropped:
+ * lcx_create() fails if one of them is switched on. */
+typedef struct {
+  int nx, ny, nz;
+  double dx, dy, dz, dt;
+  int sstp_cond, sstp_coal, sstp_cond_act, sstp_chem;
+  double x0, y0, z0, x1, y1, z1;
+  unsigned long long sd_conc;
+  int sd_conc_large_tail, aerosol_independent_of_rhod, variable_dt_switch;
+  unsigned long long sd_const_multi, n_sd_max;
+  int kernel, terminal_velocity, adve_scheme, RH_formula;
+  const double *kernel_parameters; int n_kernel_parameters;
+  int chem_switch, coal_switch, sedi_switch, subs_switch, rlx_switch,
+      turb_adve_switch, turb_cond_switch, turb_coal_switch, ice_switch,
+      exact_sstp_cond, sstp_cond_mix, adaptive_sstp_cond, time_dep_ice_nucl;
+  double RH_max;
+  int rng_seed, rng_seed_init, rng_seed_init_switch;
+  int dev_count, dev_id;
+  const double *w_LS; int n_w_LS;
+  const double *aerosol_conc_factor; int n_aerosol_conc_factor;
+  double rd_min, rd_max;
+  int no_ccn_at_init, open_side_walls, periodic_topbot_walls;
+  int src_type;
+  int th_dry, const_p;
+  int diag_incloud_time;
+  const lcx_distro_t *dry_distros; int n_dry_distros;      /* sorted by (kappa, rd_insol) like std::map */
+  const lcx_dry_size_t *dry_sizes; int n_dry_sizes;        /* sorted by (kappa, rd_insol, radius) */
+  /* --- extensions (no reference counterpart) --- */
+  int n_x_tot;          /* total nx of the decomposed domain (ctor arg n_x_tot, particles.hpp:233) */
+  int n_x_bfr;          /* x-planes owned by ranks to the left (distmem_opts.hpp:27) */
+  int bcond_lft, bcond_rgt; /* 0 sharedmem, 1 distmem, 3 open  (src/detail/bcond.hpp) */
+  int strict_fp;        /* 1: IEEE order-preserving arithmetic (parity mode, default); 0: allow contraction */
+} lcx_opts_init_t;
+
+/* POD mirror of opts_t<real_t> (opts.hpp:20-50) */
+typedef struct {
+  int adve, sedi, subs, cond, coal, src, rlx, rcyc, turb_adve, turb_cond, turb_coal, ice_nucl;
+  int chem_dsl, chem_dsc, chem_rct;
+  double RH_max;
+  double dt;
+} lcx_opts_t;
+
+/* arrinfo_t (arrinfo.hpp:11-49): data == NULL <=> "not provided".  strides in elements.
+ * on_device != 0: data is a device pointer (extension: lets a GPU-resident host model
+ * skip the PCIe round trip of particles_impl_sync.ipp:15-68). */
+typedef struct {
+  void *data;
+  const ptrdiff_t *strides;
+  int on_device;
+} lcx_arrinfo_t;
+
+typedef struct lcx_particles lcx_particles;
+
+void lcx_opts_init_default(lcx_opts_init_t *);   /* opts_init.hpp:186-247 defaults */
+void lcx_opts_default(lcx_opts_t *);             /* opts.hpp:41-48 defaults */
+const char *lcx_last_error(void);
+const char *lcx_version(void);
+
+/* factory<real_t>(backend, opts_init)  (factory.hpp:12-15, src/lib.cpp:13-40) + ctor (particles_ctor.ipp:22-75) */
+int lcx_create(const lcx_opts_init_t *, int real_kind, lcx_particles **out);
+void lcx_destroy(lcx_particles *);
+
+/* particles_t::init (particles_init.ipp:16-131) */
+int lcx_init(lcx_particles *, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+             const lcx_arrinfo_t *p, const lcx_arrinfo_t *courant_x, const lcx_arrinfo_t *courant_y,
+             const lcx_arrinfo_t *courant_z);
+/* particles_t::sync_in / step_cond / step_sync / step_async (particles_step.ipp:15-29,32-158,161-336,339-494) */
+int lcx_sync_in(lcx_particles *, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+                const lcx_arrinfo_t *courant_x, const lcx_arrinfo_t *courant_y, const lcx_arrinfo_t *courant_z,
+                const lcx_arrinfo_t *diss_rate);
+int lcx_step_cond(lcx_particles *, const lcx_opts_t *, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv);
+int lcx_step_sync(lcx_particles *, const lcx_opts_t *, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
+                  const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *courant_x, const lcx_arrinfo_t *courant_y,
+                  const lcx_arrinfo_t *courant_z, const lcx_arrinfo_t *diss_rate);
+int lcx_step_async(lcx_particles *, const lcx_opts_t *);
+
+/* diagnostics (particles_diag.ipp:148-222,224-248,411-421) */
+int lcx_diag_sd_conc(lcx_particles *);
+int lcx_diag_pressure(lcx_particles *);
+int lcx_diag_temperature(lcx_particles *);
+int lcx_diag_RH(lcx_particles *);
+int lcx_diag_all(lcx_particles *);
+int lcx_diag_water(lcx_particles *);
+int lcx_diag_dry_rng(lcx_particles *, double r_mi, double r_mx);
+int lcx_diag_wet_rng(lcx_particles *, double r_mi, double r_mx);
+int lcx_diag_kappa_rng(lcx_particles *, double k_mi, double k_mx);
+int lcx_diag_dry_rng_cons(lcx_particles *, double r_mi, double r_mx);
+int lcx_diag_wet_rng_cons(lcx_particles *, double r_mi, double r_mx);
+int lcx_diag_kappa_rng_cons(lcx_particles *, double k_mi, double k_mx);
+int lcx_diag_dry_mom(lcx_particles *, int k);
+int lcx_diag_wet_mom(lcx_particles *, int k);
+int lcx_diag_kappa_mom(lcx_particles *, int k);
+int lcx_diag_precip_rate(lcx_particles *);
+int lcx_diag_max_rw(lcx_particles *);
+/* outbuf(): pointer into library-owned HOST memory, n_cell reals, valid until the next
+ * outbuf call (particles_ctor.ipp:83-92, fill_outbuf.ipp:13-37) */
+int lcx_outbuf(lcx_particles *, const void **data, size_t *n);
+/* get_attr(name) for "rw2","rd3","kappa","x","y","z" (fill_outbuf.ipp:40-77); call with
+ * out == NULL to query the length */
+int lcx_get_attr(lcx_particles *, const char *name, void *out, size_t cap, size_t *n);
+int lcx_diag_puddle(lcx_particles *, double out[LCX_OUT_COUNT]);   /* particles_diag.ipp:411-421 */
+
+/* ---- introspection / parity hooks (no reference counterpart; used by tests and bench) ---- */
+int lcx_n_part(lcx_particles *, size_t *n);
+int lcx_n_cell(lcx_particles *, size_t *n);
+int lcx_real_kind(lcx_particles *, int *kind);
+/* integer state: "n","ijk","sorted_id","sorted_ijk","count_ijk","count_num","cell_start" (as uint64) */
+int lcx_get_state_u64(lcx_particles *, const char *name, unsigned long long *out, size_t cap, size_t *n);
+/* real state not covered by get_attr: "vt","T","p","RH","eta","th","rv","rhod","dv","lambda_D","lambda_K",
+ * "courant_x","courant_y","courant_z","vt_0" (as double whatever the real kind) */
+int lcx_get_state_real(lcx_particles *, const char *name, double *out, size_t cap, size_t *n);
+/* overwrite particle state (all arrays of length n; x/y/z may be NULL for absent dimensions);
+ * lets a test start the device from an oracle state */
+int lcx_set_particles(lcx_particles *, size_t n, const unsigned long long *mult, const double *rd3,
+                      const double *rw2, const double *kpa, const double *vt,
+                      const double *x, const double *y, const double *z);
+/* random-number replay: queue host-generated arrays that the next rand_un / rand_u01 calls consume
+ * instead of the device generator (kind 0 = u01 reals, 1 = un 32-bit integers passed as doubles).
+ * With replayed streams the integer results (sort permutation, multiplicities) are bit-comparable
+ * with the reference CPU backends (src/detail/urand.hpp:24-86). */
+int lcx_rng_replay_push(lcx_particles *, int kind, const double *data, size_t n);
+int lcx_rng_replay_pending(lcx_particles *, size_t *n_arrays);
+/* run single housekeeping stages (for stage-level parity tests) */
+int lcx_stage(lcx_particles *, const char *stage, const lcx_opts_t *opts);
+/* per-stage device time of the last step in ms: fills names/values up to cap, returns count in *n */
+int lcx_timings(lcx_particles *, const char **names, double *ms, size_t cap, size_t *n);
+int lcx_set_profiling(lcx_particles *, int on);
+
+/* ---- 1-D domain decomposition (replaces impl_multi_gpu/..._step_async_and_copy.ipp:28-206 and
+ *      distributed_memory/particles_impl_{pack,unpack}.ipp): after lcx_step_async() on a handle
+ *      created with bcond_lft/rgt = distmem, the host exchanges packed migrants with its neighbours
+ *      (RCCL send/recv) and finishes the step with lcx_migrate_finish(). ---- */
+/* counts of SDs that left through the left / right face */
+int lcx_migrate_counts(lcx_particles *, size_t *n_lft, size_t *n_rgt);
+/* pack migrants of one side (0 = left, 1 = right) into a device buffer of
+ * lcx_migrate_record_bytes() * count bytes, attribute-major: n[count] then rd3,rw2,kpa,vt,x,(y),(z)[count];
+ * x is re-based to the receiver's frame (pack.ipp:14-26,110-133) given the receiver's edge x_rmt */
+size_t lcx_migrate_record_bytes(lcx_particles *);
+int lcx_migrate_pack(lcx_particles *, int side, double x_rmt, void *dev_buf, size_t cap_bytes);
+/* append `count` immigrants from a device buffer (unpack.ipp:50-143) */
+int lcx_migrate_unpack(lcx_particles *, const void *dev_buf, size_t count);
+/* flag emigrants n=0 and run post_copy (post_copy.ipp:18-35) */
+int lcx_migrate_finish(lcx_particles *, const lcx_opts_t *);
+/* device pointer helpers so that a host language without device allocation can stage buffers */
+int lcx_dev_alloc(void **ptr, size_t bytes);
+int lcx_dev_free(void *ptr);
+int lcx_dev_copy(void *dst, const void *src, size_t bytes, int kind /*1 H2D, 2 D2H, 3 D2D*/);
+int lcx_dev_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

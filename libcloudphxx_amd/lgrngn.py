@@ -1,0 +1,524 @@
+"""Python host mirror of the reference's lgrngn call surface, on top of the C ABI (include/lcx.h).
+
+Same names, argument meaning and error behaviour as the reference's Python bindings
+(bindings/python/lgrngn.hpp:40-140, bindings/python/lib.cpp:366-434) so that tests written
+for the reference read the same here:
+
+    opts_init = lgrngn.opts_init_t(); opts_init.dry_distros = {(kappa, rd_insol): fun}
+    prtcls = lgrngn.factory(lgrngn.backend_t.HIP, opts_init)
+    prtcls.init(th, rv, rhod, Cx=..., Cz=...)
+    prtcls.step_sync(opts, th, rv, rhod); prtcls.step_async(opts)
+    prtcls.diag_all(); prtcls.diag_sd_conc(); numpy.frombuffer(prtcls.outbuf())
+
+Errors reported by the library are raised as RuntimeError with the library's message
+(the reference throws std::runtime_error, translated by Boost.Python to RuntimeError).
+"""
+import ctypes as C
+import enum
+import numpy as np
+
+from . import _lib
+
+# ----------------------------------------------------------------------------- enums
+class backend_t(enum.IntEnum):          # lgrngn/backend.hpp:8 + the two new slots
+    undefined = 0
+    serial = 1
+    OpenMP = 2
+    CUDA = 3
+    multi_CUDA = 4
+    HIP = 5
+    multi_HIP = 6
+
+
+class kernel_t(enum.IntEnum):           # lgrngn/kernel.hpp:8
+    undefined = 0
+    geometric = 1
+    golovin = 2
+    hall = 3
+    hall_davis_no_waals = 4
+    Long = 5
+    onishi_hall = 6
+    onishi_hall_davis_no_waals = 7
+    hall_pinsky_1000mb_grav = 8
+    hall_pinsky_cumulonimbus = 9
+    hall_pinsky_stratocumulus = 10
+    vohl_davis_no_waals = 11
+
+
+class vt_t(enum.IntEnum):               # lgrngn/terminal_velocity.hpp:8
+    undefined = 0
+    beard76 = 1
+    beard77 = 2
+    beard77fast = 3
+    khvorostyanov_spherical = 4
+    khvorostyanov_nonspherical = 5
+
+
+class as_t(enum.IntEnum):               # lgrngn/advection_scheme.hpp:8
+    undefined = 0
+    implicit = 1
+    euler = 2
+    pred_corr = 3
+
+
+class RH_formula_t(enum.IntEnum):       # lgrngn/RH_formula.hpp:8
+    pv_cc = 0
+    rv_cc = 1
+    pv_tet = 2
+    rv_tet = 3
+
+
+class src_t(enum.IntEnum):              # lgrngn/ccn_source.hpp:8
+    off = 0
+    simple = 1
+    matching = 2
+
+
+# common::output_names (common/output.hpp:26-42)
+output_names = ["HNO3", "NH3", "CO2", "SO2", "H2O2", "O3", "S_VI", "H", "liquid_volume", "dry_volume",
+                "particle_number", "ice_mass", "liquid_number", "ice_number"]
+
+# ----------------------------------------------------------------------------- C structs (include/lcx.h)
+DISTRO_FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+
+
+class _distro_c(C.Structure):
+    _fields_ = [("kappa", C.c_double), ("rd_insol", C.c_double), ("fn", DISTRO_FN), ("user", C.c_void_p),
+                ("n_modes", C.c_int), ("mean_rd", C.c_double * 4), ("sdev", C.c_double * 4), ("n_stp", C.c_double * 4)]
+
+
+class _dry_size_c(C.Structure):
+    _fields_ = [("kappa", C.c_double), ("rd_insol", C.c_double), ("radius", C.c_double), ("conc", C.c_double),
+                ("sd_count", C.c_int)]
+
+
+class _opts_init_c(C.Structure):
+    _fields_ = [
+        ("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+        ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double), ("dt", C.c_double),
+        ("sstp_cond", C.c_int), ("sstp_coal", C.c_int), ("sstp_cond_act", C.c_int), ("sstp_chem", C.c_int),
+        ("x0", C.c_double), ("y0", C.c_double), ("z0", C.c_double), ("x1", C.c_double), ("y1", C.c_double), ("z1", C.c_double),
+        ("sd_conc", C.c_ulonglong),
+        ("sd_conc_large_tail", C.c_int), ("aerosol_independent_of_rhod", C.c_int), ("variable_dt_switch", C.c_int),
+        ("sd_const_multi", C.c_ulonglong), ("n_sd_max", C.c_ulonglong),
+        ("kernel", C.c_int), ("terminal_velocity", C.c_int), ("adve_scheme", C.c_int), ("RH_formula", C.c_int),
+        ("kernel_parameters", C.POINTER(C.c_double)), ("n_kernel_parameters", C.c_int),
+        ("chem_switch", C.c_int), ("coal_switch", C.c_int), ("sedi_switch", C.c_int), ("subs_switch", C.c_int),
+        ("rlx_switch", C.c_int), ("turb_adve_switch", C.c_int), ("turb_cond_switch", C.c_int), ("turb_coal_switch", C.c_int),
+        ("ice_switch", C.c_int), ("exact_sstp_cond", C.c_int), ("sstp_cond_mix", C.c_int), ("adaptive_sstp_cond", C.c_int),
+        ("time_dep_ice_nucl", C.c_int),
+        ("RH_max", C.c_double),
+        ("rng_seed", C.c_int), ("rng_seed_init", C.c_int), ("rng_seed_init_switch", C.c_int),
+        ("dev_count", C.c_int), ("dev_id", C.c_int),
+        ("w_LS", C.POINTER(C.c_double)), ("n_w_LS", C.c_int),
+        ("aerosol_conc_factor", C.POINTER(C.c_double)), ("n_aerosol_conc_factor", C.c_int),
+        ("rd_min", C.c_double), ("rd_max", C.c_double),
+        ("no_ccn_at_init", C.c_int), ("open_side_walls", C.c_int), ("periodic_topbot_walls", C.c_int),
+        ("src_type", C.c_int),
+        ("th_dry", C.c_int), ("const_p", C.c_int),
+        ("diag_incloud_time", C.c_int),
+        ("dry_distros", C.POINTER(_distro_c)), ("n_dry_distros", C.c_int),
+        ("dry_sizes", C.POINTER(_dry_size_c)), ("n_dry_sizes", C.c_int),
+        ("n_x_tot", C.c_int), ("n_x_bfr", C.c_int), ("bcond_lft", C.c_int), ("bcond_rgt", C.c_int),
+        ("strict_fp", C.c_int),
+    ]
+
+
+class _opts_c(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("adve", "sedi", "subs", "cond", "coal", "src", "rlx", "rcyc", "turb_adve",
+                                        "turb_cond", "turb_coal", "ice_nucl", "chem_dsl", "chem_dsc", "chem_rct")] + \
+               [("RH_max", C.c_double), ("dt", C.c_double)]
+
+
+class _arrinfo_c(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("strides", C.POINTER(C.c_ssize_t)), ("on_device", C.c_int)]
+
+
+# ----------------------------------------------------------------------------- user-facing option structs
+class lognormal:
+    """Built-in sum of lognormal modes n(ln rd) (common/lognormal.hpp:25-37); evaluated natively,
+    no Python callback per super-droplet."""
+
+    def __init__(self, mean_rd, sdev, n_stp):
+        self.mean_rd = np.atleast_1d(np.asarray(mean_rd, dtype=float))
+        self.sdev = np.atleast_1d(np.asarray(sdev, dtype=float))
+        self.n_stp = np.atleast_1d(np.asarray(n_stp, dtype=float))
+        assert len(self.mean_rd) == len(self.sdev) == len(self.n_stp) <= 4
+
+    def __call__(self, lnrd):
+        return float(np.sum(self.n_stp / np.sqrt(2 * np.pi) / np.log(self.sdev) *
+                            np.exp(-(lnrd - np.log(self.mean_rd)) ** 2 / 2. / np.log(self.sdev) ** 2)))
+
+
+class opts_init_t:
+    """opts_init_t<real_t> with the reference's field names and defaults (opts_init.hpp:29-253)."""
+
+    def __init__(self):
+        self.dry_distros = {}
+        self.dry_sizes = {}
+        self.nx = self.ny = self.nz = 0
+        self.dx = self.dy = self.dz = 1.
+        self.dt = 0.
+        self.sstp_cond = self.sstp_coal = self.sstp_cond_act = self.sstp_chem = 1
+        self.x0 = self.y0 = self.z0 = 0.
+        self.x1 = self.y1 = self.z1 = 1.
+        self.sd_conc = 0
+        self.sd_conc_large_tail = False
+        self.aerosol_independent_of_rhod = False
+        self.variable_dt_switch = False
+        self.sd_const_multi = 0
+        self.n_sd_max = 0
+        self.kernel = kernel_t.undefined
+        self.terminal_velocity = vt_t.undefined
+        self.adve_scheme = as_t.implicit
+        self.RH_formula = RH_formula_t.pv_cc
+        self.kernel_parameters = np.zeros(0)
+        self.chem_switch = False
+        self.coal_switch = True
+        self.sedi_switch = True
+        self.subs_switch = False
+        self.rlx_switch = False
+        self.turb_adve_switch = self.turb_cond_switch = self.turb_coal_switch = False
+        self.ice_switch = False
+        self.exact_sstp_cond = False
+        self.sstp_cond_mix = True
+        self.adaptive_sstp_cond = False
+        self.time_dep_ice_nucl = False
+        self.RH_max = .95
+        self.rng_seed = 44
+        self.rng_seed_init = 44
+        self.rng_seed_init_switch = False
+        self.dev_count = 0
+        self.dev_id = -1
+        self.w_LS = np.zeros(0)
+        self.aerosol_conc_factor = np.zeros(0)
+        self.rd_min = self.rd_max = -1.
+        self.no_ccn_at_init = False
+        self.open_side_walls = False
+        self.periodic_topbot_walls = False
+        self.src_type = src_t.off
+        self.th_dry = True
+        self.const_p = False
+        self.diag_incloud_time = False
+        # extensions (include/lcx.h)
+        self.n_x_tot = 0
+        self.n_x_bfr = 0
+        self.bcond_lft = self.bcond_rgt = 0
+        self.strict_fp = True
+
+    def _to_c(self, keep):
+        c = _opts_init_c()
+        special = {"kernel_parameters", "n_kernel_parameters", "w_LS", "n_w_LS", "aerosol_conc_factor",
+                   "n_aerosol_conc_factor", "dry_distros", "n_dry_distros", "dry_sizes", "n_dry_sizes"}
+        for name, ctype in _opts_init_c._fields_:
+            if name in special:
+                continue
+            v = getattr(self, name)
+            setattr(c, name, float(v) if ctype is C.c_double else int(v))
+        for name in ("kernel_parameters", "w_LS", "aerosol_conc_factor"):
+            arr = np.ascontiguousarray(np.asarray(getattr(self, name), dtype=np.float64).ravel())
+            keep.append(arr)
+            setattr(c, name, arr.ctypes.data_as(C.POINTER(C.c_double)))
+            setattr(c, "n_" + name, arr.size)
+        # std::map iteration order = sorted by (kappa, rd_insol) (distro_t.hpp:17-21)
+        keys = sorted(self.dry_distros.keys())
+        darr = (_distro_c * max(1, len(keys)))()
+        for i, k in enumerate(keys):
+            fun = self.dry_distros[k]
+            darr[i].kappa, darr[i].rd_insol = float(k[0]), float(k[1])
+            if isinstance(fun, lognormal):
+                darr[i].n_modes = len(fun.mean_rd)
+                for m in range(len(fun.mean_rd)):
+                    darr[i].mean_rd[m], darr[i].sdev[m], darr[i].n_stp[m] = fun.mean_rd[m], fun.sdev[m], fun.n_stp[m]
+            else:
+                cb = DISTRO_FN(lambda lnrd, user, _f=fun: float(_f(lnrd)))
+                keep.append(cb)
+                darr[i].fn = cb
+        keep.append(darr)
+        c.dry_distros = C.cast(darr, C.POINTER(_distro_c))
+        c.n_dry_distros = len(keys)
+        # dry_sizes: {(kappa, rd_insol): {radius: [conc, count]}}
+        flat = []
+        for k in sorted(self.dry_sizes.keys()):
+            for r in sorted(self.dry_sizes[k].keys()):
+                conc, cnt = self.dry_sizes[k][r]
+                flat.append((float(k[0]), float(k[1]), float(r), float(conc), int(cnt)))
+        sarr = (_dry_size_c * max(1, len(flat)))()
+        for i, t in enumerate(flat):
+            sarr[i].kappa, sarr[i].rd_insol, sarr[i].radius, sarr[i].conc, sarr[i].sd_count = t
+        keep.append(sarr)
+        c.dry_sizes = C.cast(sarr, C.POINTER(_dry_size_c))
+        c.n_dry_sizes = len(flat)
+        return c
+
+
+class opts_t:
+    """opts_t<real_t> (opts.hpp:20-50)."""
+
+    def __init__(self):
+        self.adve = self.sedi = self.cond = self.coal = True
+        self.subs = self.src = self.rlx = self.rcyc = False
+        self.turb_adve = self.turb_cond = self.turb_coal = self.ice_nucl = False
+        self.chem_dsl = self.chem_dsc = self.chem_rct = False
+        self.RH_max = 44.
+        self.dt = -1.
+        self.chem = False    # accepted for source compatibility with the reference's tests (no-op)
+
+    def _to_c(self):
+        c = _opts_c()
+        for name, ctype in _opts_c._fields_:
+            v = getattr(self, name)
+            setattr(c, name, float(v) if ctype is C.c_double else int(bool(v)))
+        return c
+
+
+# ----------------------------------------------------------------------------- particles
+class DeviceArray:
+    """A device-resident n-d array handed to init/step_sync instead of a numpy array
+    (extension: lcx_arrinfo_t.on_device).  `ptr` is a raw device address, strides in elements."""
+
+    def __init__(self, ptr, shape, strides=None):
+        self.ptr = int(ptr)
+        self.shape = tuple(shape)
+        if strides is None:
+            strides, acc = [], 1
+            for s in reversed(self.shape):
+                strides.insert(0, acc)
+                acc *= s
+        self.strides = tuple(strides)
+
+
+class particles_t:
+    def __init__(self, opts_init, real_t=np.float64, lib=None, prefix="lcx_"):
+        self._lib = lib if lib is not None else _lib.load()
+        self._px = prefix
+        self._keep = []
+        self.real_t = np.dtype(real_t)
+        self.opts_init = opts_init
+        c = opts_init._to_c(self._keep)
+        self._h = C.c_void_p()
+        self._chk(self._f("create")(C.byref(c), C.c_int(self.real_t.itemsize), C.byref(self._h)))
+        self._arr_keep = []
+
+    # -- plumbing
+    def _f(self, name):
+        f = getattr(self._lib, self._px + name)
+        return f
+
+    def _chk(self, rc):
+        if rc != 0:
+            f = self._f("last_error")
+            f.restype = C.c_char_p
+            raise RuntimeError(f().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._f("destroy")(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _arr(self, a):
+        if a is None:
+            return None
+        ai = _arrinfo_c()
+        if isinstance(a, DeviceArray):
+            st = (C.c_ssize_t * max(1, len(a.strides)))(*a.strides) if a.strides else (C.c_ssize_t * 1)(1)
+            ai.data, ai.strides, ai.on_device = a.ptr, C.cast(st, C.POINTER(C.c_ssize_t)), 1
+            self._arr_keep.append(st)
+            return ai
+        if a.dtype != self.real_t:
+            raise RuntimeError("libcloudph++: array dtype does not match real_t")
+        if a.ndim == 0 or a.size == 0:
+            raise RuntimeError("libcloudph++: empty array")
+        if any(s % a.itemsize for s in a.strides):
+            raise RuntimeError("libcloudph++: unsupported strides")
+        # the reference passes numpy strides in elements (bindings/python/lgrngn.hpp np2ai)
+        st = (C.c_ssize_t * a.ndim)(*[s // a.itemsize for s in a.strides])
+        ai.data, ai.strides, ai.on_device = a.ctypes.data, C.cast(st, C.POINTER(C.c_ssize_t)), 0
+        self._arr_keep.append((a, st))
+        return ai
+
+    @staticmethod
+    def _p(ai):
+        return C.byref(ai) if ai is not None else None
+
+    # -- API (particles.hpp:17-134)
+    def init(self, th, rv, rhod, p=None, Cx=None, Cy=None, Cz=None):
+        self._arr_keep = []
+        a = [self._arr(x) for x in (th, rv, rhod, p, Cx, Cy, Cz)]
+        self._chk(self._f("init")(self._h, *[self._p(x) for x in a]))
+
+    def sync_in(self, th, rv, rhod=None, Cx=None, Cy=None, Cz=None, diss_rate=None):
+        self._arr_keep = []
+        a = [self._arr(x) for x in (th, rv, rhod, Cx, Cy, Cz, diss_rate)]
+        self._chk(self._f("sync_in")(self._h, *[self._p(x) for x in a]))
+
+    def step_cond(self, opts, th, rv):
+        self._arr_keep = []
+        a = [self._arr(x) for x in (th, rv)]
+        oc = opts._to_c()
+        self._chk(self._f("step_cond")(self._h, C.byref(oc), *[self._p(x) for x in a]))
+
+    def step_sync(self, opts, th, rv, rhod=None, Cx=None, Cy=None, Cz=None, diss_rate=None):
+        self._arr_keep = []
+        a = [self._arr(x) for x in (th, rv, rhod, Cx, Cy, Cz, diss_rate)]
+        oc = opts._to_c()
+        self._chk(self._f("step_sync")(self._h, C.byref(oc), *[self._p(x) for x in a]))
+
+    def step_async(self, opts):
+        oc = opts._to_c()
+        self._chk(self._f("step_async")(self._h, C.byref(oc)))
+
+    def _diag0(name):
+        def f(self):
+            self._chk(self._f(name)(self._h))
+        f.__name__ = name
+        return f
+
+    def _diag2(name):
+        def f(self, a, b):
+            self._chk(self._f(name)(self._h, C.c_double(a), C.c_double(b)))
+        f.__name__ = name
+        return f
+
+    def _diagk(name):
+        def f(self, k):
+            self._chk(self._f(name)(self._h, C.c_int(int(k))))
+        f.__name__ = name
+        return f
+
+    diag_sd_conc = _diag0("diag_sd_conc")
+    diag_pressure = _diag0("diag_pressure")
+    diag_temperature = _diag0("diag_temperature")
+    diag_RH = _diag0("diag_RH")
+    diag_all = _diag0("diag_all")
+    diag_water = _diag0("diag_water")
+    diag_precip_rate = _diag0("diag_precip_rate")
+    diag_max_rw = _diag0("diag_max_rw")
+    diag_dry_rng = _diag2("diag_dry_rng")
+    diag_wet_rng = _diag2("diag_wet_rng")
+    diag_kappa_rng = _diag2("diag_kappa_rng")
+    diag_dry_rng_cons = _diag2("diag_dry_rng_cons")
+    diag_wet_rng_cons = _diag2("diag_wet_rng_cons")
+    diag_kappa_rng_cons = _diag2("diag_kappa_rng_cons")
+    diag_dry_mom = _diagk("diag_dry_mom")
+    diag_wet_mom = _diagk("diag_wet_mom")
+    diag_kappa_mom = _diagk("diag_kappa_mom")
+
+    def outbuf(self):
+        """bytes-like view of n_cell reals (use numpy.frombuffer(..., dtype=real_t), default float64)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._f("outbuf")(self._h, C.byref(ptr), C.byref(n)))
+        buf = (C.c_char * (n.value * self.real_t.itemsize)).from_address(ptr.value)
+        return memoryview(buf)
+
+    def outbuf_array(self):
+        return np.frombuffer(self.outbuf(), dtype=self.real_t).copy()
+
+    def get_attr(self, name):
+        n = C.c_size_t()
+        self._chk(self._f("get_attr")(self._h, name.encode(), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty(n.value, dtype=self.real_t)
+        self._chk(self._f("get_attr")(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.size), C.byref(n)))
+        return out
+
+    def diag_puddle(self):
+        out = (C.c_double * len(output_names))()
+        self._chk(self._f("diag_puddle")(self._h, out))
+        return {nm: out[i] for i, nm in enumerate(output_names)}
+
+    # -- introspection hooks (no reference counterpart)
+    @property
+    def n_part(self):
+        n = C.c_size_t()
+        self._chk(self._f("n_part")(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def n_cell(self):
+        n = C.c_size_t()
+        self._chk(self._f("n_cell")(self._h, C.byref(n)))
+        return n.value
+
+    def state_u64(self, name):
+        n = C.c_size_t()
+        self._chk(self._f("get_state_u64")(self._h, name.encode(), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint64)
+        self._chk(self._f("get_state_u64")(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_ulonglong)),
+                                           C.c_size_t(out.size), C.byref(n)))
+        return out
+
+    def state_real(self, name):
+        n = C.c_size_t()
+        self._chk(self._f("get_state_real")(self._h, name.encode(), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        self._chk(self._f("get_state_real")(self._h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                            C.c_size_t(out.size), C.byref(n)))
+        return out
+
+    def set_particles(self, n, rd3, rw2, kpa, vt, x=None, y=None, z=None):
+        def d(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self._arr_keep.append(a)
+            return a.ctypes.data_as(C.POINTER(C.c_double))
+        nn = np.ascontiguousarray(n, dtype=np.uint64)
+        self._chk(self._f("set_particles")(self._h, C.c_size_t(nn.size), nn.ctypes.data_as(C.POINTER(C.c_ulonglong)),
+                                           d(rd3), d(rw2), d(kpa), d(vt), d(x), d(y), d(z)))
+
+    def rng_replay_push(self, kind, data):
+        a = np.ascontiguousarray(data, dtype=np.float64)
+        self._chk(self._f("rng_replay_push")(self._h, C.c_int(kind), a.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(a.size)))
+
+    def stage(self, name, opts=None):
+        oc = opts._to_c() if opts is not None else None
+        self._chk(self._f("stage")(self._h, name.encode(), C.byref(oc) if oc is not None else None))
+
+    def timings(self):
+        cap = 64
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        n = C.c_size_t()
+        self._chk(self._f("timings")(self._h, names, ms, C.c_size_t(cap), C.byref(n)))
+        return {names[i].decode(): ms[i] for i in range(n.value)}
+
+    def set_profiling(self, on):
+        self._chk(self._f("set_profiling")(self._h, C.c_int(int(on))))
+
+    # -- 1-D decomposition primitives
+    def migrate_counts(self):
+        l, r = C.c_size_t(), C.c_size_t()
+        self._chk(self._f("migrate_counts")(self._h, C.byref(l), C.byref(r)))
+        return l.value, r.value
+
+    def migrate_record_bytes(self):
+        f = self._f("migrate_record_bytes")
+        f.restype = C.c_size_t
+        return f(self._h)
+
+    def migrate_pack(self, side, x_rmt, buf_ptr, cap_bytes):
+        self._chk(self._f("migrate_pack")(self._h, C.c_int(side), C.c_double(x_rmt), C.c_void_p(buf_ptr), C.c_size_t(cap_bytes)))
+
+    def migrate_unpack(self, buf_ptr, count):
+        self._chk(self._f("migrate_unpack")(self._h, C.c_void_p(buf_ptr), C.c_size_t(count)))
+
+    def migrate_finish(self, opts):
+        oc = opts._to_c()
+        self._chk(self._f("migrate_finish")(self._h, C.byref(oc)))
+
+
+def factory(backend, opts_init, real_t=np.float64):
+    """factory<real_t>(backend, opts_init)  (factory.hpp:12-15, src/lib.cpp:13-40).
+
+    Only the HIP backends exist in this library; asking for a backend that was not compiled in
+    raises, as the reference does (src/lib.cpp:21,27,33,38)."""
+    backend = backend_t(backend)
+    if backend == backend_t.HIP or backend == backend_t.CUDA:
+        return particles_t(opts_init, real_t)
+    if backend in (backend_t.multi_HIP, backend_t.multi_CUDA):
+        from .multi import particles_multi_t
+        return particles_multi_t(opts_init, real_t)
+    raise RuntimeError("libcloudph++: backend %s not compiled in this library (available: HIP, multi_HIP)" % backend.name)

@@ -1,0 +1,1153 @@
+/*
+ * lcx_oracle.c -- TEST INFRASTRUCTURE.  CPU oracle for the lgrngn hot path.
+ *
+ * A serial, plain-C (double precision) restatement of what the reference's serial backend
+ * (thrust::cpp) does on particles_t::init / step_sync / step_async / diag_*, following the
+ * reference's control flow and evaluation order file by file (citations at each function,
+ * paths relative to the reference checkout).  It exports the same entry points as the product
+ * C ABI (include/lcx.h) with the prefix orc_ so that one test harness can drive both.
+ *
+ * PINNING.  The reference itself cannot be built in this image (its headers need Boost.units /
+ * Boost.math, which are absent, and stand-ins are not allowed), so this restatement is pinned
+ * against the reference's own known answers and golden data instead (tests/test_oracle_pins.py):
+ *   - tests/python/physics/refdata/lgrngn_cond_substepping_refdata.csv (56 per-cell-substepping rows)
+ *   - tests/python/physics/lgrngn_cond.py:52-56,131-132,152-187 (th / rv known answers, sstp scaling)
+ *   - tests/python/physics/puddle.py:74-81 (precipitation totals), test_coal.py:95-101 (conservation)
+ *   - tests/python/physics/coalescence_golovin.py:147-153 (analytic Golovin RMSD)
+ *   - tests/python/unit/lgrngn_adve.py:97-105, tests/common/test_common_pvs.cpp:6-8, tests/toms748
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * It is never on the product path.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdint.h>
+#include "../include/lcx.h"
+#include "orc_physics.h"
+
+typedef unsigned long long n_t;       /* impl::n_t, src/impl/particles_impl.ipp:29 */
+typedef size_t sz;                    /* thrust_size_t, src/detail/thrust.hpp:11 */
+
+static __thread char orc_err[512];
+#define FAIL(...) do { snprintf(orc_err, sizeof orc_err, __VA_ARGS__); return 1; } while (0)
+
+/* ---------------- RNG: std::mt19937 + libstdc++ distributions (src/detail/urand.hpp:24-86) ------------- */
+typedef struct { uint32_t mt[624]; int idx; } mt19937_t;
+static void mt_seed(mt19937_t *g, uint32_t s)
+{
+  g->mt[0] = s;
+  for (int i = 1; i < 624; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->idx = 624;
+}
+static uint32_t mt_next(mt19937_t *g)
+{
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      uint32_t y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  uint32_t y = g->mt[g->idx++];
+  y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+  return y;
+}
+/* uniform_real_distribution<double>(0,1) == generate_canonical<double,53>: two 32-bit draws */
+static double rng_u01(mt19937_t *g)
+{
+  const double x0 = (double)mt_next(g);
+  const double x1 = (double)mt_next(g);
+  double r = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
+  if (r >= 1.0) r = nextafter(1.0, 0.0);
+  return r;
+}
+/* uniform_int_distribution<unsigned>(0,UINT_MAX): one draw; fnctr_un returns it through real_t */
+static double rng_un(mt19937_t *g) { return (double)mt_next(g); }
+
+/* ---------------- state (src/impl/particles_impl.ipp:26-325) ---------------- */
+typedef struct { double *q; sz len, pos; } fifo_arr;
+
+struct orc_particles {
+  lcx_opts_init_t o;
+  lcx_distro_t *distros; lcx_dry_size_t *sizes;
+  double *kernel_parameters; sz n_kernel_parameters; double kernel_r_max; int n_user_params;
+  double *w_LS, *aerosol_conc_factor;
+  int n_dims; sz n_cell, n_part, n_part_old, n_part_to_init, cap;
+  int init_called, should_now_run_async, should_now_run_cond, selected_before_counting, var_rho, sorted;
+  int sstp_cond, sstp_coal, allow_sstp_cond, pure_const_multi, increase_sstp_coal;
+  double dt; int adve_scheme;
+  mt19937_t rng;
+  /* particle attributes */
+  n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
+  sz *ijk, *sorted_id, *sorted_ijk;
+  double *n_filtered, *tmp_part, *col;
+  /* cell fields */
+  double *rhod, *th, *rv, *p, *T, *RH, *eta, *dv, *lambda_D, *lambda_K;
+  double *sstp_tmp_rv, *sstp_tmp_th, *sstp_tmp_rh, *drw_mom3, *rw_mom3, *scl;
+  double *courant_x, *courant_y, *courant_z; sz n_cx, n_cy, n_cz;
+  sz *count_ijk, *off; n_t *count_num; double *count_mom; sz count_n;
+  double vt_0[10000]; double vt0_ln_r_min, vt0_ln_r_max;
+  double log_rd_min, log_rd_max, multiplier;
+  double puddle[LCX_OUT_COUNT];
+  double *outbuf;
+  double eps_tol;
+  /* distmem */
+  sz *lft_id, *rgt_id; sz lft_count, rgt_count;
+};
+typedef struct orc_particles orc_particles;
+
+static int m1(int n) { return n == 0 ? 1 : n; }
+#define NEW(T, n) ((T *)calloc((n) ? (n) : 1, sizeof(T)))
+
+const char *orc_last_error(void) { return orc_err; }
+const char *orc_version(void) { return "lcx-oracle 1 (double, serial)"; }
+
+void orc_opts_init_default(lcx_opts_init_t *o)
+{                                           /* opts_init.hpp:186-247 */
+  memset(o, 0, sizeof *o);
+  o->dx = o->dy = o->dz = 1; o->x1 = o->y1 = o->z1 = 1;
+  o->sstp_cond = o->sstp_coal = o->sstp_chem = o->sstp_cond_act = 1;
+  o->sedi_switch = 1; o->coal_switch = 1; o->sstp_cond_mix = 1;
+  o->RH_max = .95; o->rng_seed = 44; o->rng_seed_init = 44;
+  o->adve_scheme = LCX_ADVE_IMPLICIT; o->RH_formula = LCX_RH_PV_CC;
+  o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 1;
+}
+void orc_opts_default(lcx_opts_t *o)
+{                                           /* opts.hpp:41-48 */
+  memset(o, 0, sizeof *o);
+  o->adve = o->sedi = o->cond = o->coal = 1; o->RH_max = 44; o->dt = -1;
+}
+
+static int distmem(const orc_particles *s) { return s->o.bcond_lft == 1 || s->o.bcond_rgt == 1; }
+
+int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
+{
+  if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
+  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->turb_adve_switch ||
+      oi->turb_cond_switch || oi->turb_coal_switch || oi->exact_sstp_cond || oi->adaptive_sstp_cond ||
+      oi->sd_const_multi || oi->sd_conc_large_tail || oi->diag_incloud_time)
+    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/exact_sstp/const_multi/tail)");
+  if (oi->adve_scheme == LCX_ADVE_PRED_CORR) FAIL("libcloudph++: pred_corr advection not supported by this backend");
+  orc_particles *s = NEW(orc_particles, 1);
+  s->o = *oi;
+  s->distros = NEW(lcx_distro_t, oi->n_dry_distros);
+  memcpy(s->distros, oi->dry_distros, sizeof(lcx_distro_t) * oi->n_dry_distros);
+  s->sizes = NEW(lcx_dry_size_t, oi->n_dry_sizes);
+  if (oi->n_dry_sizes) memcpy(s->sizes, oi->dry_sizes, sizeof(lcx_dry_size_t) * oi->n_dry_sizes);
+  s->n_user_params = oi->n_kernel_parameters;
+  s->n_kernel_parameters = oi->n_kernel_parameters;
+  s->kernel_parameters = NEW(double, oi->n_kernel_parameters);
+  if (oi->n_kernel_parameters) memcpy(s->kernel_parameters, oi->kernel_parameters, sizeof(double) * oi->n_kernel_parameters);
+  s->w_LS = NEW(double, oi->n_w_LS);
+  if (oi->n_w_LS) memcpy(s->w_LS, oi->w_LS, sizeof(double) * oi->n_w_LS);
+  s->aerosol_conc_factor = NEW(double, oi->n_aerosol_conc_factor);
+  if (oi->n_aerosol_conc_factor) memcpy(s->aerosol_conc_factor, oi->aerosol_conc_factor, sizeof(double) * oi->n_aerosol_conc_factor);
+  /* particles_impl.ipp:327-345 */
+  s->n_dims = oi->nx / m1(oi->nx) + oi->ny / m1(oi->ny) + oi->nz / m1(oi->nz);
+  s->n_cell = (sz)m1(oi->nx) * m1(oi->ny) * m1(oi->nz);
+  s->sstp_cond = oi->sstp_cond; s->sstp_coal = oi->sstp_coal;
+  s->allow_sstp_cond = oi->sstp_cond > 1 || oi->sstp_cond_act > 1;
+  s->pure_const_multi = (oi->sd_conc == 0) && (oi->sd_const_multi > 0 || oi->n_dry_sizes > 0);
+  s->adve_scheme = oi->adve_scheme;
+  if (s->o.n_x_tot == 0) s->o.n_x_tot = oi->nx;
+  mt_seed(&s->rng, (uint32_t)oi->rng_seed);
+  s->eps_tol = orc_eps_tolerance(sizeof(double) * 8 / 4);   /* src/detail/config.hpp:39 */
+  s->vt0_ln_r_min = log(5e-7); s->vt0_ln_r_max = log(3e-3); /* config.hpp:36-38 */
+  s->cap = (sz)oi->n_sd_max;
+  sz c = s->cap, nc = s->n_cell;
+  s->n = NEW(n_t, c); s->rd3 = NEW(double, c); s->rw2 = NEW(double, c); s->kpa = NEW(double, c);
+  s->x = NEW(double, c); s->y = NEW(double, c); s->z = NEW(double, c); s->vt = NEW(double, c);
+  s->ijk = NEW(sz, c); s->sorted_id = NEW(sz, c); s->sorted_ijk = NEW(sz, c);
+  s->n_filtered = NEW(double, c); s->tmp_part = NEW(double, c); s->col = NEW(double, c);
+  s->lft_id = NEW(sz, c); s->rgt_id = NEW(sz, c);
+  s->rhod = NEW(double, nc); s->th = NEW(double, nc); s->rv = NEW(double, nc); s->p = NEW(double, nc);
+  s->T = NEW(double, nc); s->RH = NEW(double, nc); s->eta = NEW(double, nc); s->dv = NEW(double, nc);
+  s->lambda_D = NEW(double, nc); s->lambda_K = NEW(double, nc);
+  s->sstp_tmp_rv = NEW(double, nc); s->sstp_tmp_th = NEW(double, nc); s->sstp_tmp_rh = NEW(double, nc);
+  s->drw_mom3 = NEW(double, nc); s->rw_mom3 = NEW(double, nc); s->scl = NEW(double, nc);
+  s->count_ijk = NEW(sz, nc); s->off = NEW(sz, nc + 1); s->count_num = NEW(n_t, nc); s->count_mom = NEW(double, nc);
+  s->outbuf = NEW(double, nc);
+  *out = s;
+  return 0;
+}
+void orc_destroy(orc_particles *s)
+{
+  if (!s) return;
+  void *ptrs[] = {s->distros, s->sizes, s->kernel_parameters, s->w_LS, s->aerosol_conc_factor, s->n, s->rd3, s->rw2,
+    s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col,
+    s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
+    s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
+    s->count_num, s->count_mom, s->outbuf, s->courant_x, s->courant_y, s->courant_z};
+  for (sz i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) free(ptrs[i]);
+  free(s);
+}
+
+/* ---------------- Eulerian <-> Lagrangian sync (particles_impl_sync.ipp:15-68, init_e2l.ipp:34-114) ----- */
+/* device index c (z fastest) of a field with extents (nx+ex, ny+ey, nz+ez) -> element offset in the user's array */
+static ptrdiff_t l2e(const orc_particles *s, const lcx_arrinfo_t *a, sz c, int ex, int ey, int ez)
+{
+  const int ny = s->o.ny + ey, nz = s->o.nz + ez;
+  (void)ex;
+  switch (s->n_dims) {
+    case 0: return 0;
+    case 1: return (ptrdiff_t)c + s->o.n_x_bfr;
+    case 2: return a->strides[0] * (ptrdiff_t)(c / nz + s->o.n_x_bfr) + a->strides[1] * (ptrdiff_t)(c % nz);
+    default: return a->strides[0] * (ptrdiff_t)(c / ((sz)nz * ny) + s->o.n_x_bfr) +
+                    a->strides[1] * (ptrdiff_t)((c / nz) % ny) + a->strides[2] * (ptrdiff_t)(c % nz);
+  }
+}
+static int arr_null(const lcx_arrinfo_t *a) { return !a || !a->data || !a->strides; }
+static void sync_in_arr(const orc_particles *s, const lcx_arrinfo_t *a, double *to, sz n, int ex, int ey, int ez)
+{
+  if (arr_null(a)) return;
+  const double *d = (const double *)a->data;
+  for (sz c = 0; c < n; ++c) to[c] = d[l2e(s, a, c, ex, ey, ez)];
+}
+static void sync_out_arr(const orc_particles *s, const double *from, const lcx_arrinfo_t *a, sz n)
+{
+  if (arr_null(a)) return;
+  double *d = (double *)a->data;
+  for (sz c = 0; c < n; ++c) d[l2e(s, a, c, 0, 0, 0)] = from[c];
+}
+
+/* ---------------- housekeeping ---------------- */
+/* hskpng_Tpr.ipp:219-305 */
+static void hskpng_Tpr(orc_particles *s)
+{
+  for (sz c = 0; c < s->n_cell; ++c) {
+    if (s->o.th_dry) s->T[c] = theta_dry_T(s->th[c], s->rhod[c]);
+    else             s->T[c] = s->th[c] * theta_std_exner(s->p[c]);
+    if (!s->o.const_p) s->p[c] = theta_dry_p(s->rhod[c], s->rv[c], s->T[c]);
+    s->RH[c] = RH_of(s->o.RH_formula, s->p[c], s->rv[c], s->T[c]);
+    s->eta[c] = visc(s->T[c]);
+    if (s->n_dims == 0) s->dv[c] = 1. / s->rhod[c];
+  }
+}
+/* hskpng_mfp.ipp:42-51 */
+static void hskpng_mfp(orc_particles *s)
+{
+  for (sz c = 0; c < s->n_cell; ++c) {
+    s->lambda_D[c] = lambda_D_of(s->T[c]);
+    s->lambda_K[c] = lambda_K_of(s->T[c], s->p[c]);
+  }
+}
+/* hskpng_ijk.ipp:159-200, :33-82 : size_t(double(x)/double(dx)), z fastest */
+static void hskpng_ijk(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  for (sz p = 0; p < s->n_part; ++p) {
+    sz i = o->nx ? (sz)(s->x[p] / o->dx) : 0, j = o->ny ? (sz)(s->y[p] / o->dy) : 0, k = o->nz ? (sz)(s->z[p] / o->dz) : 0;
+    switch (s->n_dims) {
+      case 0: break;
+      case 1: s->ijk[p] = i; break;
+      case 2: s->ijk[p] = i * o->nz + k; break;
+      default: s->ijk[p] = i * ((sz)o->nz * o->ny) + j * o->nz + k;
+    }
+  }
+  s->sorted = 0;
+}
+/* stable sort of (key,val) pairs by key; keys < nkeys when nkeys>0 (counting sort) else 32-bit LSD radix */
+static void stable_sort_by_key(sz *key, sz *val, sz n, sz nkeys)
+{
+  sz *k2 = NEW(sz, n), *v2 = NEW(sz, n);
+  if (nkeys) {
+    sz *cnt = NEW(sz, nkeys + 1);
+    for (sz i = 0; i < n; ++i) cnt[key[i] + 1]++;
+    for (sz c = 0; c < nkeys; ++c) cnt[c + 1] += cnt[c];
+    for (sz i = 0; i < n; ++i) { sz d = cnt[key[i]]++; k2[d] = key[i]; v2[d] = val[i]; }
+    memcpy(key, k2, n * sizeof(sz)); memcpy(val, v2, n * sizeof(sz));
+    free(cnt);
+  } else {
+    for (int pass = 0; pass < 2; ++pass) {
+      sz *cnt = NEW(sz, 65537);
+      const int sh = 16 * pass;
+      for (sz i = 0; i < n; ++i) cnt[((key[i] >> sh) & 0xffff) + 1]++;
+      for (sz c = 0; c < 65536; ++c) cnt[c + 1] += cnt[c];
+      for (sz i = 0; i < n; ++i) { sz d = cnt[(key[i] >> sh) & 0xffff]++; k2[d] = key[i]; v2[d] = val[i]; }
+      memcpy(key, k2, n * sizeof(sz)); memcpy(val, v2, n * sizeof(sz));
+      free(cnt);
+    }
+  }
+  free(k2); free(v2);
+}
+/* hskpng_sort.ipp:15-57 */
+static void hskpng_sort_helper(orc_particles *s, int shuffle)
+{
+  const sz n = s->n_part;
+  for (sz p = 0; p < n; ++p) s->sorted_id[p] = p;
+  if (!shuffle) memcpy(s->sorted_ijk, s->ijk, n * sizeof(sz));
+  else {
+    sz *un = NEW(sz, n);
+    for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un(&s->rng);
+    stable_sort_by_key(un, s->sorted_id, n, 0);
+    for (sz p = 0; p < n; ++p) s->sorted_ijk[p] = s->ijk[s->sorted_id[p]];
+    free(un);
+  }
+  stable_sort_by_key(s->sorted_ijk, s->sorted_id, n, s->n_cell);
+  s->sorted = 1;
+}
+static void hskpng_sort(orc_particles *s) { if (!s->sorted) hskpng_sort_helper(s, 0); }
+/* hskpng_count.ipp:16-48 */
+static void hskpng_count(orc_particles *s)
+{
+  hskpng_sort(s);
+  sz cn = 0;
+  for (sz p = 0; p < s->n_part; ++p) {
+    if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_num[cn] = 0; ++cn; }
+    s->count_num[cn - 1] += 1;
+  }
+  s->count_n = cn;
+}
+/* hskpng_vterm.ipp:15-33,185-342 */
+static int vt0_bin(const orc_particles *s, double rw2)
+{
+  const int n_bin = 10000;
+  const double dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
+  const double lnr = .5 * log(rw2);
+  return lnr <= s->vt0_ln_r_min ? 0 : lnr >= s->vt0_ln_r_max ? n_bin - 1 : (int)((lnr - s->vt0_ln_r_min) / dlnr);
+}
+static double vt_of(const orc_particles *s, double rw2, sz c)
+{
+  const double r = sqrt(rw2);
+  switch (s->o.terminal_velocity) {
+    case LCX_VT_BEARD76: return vt_beard76(r, s->T[c], s->p[c], s->rhod[c], s->eta[c]);
+    case LCX_VT_BEARD77: return vt_beard77_fact(r, s->p[c], s->rhod[c], s->eta[c]) * vt_beard77_v0(r);
+    case LCX_VT_BEARD77FAST: return vt_beard77_fact(r, s->p[c], s->rhod[c], s->eta[c]) * s->vt_0[vt0_bin(s, rw2)];
+    case LCX_VT_KHVOROSTYANOV_SPHERICAL: return vt_khvorostyanov(r, s->T[c], s->rhod[c], s->eta[c], 1);
+    case LCX_VT_KHVOROSTYANOV_NONSPHERICAL: return vt_khvorostyanov(r, s->T[c], s->rhod[c], s->eta[c], 0);
+    default: return 0.;
+  }
+}
+static void hskpng_vterm(orc_particles *s, int only_invalid)
+{
+  for (sz p = 0; p < s->n_part; ++p) {
+    if (only_invalid ? (s->vt[p] == -1. && s->rw2[p] > 0) : (s->rw2[p] > 0))
+      s->vt[p] = vt_of(s, s->rw2[p], s->ijk[p]);
+  }
+}
+/* init_vterm.ipp:36-59 */
+static void init_vterm(orc_particles *s)
+{
+  if (s->o.terminal_velocity != LCX_VT_BEARD77FAST) return;
+  const int n_bin = 10000;
+  const double dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
+  for (int it = 0; it < n_bin; ++it) s->vt_0[it] = vt_beard77_v0(exp(s->vt0_ln_r_min + (it + 0.5) * dlnr));
+}
+/* hskpng_remove.ipp:20-76 (stable), hskpng_resize.ipp:7-32 */
+static int hskpng_remove_n0(orc_particles *s)
+{
+  sz w = 0;
+  for (sz p = 0; p < s->n_part; ++p) {
+    if (s->n[p] == 0) continue;
+    if (w != p) {
+      s->n[w] = s->n[p]; s->rd3[w] = s->rd3[p]; s->rw2[w] = s->rw2[p]; s->kpa[w] = s->kpa[p];
+      s->vt[w] = s->vt[p]; s->x[w] = s->x[p]; s->y[w] = s->y[p]; s->z[w] = s->z[p];
+    }
+    ++w;
+  }
+  s->n_part = w;
+  return 0;
+}
+
+/* ---------------- moments (particles_impl_moms.ipp:50-387) ---------------- */
+static void moms_all(orc_particles *s)
+{
+  hskpng_sort(s);
+  for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = (double)s->n[p];
+  s->selected_before_counting = 1;
+}
+static void moms_rng(orc_particles *s, double mn, double mx, const double *vec, int cons)
+{
+  hskpng_sort(s);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const double y = cons ? s->n_filtered[p] : (double)s->n[p];
+    s->n_filtered[p] = (vec[p] >= mn && vec[p] < mx) ? y : 0;
+  }
+  s->selected_before_counting = 1;
+}
+static void moms_gt0(orc_particles *s, const double *vec, int cons)
+{
+  hskpng_sort(s);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const double y = cons ? s->n_filtered[p] : (double)s->n[p];
+    s->n_filtered[p] = y * (vec[p] > 0);
+  }
+  s->selected_before_counting = 1;
+}
+static double moment_counter(double n, double x, double xp)
+{
+  return x >= 0 ? n * pow(x, xp) : n * pow(x, (double)(int)xp);
+}
+static void moms_calc(orc_particles *s, const double *vec, double power, int specific)
+{
+  sz cn = 0;
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz id = s->sorted_id[p];
+    const double v = moment_counter(s->n_filtered[id], vec[id], power);
+    if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
+    else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
+  }
+  s->count_n = cn;
+  if (specific && s->n_dims > 0)
+    for (sz i = 0; i < cn; ++i) {
+      s->count_mom[i] = s->count_mom[i] / s->dv[s->count_ijk[i]];
+      s->count_mom[i] = s->count_mom[i] / s->rhod[s->count_ijk[i]];
+    }
+}
+
+/* ---------------- condensation driver ---------------- */
+/* sstp_save.ipp:7-30 (per-cell version) */
+static void sstp_save(orc_particles *s)
+{
+  if (!s->allow_sstp_cond) return;
+  memcpy(s->sstp_tmp_rv, s->rv, s->n_cell * sizeof(double));
+  memcpy(s->sstp_tmp_th, s->th, s->n_cell * sizeof(double));
+  memcpy(s->sstp_tmp_rh, s->rhod, s->n_cell * sizeof(double));
+}
+/* sstp_percell_step.ipp:7-48 */
+static void sstp_percell_step(orc_particles *s, int step)
+{
+  if (s->sstp_cond == 1) return;
+  double *scl[3] = {s->rv, s->th, s->rhod}, *tmp[3] = {s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh};
+  const double sstp = s->sstp_cond;
+  for (int ix = 0; ix < (s->var_rho ? 3 : 2); ++ix)
+    for (sz c = 0; c < s->n_cell; ++c) {
+      if (step == 0) {
+        tmp[ix][c] = scl[ix][c] - tmp[ix][c];
+        scl[ix][c] = scl[ix][c] - (sstp - 1) * tmp[ix][c] / sstp;
+      } else scl[ix][c] = scl[ix][c] + tmp[ix][c] / sstp;
+    }
+}
+/* save_liq_ice_content_before_change.ipp:13-31 */
+static void save_liq_before(orc_particles *s)
+{
+  hskpng_sort(s);
+  moms_all(s);
+  moms_calc(s, s->rw2, 3. / 2., 1);
+  if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = 0.;
+  for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = -s->count_mom[i];
+}
+/* percell/particles_impl_cond.ipp:13-139 */
+static void cond(orc_particles *s, double dt, double RH_max, int step)
+{
+  hskpng_sort(s);
+  if (step == 0) { if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->rw_mom3[c] = 0.; }
+  else for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = -s->rw_mom3[c];
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    cond_ctx cc = {s->rw2[p], dt / s->sstp_cond, s->rhod[c], s->rv[c], s->T[c], s->p[c], s->RH[c], s->eta[c],
+                   s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};
+    s->rw2[p] = advance_rw2(&cc, s->eps_tol, 2., 100);     /* config.hpp:13,26: n_iter 100, cond_mlt 2 */
+  }
+  moms_all(s);
+  moms_calc(s, s->rw2, 3. / 2., 1);
+  if (step < s->sstp_cond - 1) {
+    for (sz i = 0; i < s->count_n; ++i) s->rw_mom3[s->count_ijk[i]] = s->count_mom[i];
+    for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = s->rw_mom3[c] + s->drw_mom3[c];
+  } else
+    for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = s->count_mom[i] + s->drw_mom3[s->count_ijk[i]];
+}
+/* particles_impl_update_th_rv.ipp:74-191 */
+static void update_th_rv(orc_particles *s)
+{
+  const double mlt = rho_w * (4. / 3) * ORC_PI;
+  for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = s->drw_mom3[c] * mlt;
+  for (sz c = 0; c < s->n_cell; ++c) s->rv[c] = s->rv[c] - s->drw_mom3[c];
+  for (sz c = 0; c < s->n_cell; ++c) s->th[c] = s->th[c] - s->drw_mom3[c] * d_th_d_rv(s->T[c], s->th[c]);
+}
+/* particles_impl_adjust_timesteps.ipp:13-24 */
+static int adjust_timesteps(orc_particles *s, double dt)
+{
+  if (dt > 0 && !s->o.variable_dt_switch) FAIL("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
+  s->sstp_cond = dt > 0 && s->o.sstp_cond > 1 ? (int)ceil(s->o.sstp_cond * dt / s->o.dt) : s->o.sstp_cond;
+  s->sstp_coal = dt > 0 && s->o.sstp_coal > 1 ? (int)ceil(s->o.sstp_coal * dt / s->o.dt) : s->o.sstp_coal;
+  s->dt = dt > 0 ? dt : s->o.dt;
+  return 0;
+}
+
+/* ---------------- coalescence (particles_impl_coal.ipp:99-546, src/detail/kernels.hpp:38-202) ---------------- */
+static int kernel_index(n_t R) { return R <= 100. ? (int)R : (int)(100 + (R - 100.) / 10.); }       /* kernel_utils.hpp:10-18 */
+static sz kernel_vector_index(int i, int j, n_t nup)
+{                                                                                             /* kernel_utils.hpp:21-29 */
+  return i >= j ? (sz)(0.5 * i * (i + 1) + j + nup) : (sz)(0.5 * j * (j + 1) + i + nup);
+}
+static double interpolated_efficiency(const orc_particles *s, double r1, double r2)
+{                                                                                             /* kernel_interpolation.hpp:9-65 */
+  const double *kp = s->kernel_parameters; const n_t nup = s->n_user_params;
+  r1 *= 1e6; r2 *= 1e6;
+  if (r1 >= s->kernel_r_max) r1 = s->kernel_r_max - 1e-6;
+  if (r2 >= s->kernel_r_max) r2 = s->kernel_r_max - 1e-6;
+  n_t dx, dy, x[4];
+  if (r1 >= 100.) { x[0] = (n_t)(floor(r1 / 10.) * 10); dx = 10; } else { x[0] = (n_t)floor(r1); dx = 1; }
+  if (r2 >= 100.) { x[2] = (n_t)(floor(r2 / 10.) * 10); dy = 10; } else { x[2] = (n_t)floor(r2); dy = 1; }
+  x[1] = x[0] + dx; x[3] = x[2] + dy;
+  sz iv[4];
+  iv[0] = kernel_vector_index(kernel_index(x[0]), kernel_index(x[2]), nup);
+  iv[1] = kernel_vector_index(kernel_index(x[1]), kernel_index(x[2]), nup);
+  iv[2] = kernel_vector_index(kernel_index(x[0]), kernel_index(x[3]), nup);
+  iv[3] = kernel_vector_index(kernel_index(x[1]), kernel_index(x[3]), nup);
+  double w[4];
+  w[0] = r1 - x[0]; w[1] = x[1] - r1; w[2] = r2 - x[2]; w[3] = x[3] - r2;
+  return (kp[iv[0]] * w[1] * w[3] + kp[iv[1]] * w[0] * w[3] + kp[iv[2]] * w[1] * w[2] + kp[iv[3]] * w[0] * w[2]) / dx / dy;
+}
+static double k_geometric(n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb)
+{
+  const n_t nmax = na < nb ? nb : na;
+  return ORC_PI * nmax * fabs(vta - vtb) * (rw2a + rw2b + 2. * sqrt(rw2a * rw2b));
+}
+static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb)
+{
+  switch (s->o.kernel) {
+    case LCX_KERNEL_GOLOVIN: {
+      const n_t nmax = na < nb ? nb : na;
+      return ORC_PI * 4. / 3. * s->kernel_parameters[0] * nmax * (rw2a * sqrt(rw2a) + rw2b * sqrt(rw2b));
+    }
+    case LCX_KERNEL_GEOMETRIC:
+      if (s->n_user_params == 1) return k_geometric(na, nb, rw2a, rw2b, vta, vtb) * s->kernel_parameters[0];
+      return k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+    case LCX_KERNEL_LONG: {
+      double res = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+      const double r_L = dmax(sqrt(rw2a), sqrt(rw2b));
+      if (r_L < 50.e-6) {
+        const double r_s = dmin(sqrt(rw2a), sqrt(rw2b));
+        if (r_s <= 3e-6) res = 0.; else res *= 4.5e8 * r_L * r_L * (1. - 3e-6 / r_s);
+      }
+      return res;
+    }
+    default: /* geometric with tabulated efficiencies */
+      return interpolated_efficiency(s, sqrt(rw2a), sqrt(rw2b)) * k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+  }
+}
+/* collide<>, coal.ipp:110-143: _a has the higher multiplicity */
+static void collide(orc_particles *s, sz a, sz b, n_t col_no)
+{
+  s->n[a] -= col_no * s->n[b];
+  const double rw_b = cbrt(col_no * s->rw2[a] * sqrt(s->rw2[a]) + s->rw2[b] * sqrt(s->rw2[b]));
+  s->rw2[b] = rw_b * rw_b;
+  s->rd3[b] = col_no * s->rd3[a] + s->rd3[b];
+  s->vt[b] = -1.;
+}
+static void coal(orc_particles *s, double dt)
+{
+  hskpng_sort_helper(s, 1);
+  s->sorted = 1;
+  { sz cn = 0;                                   /* hskpng_count on the shuffled order */
+    for (sz p = 0; p < s->n_part; ++p) {
+      if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_num[cn] = 0; ++cn; }
+      s->count_num[cn - 1] += 1;
+    }
+    s->count_n = cn; }
+  for (sz c = 0; c < s->n_cell; ++c) { s->scl[c] = 0.; s->off[c] = 0; }
+  for (sz i = 0; i < s->count_n; ++i) {
+    const n_t n = s->count_num[i];
+    s->scl[s->count_ijk[i]] = n > 1 ? ((double)(n * (n - 1)) / 2) / (n / 2) : 0;      /* scale_factor, coal.ipp:99-107 */
+    s->off[s->count_ijk[i]] = (sz)n;
+  }
+  { sz acc = 0; for (sz c = 0; c < s->n_cell; ++c) { sz t = s->off[c]; s->off[c] = acc; acc += t; } }
+  double *u01 = s->col;
+  for (sz p = 0; p < s->n_part; ++p) u01[p] = rng_u01(&s->rng);
+  for (sz p = 0; p + 1 < s->n_part; ++p) {                 /* collider::operator(), coal.ipp:180-267 */
+    const sz ca = s->sorted_ijk[p], cb = s->sorted_ijk[p + 1];
+    const sz cix_a = p - s->off[ca];
+    if (cix_a % 2 != 0) continue;
+    const sz cix_b = (p + 1) - s->off[cb];
+    if (cix_a != cix_b - 1) { s->col[p] = 0.; continue; }
+    const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
+    const double prob = dt / s->dv[ca] * s->scl[ca] * kernel_calc(s, s->n[a], s->n[b], s->rw2[a], s->rw2[b], s->vt[a], s->vt[b]);
+    n_t col_no = (n_t)prob;
+    if (s->pure_const_multi && col_no >= 1) s->increase_sstp_coal = 1;
+    if (u01[p] < prob - col_no) ++col_no;
+    if (col_no == 0) { s->col[p] = 0.; s->col[p + 1] = 0.; continue; }
+    if (s->n[a] >= s->n[b]) {
+      if (s->n[b] > 0) { n_t q = s->n[a] / s->n[b]; if (q < col_no) col_no = q; }
+      collide(s, a, b, col_no);
+      s->col[p + 1] = -2.;
+    } else {
+      if (s->n[a] > 0) { n_t q = s->n[b] / s->n[a]; if (q < col_no) col_no = q; }
+      collide(s, b, a, col_no);
+      s->col[p + 1] = -1.;
+    }
+    s->col[p] = (double)col_no;
+  }
+  if (s->o.n_dry_distros + s->o.n_dry_sizes > 1)           /* weighted_summator, coal.ipp:57-97,458-480 */
+    for (sz p = 0; p + 1 < s->n_part; ++p) {
+      if (s->col[p] <= 0) continue;
+      const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
+      const int na_ge_nb = s->col[p + 1] == -2.;
+      double rd3_old = na_ge_nb ? s->rd3[b] - s->col[p] * s->rd3[a] : s->rd3[a] - s->col[p] * s->rd3[b];
+      for (int ci = 0; ci < s->col[p]; ++ci) {
+        if (na_ge_nb) { s->kpa[b] = (s->kpa[a] * s->rd3[a] + s->kpa[b] * rd3_old) / (s->rd3[a] + rd3_old); rd3_old += s->rd3[a]; }
+        else          { s->kpa[a] = (s->kpa[b] * s->rd3[b] + s->kpa[a] * rd3_old) / (s->rd3[b] + rd3_old); rd3_old += s->rd3[b]; }
+      }
+    }
+}
+
+/* ---------------- advection, sedimentation, boundary (adve.ipp:28-304, sedi.ipp:13-25, subs.ipp:13-25, bcnd.ipp:99-368) -------- */
+static double adve_1d(int scheme, double x, sz fl, double C_l, double C_r, double dx)
+{
+  if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - fl * (C_r - C_l))) / (1 - (C_r - C_l));
+  return 1 * x + (C_r - C_l) * (x - dx * fl) + dx * C_l;
+}
+static void adve(orc_particles *s)
+{
+  if (s->n_dims == 0) return;
+  const lcx_opts_init_t *o = &s->o;
+  const sz nz = m1(o->nz), ny = m1(o->ny);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    sz i, j = 0, k = 0;
+    if (s->n_dims == 1) i = c; else if (s->n_dims == 2) { i = c / nz; k = c % nz; } else { i = c / (nz * ny); j = (c / nz) % ny; k = c % nz; }
+    /* init_grid.ipp:57-158 face maps */
+    const sz lft = c, rgt = c + (s->n_dims == 3 ? nz * ny : (sz)o->nz); /* 1-D: rgt == lft as in init_grid.ipp:96-107 */
+    s->x[p] = adve_1d(s->adve_scheme, s->x[p], i, s->courant_x[lft], s->courant_x[rgt], o->dx);
+    if (s->n_dims > 2) {
+      const sz fre = c + (c / (nz * ny)) * nz, hnd = fre + nz;
+      s->y[p] = adve_1d(s->adve_scheme, s->y[p], j, s->courant_y[fre], s->courant_y[hnd], o->dy);
+    }
+    if (s->n_dims > 1) {
+      const sz blw = s->n_dims == 2 ? c + c / nz : c + ny * (c / (nz * ny)) + (c - (c / (nz * ny)) * (nz * ny)) / nz;
+      s->z[p] = adve_1d(s->adve_scheme, s->z[p], k, s->courant_z[blw], s->courant_z[blw + 1], o->dz);
+    }
+  }
+}
+static void sedi(orc_particles *s, double dt) { for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->vt[p]; }
+static void subs(orc_particles *s, double dt)
+{
+  const sz nz = m1(s->o.nz);
+  for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->w_LS[s->ijk[p] % nz];
+}
+static double periodic(double x, double a, double b) { return a + fmod((x - a) + 10 * (b - a), b - a); }
+static void bcnd(orc_particles *s)
+{
+  if (s->n_dims == 0) return;
+  const lcx_opts_init_t *o = &s->o;
+  if (!distmem(s)) {
+    if (!o->open_side_walls) for (sz p = 0; p < s->n_part; ++p) s->x[p] = periodic(s->x[p], o->x0, o->x1);
+    else for (sz p = 0; p < s->n_part; ++p) if (s->x[p] >= o->x1 || s->x[p] < o->x0) s->n[p] = 0;
+  } else {
+    s->lft_count = s->rgt_count = 0;
+    for (sz p = 0; p < s->n_part; ++p) if (s->x[p] < o->x0) s->lft_id[s->lft_count++] = p;
+    for (sz p = 0; p < s->n_part; ++p) if (s->x[p] >= o->x1) s->rgt_id[s->rgt_count++] = p;
+    if (o->bcond_lft == 3) for (sz i = 0; i < s->lft_count; ++i) s->n[s->lft_id[i]] = 0;
+    if (o->bcond_rgt == 3) for (sz i = 0; i < s->rgt_count; ++i) s->n[s->rgt_id[i]] = 0;
+  }
+  if (s->n_dims == 3) {
+    if (!o->open_side_walls) for (sz p = 0; p < s->n_part; ++p) s->y[p] = periodic(s->y[p], o->y0, o->y1);
+    else for (sz p = 0; p < s->n_part; ++p) if (s->y[p] >= o->y1 || s->y[p] < o->y0) s->n[p] = 0;
+  }
+  if (s->n_dims > 1) {
+    if (!o->periodic_topbot_walls) {
+      for (sz p = 0; p < s->n_part; ++p) if (s->z[p] >= o->z1) s->n[p] = 0;
+      double liq_vol = 0, dry_vol = 0, liq_num = 0, prtcl_num = 0;
+      for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = s->z[p] < o->z0 ? (double)s->n[p] : 0.;
+      for (sz p = 0; p < s->n_part; ++p) liq_vol = liq_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rw2[p], 3. / 2.);
+      for (sz p = 0; p < s->n_part; ++p) dry_vol = dry_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rd3[p], 1.);
+      for (sz p = 0; p < s->n_part; ++p) liq_num = liq_num + (s->rw2[p] == 0. ? 0. : s->n_filtered[p]);
+      for (sz p = 0; p < s->n_part; ++p) prtcl_num = prtcl_num + s->n_filtered[p];
+      s->puddle[LCX_OUT_LIQ_VOL] += liq_vol; s->puddle[LCX_OUT_DRY_VOL] += dry_vol;
+      s->puddle[LCX_OUT_LIQ_NUM] += liq_num; s->puddle[LCX_OUT_PRTCL_NUM] += prtcl_num;
+      for (sz p = 0; p < s->n_part; ++p) if (s->z[p] < o->z0) s->n[p] = 0;
+    } else for (sz p = 0; p < s->n_part; ++p) s->z[p] = periodic(s->z[p], o->z0, o->z1);
+  }
+}
+/* post_copy.ipp:18-35 */
+static int post_copy(orc_particles *s, const lcx_opts_t *opts)
+{
+  if (opts->rcyc) FAIL("libcloudph++: rcyc not supported by this backend");
+  hskpng_remove_n0(s);
+  hskpng_ijk(s);
+  hskpng_count(s);
+  return 0;
+}
+
+/* ---------------- initialisation (particles_init.ipp:16-131 and src/impl/initialization/) ---------------- */
+static double eval_distro(const lcx_distro_t *d, double lnrd)
+{
+  if (d->fn) return d->fn(lnrd, d->user);
+  double res = 0;                                   /* common/lognormal.hpp:25-37, sum of modes */
+  for (int m = 0; m < d->n_modes; ++m)
+    res += d->n_stp[m] / sqrt(2 * ORC_PI) / log(d->sdev[m]) *
+           exp(-pow((lnrd - log(d->mean_rd[m])), 2) / 2. / pow(log(d->sdev[m]), 2));
+  return res;
+}
+/* init_dist_analysis.ipp:17-77 */
+static int init_dist_analysis_sd_conc(orc_particles *s, const lcx_distro_t *d, n_t sd_conc, double dt)
+{
+  const lcx_opts_init_t *o = &s->o;
+  const double vol = s->n_dims == 0 ? s->dv[0] : (o->dx * o->dy * o->dz);
+  if (o->rd_min >= 0 && o->rd_max >= 0) {
+    s->multiplier = log(o->rd_max / o->rd_min) / sd_conc * dt * vol;
+    s->log_rd_min = log(o->rd_min); s->log_rd_max = log(o->rd_max);
+  } else if (o->rd_min < 0 && o->rd_max < 0) {
+    double rd_min = 1e-14, rd_max = 1e-3;            /* config.hpp:23-24 */
+    int found = 0;
+    while (!found) {
+      s->multiplier = log(rd_max / rd_min) / sd_conc * dt * vol;
+      s->log_rd_min = log(rd_min); s->log_rd_max = log(rd_max);
+      const n_t n_min = (n_t)(eval_distro(d, s->log_rd_min) * s->multiplier),
+                n_max = (n_t)(eval_distro(d, s->log_rd_max) * s->multiplier);
+      if (rd_min == 1e-14 && n_min != 0) FAIL("Initial dry radii distribution is non-zero (%llu) for rd_min_init (1e-14)", n_min);
+      if (rd_max == 1e-3 && n_max != 0) FAIL("Initial dry radii distribution is non-zero (%llu) for rd_max_init (0.001)", n_max);
+      if (n_min == 0) rd_min *= 1.01; else if (n_max == 0) rd_max /= 1.01; else found = 1;
+    }
+  } else FAIL("opts_init.rd_min * opts_init.rd_max < 0");
+  return 0;
+}
+static int resize_npart(orc_particles *s)
+{                                                   /* hskpng_resize.ipp:7-32; new vt = invalid */
+  if (s->n_part > s->o.n_sd_max) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, s->n_part);
+  return 0;
+}
+static int init_SD_with_distros(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  double tot_lnrd_rng = 0.;
+  if (o->sd_conc > 0)
+    for (int d = 0; d < o->n_dry_distros; ++d) {
+      if (init_dist_analysis_sd_conc(s, &s->distros[d], o->sd_conc, 1.)) return 1;
+      tot_lnrd_rng += s->log_rd_max - s->log_rd_min;
+    }
+  for (int d = 0; d < o->n_dry_distros; ++d) {
+    const lcx_distro_t *dd = &s->distros[d];
+    /* init_SD_with_distros_sd_conc.ipp:14-46 */
+    if (init_dist_analysis_sd_conc(s, dd, o->sd_conc, 1.)) return 1;
+    if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
+    const double fraction = (s->log_rd_max - s->log_rd_min) / tot_lnrd_rng;
+    s->multiplier *= o->sd_conc / (n_t)(int)(fraction * o->sd_conc + 0.5);
+    const n_t per_cell = (n_t)(fraction * o->sd_conc);               /* init_count_num.ipp:32-35 */
+    for (sz c = 0; c < s->n_cell; ++c) s->count_num[c] = per_cell;
+    s->n_part_old = s->n_part;
+    s->n_part_to_init = (sz)per_cell * s->n_cell;
+    s->n_part += s->n_part_to_init;
+    if (resize_npart(s)) return 1;
+    for (sz p = s->n_part_old; p < s->n_part; ++p) s->vt[p] = -1.;
+    /* init_ijk.ipp:36-52 */
+    { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
+    /* init_dry_sd_conc.ipp:43-86 */
+    for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+    for (sz g = 0; g < s->n_part_to_init; ++g) {
+      const sz c = s->ijk[s->n_part_old + g];
+      const sz ptr = (sz)per_cell * c;
+      const double lnrd = s->log_rd_min + ((double)(g - ptr) + s->tmp_part[g]) * (s->log_rd_max - s->log_rd_min) / (double)s->count_num[c];
+      s->rd3[s->n_part_old + g] = exp(3 * lnrd);
+    }
+    /* init_n.ipp:48-143 */
+    for (sz g = 0; g < s->n_part_to_init; ++g) {
+      const sz p = s->n_part_old + g, c = s->ijk[p];
+      const double lnrd = log(s->rd3[p]) / 3.;
+      double v = s->multiplier * eval_distro(dd, lnrd);
+      if (!o->aerosol_independent_of_rhod) v = v * s->rhod[c] / rho_stp;
+      if (o->n_aerosol_conc_factor > 0) v = v * s->aerosol_conc_factor[c % o->nz];
+      if (s->n_dims > 0) v = v * s->dv[c] / (o->dx * o->dy * o->dz);
+      s->n[p] = (n_t)(v + 0.5);
+    }
+    /* init_SD_with_distros_finalize: init_kappa, init_wet (init_wet.ipp:17-78) */
+    for (sz p = s->n_part_old; p < s->n_part; ++p) s->kpa[p] = dd->kappa;
+    for (sz p = s->n_part_old; p < s->n_part; ++p) {
+      const sz c = s->ijk[p];
+      s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
+    }
+    /* init_xyz.ipp:40-74 */
+    const int nn[3] = {o->nx, o->ny, o->nz};
+    const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
+    double *v[3] = {s->x, s->y, s->z};
+    const sz nz = m1(o->nz), ny = m1(o->ny);
+    for (int ix = 0; ix < 3; ++ix) {
+      if (nn[ix] == 0) continue;
+      for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+      for (sz g = 0; g < s->n_part_to_init; ++g) {
+        const sz p = s->n_part_old + g, c = s->ijk[p];
+        sz ii;
+        if (s->n_dims == 1) ii = c;
+        else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
+        else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
+        const double u = s->tmp_part[g];
+        v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
+      }
+    }
+  }
+  return 0;
+}
+/* init_grid.ipp:14-54 */
+static void init_grid(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  if (s->n_dims == 0) return;
+  const int nz = m1(o->nz), ny = m1(o->ny);
+  for (sz c = 0; c < s->n_cell; ++c) {
+    const int ijk = (int)c;
+    const int i = (ijk / nz) / ny, j = (ijk / nz) % ny, k = ijk % nz;
+    s->dv[c] = dmax(0., (dmin((i + 1) * o->dx, o->x1) - dmax(i * o->dx, o->x0)) *
+                        (dmin((j + 1) * o->dy, o->y1) - dmax(j * o->dy, o->y0)) *
+                        (dmin((k + 1) * o->dz, o->z1) - dmax(k * o->dz, o->z0)));
+  }
+}
+#include "orc_tables.h"
+/* init_kernel.ipp:6-233 */
+static int init_kernel(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  switch (o->kernel) {
+    case LCX_KERNEL_GEOMETRIC:
+      if (s->n_user_params > 1) FAIL("Not more than 1 parameter is required by the geometric kernel, %d given", s->n_user_params);
+      return 0;
+    case LCX_KERNEL_GOLOVIN:
+      if (s->n_user_params != 1) FAIL("Golovin kernel accepts exactly one parameter, %d given", s->n_user_params);
+      return 0;
+    case LCX_KERNEL_LONG:
+      if (s->n_user_params != 0) FAIL("Long kernel doesn't accept parameters, %d given", s->n_user_params);
+      return 0;
+    default: {
+      if (s->n_user_params != 0) FAIL("this kernel doesn't accept parameters");
+      sz n = 0; double r_max = 0;
+      const double *tab = orc_efficiency_table(o->kernel, &n, &r_max);
+      if (!tab) FAIL("libcloudph++: kernel %d not available in this backend", o->kernel);
+      free(s->kernel_parameters);
+      s->kernel_parameters = NEW(double, n);
+      memcpy(s->kernel_parameters, tab, n * sizeof(double));
+      s->n_kernel_parameters = n; s->kernel_r_max = r_max;
+      return 0;
+    }
+  }
+}
+/* init_sanity_check.ipp (subset relevant to the supported options) */
+static int init_sanity_check(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+                             const lcx_arrinfo_t *p, const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz)
+{
+  const lcx_opts_init_t *o = &s->o;
+  if (s->init_called) FAIL("libcloudph++: init() may be called just once");
+  s->init_called = 1;
+  if (arr_null(th) || arr_null(rv) || arr_null(rhod)) FAIL("libcloudph++: passing th, rv and rhod is mandatory");
+  if (!arr_null(cx) || !arr_null(cy) || !arr_null(cz)) {
+    if (s->n_dims == 0) FAIL("libcloudph++: Courant numbers passed in 0D setup");
+    if (s->n_dims == 1 && (arr_null(cx) || !arr_null(cy) || !arr_null(cz))) FAIL("libcloudph++: Only X Courant number allowed in 1D setup");
+    if (s->n_dims == 2 && (arr_null(cx) || !arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: Only X and Z Courant numbers allowed in 2D setup");
+    if (s->n_dims == 3 && (arr_null(cx) || arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: All XYZ Courant number components required in 3D setup");
+  }
+  if (o->n_dry_distros == 0 && o->n_dry_sizes == 0) FAIL("libcloudph++: Both dry_distros and dry_sizes are undefined");
+  if (s->n_dims > 0) {
+    if (!(o->x0 >= 0 && o->x0 < m1(o->nx) * o->dx)) FAIL("libcloudph++: !(x0 >= 0 & x0 < min(1,nx)*dz)");
+    if (!(o->y0 >= 0 && o->y0 < m1(o->ny) * o->dy)) FAIL("libcloudph++: !(y0 >= 0 & y0 < min(1,ny)*dy)");
+    if (!(o->z0 >= 0 && o->z0 < m1(o->nz) * o->dz)) FAIL("libcloudph++: !(z0 >= 0 & z0 < min(1,nz)*dz)");
+    if (!(o->y1 > o->y0 && o->y1 <= m1(o->ny) * o->dy)) FAIL("libcloudph++: !(y1 > y0 & y1 <= min(1,ny)*dy)");
+    if (!(o->z1 > o->z0 && o->z1 <= m1(o->nz) * o->dz)) FAIL("libcloudph++: !(z1 > z0 & z1 <= min(1,nz)*dz)");
+  }
+  if (o->dt == 0) FAIL("libcloudph++: please specify opts_init.dt");
+  if (o->sd_conc * o->sd_const_multi != 0) FAIL("libcloudph++: specify either opts_init.sd_conc or opts_init.sd_const_multi, not both");
+  if (o->sd_conc == 0 && o->sd_const_multi == 0 && o->n_dry_sizes == 0) FAIL("libcloudph++: please specify opts_init.sd_conc, opts_init.sd_const_multi or opts_init.dry_sizes");
+  if (o->coal_switch) {
+    if (o->terminal_velocity == LCX_VT_UNDEFINED) FAIL("libcloudph++: please specify opts_init.terminal_velocity or turn off opts_init.coal_switch");
+    if (o->kernel == LCX_KERNEL_UNDEFINED) FAIL("libcloudph++: please specify opts_init.kernel");
+  }
+  if (o->sedi_switch && o->terminal_velocity == LCX_VT_UNDEFINED) FAIL("libcloudph++: please specify opts_init.terminal_velocity or turn off opts_init.sedi_switch");
+  if (o->sedi_switch && o->nz == 0) FAIL("libcloudph++: opts_init.sedi_switch can be True only if n_dims > 1");
+  if (o->subs_switch && o->nz == 0) FAIL("libcloudph++: opts_init.subs_switch can be True only if n_dims > 1");
+  if (o->subs_switch && o->nz != o->n_w_LS) FAIL("libcloudph++: opts_init.subs_switch == True, but subsidence velocity profile size != nz");
+  if (o->n_aerosol_conc_factor && s->n_dims < 2) FAIL("libcloudph++: aerosol_conc_factor can only be used in 2D and 3D");
+  if (o->n_aerosol_conc_factor && o->nz != o->n_aerosol_conc_factor) FAIL("libcloudph++: aerosol_conc_factor size needs to be either 0 or nz");
+  if (o->n_aerosol_conc_factor && !o->aerosol_independent_of_rhod) FAIL("libcloudph++: aerosol_conc_factor can only be used if aerosol_independent_of_rhod==true");
+  if (o->const_p && arr_null(p)) FAIL("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
+  if (!o->const_p && !arr_null(p)) FAIL("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
+  if (o->sstp_cond < 1) FAIL("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+  if (!o->sstp_cond_mix && !o->exact_sstp_cond) FAIL("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
+  return 0;
+}
+static void alloc_courants(orc_particles *s)
+{                                                   /* init_sync.ipp:28-44 (halo_size 0) */
+  const lcx_opts_init_t *o = &s->o;
+  switch (s->n_dims) {
+    case 3: s->n_cx = (sz)(o->nx + 1) * o->ny * o->nz; s->n_cy = (sz)o->nx * (o->ny + 1) * o->nz; s->n_cz = (sz)o->nx * o->ny * (o->nz + 1); break;
+    case 2: s->n_cx = (sz)(o->nx + 1) * o->nz; s->n_cz = (sz)o->nx * (o->nz + 1); break;
+    case 1: s->n_cx = (sz)o->nx + 1; break;
+    default: break;
+  }
+  s->courant_x = NEW(double, s->n_cx); s->courant_y = NEW(double, s->n_cy); s->courant_z = NEW(double, s->n_cz);
+}
+int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+             const lcx_arrinfo_t *p, const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz)
+{
+  if (init_sanity_check(s, th, rv, rhod, p, cx, cy, cz)) return 1;
+  if (s->o.rng_seed_init_switch) mt_seed(&s->rng, (uint32_t)s->o.rng_seed_init);
+  alloc_courants(s);
+  sync_in_arr(s, th, s->th, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, rv, s->rv, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, rhod, s->rhod, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, p, s->p, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
+  sync_in_arr(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
+  sync_in_arr(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
+  init_grid(s);
+  hskpng_Tpr(s);
+  if (!s->o.no_ccn_at_init) {
+    if (s->o.n_dry_distros > 0 && init_SD_with_distros(s)) return 1;
+    if (s->o.n_dry_sizes > 0) FAIL("libcloudph++: dry_sizes initialisation not supported by this backend yet");
+  }
+  if (s->o.coal_switch && init_kernel(s)) return 1;
+  init_vterm(s);
+  hskpng_vterm(s, 1);
+  sstp_save(s);
+  hskpng_count(s);
+  mt_seed(&s->rng, (uint32_t)s->o.rng_seed);
+  return 0;
+}
+
+/* ---------------- time stepping (particles_step.ipp) ---------------- */
+int orc_sync_in(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+                const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss)
+{
+  if (!s->init_called) FAIL("libcloudph++: please call init() before calling step_sync()");
+  if (s->should_now_run_async) FAIL("libcloudph++: please call step_async() before calling step_sync() again");
+  if (arr_null(th) || arr_null(rv)) FAIL("libcloudph++: passing th and rv is mandatory");
+  if (!arr_null(cx) || !arr_null(cy) || !arr_null(cz)) {
+    if (s->n_dims == 0) FAIL("libcloudph++: Courant numbers passed in 0D setup");
+    if (s->n_dims == 1 && (arr_null(cx) || !arr_null(cy) || !arr_null(cz))) FAIL("libcloudph++: Only X Courant number allowed in 1D setup");
+    if (s->n_dims == 2 && (arr_null(cx) || !arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: Only X and Z Courant numbers allowed in 2D setup");
+    if (s->n_dims == 3 && (arr_null(cx) || arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: All XYZ Courant number components required in 3D setup");
+  }
+  if (!arr_null(diss)) FAIL("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
+  s->var_rho = !arr_null(rhod);
+  sync_in_arr(s, th, s->th, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, rv, s->rv, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, rhod, s->rhod, s->n_cell, 0, 0, 0);
+  sync_in_arr(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
+  sync_in_arr(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
+  sync_in_arr(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
+  s->should_now_run_cond = 1;
+  return 0;
+}
+int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv)
+{
+  if (!s->should_now_run_cond) FAIL("libcloudph++: please call sync_in() before calling step_cond()");
+  if (opts->turb_cond) FAIL("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+  s->should_now_run_cond = 0;
+  if (adjust_timesteps(s, opts->dt)) return 1;
+  if (opts->cond) {
+    hskpng_sort(s);
+    hskpng_mfp(s);
+    for (int step = 0; step < s->sstp_cond; ++step) {
+      sstp_percell_step(s, step);
+      hskpng_Tpr(s);
+      if (step == 0) save_liq_before(s);
+      cond(s, s->dt, opts->RH_max, step);
+      update_th_rv(s);
+    }
+    sstp_save(s);
+    sync_out_arr(s, s->th, th, s->n_cell);
+    sync_out_arr(s, s->rv, rv, s->n_cell);
+  }
+  s->should_now_run_async = 1;
+  s->selected_before_counting = 0;
+  return 0;
+}
+int orc_step_sync(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
+                  const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy,
+                  const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss)
+{
+  if (orc_sync_in(s, th, rv, rhod, cx, cy, cz, diss)) return 1;
+  return orc_step_cond(s, opts, th, rv);
+}
+int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
+{
+  if (!s->should_now_run_async) FAIL("libcloudph++: please call step_sync() before calling step_async() again");
+  s->should_now_run_async = 0;
+  if (opts->chem_dsl || opts->chem_dsc || opts->chem_rct) FAIL("libcloudph++: all chemistry was switched off in opts_init");
+  if (opts->coal && !s->o.coal_switch) FAIL("libcloudph++: coalescence was switched off in opts_init");
+  if (opts->sedi && !s->o.sedi_switch) FAIL("libcloudph++: sedimentation was switched off in opts_init");
+  if (opts->subs && !s->o.subs_switch) FAIL("libcloudph++: subsidence was switched off in opts_init");
+  if (opts->turb_adve) FAIL("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+  if (opts->src) FAIL("libcloudph++: aerosol source was switched off in opts_init");
+  if (opts->rlx) FAIL("libcloudph++: aerosol relaxation was switched off in opts_init");
+  if (adjust_timesteps(s, opts->dt)) return 1;
+  hskpng_Tpr(s);
+  if (opts->sedi || opts->coal || opts->cond) hskpng_vterm(s, 0);
+  if (opts->coal) {
+    for (int step = 0; step < s->sstp_coal; ++step) {
+      coal(s, s->dt / s->sstp_coal);
+      if (step + 1 != s->sstp_coal) hskpng_vterm(s, 1);
+    }
+    if (s->increase_sstp_coal) { ++s->sstp_coal; s->increase_sstp_coal = 0; }
+  }
+  if (opts->adve) adve(s);
+  s->adve_scheme = s->o.adve_scheme;
+  if (opts->sedi) sedi(s, s->dt);
+  if (opts->subs) subs(s, s->dt);
+  bcnd(s);
+  if (!distmem(s)) { if (post_copy(s, opts)) return 1; }
+  s->selected_before_counting = 0;
+  return 0;
+}
+
+/* ---------------- diagnostics (particles_diag.ipp, fill_outbuf.ipp) ---------------- */
+static void diag_cellfield(orc_particles *s, const double *f)
+{
+  hskpng_Tpr(s);
+  memcpy(s->count_mom, f, s->n_cell * sizeof(double));
+  s->count_n = s->n_cell;
+  for (sz c = 0; c < s->n_cell; ++c) s->count_ijk[c] = c;
+}
+int orc_diag_pressure(orc_particles *s) { diag_cellfield(s, s->p); return 0; }
+int orc_diag_temperature(orc_particles *s) { diag_cellfield(s, s->T); return 0; }
+int orc_diag_RH(orc_particles *s) { diag_cellfield(s, s->RH); return 0; }
+int orc_diag_sd_conc(orc_particles *s)
+{
+  hskpng_sort(s);
+  sz cn = 0;
+  for (sz p = 0; p < s->n_part; ++p) {
+    const double v = s->n_filtered[s->sorted_id[p]] > 0. ? 1 : 0;
+    if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
+    else s->count_mom[cn - 1] += v;
+  }
+  s->count_n = cn;
+  return 0;
+}
+int orc_diag_all(orc_particles *s) { moms_all(s); return 0; }
+int orc_diag_water(orc_particles *s) { moms_gt0(s, s->rw2, 0); return 0; }
+int orc_diag_dry_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 0); return 0; }
+int orc_diag_wet_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 0); return 0; }
+int orc_diag_kappa_rng(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 0); return 0; }
+int orc_diag_dry_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 1); return 0; }
+int orc_diag_wet_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 1); return 0; }
+int orc_diag_kappa_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 1); return 0; }
+int orc_diag_dry_mom(orc_particles *s, int k) { moms_calc(s, s->rd3, k / 3., 1); return 0; }
+int orc_diag_wet_mom(orc_particles *s, int k) { moms_calc(s, s->rw2, k / 2., 1); return 0; }
+int orc_diag_kappa_mom(orc_particles *s, int k) { moms_calc(s, s->kpa, k, 1); return 0; }
+int orc_outbuf(orc_particles *s, const void **data, size_t *n)
+{
+  for (sz c = 0; c < s->n_cell; ++c) s->outbuf[c] = 0;
+  for (sz i = 0; i < s->count_n; ++i) s->outbuf[s->count_ijk[i]] = s->count_mom[i];
+  hskpng_count(s);                                  /* particles_ctor.ipp:83-92 */
+  *data = s->outbuf; *n = s->n_cell;
+  return 0;
+}
+int orc_get_attr(orc_particles *s, const char *name, void *out, size_t cap, size_t *n)
+{
+  const double *v = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "kappa") ? s->kpa :
+                    !strcmp(name, "x") ? s->x : !strcmp(name, "y") ? s->y : !strcmp(name, "z") ? s->z : NULL;
+  if (!v) FAIL("Unknown attribute name passed to get_attr.");
+  *n = s->n_part;
+  if (out) { if (cap < s->n_part) FAIL("get_attr: buffer too small"); memcpy(out, v, s->n_part * sizeof(double)); }
+  return 0;
+}
+int orc_diag_puddle(orc_particles *s, double out[LCX_OUT_COUNT]) { memcpy(out, s->puddle, sizeof s->puddle); return 0; }
+
+/* ---------------- introspection hooks ---------------- */
+int orc_n_part(orc_particles *s, size_t *n) { *n = s->n_part; return 0; }
+int orc_n_cell(orc_particles *s, size_t *n) { *n = s->n_cell; return 0; }
+int orc_real_kind(orc_particles *s, int *k) { (void)s; *k = 8; return 0; }
+int orc_get_state_u64(orc_particles *s, const char *name, unsigned long long *out, size_t cap, size_t *n)
+{
+  sz len = s->n_part; const sz *v = NULL;
+  if (!strcmp(name, "n")) { *n = len; if (out) { if (cap < len) FAIL("buffer too small"); memcpy(out, s->n, len * sizeof(n_t)); } return 0; }
+  if (!strcmp(name, "ijk")) v = s->ijk; else if (!strcmp(name, "sorted_id")) v = s->sorted_id;
+  else if (!strcmp(name, "sorted_ijk")) v = s->sorted_ijk;
+  else if (!strcmp(name, "count_ijk")) { v = s->count_ijk; len = s->count_n; }
+  else if (!strcmp(name, "count_num")) { *n = s->count_n; if (out) { if (cap < s->count_n) FAIL("buffer too small"); memcpy(out, s->count_num, s->count_n * sizeof(n_t)); } return 0; }
+  else FAIL("unknown u64 state '%s'", name);
+  *n = len;
+  if (out) { if (cap < len) FAIL("buffer too small"); for (sz i = 0; i < len; ++i) out[i] = v[i]; }
+  return 0;
+}
+int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t cap, size_t *n)
+{
+  struct { const char *nm; const double *v; sz len; } tab[] = {
+    {"vt", s->vt, s->n_part}, {"T", s->T, s->n_cell}, {"p", s->p, s->n_cell}, {"RH", s->RH, s->n_cell},
+    {"eta", s->eta, s->n_cell}, {"th", s->th, s->n_cell}, {"rv", s->rv, s->n_cell}, {"rhod", s->rhod, s->n_cell},
+    {"dv", s->dv, s->n_cell}, {"lambda_D", s->lambda_D, s->n_cell}, {"lambda_K", s->lambda_K, s->n_cell},
+    {"courant_x", s->courant_x, s->n_cx}, {"courant_y", s->courant_y, s->n_cy}, {"courant_z", s->courant_z, s->n_cz},
+    {"vt_0", s->vt_0, 10000}, {"count_mom", s->count_mom, s->count_n}, {"col", s->col, s->n_part},
+    {"rw2", s->rw2, s->n_part}, {"rd3", s->rd3, s->n_part}, {"kappa", s->kpa, s->n_part},
+    {"x", s->x, s->n_part}, {"y", s->y, s->n_part}, {"z", s->z, s->n_part}};
+  for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
+    if (!strcmp(name, tab[i].nm)) {
+      *n = tab[i].len;
+      if (out) { if (cap < tab[i].len) FAIL("buffer too small"); memcpy(out, tab[i].v, tab[i].len * sizeof(double)); }
+      return 0;
+    }
+  FAIL("unknown real state '%s'", name);
+}
+int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult, const double *rd3, const double *rw2,
+                      const double *kpa, const double *vt, const double *x, const double *y, const double *z)
+{
+  if (n > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, n);
+  s->n_part = n;
+  memcpy(s->n, mult, n * sizeof(n_t)); memcpy(s->rd3, rd3, n * 8); memcpy(s->rw2, rw2, n * 8);
+  memcpy(s->kpa, kpa, n * 8); memcpy(s->vt, vt, n * 8);
+  if (x) memcpy(s->x, x, n * 8);
+  if (y) memcpy(s->y, y, n * 8);
+  if (z) memcpy(s->z, z, n * 8);
+  hskpng_ijk(s);
+  hskpng_count(s);
+  return 0;
+}
+/* preview of the next random arrays WITHOUT advancing the engine: kinds[i] 0 = u01, 1 = un; lens[i] values each;
+ * out receives the concatenation.  Used to replay the CPU stream on the device. */
+int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int ncalls, double *out)
+{
+  mt19937_t g = s->rng;
+  for (int c = 0; c < ncalls; ++c)
+    for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : rng_un(&g);
+  return 0;
+}
+int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
+{
+  if (!strcmp(st, "hskpng_Tpr")) hskpng_Tpr(s);
+  else if (!strcmp(st, "hskpng_mfp")) hskpng_mfp(s);
+  else if (!strcmp(st, "hskpng_ijk")) hskpng_ijk(s);
+  else if (!strcmp(st, "hskpng_sort")) hskpng_sort(s);
+  else if (!strcmp(st, "hskpng_shuffle_and_sort")) hskpng_sort_helper(s, 1);
+  else if (!strcmp(st, "hskpng_count")) hskpng_count(s);
+  else if (!strcmp(st, "hskpng_vterm_all")) hskpng_vterm(s, 0);
+  else if (!strcmp(st, "hskpng_vterm_invalid")) hskpng_vterm(s, 1);
+  else if (!strcmp(st, "coal")) { if (adjust_timesteps(s, opts ? opts->dt : -1)) return 1; coal(s, s->dt / s->sstp_coal); }
+  else if (!strcmp(st, "adve")) adve(s);
+  else if (!strcmp(st, "sedi")) { if (adjust_timesteps(s, opts ? opts->dt : -1)) return 1; sedi(s, s->dt); }
+  else if (!strcmp(st, "bcnd")) bcnd(s);
+  else if (!strcmp(st, "post_copy")) { lcx_opts_t o; orc_opts_default(&o); return post_copy(s, opts ? opts : &o); }
+  else FAIL("unknown stage '%s'", st);
+  return 0;
+}
+
+/* ---------------- 1-D decomposition helpers (pack.ipp:14-133, unpack.ipp:14-143) ---------------- */
+int orc_migrate_counts(orc_particles *s, size_t *l, size_t *r) { *l = s->lft_count; *r = s->rgt_count; return 0; }
+size_t orc_migrate_record_bytes(orc_particles *s) { return 8 + 8 * (4 + (size_t)s->n_dims); }
+int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t cap_bytes)
+{
+  const sz cnt = side == 0 ? s->lft_count : s->rgt_count;
+  const sz *id = side == 0 ? s->lft_id : s->rgt_id;
+  if (cap_bytes < cnt * orc_migrate_record_bytes(s)) FAIL("migrate_pack: buffer too small");
+  const double x_lcl = side == 0 ? s->o.x0 : s->o.x1;
+  for (sz i = 0; i < cnt; ++i) s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;   /* detail::remote, pack.ipp:14-26 */
+  n_t *nb = (n_t *)buf; double *rb = (double *)buf + cnt;
+  const double *attrs[7] = {s->rd3, s->rw2, s->kpa, s->vt, s->x, s->y, s->z};
+  const int use[7] = {1, 1, 1, 1, s->o.nx != 0, s->o.ny != 0, s->o.nz != 0};
+  for (sz i = 0; i < cnt; ++i) nb[i] = s->n[id[i]];
+  sz slab = 0;
+  for (int a = 0; a < 7; ++a) { if (!use[a]) continue; for (sz i = 0; i < cnt; ++i) rb[slab * cnt + i] = attrs[a][id[i]]; ++slab; }
+  return 0;
+}
+int orc_migrate_unpack(orc_particles *s, const void *buf, size_t cnt)
+{
+  if (cnt == 0) return 0;
+  const sz old = s->n_part;
+  if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
+  const n_t *nb = (const n_t *)buf; const double *rb = (const double *)buf + cnt;
+  double *attrs[7] = {s->rd3, s->rw2, s->kpa, s->vt, s->x, s->y, s->z};
+  const int use[7] = {1, 1, 1, 1, s->o.nx != 0, s->o.ny != 0, s->o.nz != 0};
+  for (sz i = 0; i < cnt; ++i) s->n[old + i] = nb[i];
+  sz slab = 0;
+  for (int a = 0; a < 7; ++a) { if (!use[a]) continue; for (sz i = 0; i < cnt; ++i) attrs[a][old + i] = rb[slab * cnt + i]; ++slab; }
+  const double tol = 5e-4;                          /* config.hpp:31, tolerance_away_from_bcond */
+  for (sz i = old; i < old + cnt; ++i) { const double x = s->x[i]; s->x[i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x; }
+  s->n_part = old + cnt;
+  return 0;
+}
+int orc_migrate_finish(orc_particles *s, const lcx_opts_t *opts)
+{
+  /* emigrants were the first lft_count/rgt_count ids recorded by bcnd: flag them (flag_lft/rgt, unpack.ipp:118-141) */
+  for (sz i = 0; i < s->lft_count; ++i) s->n[s->lft_id[i]] = 0;
+  for (sz i = 0; i < s->rgt_count; ++i) s->n[s->rgt_id[i]] = 0;
+  s->lft_count = s->rgt_count = 0;
+  return post_copy(s, opts);
+}
