@@ -1,0 +1,1060 @@
+// lcx_core.hip -- host orchestration of the HIP kernels + the C ABI (include/lcx.h).
+//
+// Particles<real_t> owns the device state of one particles_t<real_t, HIP> object and implements the
+// reference's time-step orchestration (src/particles_step.ipp, src/particles_init.ipp, src/particles_diag.ipp)
+// as a sequence of kernel launches on one HIP stream.  The C ABI at the bottom is what the host-language
+// shims bind (C++: include/libcloudphxx_amd/lgrngn/particles.hpp, Python: libcloudphxx_amd/lgrngn.py).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lcx.h"
+#include "lcx_kernels.hpp"
+
+namespace lcx {
+
+struct lcx_error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+  throw lcx_error(std::string("libcloudph++ (HIP): ") + hipGetErrorString(e_) + " at " #expr); } while (0)
+
+static inline unsigned nblk(size_t n, unsigned bs = BS) { return unsigned((n + bs - 1) / bs); }
+
+template <class T> struct DevBuf {
+  T *p = nullptr; size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void alloc(size_t m) { if (m <= n && p) return; release(); HIPCHK(hipMalloc((void **)&p, std::max<size_t>(m, 1) * sizeof(T))); n = std::max<size_t>(m, 1); }
+  void alloc_zero(size_t m, hipStream_t s) { alloc(m); HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+  void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+};
+
+// ---- efficiency tables (numeric data files, see tools/extract_efficiency_tables.py) ----
+static bool load_efficiency_table(int kernel, std::vector<double> &tab, double &r_max)
+{
+  const char *dir = getenv("LCX_DATA_DIR");
+  char path[1024];
+  snprintf(path, sizeof path, "%s/kernel_eff_%d.f64", dir ? dir : "libcloudphxx_amd/data", kernel);
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  double hdr[2];
+  bool ok = fread(hdr, sizeof(double), 2, f) == 2;
+  if (ok) { tab.resize(size_t(hdr[1])); ok = fread(tab.data(), sizeof(double), tab.size(), f) == tab.size(); r_max = hdr[0]; }
+  fclose(f);
+  return ok;
+}
+
+struct IParticles {
+  virtual ~IParticles() {}
+  virtual int real_kind() const = 0;
+  virtual void init(const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *p,
+                    const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) = 0;
+  virtual void sync_in(const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,
+                       const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) = 0;
+  virtual void step_cond(const lcx_opts_t &, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv) = 0;
+  virtual void step_async(const lcx_opts_t &) = 0;
+  virtual void diag_cell(int which) = 0;               // 0 p, 1 T, 2 RH
+  virtual void diag_sd_conc() = 0;
+  virtual void diag_select(int mode, int cons, int attr, double a, double b) = 0;   // attr: 0 rd3, 1 rw2, 2 kpa
+  virtual void diag_mom(int attr, double power) = 0;
+  virtual void diag_precip_rate() = 0;
+  virtual void diag_max_rw() = 0;
+  virtual void outbuf(const void **data, size_t *n) = 0;
+  virtual void get_attr(const char *name, void *out, size_t cap, size_t *n) = 0;
+  virtual void diag_puddle(double *out) = 0;
+  virtual size_t n_part() = 0;
+  virtual size_t n_cell() = 0;
+  virtual void get_state_u64(const char *name, unsigned long long *out, size_t cap, size_t *n) = 0;
+  virtual void get_state_real(const char *name, double *out, size_t cap, size_t *n) = 0;
+  virtual void set_particles(size_t n, const unsigned long long *mult, const double *rd3, const double *rw2, const double *kpa,
+                             const double *vt, const double *x, const double *y, const double *z) = 0;
+  virtual void rng_replay_push(int kind, const double *data, size_t n) = 0;
+  virtual size_t rng_replay_pending() = 0;
+  virtual void stage(const char *name, const lcx_opts_t *opts) = 0;
+  virtual void timings(const char **names, double *ms, size_t cap, size_t *n) = 0;
+  virtual void set_profiling(int on) = 0;
+  virtual void migrate_counts(size_t *l, size_t *r) = 0;
+  virtual size_t migrate_record_bytes() = 0;
+  virtual void migrate_pack(int side, double x_rmt, void *buf, size_t cap) = 0;
+  virtual void migrate_unpack(const void *buf, size_t count) = 0;
+  virtual void migrate_finish(const lcx_opts_t &) = 0;
+};
+
+template <class real_t>
+struct Particles : IParticles {
+  using T = real_t;
+  // ---- options (deep copies) ----
+  lcx_opts_init_t o;
+  std::vector<lcx_distro_t> distros;
+  std::vector<double> kernel_parameters_h, w_LS_h, conc_factor_h;
+  int n_dims; size_t ncell, npart = 0, cap;
+  grid_t g;
+  // ---- order-of-operation flags (particles_impl.ipp:32) ----
+  bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
+  bool var_rho = false, sorted = false, sorted_shuffled = false;
+  int sstp_cond, sstp_coal; bool allow_sstp_cond, pure_const_multi; double dt;
+  int adve_scheme;
+  hipStream_t st = nullptr;
+  // ---- particle attributes (two buffer sets: stable compaction writes from one into the other) ----
+  struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z; } A, B;
+  DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
+  DevBuf<uint8_t> mig;
+  DevBuf<uint64_t> sort_scratch;
+  DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
+  // ---- cell fields ----
+  DevBuf<T> rhod, th, rv, p, Tk, RH, eta, dv, lambda_D, lambda_K, sstp_tmp_rv, sstp_tmp_th, sstp_tmp_rh, rw_mom3, count_mom;
+  DevBuf<T> courant_x, courant_y, courant_z, w_LS, conc_factor, vt_0, kparams;
+  size_t n_cx = 0, n_cy = 0, n_cz = 0;
+  DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
+  DevBuf<double> puddle_partial; std::vector<double> puddle_partial_h;
+  DevBuf<int> d_flag;
+  double puddle[LCX_OUT_COUNT];
+  bool count_mom_valid_all = true;
+  double kernel_r_max = 0; int n_user_params = 0;
+  double log_rd_min = 0, log_rd_max = 0, multiplier = 0;
+  T eps_tol;
+  vt_cfg vtc;
+  uint64_t rng_call = 0;
+  size_t lft_count = 0, rgt_count = 0;
+  // replay queues: device arrays consumed by the next rand_u01 / rand_un
+  struct Replay { int kind; std::unique_ptr<DevBuf<T>> u01; std::unique_ptr<DevBuf<uint32_t>> un; size_t n; };
+  std::deque<Replay> replay;
+  std::vector<std::unique_ptr<DevBuf<T>>> replay_keep_T; std::vector<std::unique_ptr<DevBuf<uint32_t>>> replay_keep_u;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
+  std::map<std::string, double> prof_ms; std::vector<std::string> prof_order;
+
+  int real_kind() const override { return int(sizeof(T)); }
+  bool distmem() const { return o.bcond_lft == 1 || o.bcond_rgt == 1; }
+  static int m1(int n) { return n == 0 ? 1 : n; }
+
+  // ------------------------------------------------------------------------------------------
+  explicit Particles(const lcx_opts_init_t &oi) : o(oi)
+  {
+    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_adve_switch || oi.turb_cond_switch ||
+        oi.turb_coal_switch || oi.exact_sstp_cond || oi.adaptive_sstp_cond || oi.sd_const_multi || oi.sd_conc_large_tail ||
+        oi.diag_incloud_time)
+      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/exact_sstp/const_multi/tail)");
+    if (oi.adve_scheme == LCX_ADVE_PRED_CORR) throw lcx_error("libcloudph++: pred_corr advection not supported by this backend");
+    if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
+    distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
+    kernel_parameters_h.assign(oi.kernel_parameters, oi.kernel_parameters + oi.n_kernel_parameters);
+    w_LS_h.assign(oi.w_LS, oi.w_LS + oi.n_w_LS);
+    conc_factor_h.assign(oi.aerosol_conc_factor, oi.aerosol_conc_factor + oi.n_aerosol_conc_factor);
+    o.dry_distros = nullptr; o.kernel_parameters = nullptr; o.w_LS = nullptr; o.aerosol_conc_factor = nullptr; o.dry_sizes = nullptr;
+    n_user_params = oi.n_kernel_parameters;
+    n_dims = oi.nx / m1(oi.nx) + oi.ny / m1(oi.ny) + oi.nz / m1(oi.nz);             // particles_impl.ipp:335-345
+    ncell = size_t(m1(oi.nx)) * m1(oi.ny) * m1(oi.nz);
+    if (ncell >= (1ull << 32)) throw lcx_error("libcloudph++: n_cell must be < 2^32");
+    g = grid_t{oi.nx, oi.ny, oi.nz, n_dims, double(T(oi.dx)), double(T(oi.dy)), double(T(oi.dz))};
+    sstp_cond = oi.sstp_cond; sstp_coal = oi.sstp_coal;
+    allow_sstp_cond = oi.sstp_cond > 1 || oi.sstp_cond_act > 1;
+    pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
+    adve_scheme = oi.adve_scheme;
+    if (o.n_x_tot == 0) o.n_x_tot = oi.nx;
+    dt = oi.dt;
+    eps_tol = eps_tolerance<T>(sizeof(T) * 8 / 4);                                   // src/detail/config.hpp:39
+    vtc = vt_cfg{oi.terminal_velocity, double(T(std::log(5e-7))), double(T(std::log(3e-3))), 10000};   // config.hpp:27-38
+    cap = size_t(oi.n_sd_max);
+    for (double &v : puddle) v = 0;
+    if (oi.dev_id >= 0) HIPCHK(hipSetDevice(oi.dev_id));                             // particles_ctor.ipp:60-63
+    HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    alloc_attrs(A);
+    ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
+    cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
+    tile_sums.alloc(std::max(cap, ncell) / SCAN_TILE + 2); scan_total.alloc(4);
+    big_list.alloc(std::min<size_t>(ncell, cap / CELLSORT_MAX + 1) + 1); big_meta.alloc(2);
+    m3_before.alloc(cap); m3_after.alloc(cap);
+    if (oi.coal_switch) col.alloc(cap);
+    for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
+      b->alloc_zero(ncell, st);
+    d_flag.alloc_zero(1, st);
+    puddle_partial.alloc(size_t(nblk(cap)) * 4);
+    outbuf_h.assign(ncell, T(0));
+    if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
+  }
+  ~Particles() override { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+
+  void alloc_attrs(Attrs &a)
+  {
+    a.n.alloc(cap); a.rd3.alloc(cap); a.rw2.alloc(cap); a.kpa.alloc(cap); a.vt.alloc(cap);
+    if (o.nx) a.x.alloc(cap); if (o.ny) a.y.alloc(cap); if (o.nz) a.z.alloc(cap);
+  }
+  attr_set<T> aset(Attrs &a) { return attr_set<T>{a.n.p, a.rd3.p, a.rw2.p, a.kpa.p, a.vt.p, a.x.p, a.y.p, a.z.p}; }
+  void sync() { HIPCHK(hipStreamSynchronize(st)); }
+
+  // ---- profiling ranges (hipEvents on OUR stream) ----
+  struct Range {
+    Particles *self; std::string name; hipEvent_t a = nullptr, b = nullptr;
+    Range(Particles *s, const char *nm) : self(s), name(nm)
+    { if (self->profiling) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, self->st); } }
+    ~Range() { if (self->profiling && a) { (void)hipEventRecord(b, self->st); self->prof_events.push_back({name, {a, b}}); } }
+  };
+  void collect_profile()
+  {
+    if (!profiling) return;
+    sync();
+    for (auto &e : prof_events) {
+      float ms = 0; (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
+      if (!prof_ms.count(e.first)) prof_order.push_back(e.first);
+      prof_ms[e.first] += ms;
+      (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+    }
+    prof_events.clear();
+  }
+  void set_profiling(int on) override { collect_profile(); profiling = on != 0; prof_ms.clear(); prof_order.clear(); }
+  void timings(const char **names, double *ms, size_t capn, size_t *n) override
+  {
+    collect_profile();
+    size_t k = 0;
+    for (auto &nm : prof_order) { if (k >= capn) break; names[k] = nm.c_str(); ms[k] = prof_ms[nm]; ++k; }
+    *n = k;
+  }
+
+  // ---- device exclusive scan: out[0..m) = exclusive scan of in, out[m] (if out_last) = total; returns nothing (async) ----
+  void exclusive_scan(const uint32_t *in, uint32_t *out, size_t m, uint32_t *out_last)
+  {
+    const size_t tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
+    if (tiles == 0) { if (out_last) HIPCHK(hipMemsetAsync(out_last, 0, sizeof(uint32_t), st)); HIPCHK(hipMemsetAsync(scan_total.p, 0, sizeof(uint32_t), st)); return; }
+    hipLaunchKernelGGL(k_scan_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, in, out, tile_sums.p, m);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblk(m)), dim3(BS), 0, st, out, tile_sums.p, m, scan_total.p, out_last);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Eulerian <-> Lagrangian sync (particles_impl_sync.ipp:15-68, init_e2l.ipp:34-114)
+  // ------------------------------------------------------------------------------------------
+  static bool is_null(const lcx_arrinfo_t *a) { return !a || !a->data || !a->strides; }
+  void arr_geom(const lcx_arrinfo_t *a, int ex, int ey, int ez, int &n1, int &n2, long &s0, long &s1, long &s2) const
+  {
+    (void)ex;
+    n1 = o.ny + ey; n2 = o.nz + ez; s0 = s1 = s2 = 0;
+    switch (n_dims) {
+      case 0: break;
+      case 1: s0 = 1; break;
+      case 2: s0 = a->strides[0]; s1 = a->strides[1]; break;
+      default: s0 = a->strides[0]; s1 = a->strides[1]; s2 = a->strides[2];
+    }
+  }
+  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez)
+  {
+    if (is_null(a)) return;
+    int n1, n2; long s0, s1, s2;
+    arr_geom(a, ex, ey, ez, n1, n2, s0, s1, s2);
+    if (a->on_device) {
+      hipLaunchKernelGGL(k_gather_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, to.p, (const T *)a->data, n, n_dims, n1, n2, s0, s1, s2, long(o.n_x_bfr));
+      return;
+    }
+    stage_host.resize(n);
+    const T *d = (const T *)a->data;
+    const long ioff = o.n_x_bfr;
+    switch (n_dims) {
+      case 0: stage_host[0] = d[0]; break;
+      case 1: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c) + ioff) * s0]; break;
+      case 2: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c / n2) + ioff) * s0 + long(c % n2) * s1]; break;
+      default: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c / (size_t(n2) * n1)) + ioff) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2];
+    }
+    HIPCHK(hipMemcpyAsync(to.p, stage_host.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
+    sync();     // stage_host is reused by the next field
+  }
+  void sync_out_arr(DevBuf<T> &from, const lcx_arrinfo_t *a, size_t n)
+  {
+    if (is_null(a)) return;
+    int n1, n2; long s0, s1, s2;
+    arr_geom(a, 0, 0, 0, n1, n2, s0, s1, s2);
+    if (a->on_device) {
+      hipLaunchKernelGGL(k_scatter_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, (T *)a->data, (const T *)from.p, n, n_dims, n1, n2, s0, s1, s2, long(o.n_x_bfr));
+      return;
+    }
+    stage_host.resize(n);
+    HIPCHK(hipMemcpyAsync(stage_host.data(), from.p, n * sizeof(T), hipMemcpyDeviceToHost, st));
+    sync();
+    T *d = (T *)a->data;
+    const long ioff = o.n_x_bfr;
+    switch (n_dims) {
+      case 0: d[0] = stage_host[0]; break;
+      case 1: for (size_t c = 0; c < n; ++c) d[(long(c) + ioff) * s0] = stage_host[c]; break;
+      case 2: for (size_t c = 0; c < n; ++c) d[(long(c / n2) + ioff) * s0 + long(c % n2) * s1] = stage_host[c]; break;
+      default: for (size_t c = 0; c < n; ++c) d[(long(c / (size_t(n2) * n1)) + ioff) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2] = stage_host[c];
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // random numbers (src/detail/urand.hpp): Philox on the fly, or a replayed host stream
+  // ------------------------------------------------------------------------------------------
+  u01_src<T> rand_u01(size_t n)
+  {
+    if (!replay.empty()) {
+      Replay r = std::move(replay.front()); replay.pop_front();
+      if (r.kind != 0 || r.n < n) throw lcx_error("libcloudph++: rng replay queue does not match the requested rand_u01 call");
+      const T *ptr = r.u01->p;
+      replay_keep_T.push_back(std::move(r.u01));
+      return u01_src<T>{ptr, 0, 0};
+    }
+    return u01_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+  }
+  rng_src rand_un(size_t n)
+  {
+    if (!replay.empty()) {
+      Replay r = std::move(replay.front()); replay.pop_front();
+      if (r.kind != 1 || r.n < n) throw lcx_error("libcloudph++: rng replay queue does not match the requested rand_un call");
+      const uint32_t *ptr = r.un->p;
+      replay_keep_u.push_back(std::move(r.un));
+      return rng_src{ptr, 0, 0};
+    }
+    return rng_src{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+  }
+  void release_replay_keep() { sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
+  void rng_replay_push(int kind, const double *data, size_t n) override
+  {
+    Replay r; r.kind = kind; r.n = n;
+    if (kind == 0) {
+      std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(data[i]);
+      r.u01.reset(new DevBuf<T>()); r.u01->alloc(n);
+      HIPCHK(hipMemcpy(r.u01->p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    } else if (kind == 1) {
+      std::vector<uint32_t> h(n); for (size_t i = 0; i < n; ++i) h[i] = uint32_t(T(data[i]));   // fnctr_un goes through real_t
+      r.un.reset(new DevBuf<uint32_t>()); r.un->alloc(n);
+      HIPCHK(hipMemcpy(r.un->p, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    } else throw lcx_error("libcloudph++: unknown rng replay kind");
+    replay.push_back(std::move(r));
+  }
+  size_t rng_replay_pending() override { return replay.size(); }
+
+  // ------------------------------------------------------------------------------------------
+  // housekeeping
+  // ------------------------------------------------------------------------------------------
+  void hskpng_Tpr()
+  {
+    Range r(this, "hskpng_Tpr");
+    hipLaunchKernelGGL(k_cell_Tpr<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p,
+                       o.th_dry, o.const_p, o.RH_formula, n_dims);
+  }
+  void hskpng_mfp()
+  {
+    hipLaunchKernelGGL(k_cell_mfp<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, Tk.p, p.p, lambda_D.p, lambda_K.p);
+  }
+  // cell index of every SD (+ optionally the cell histogram with per-SD ranks in the same pass)
+  void ijk_and_hist(bool do_ijk, bool do_hist)
+  {
+    if (do_hist) HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
+    if (npart)
+      hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, g, A.x.p, A.y.p, A.z.p, ijk.p,
+                         do_hist ? cell_cnt.p : nullptr, rank.p, int(do_ijk));
+  }
+  void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(true, false); sorted = false; }
+  // finish a sort given cell_cnt/rank: scan -> scatter -> per-cell order
+  void sort_from_hist(bool shuffle)
+  {
+    exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell);
+    if (npart) {
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(npart)), dim3(BS), 0, st, npart, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
+      rng_src rs{nullptr, 0, 0};
+      if (shuffle) rs = rand_un(npart);
+      if (ncell == 1 && !shuffle) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
+      else {
+        HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
+        const unsigned blocks = unsigned(std::min<size_t>((ncell + 3) / 4, 4096));
+        hipLaunchKernelGGL(k_cellsort, dim3(blocks), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, int(shuffle), rs,
+                           big_list.p, big_meta.p, big_meta.p + 1);
+        uint32_t meta[2];
+        HIPCHK(hipMemcpyAsync(meta, big_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
+        sync();
+        if (meta[0]) {
+          size_t P = 1; while (P < meta[1]) P <<= 1;
+          const unsigned nb = std::min<unsigned>(meta[0], 64u);
+          sort_scratch.alloc(P * nb);
+          hipLaunchKernelGGL(k_cellsort_big, dim3(nb), dim3(1024), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, int(shuffle), rs,
+                             sort_scratch.p, P);
+        }
+      }
+    }
+    sorted = true; sorted_shuffled = shuffle;
+  }
+  void hskpng_sort_helper(bool shuffle)
+  {
+    Range r(this, shuffle ? "hskpng_shuffle_and_sort" : "hskpng_sort");
+    ijk_and_hist(false, true);
+    sort_from_hist(shuffle);
+  }
+  void hskpng_sort() { if (!sorted) hskpng_sort_helper(false); }
+  void hskpng_count() { hskpng_sort(); }
+  void hskpng_vterm(bool only_invalid)
+  {
+    Range r(this, only_invalid ? "hskpng_vterm_invalid" : "hskpng_vterm_all");
+    if (npart)
+      hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
+  }
+  void check_npart(size_t n) const
+  {                                                                                      // hskpng_resize.ipp:9
+    if (n > o.n_sd_max) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part (" + std::to_string(n) + ")");
+  }
+
+  // post_copy.ipp:18-35: remove n==0 (stable) -> ijk -> count(sort), fused into one pass over the attributes
+  void post_copy(const lcx_opts_t &opts)
+  {
+    if (opts.rcyc) throw lcx_error("libcloudph++: rcyc not supported by this backend");
+    Range r(this, "post_copy");
+    const size_t tiles = (npart + SCAN_TILE - 1) / SCAN_TILE;
+    uint32_t alive = 0;
+    if (tiles) {
+      hipLaunchKernelGGL(k_alive_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, A.n.p, npart, tile_sums.p);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+      HIPCHK(hipMemcpyAsync(&alive, scan_total.p, sizeof alive, hipMemcpyDeviceToHost, st));
+      sync();
+    }
+    if (alive == npart) ijk_and_hist(true, true);                  // nobody died: re-index in place
+    else {
+      if (!B.n.p) alloc_attrs(B);
+      HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, npart, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
+      A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
+      npart = alive;
+    }
+    sort_from_hist(false);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // condensation (particles_step.ipp:188-267)
+  // ------------------------------------------------------------------------------------------
+  void sstp_save()
+  {
+    if (!allow_sstp_cond) return;
+    HIPCHK(hipMemcpyAsync(sstp_tmp_rv.p, rv.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(sstp_tmp_th.p, th.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(sstp_tmp_rh.p, rhod.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
+  }
+  void sstp_percell_step(int step)
+  {
+    if (sstp_cond == 1) return;
+    T *scl[3] = {rv.p, th.p, rhod.p}, *tmp[3] = {sstp_tmp_rv.p, sstp_tmp_th.p, sstp_tmp_rh.p};
+    for (int ix = 0; ix < (var_rho ? 3 : 2); ++ix)
+      hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
+  }
+  void cond_substep(double RH_max, int step)
+  {
+    hskpng_sort();
+    if (npart) {
+      Range r(this, "cond");
+      cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
+                     lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0};
+      hipLaunchKernelGGL(k_cond<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
+    }
+    {
+      Range r(this, "cond_cellfinish");
+      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
+    }
+  }
+  void adjust_timesteps(double dt_)
+  {                                                                                      // particles_impl_adjust_timesteps.ipp:13-24
+    if (dt_ > 0 && !o.variable_dt_switch) throw lcx_error("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
+    sstp_cond = dt_ > 0 && o.sstp_cond > 1 ? int(std::ceil(o.sstp_cond * dt_ / o.dt)) : o.sstp_cond;
+    sstp_coal = dt_ > 0 && o.sstp_coal > 1 ? int(std::ceil(o.sstp_coal * dt_ / o.dt)) : o.sstp_coal;
+    dt = dt_ > 0 ? dt_ : o.dt;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // coalescence (coal.ipp:273-546)
+  // ------------------------------------------------------------------------------------------
+  void coal(double dt_sub)
+  {
+    hskpng_sort_helper(true);
+    if (npart < 2) { if (npart) (void)rand_u01(npart); return; }
+    Range r(this, "coal");
+    const u01_src<T> rs = rand_u01(npart);
+    coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p};
+    hipLaunchKernelGGL(k_coal<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
+                       A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p);
+    if (o.n_dry_distros + o.n_dry_sizes > 1)
+      hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // adve + sedi + subs + bcnd in one pass
+  // ------------------------------------------------------------------------------------------
+  void move(bool do_adve, bool do_sedi, bool do_subs, bool do_bcnd)
+  {
+    if (n_dims == 0 || npart == 0) { if (do_bcnd) { lft_count = rgt_count = 0; } return; }
+    Range r(this, "move(adve+sedi+bcnd)");
+    move_args<T> a;
+    a.n_part = npart; a.g = g;
+    a.dx = T(o.dx); a.dy = T(o.dy); a.dz = T(o.dz); a.x0 = T(o.x0); a.y0 = T(o.y0); a.z0 = T(o.z0); a.x1 = T(o.x1); a.y1 = T(o.y1); a.z1 = T(o.z1);
+    a.dt = T(dt);
+    a.x = A.x.p; a.y = A.y.p; a.z = A.z.p; a.vt = A.vt.p; a.rw2 = A.rw2.p; a.rd3 = A.rd3.p; a.n = A.n.p; a.ijk = ijk.p;
+    a.courant_x = courant_x.p; a.courant_y = courant_y.p; a.courant_z = courant_z.p; a.w_LS = w_LS.p;
+    a.do_adve = do_adve; a.scheme = adve_scheme; a.do_sedi = do_sedi; a.do_subs = do_subs; a.do_bcnd = do_bcnd;
+    a.distmem = distmem(); a.bcond_lft = o.bcond_lft; a.bcond_rgt = o.bcond_rgt;
+    a.open_side_walls = o.open_side_walls; a.periodic_topbot = o.periodic_topbot_walls;
+    const bool want_puddle = do_bcnd && n_dims > 1 && !o.periodic_topbot_walls;
+    const unsigned blocks = nblk(npart);
+    a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
+    a.mig = mig.p;
+    hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
+    if (want_puddle) {
+      puddle_partial_h.resize(size_t(blocks) * 4);
+      HIPCHK(hipMemcpyAsync(puddle_partial_h.data(), puddle_partial.p, puddle_partial_h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      sync();
+      double s[4] = {0, 0, 0, 0};
+      for (unsigned b = 0; b < blocks; ++b) for (int k = 0; k < 4; ++k) s[k] += puddle_partial_h[size_t(b) * 4 + k];
+      puddle[LCX_OUT_LIQ_VOL] += s[0]; puddle[LCX_OUT_DRY_VOL] += s[1]; puddle[LCX_OUT_LIQ_NUM] += s[2]; puddle[LCX_OUT_PRTCL_NUM] += s[3];
+    }
+    if (do_bcnd && distmem()) build_migrant_lists();
+  }
+  void build_migrant_lists()
+  {
+    const size_t tiles = (npart + SCAN_TILE - 1) / SCAN_TILE;
+    size_t *cnt[2] = {&lft_count, &rgt_count};
+    for (int side = 0; side < 2; ++side) {
+      uint32_t tot = 0;
+      hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, npart, uint8_t(side + 1), tile_sums.p);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+      hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, npart, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
+      HIPCHK(hipMemcpyAsync(&tot, scan_total.p, sizeof tot, hipMemcpyDeviceToHost, st));
+      sync();
+      *cnt[side] = tot;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // initialisation (particles_init.ipp:16-131)
+  // ------------------------------------------------------------------------------------------
+  double eval_distro(const lcx_distro_t &d, double lnrd) const
+  {
+    if (d.fn) return d.fn(lnrd, d.user);
+    double res = 0;
+    for (int m = 0; m < d.n_modes; ++m)
+      res += d.n_stp[m] / std::sqrt(2 * M_PI) / std::log(d.sdev[m]) * std::exp(-std::pow((lnrd - std::log(d.mean_rd[m])), 2) / 2. / std::pow(std::log(d.sdev[m]), 2));
+    return res;
+  }
+  void init_dist_analysis_sd_conc(const lcx_distro_t &d, n_t sd_conc, T dv0)
+  {                                                                                      // init_dist_analysis.ipp:17-77
+    const T vol = n_dims == 0 ? dv0 : T(T(o.dx) * T(o.dy) * T(o.dz));
+    if (o.rd_min >= 0 && o.rd_max >= 0) {
+      const T rd_min = T(o.rd_min), rd_max = T(o.rd_max);
+      multiplier = T(std::log(rd_max / rd_min) / sd_conc * T(1) * vol);
+      log_rd_min = T(std::log(rd_min)); log_rd_max = T(std::log(rd_max));
+    } else if (o.rd_min < 0 && o.rd_max < 0) {
+      T rd_min = T(1e-14), rd_max = T(1e-3);                                             // config.hpp:23-24
+      bool found = false;
+      while (!found) {
+        multiplier = T(std::log(rd_max / rd_min) / sd_conc * T(1) * vol);
+        log_rd_min = T(std::log(rd_min)); log_rd_max = T(std::log(rd_max));
+        const n_t n_min = n_t(T(eval_distro(d, log_rd_min)) * T(multiplier)), n_max = n_t(T(eval_distro(d, log_rd_max)) * T(multiplier));
+        if (rd_min == T(1e-14) && n_min != 0) throw lcx_error("Initial dry radii distribution is non-zero (" + std::to_string(n_min) + ") for rd_min_init (1e-14)");
+        if (rd_max == T(1e-3) && n_max != 0) throw lcx_error("Initial dry radii distribution is non-zero (" + std::to_string(n_max) + ") for rd_max_init (0.001)");
+        if (n_min == 0) rd_min *= T(1.01); else if (n_max == 0) rd_max /= T(1.01); else found = true;
+      }
+    } else throw lcx_error("opts_init.rd_min * opts_init.rd_max < 0");
+  }
+  void init_SD_with_distros()
+  {
+    T dv0 = 0;
+    if (n_dims == 0) { HIPCHK(hipMemcpyAsync(&dv0, dv.p, sizeof(T), hipMemcpyDeviceToHost, st)); sync(); }
+    T tot_lnrd_rng = 0;
+    for (auto &d : distros) { init_dist_analysis_sd_conc(d, o.sd_conc, dv0); tot_lnrd_rng += T(log_rd_max - log_rd_min); }
+    for (auto &d : distros) {
+      init_dist_analysis_sd_conc(d, o.sd_conc, dv0);                                     // init_SD_with_distros_sd_conc.ipp:14-46
+      if (log_rd_min >= log_rd_max) throw lcx_error("Distribution analysis error: rd_min >= rd_max");
+      const T fraction = T(log_rd_max - log_rd_min) / tot_lnrd_rng;
+      multiplier = T(T(multiplier) * T(o.sd_conc / n_t(int(fraction * o.sd_conc + 0.5))));
+      const n_t per_cell = n_t(fraction * o.sd_conc);                                    // init_count_num.ipp:32-35
+      const size_t n_old = npart, n_new = size_t(per_cell) * ncell;
+      check_npart(n_old + n_new);
+      npart = n_old + n_new;
+      if (n_new == 0) continue;
+      const unsigned nb = nblk(n_new);
+      {
+        const u01_src<T> rs = rand_u01(n_new);
+        hipLaunchKernelGGL(k_init_dry<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, per_cell, T(log_rd_min), T(log_rd_max), rs, ijk.p, A.rd3.p, A.kpa.p, T(d.kappa), A.vt.p);
+      }
+      lognormal_modes lm{d.n_modes, {0}, {0}, {0}};
+      for (int m = 0; m < 4; ++m) { lm.mean_rd[m] = d.mean_rd[m]; lm.sdev[m] = d.sdev[m]; lm.n_stp[m] = d.n_stp[m]; }
+      const T *fv = nullptr;
+      if (d.fn) {                                                                        // host evaluation of the user functor (init_n.ipp:56-84)
+        std::vector<T> h(n_new);
+        HIPCHK(hipMemcpyAsync(h.data(), A.rd3.p + n_old, n_new * sizeof(T), hipMemcpyDeviceToHost, st));
+        sync();
+        for (size_t i = 0; i < n_new; ++i) { const T lnrd = T(std::log(h[i]) / 3.); h[i] = T(d.fn(lnrd, d.user)); }
+        fvals.alloc(n_new);
+        HIPCHK(hipMemcpyAsync(fvals.p, h.data(), n_new * sizeof(T), hipMemcpyHostToDevice, st));
+        sync();
+        fv = fvals.p;
+      }
+      hipLaunchKernelGGL(k_init_n<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, A.rd3.p, ijk.p, fv, lm, T(multiplier), rhod.p, dv.p,
+                         conc_factor_h.empty() ? (const T *)nullptr : conc_factor.p, m1(o.nz), o.aerosol_independent_of_rhod, n_dims,
+                         T(T(o.dx) * T(o.dy) * T(o.dz)), A.n.p);
+      hipLaunchKernelGGL(k_init_wet<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, A.rd3.p, A.kpa.p, ijk.p, RH.p, Tk.p, T(o.RH_max), A.rw2.p);
+      const int nn[3] = {o.nx, o.ny, o.nz};
+      const T a0[3] = {T(o.x0), T(o.y0), T(o.z0)}, b1[3] = {T(o.x1), T(o.y1), T(o.z1)}, dd[3] = {T(o.dx), T(o.dy), T(o.dz)};
+      T *pos[3] = {A.x.p, A.y.p, A.z.p};
+      for (int ix = 0; ix < 3; ++ix) {
+        if (!nn[ix]) continue;
+        const u01_src<T> rs = rand_u01(n_new);
+        hipLaunchKernelGGL(k_init_pos<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, ix, g, ijk.p, rs, a0[ix], b1[ix], dd[ix], pos[ix]);
+      }
+    }
+    release_replay_keep();
+  }
+  void init_kernel()
+  {                                                                                      // init_kernel.ipp:6-233
+    std::vector<double> params = kernel_parameters_h;
+    switch (o.kernel) {
+      case LCX_KERNEL_GEOMETRIC: if (n_user_params > 1) throw lcx_error("Not more than 1 parameter is required by the geometric kernel"); break;
+      case LCX_KERNEL_GOLOVIN: if (n_user_params != 1) throw lcx_error("Golovin kernel accepts exactly one parameter"); break;
+      case LCX_KERNEL_LONG: if (n_user_params != 0) throw lcx_error("Long kernel doesn't accept parameters"); break;
+      default:
+        if (n_user_params != 0) throw lcx_error("this kernel doesn't accept parameters");
+        if (!load_efficiency_table(o.kernel, params, kernel_r_max))
+          throw lcx_error("libcloudph++: kernel " + std::to_string(o.kernel) + " not available in this backend");
+    }
+    std::vector<T> h(params.begin(), params.end());
+    kparams.alloc(h.size());
+    if (!h.empty()) HIPCHK(hipMemcpy(kparams.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  }
+  void sanity_init(const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *p_,
+                   const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz)
+  {                                                                                      // init_sanity_check.ipp
+    if (init_called) throw lcx_error("libcloudph++: init() may be called just once");
+    init_called = true;
+    if (is_null(th_) || is_null(rv_) || is_null(rhod_)) throw lcx_error("libcloudph++: passing th, rv and rhod is mandatory");
+    courant_checks(cx, cy, cz);
+    if (distros.empty() && o.n_dry_sizes == 0) throw lcx_error("libcloudph++: Both dry_distros and dry_sizes are undefined");
+    if (n_dims > 0) {
+      if (!(o.x0 >= 0 && o.x0 < m1(o.nx) * o.dx)) throw lcx_error("libcloudph++: !(x0 >= 0 & x0 < min(1,nx)*dz)");
+      if (!(o.y0 >= 0 && o.y0 < m1(o.ny) * o.dy)) throw lcx_error("libcloudph++: !(y0 >= 0 & y0 < min(1,ny)*dy)");
+      if (!(o.z0 >= 0 && o.z0 < m1(o.nz) * o.dz)) throw lcx_error("libcloudph++: !(z0 >= 0 & z0 < min(1,nz)*dz)");
+      if (!(o.y1 > o.y0 && o.y1 <= m1(o.ny) * o.dy)) throw lcx_error("libcloudph++: !(y1 > y0 & y1 <= min(1,ny)*dy)");
+      if (!(o.z1 > o.z0 && o.z1 <= m1(o.nz) * o.dz)) throw lcx_error("libcloudph++: !(z1 > z0 & z1 <= min(1,nz)*dz)");
+    }
+    if (o.dt == 0) throw lcx_error("libcloudph++: please specify opts_init.dt");
+    if (o.sd_conc * o.sd_const_multi != 0) throw lcx_error("libcloudph++: specify either opts_init.sd_conc or opts_init.sd_const_multi, not both");
+    if (o.sd_conc == 0 && o.sd_const_multi == 0 && o.n_dry_sizes == 0) throw lcx_error("libcloudph++: please specify opts_init.sd_conc, opts_init.sd_const_multi or opts_init.dry_sizes");
+    if (o.coal_switch) {
+      if (o.terminal_velocity == LCX_VT_UNDEFINED) throw lcx_error("libcloudph++: please specify opts_init.terminal_velocity or turn off opts_init.coal_switch");
+      if (o.kernel == LCX_KERNEL_UNDEFINED) throw lcx_error("libcloudph++: please specify opts_init.kernel");
+    }
+    if (o.sedi_switch && o.terminal_velocity == LCX_VT_UNDEFINED) throw lcx_error("libcloudph++: please specify opts_init.terminal_velocity or turn off opts_init.sedi_switch");
+    if (o.sedi_switch && o.nz == 0) throw lcx_error("libcloudph++: opts_init.sedi_switch can be True only if n_dims > 1");
+    if (o.subs_switch && o.nz == 0) throw lcx_error("libcloudph++: opts_init.subs_switch can be True only if n_dims > 1");
+    if (o.subs_switch && o.nz != int(w_LS_h.size())) throw lcx_error("libcloudph++: opts_init.subs_switch == True, but subsidence velocity profile size != nz");
+    if (!conc_factor_h.empty() && n_dims < 2) throw lcx_error("libcloudph++: aerosol_conc_factor can only be used in 2D and 3D");
+    if (!conc_factor_h.empty() && o.nz != int(conc_factor_h.size())) throw lcx_error("libcloudph++: aerosol_conc_factor size needs to be either 0 or nz");
+    if (!conc_factor_h.empty() && !o.aerosol_independent_of_rhod) throw lcx_error("libcloudph++: aerosol_conc_factor can only be used if aerosol_independent_of_rhod==true");
+    if (o.const_p && is_null(p_)) throw lcx_error("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
+    if (!o.const_p && !is_null(p_)) throw lcx_error("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
+    if (o.sstp_cond < 1) throw lcx_error("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+    if (!o.sstp_cond_mix && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
+    if (o.n_dry_sizes > 0) throw lcx_error("libcloudph++: dry_sizes initialisation not supported by this backend yet");
+  }
+  void courant_checks(const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) const
+  {
+    if (!is_null(cx) || !is_null(cy) || !is_null(cz)) {
+      if (n_dims == 0) throw lcx_error("libcloudph++: Courant numbers passed in 0D setup");
+      if (n_dims == 1 && (is_null(cx) || !is_null(cy) || !is_null(cz))) throw lcx_error("libcloudph++: Only X Courant number allowed in 1D setup");
+      if (n_dims == 2 && (is_null(cx) || !is_null(cy) || is_null(cz))) throw lcx_error("libcloudph++: Only X and Z Courant numbers allowed in 2D setup");
+      if (n_dims == 3 && (is_null(cx) || is_null(cy) || is_null(cz))) throw lcx_error("libcloudph++: All XYZ Courant number components required in 3D setup");
+    }
+  }
+  void init(const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *p_,
+            const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) override
+  {
+    sanity_init(th_, rv_, rhod_, p_, cx, cy, cz);
+    switch (n_dims) {                                                                    // init_sync.ipp:28-44 (halo 0)
+      case 3: n_cx = size_t(o.nx + 1) * o.ny * o.nz; n_cy = size_t(o.nx) * (o.ny + 1) * o.nz; n_cz = size_t(o.nx) * o.ny * (o.nz + 1); break;
+      case 2: n_cx = size_t(o.nx + 1) * o.nz; n_cz = size_t(o.nx) * (o.nz + 1); break;
+      case 1: n_cx = size_t(o.nx) + 1; break;
+      default: break;
+    }
+    courant_x.alloc_zero(n_cx, st); courant_y.alloc_zero(n_cy, st); courant_z.alloc_zero(n_cz, st);
+    if (!w_LS_h.empty()) { std::vector<T> h(w_LS_h.begin(), w_LS_h.end()); w_LS.alloc(h.size()); HIPCHK(hipMemcpy(w_LS.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    if (!conc_factor_h.empty()) { std::vector<T> h(conc_factor_h.begin(), conc_factor_h.end()); conc_factor.alloc(h.size()); HIPCHK(hipMemcpy(conc_factor.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
+    sync_in_arr(p_, p, ncell, 0, 0, 0);
+    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1);
+    if (n_dims > 0)
+      hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
+                         T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
+    hskpng_Tpr();
+    if (!o.no_ccn_at_init && !distros.empty()) init_SD_with_distros();
+    if (o.coal_switch) init_kernel();
+    if (o.terminal_velocity == LCX_VT_BEARD77FAST) {
+      vt_0.alloc(size_t(vtc.n_bin));
+      hipLaunchKernelGGL(k_init_vt0<T>, dim3(nblk(size_t(vtc.n_bin))), dim3(BS), 0, st, vt_0.p, vtc);
+    }
+    hskpng_vterm(true);
+    sstp_save();
+    sorted = false;
+    hskpng_count();
+    sync();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // time stepping (particles_step.ipp)
+  // ------------------------------------------------------------------------------------------
+  void sync_in(const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *cx,
+               const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) override
+  {
+    if (!init_called) throw lcx_error("libcloudph++: please call init() before calling step_sync()");
+    if (should_now_run_async) throw lcx_error("libcloudph++: please call step_async() before calling step_sync() again");
+    if (is_null(th_) || is_null(rv_)) throw lcx_error("libcloudph++: passing th and rv is mandatory");
+    courant_checks(cx, cy, cz);
+    if (!is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
+    Range r(this, "sync_in");
+    var_rho = !is_null(rhod_);
+    sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
+    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1);
+    should_now_run_cond = true;
+  }
+  void step_cond(const lcx_opts_t &opts, const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_) override
+  {
+    if (!should_now_run_cond) throw lcx_error("libcloudph++: please call sync_in() before calling step_cond()");
+    if (opts.turb_cond) throw lcx_error("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+    should_now_run_cond = false;
+    adjust_timesteps(opts.dt);
+    if (opts.cond) {
+      hskpng_sort();
+      hskpng_mfp();
+      for (int step = 0; step < sstp_cond; ++step) {
+        sstp_percell_step(step);
+        hskpng_Tpr();
+        cond_substep(opts.RH_max, step);
+      }
+      sstp_save();
+      { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); }
+    }
+    sync();
+    should_now_run_async = true;
+    selected_before_counting = false;
+  }
+  void step_async(const lcx_opts_t &opts) override
+  {
+    if (!should_now_run_async) throw lcx_error("libcloudph++: please call step_sync() before calling step_async() again");
+    should_now_run_async = false;
+    if (opts.chem_dsl || opts.chem_dsc || opts.chem_rct) throw lcx_error("libcloudph++: all chemistry was switched off in opts_init");
+    if (opts.coal && !o.coal_switch) throw lcx_error("libcloudph++: coalescence was switched off in opts_init");
+    if (opts.sedi && !o.sedi_switch) throw lcx_error("libcloudph++: sedimentation was switched off in opts_init");
+    if (opts.subs && !o.subs_switch) throw lcx_error("libcloudph++: subsidence was switched off in opts_init");
+    if (opts.turb_adve) throw lcx_error("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+    if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
+    if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
+    adjust_timesteps(opts.dt);
+    hskpng_Tpr();
+    if (opts.sedi || opts.coal || opts.cond) hskpng_vterm(false);
+    if (opts.coal) {
+      for (int step = 0; step < sstp_coal; ++step) {
+        coal(dt / sstp_coal);
+        if (step + 1 != sstp_coal) hskpng_vterm(true);
+      }
+      if (pure_const_multi) {
+        int flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, d_flag.p, sizeof flag, hipMemcpyDeviceToHost, st)); sync();
+        if (flag) { ++sstp_coal; HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st)); }
+      }
+      release_replay_keep();
+    }
+    move(opts.adve, opts.sedi, opts.subs, true);
+    adve_scheme = o.adve_scheme;
+    if (!distmem()) post_copy(opts);
+    sync();
+    selected_before_counting = false;
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // diagnostics (particles_diag.ipp, moms.ipp, fill_outbuf.ipp)
+  // ------------------------------------------------------------------------------------------
+  void diag_cell(int which) override
+  {
+    hskpng_Tpr();
+    const T *src = which == 0 ? p.p : which == 1 ? Tk.p : RH.p;
+    HIPCHK(hipMemcpyAsync(count_mom.p, src, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
+    sync();
+  }
+  void need_nfiltered() { if (!n_filtered.p) n_filtered.alloc(cap); }
+  T *attr_ptr(int attr) { return attr == 0 ? A.rd3.p : attr == 1 ? A.rw2.p : attr == 2 ? A.kpa.p : A.vt.p; }
+  void diag_select(int mode, int cons, int attr, double a, double b) override
+  {
+    hskpng_sort();
+    need_nfiltered();
+    if (cons && !selected_before_counting) throw lcx_error("libcloudph++: consecutive selection without a previous selection");
+    if (npart)
+      hipLaunchKernelGGL(k_nfilt<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, mode, cons, A.n.p, attr_ptr(attr), T(a), T(b), n_filtered.p);
+    selected_before_counting = true;
+    sync();
+  }
+  void moms_sum(const T *vec, T power, int kind, bool specific)
+  {
+    if (!selected_before_counting) throw lcx_error("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
+    hskpng_sort();
+    if (npart)
+      hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, power, kind, m3_after.p);
+    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p,
+                       int(specific && n_dims > 0), count_mom.p);
+    sync();
+  }
+  void diag_sd_conc() override { moms_sum(A.rw2.p, T(0), 1, false); }
+  void diag_mom(int attr, double power) override { moms_sum(attr_ptr(attr), T(power), 0, true); }
+  void diag_precip_rate() override
+  {                                                                                      // particles_diag.ipp:529-547
+    throw lcx_error("libcloudph++: diag_precip_rate not supported by this backend yet");
+  }
+  void diag_max_rw() override
+  {
+    hskpng_sort();
+    hipLaunchKernelGGL(k_cell_max<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, A.rw2.p, count_mom.p);
+    sync();
+  }
+  void outbuf(const void **data, size_t *n) override
+  {
+    HIPCHK(hipMemcpyAsync(outbuf_h.data(), count_mom.p, ncell * sizeof(T), hipMemcpyDeviceToHost, st));
+    hskpng_count();                                                                      // particles_ctor.ipp:83-92
+    sync();
+    *data = outbuf_h.data(); *n = ncell;
+  }
+  void get_attr(const char *name, void *out, size_t capn, size_t *n) override
+  {
+    const std::string s(name);
+    const T *v = s == "rw2" ? A.rw2.p : s == "rd3" ? A.rd3.p : s == "kappa" ? A.kpa.p : s == "x" ? A.x.p : s == "y" ? A.y.p : s == "z" ? A.z.p : nullptr;
+    if (s != "rw2" && s != "rd3" && s != "kappa" && s != "x" && s != "y" && s != "z") throw lcx_error("Unknown attribute name passed to get_attr.");
+    *n = npart;
+    if (!out) return;
+    if (capn < npart) throw lcx_error("get_attr: buffer too small");
+    if (v && npart) { HIPCHK(hipMemcpyAsync(out, v, npart * sizeof(T), hipMemcpyDeviceToHost, st)); sync(); }
+    else if (npart) memset(out, 0, npart * sizeof(T));
+  }
+  void diag_puddle(double *out) override { for (int i = 0; i < LCX_OUT_COUNT; ++i) out[i] = puddle[i]; }
+  size_t n_part() override { return npart; }
+  size_t n_cell() override { return ncell; }
+
+  // ------------------------------------------------------------------------------------------
+  // introspection hooks
+  // ------------------------------------------------------------------------------------------
+  template <class S> std::vector<S> d2h(const S *p_, size_t n) { std::vector<S> h(n); if (n) { HIPCHK(hipMemcpyAsync(h.data(), p_, n * sizeof(S), hipMemcpyDeviceToHost, st)); sync(); } return h; }
+  void get_state_u64(const char *name, unsigned long long *out, size_t capn, size_t *n) override
+  {
+    const std::string s(name);
+    std::vector<unsigned long long> v;
+    if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "sorted_id") { hskpng_sort(); auto h = d2h(sorted_id.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "sorted_ijk") { hskpng_sort(); auto h = d2h(sorted_ijk.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "cell_start") { hskpng_sort(); auto h = d2h(cell_start.p, ncell + 1); v.assign(h.begin(), h.end()); }
+    else if (s == "count_ijk" || s == "count_num") {
+      hskpng_sort();
+      auto h = d2h(cell_start.p, ncell + 1);
+      for (size_t c = 0; c < ncell; ++c) if (h[c + 1] > h[c]) v.push_back(s == "count_ijk" ? c : (unsigned long long)(h[c + 1] - h[c]));
+    } else throw lcx_error("unknown u64 state '" + s + "'");
+    *n = v.size();
+    if (!out) return;
+    if (capn < v.size()) throw lcx_error("buffer too small");
+    std::copy(v.begin(), v.end(), out);
+  }
+  void get_state_real(const char *name, double *out, size_t capn, size_t *n) override
+  {
+    const std::string s(name);
+    struct E { const char *nm; const T *p; size_t len; };
+    const E tab[] = {{"vt", A.vt.p, npart}, {"T", Tk.p, ncell}, {"p", p.p, ncell}, {"RH", RH.p, ncell}, {"eta", eta.p, ncell}, {"th", th.p, ncell},
+      {"rv", rv.p, ncell}, {"rhod", rhod.p, ncell}, {"dv", dv.p, ncell}, {"lambda_D", lambda_D.p, ncell}, {"lambda_K", lambda_K.p, ncell},
+      {"courant_x", courant_x.p, n_cx}, {"courant_y", courant_y.p, n_cy}, {"courant_z", courant_z.p, n_cz},
+      {"vt_0", vt_0.p, vt_0.p ? size_t(vtc.n_bin) : 0}, {"count_mom", count_mom.p, ncell}, {"col", col.p, col.p ? npart : 0},
+      {"rw2", A.rw2.p, npart}, {"rd3", A.rd3.p, npart}, {"kappa", A.kpa.p, npart},
+      {"x", A.x.p, A.x.p ? npart : 0}, {"y", A.y.p, A.y.p ? npart : 0}, {"z", A.z.p, A.z.p ? npart : 0}};
+    for (const E &e : tab)
+      if (s == e.nm) {
+        *n = e.len;
+        if (!out) return;
+        if (capn < e.len) throw lcx_error("buffer too small");
+        auto h = d2h(e.p, e.len);
+        for (size_t i = 0; i < e.len; ++i) out[i] = double(h[i]);
+        return;
+      }
+    throw lcx_error("unknown real state '" + s + "'");
+  }
+  void set_particles(size_t n, const unsigned long long *mult, const double *rd3_, const double *rw2_, const double *kpa_, const double *vt_,
+                     const double *x_, const double *y_, const double *z_) override
+  {
+    check_npart(n);
+    npart = n;
+    auto up = [&](DevBuf<T> &b, const double *src) {
+      if (!src || !b.p || !n) return;
+      std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(src[i]);
+      HIPCHK(hipMemcpy(b.p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+    };
+    if (n) HIPCHK(hipMemcpy(A.n.p, mult, n * sizeof(n_t), hipMemcpyHostToDevice));
+    up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
+    hskpng_ijk();
+    hskpng_count();
+    sync();
+  }
+  void stage(const char *name, const lcx_opts_t *opts) override
+  {
+    const std::string s(name);
+    if (s == "hskpng_Tpr") hskpng_Tpr();
+    else if (s == "hskpng_mfp") hskpng_mfp();
+    else if (s == "hskpng_ijk") hskpng_ijk();
+    else if (s == "hskpng_sort") hskpng_sort();
+    else if (s == "hskpng_shuffle_and_sort") hskpng_sort_helper(true);
+    else if (s == "hskpng_count") hskpng_count();
+    else if (s == "hskpng_vterm_all") hskpng_vterm(false);
+    else if (s == "hskpng_vterm_invalid") hskpng_vterm(true);
+    else if (s == "coal") { adjust_timesteps(opts ? opts->dt : -1); coal(dt / sstp_coal); }
+    else if (s == "adve") move(true, false, false, false);
+    else if (s == "sedi") { adjust_timesteps(opts ? opts->dt : -1); move(false, true, false, false); }
+    else if (s == "bcnd") move(false, false, false, true);
+    else if (s == "post_copy") { lcx_opts_t od; lcx_opts_default(&od); post_copy(opts ? *opts : od); }
+    else throw lcx_error("unknown stage '" + s + "'");
+    sync();
+    release_replay_keep();
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // 1-D decomposition primitives
+  // ------------------------------------------------------------------------------------------
+  void migrate_counts(size_t *l, size_t *r) override { *l = lft_count; *r = rgt_count; }
+  size_t migrate_record_bytes() override { return sizeof(n_t) + sizeof(T) * (4 + size_t(n_dims)); }
+  void migrate_pack(int side, double x_rmt, void *buf, size_t capb) override
+  {
+    const size_t cnt = side == 0 ? lft_count : rgt_count;
+    if (capb < cnt * migrate_record_bytes()) throw lcx_error("migrate_pack: buffer too small");
+    if (!cnt) return;
+    Range r(this, "migrate_pack");
+    n_t *nb = (n_t *)buf; T *rb = (T *)((n_t *)buf + cnt);
+    hipLaunchKernelGGL(k_pack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, mig_ids[side].p, aset(A), g, T(x_rmt), T(side == 0 ? o.x0 : o.x1), nb, rb);
+    sync();
+  }
+  void migrate_unpack(const void *buf, size_t cnt) override
+  {
+    if (!cnt) return;
+    check_npart(npart + cnt);
+    Range r(this, "migrate_unpack");
+    const n_t *nb = (const n_t *)buf; const T *rb = (const T *)((const n_t *)buf + cnt);
+    hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, npart, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4));
+    npart += cnt;
+    sync();
+  }
+  void migrate_finish(const lcx_opts_t &opts) override
+  {
+    if (lft_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(lft_count)), dim3(BS), 0, st, lft_count, mig_ids[0].p, A.n.p);
+    if (rgt_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(rgt_count)), dim3(BS), 0, st, rgt_count, mig_ids[1].p, A.n.p);
+    lft_count = rgt_count = 0;
+    post_copy(opts);
+    sync();
+  }
+};
+
+} // namespace lcx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using lcx::IParticles;
+static thread_local std::string g_err;
+struct lcx_particles { std::unique_ptr<IParticles> impl; };
+
+#define LCX_TRY(body) try { body; return 0; } catch (const std::exception &e) { g_err = e.what(); return 1; } catch (...) { g_err = "libcloudph++: unknown error"; return 1; }
+#define H (h->impl)
+
+extern "C" {
+
+const char *lcx_last_error(void) { return g_err.c_str(); }
+const char *lcx_version(void) { return "libcloudphxx_amd 0.1 (HIP gfx950)"; }
+
+void lcx_opts_init_default(lcx_opts_init_t *o)
+{
+  memset(o, 0, sizeof *o);
+  o->dx = o->dy = o->dz = 1; o->x1 = o->y1 = o->z1 = 1;
+  o->sstp_cond = o->sstp_coal = o->sstp_chem = o->sstp_cond_act = 1;
+  o->sedi_switch = 1; o->coal_switch = 1; o->sstp_cond_mix = 1;
+  o->RH_max = .95; o->rng_seed = 44; o->rng_seed_init = 44;
+  o->adve_scheme = LCX_ADVE_IMPLICIT; o->RH_formula = LCX_RH_PV_CC;
+  o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 1;
+}
+void lcx_opts_default(lcx_opts_t *o)
+{
+  memset(o, 0, sizeof *o);
+  o->adve = o->sedi = o->cond = o->coal = 1; o->RH_max = 44; o->dt = -1;
+}
+int lcx_create(const lcx_opts_init_t *oi, int real_kind, lcx_particles **out)
+{
+  LCX_TRY({
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      throw std::runtime_error("libcloudph++: no HIP device available (this backend has no CPU fallback)");
+    std::unique_ptr<lcx_particles> h(new lcx_particles);
+    if (real_kind == 8) h->impl.reset(new lcx::Particles<double>(*oi));
+    else if (real_kind == 4) h->impl.reset(new lcx::Particles<float>(*oi));
+    else throw std::runtime_error("libcloudph++: real_kind must be 4 (float) or 8 (double)");
+    *out = h.release();
+  })
+}
+void lcx_destroy(lcx_particles *h) { delete h; }
+int lcx_init(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *p,
+             const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) { LCX_TRY(H->init(th, rv, rhod, p, cx, cy, cz)) }
+int lcx_sync_in(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,
+                const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) { LCX_TRY(H->sync_in(th, rv, rhod, cx, cy, cz, diss)) }
+int lcx_step_cond(lcx_particles *h, const lcx_opts_t *o, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv) { LCX_TRY(H->step_cond(*o, th, rv)) }
+int lcx_step_sync(lcx_particles *h, const lcx_opts_t *o, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
+                  const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss)
+{ LCX_TRY({ H->sync_in(th, rv, rhod, cx, cy, cz, diss); H->step_cond(*o, th, rv); }) }
+int lcx_step_async(lcx_particles *h, const lcx_opts_t *o) { LCX_TRY(H->step_async(*o)) }
+int lcx_diag_sd_conc(lcx_particles *h) { LCX_TRY(H->diag_sd_conc()) }
+int lcx_diag_pressure(lcx_particles *h) { LCX_TRY(H->diag_cell(0)) }
+int lcx_diag_temperature(lcx_particles *h) { LCX_TRY(H->diag_cell(1)) }
+int lcx_diag_RH(lcx_particles *h) { LCX_TRY(H->diag_cell(2)) }
+int lcx_diag_all(lcx_particles *h) { LCX_TRY(H->diag_select(0, 0, 1, 0, 0)) }
+int lcx_diag_water(lcx_particles *h) { LCX_TRY(H->diag_select(2, 0, 1, 0, 0)) }
+int lcx_diag_dry_rng(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 0, 0, std::pow(a, 3), std::pow(b, 3))) }
+int lcx_diag_wet_rng(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 0, 1, std::pow(a, 2), std::pow(b, 2))) }
+int lcx_diag_kappa_rng(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 0, 2, a, b)) }
+int lcx_diag_dry_rng_cons(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 1, 0, std::pow(a, 3), std::pow(b, 3))) }
+int lcx_diag_wet_rng_cons(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 1, 1, std::pow(a, 2), std::pow(b, 2))) }
+int lcx_diag_kappa_rng_cons(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 1, 2, a, b)) }
+int lcx_diag_dry_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(0, k / 3.)) }
+int lcx_diag_wet_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(1, k / 2.)) }
+int lcx_diag_kappa_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(2, k)) }
+int lcx_diag_precip_rate(lcx_particles *h) { LCX_TRY(H->diag_precip_rate()) }
+int lcx_diag_max_rw(lcx_particles *h) { LCX_TRY(H->diag_max_rw()) }
+int lcx_outbuf(lcx_particles *h, const void **data, size_t *n) { LCX_TRY(H->outbuf(data, n)) }
+int lcx_get_attr(lcx_particles *h, const char *name, void *out, size_t cap, size_t *n) { LCX_TRY(H->get_attr(name, out, cap, n)) }
+int lcx_diag_puddle(lcx_particles *h, double *out) { LCX_TRY(H->diag_puddle(out)) }
+int lcx_n_part(lcx_particles *h, size_t *n) { LCX_TRY(*n = H->n_part()) }
+int lcx_n_cell(lcx_particles *h, size_t *n) { LCX_TRY(*n = H->n_cell()) }
+int lcx_real_kind(lcx_particles *h, int *k) { LCX_TRY(*k = H->real_kind()) }
+int lcx_get_state_u64(lcx_particles *h, const char *name, unsigned long long *out, size_t cap, size_t *n) { LCX_TRY(H->get_state_u64(name, out, cap, n)) }
+int lcx_get_state_real(lcx_particles *h, const char *name, double *out, size_t cap, size_t *n) { LCX_TRY(H->get_state_real(name, out, cap, n)) }
+int lcx_set_particles(lcx_particles *h, size_t n, const unsigned long long *mult, const double *rd3, const double *rw2, const double *kpa,
+                      const double *vt, const double *x, const double *y, const double *z) { LCX_TRY(H->set_particles(n, mult, rd3, rw2, kpa, vt, x, y, z)) }
+int lcx_rng_replay_push(lcx_particles *h, int kind, const double *data, size_t n) { LCX_TRY(H->rng_replay_push(kind, data, n)) }
+int lcx_rng_replay_pending(lcx_particles *h, size_t *n) { LCX_TRY(*n = H->rng_replay_pending()) }
+int lcx_stage(lcx_particles *h, const char *stage, const lcx_opts_t *o) { LCX_TRY(H->stage(stage, o)) }
+int lcx_timings(lcx_particles *h, const char **names, double *ms, size_t cap, size_t *n) { LCX_TRY(H->timings(names, ms, cap, n)) }
+int lcx_set_profiling(lcx_particles *h, int on) { LCX_TRY(H->set_profiling(on)) }
+int lcx_migrate_counts(lcx_particles *h, size_t *l, size_t *r) { LCX_TRY(H->migrate_counts(l, r)) }
+size_t lcx_migrate_record_bytes(lcx_particles *h) { return H->migrate_record_bytes(); }
+int lcx_migrate_pack(lcx_particles *h, int side, double x_rmt, void *buf, size_t cap) { LCX_TRY(H->migrate_pack(side, x_rmt, buf, cap)) }
+int lcx_migrate_unpack(lcx_particles *h, const void *buf, size_t count) { LCX_TRY(H->migrate_unpack(buf, count)) }
+int lcx_migrate_finish(lcx_particles *h, const lcx_opts_t *o) { LCX_TRY(H->migrate_finish(*o)) }
+int lcx_dev_alloc(void **ptr, size_t bytes) { LCX_TRY({ if (hipMalloc(ptr, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed"); }) }
+int lcx_dev_free(void *ptr) { LCX_TRY({ if (hipFree(ptr) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipFree failed"); }) }
+int lcx_dev_copy(void *dst, const void *src, size_t bytes, int kind)
+{
+  LCX_TRY({
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (hipMemcpy(dst, src, bytes, k) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMemcpy failed");
+  })
+}
+int lcx_dev_sync(void) { LCX_TRY({ if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): device synchronize failed"); }) }
+
+} // extern "C"

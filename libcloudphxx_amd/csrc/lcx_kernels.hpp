@@ -1,0 +1,833 @@
+// lcx_kernels.hpp -- hand-written HIP kernels of the lgrngn hot path for gfx950 (CDNA4, wave64).
+//
+// Data layout in HBM: structure of arrays, one contiguous array per super-droplet attribute
+//   n (u64), rd3, rw2, kpa, vt, x, y, z (real_t)   -- storage order == the reference's storage order
+//   ijk, sorted_id, sorted_ijk (u32)               -- housekeeping (u32: n_cell, n_part < 2^32)
+//   cell_start (u32, n_cell+1)                     -- CSR offsets of the cell-sorted order
+// Every streaming kernel is launched dense over its index space (lane i <-> element i) so that the
+// 64 lanes of a wave touch 64 consecutive elements (512 B of fp64) per load; kernels that walk the
+// cell-sorted order read the gather index coalesced and the cell fields as wave-wide broadcasts.
+// No MFMA anywhere: there is no dense contraction on this path; the roofline is HBM (and fp64 VALU
+// for the condensation root finder).
+#pragma once
+#include "lcx_math.hpp"
+
+namespace lcx {
+
+constexpr int BS = 256;                 // 4 waves per workgroup
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ size_t gid() { return size_t(blockIdx.x) * blockDim.x + threadIdx.x; }
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ unsigned wave_id() { return threadIdx.x / WAVE; }
+
+// ============================================================================================
+// generic helpers
+// ============================================================================================
+template <class T> __global__ void k_fill(T *a, size_t n, T v) { size_t i = gid(); if (i < n) a[i] = v; }
+__global__ void k_iota(uint32_t *a, size_t n) { size_t i = gid(); if (i < n) a[i] = uint32_t(i); }
+template <class D, class S> __global__ void k_convert(D *d, const S *s, size_t n) { size_t i = gid(); if (i < n) d[i] = D(s[i]); }
+
+// strided host-layout array -> contiguous library layout (particles_impl_sync.ipp:15-68, init_e2l.ipp:34-114)
+// ext: extents (n0,n1,n2) of the device-layout field (z fastest), st: element strides of the source,
+// i_off: index offset in the first dimension (x-planes owned by ranks to the left)
+template <class T>
+__global__ void k_gather_strided(T *dst, const T *src, size_t n, int ndims, int n1, int n2, long s0, long s1, long s2, long i_off)
+{
+  size_t c = gid(); if (c >= n) return;
+  long off;
+  if (ndims == 0) off = 0;
+  else if (ndims == 1) off = (long(c) + i_off) * s0;
+  else if (ndims == 2) off = (long(c / n2) + i_off) * s0 + long(c % n2) * s1;
+  else off = (long(c / (size_t(n2) * n1)) + i_off) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2;
+  dst[c] = src[off];
+}
+template <class T>
+__global__ void k_scatter_strided(T *dst, const T *src, size_t n, int ndims, int n1, int n2, long s0, long s1, long s2, long i_off)
+{
+  size_t c = gid(); if (c >= n) return;
+  long off;
+  if (ndims == 0) off = 0;
+  else if (ndims == 1) off = (long(c) + i_off) * s0;
+  else if (ndims == 2) off = (long(c / n2) + i_off) * s0 + long(c % n2) * s1;
+  else off = (long(c / (size_t(n2) * n1)) + i_off) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2;
+  dst[off] = src[c];
+}
+
+// ---- exclusive scan of u32 (three launches: per-tile scan, scan of tile sums, add) ----
+constexpr int SCAN_TILE = 2048;         // 256 threads x 8 items, items interleaved for coalescing
+
+// block-wide exclusive prefix of one value per thread (wave shuffles + LDS across the 4 waves)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &total, uint32_t *lds /*>=5*/)
+{
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) { uint32_t t = __shfl_up(inc, d); if (lane_id() >= unsigned(d)) inc += t; }
+  if (lane_id() == WAVE - 1) lds[wave_id()] = inc;
+  __syncthreads();
+  uint32_t woff = 0, tot = 0;
+  for (unsigned w = 0; w < blockDim.x / WAVE; ++w) { uint32_t s = lds[w]; if (w < wave_id()) woff += s; tot += s; }
+  __syncthreads();
+  total = tot;
+  return woff + inc - v;
+}
+__global__ void k_scan_tiles(const uint32_t *in, uint32_t *out, uint32_t *tile_sums, size_t n)
+{
+  __shared__ uint32_t lds[8];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t run = 0;
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan(v, tot, lds);
+    if (i < n) out[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = run;
+}
+// single workgroup: in-place exclusive scan of the tile sums; writes the grand total to *total
+__global__ void k_scan_sums(uint32_t *sums, size_t m, uint32_t *total)
+{
+  __shared__ uint32_t lds[8];
+  uint32_t run = 0;
+  for (size_t base = 0; base < m; base += blockDim.x) {
+    const size_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? sums[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan(v, tot, lds);
+    if (i < m) sums[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) *total = run;
+}
+__global__ void k_scan_add(uint32_t *out, const uint32_t *tile_offs, size_t n, const uint32_t *total, uint32_t *out_last)
+{
+  const size_t i = gid();
+  if (i < n) out[i] += tile_offs[i / SCAN_TILE];
+  if (i == 0 && out_last) *out_last = *total;        // out[n] = total (CSR end)
+}
+
+// ============================================================================================
+// cell kernels (n_cell threads)
+// ============================================================================================
+// hskpng_Tpr.ipp:219-305
+template <class T>
+__global__ void k_cell_Tpr(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv,
+                           int th_dry, int const_p, int RH_formula, int ndims)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const T t = th_dry ? theta_dry_T(th[c], rhod[c]) : T(th[c] * exner(p[c]));
+  Tk[c] = t;
+  T pp = p[c];
+  if (!const_p) { pp = theta_dry_p(rhod[c], rv[c], t); p[c] = pp; }
+  RH[c] = RH_of(RH_formula, pp, rv[c], t);
+  eta[c] = visc(t);
+  if (ndims == 0) dv[c] = T(1) / rhod[c];
+}
+// hskpng_mfp.ipp:42-51
+template <class T>
+__global__ void k_cell_mfp(size_t n_cell, const T *Tk, const T *p, T *lambda_D, T *lambda_K)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  lambda_D[c] = lambda_D_of(Tk[c]);
+  lambda_K[c] = lambda_K_of(Tk[c], p[c]);
+}
+// sstp_percell_step.ipp:7-48 for one field
+template <class T>
+__global__ void k_sstp_step(size_t n_cell, int step, T sstp, T *scl, T *tmp)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  if (step == 0) {
+    const T d = scl[c] - tmp[c];
+    tmp[c] = d;
+    scl[c] = scl[c] - (sstp - 1) * d / sstp;
+  } else scl[c] = scl[c] + tmp[c] / sstp;
+}
+// init_grid.ipp:14-54
+template <class T>
+__global__ void k_init_dv(size_t n_cell, T *dv, int ny, int nz, T dx, T dy, T dz, T x0, T y0, T z0, T x1, T y1, T z1)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const int ijk = int(c);
+  const int i = (ijk / nz) / ny, j = (ijk / nz) % ny, k = ijk % nz;
+  dv[c] = mx(T(0), (mn(T((i + 1) * dx), x1) - mx(T(i * dx), x0)) *
+                   (mn(T((j + 1) * dy), y1) - mx(T(j * dy), y0)) *
+                   (mn(T((k + 1) * dz), z1) - mx(T(k * dz), z0)));
+}
+
+// ============================================================================================
+// housekeeping: cell index, sort
+// ============================================================================================
+struct grid_t { int nx, ny, nz, ndims; double dx, dy, dz; };
+
+// hskpng_ijk.ipp:159-200,33-82: size_t(double(x)/double(dx)), z fastest
+template <class T>
+__device__ __forceinline__ uint32_t cell_of(const grid_t &g, T x, T y, T z)
+{
+  const size_t i = g.nx ? size_t(double(x) / g.dx) : 0, j = g.ny ? size_t(double(y) / g.dy) : 0, k = g.nz ? size_t(double(z) / g.dz) : 0;
+  switch (g.ndims) {
+    case 0: return 0u;
+    case 1: return uint32_t(i);
+    case 2: return uint32_t(i * g.nz + k);
+    default: return uint32_t(i * (size_t(g.nz) * g.ny) + j * g.nz + k);
+  }
+}
+// ijk + histogram with per-SD arrival rank (rank order is arbitrary; the per-cell sort below makes
+// the final order deterministic and equal to the stable sort of the reference)
+template <class T>
+__global__ void k_ijk_hist(size_t n, grid_t g, const T *x, const T *y, const T *z, uint32_t *ijk, uint32_t *cnt, uint32_t *rank, int do_ijk)
+{
+  const size_t i = gid(); if (i >= n) return;
+  uint32_t c;
+  if (do_ijk) { c = cell_of(g, g.nx ? x[i] : T(0), g.ny ? y[i] : T(0), g.nz ? z[i] : T(0)); ijk[i] = c; }
+  else c = ijk[i];
+  if (cnt) rank[i] = atomicAdd(&cnt[c], 1u);
+}
+__global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
+                                 uint32_t *sorted_id, uint32_t *sorted_ijk)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const uint32_t c = ijk[i];
+  const uint32_t pos = cell_start[c] + rank[i];
+  sorted_id[pos] = uint32_t(i);
+  sorted_ijk[pos] = c;
+}
+
+// Per-cell ordering.  Reference semantics (hskpng_sort.ipp:15-57): sorted_id = stable_sort_by_key(ijk) of the
+// sequence 0..n-1  => inside a cell ids ascend; shuffled variant: first stable sort by the random key un[id],
+// then stable sort by cell => inside a cell (un[id], id) ascends.  Each wave owns one cell segment staged in
+// LDS and ranks every element by counting smaller keys (keys are unique): O(count^2/64) LDS broadcast reads
+// per lane, no data-dependent branching, no inter-wave traffic.
+constexpr int CELLSORT_MAX = 1024;      // largest segment handled in LDS by one wave (8 KiB of u64 keys)
+struct rng_src { const uint32_t *un; uint64_t call, seed; };
+
+__device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng_src &r)
+{
+  if (!shuffle) return id;
+  const uint32_t u = r.un ? r.un[id] : philox::un(id, r.call, r.seed);
+  return (uint64_t(u) << 32) | id;
+}
+__global__ void __launch_bounds__(BS)
+k_cellsort(size_t n_cell, const uint32_t *cell_start, uint32_t *sorted_id, int shuffle, rng_src r,
+           uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+{
+  __shared__ uint64_t keys[BS / WAVE][CELLSORT_MAX];
+  const unsigned w = wave_id(), l = lane_id(), wpb = BS / WAVE;
+  const size_t waves_total = size_t(gridDim.x) * wpb;
+  const size_t iters = (n_cell + waves_total - 1) / waves_total;      // uniform trip count: barriers are legal
+  for (size_t it = 0; it < iters; ++it) {
+    const size_t c = it * waves_total + size_t(blockIdx.x) * wpb + w;
+    uint32_t start = 0, cnt = 0;
+    if (c < n_cell) { start = cell_start[c]; cnt = cell_start[c + 1] - start; }
+    if (cnt > CELLSORT_MAX) {
+      if (l == 0) { const uint32_t k = atomicAdd(big_count, 1u); big_list[k] = uint32_t(c); atomicMax(big_max, cnt); }
+      cnt = 0;
+    }
+    const bool active = cnt > 1;
+    if (active) for (uint32_t j = l; j < cnt; j += WAVE) keys[w][j] = sort_key(sorted_id[start + j], shuffle, r);
+    __syncthreads();
+    if (active)
+      for (uint32_t m = l; m < cnt; m += WAVE) {
+        const uint64_t mine = keys[w][m];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < cnt; ++j) rank += keys[w][j] < mine;
+        sorted_id[start + rank] = uint32_t(mine);
+      }
+    __syncthreads();
+  }
+}
+// segments larger than CELLSORT_MAX (e.g. a 0-D parcel): one workgroup per segment, bitonic network on a
+// power-of-two padded scratch copy in global memory
+__global__ void __launch_bounds__(1024)
+k_cellsort_big(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, int shuffle, rng_src r,
+               uint64_t *scratch, size_t scratch_stride)
+{
+  uint64_t *a = scratch + size_t(blockIdx.x) * scratch_stride;
+  for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+    const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
+    size_t P = 1; while (P < cnt) P <<= 1;
+    for (size_t i = threadIdx.x; i < P; i += blockDim.x) a[i] = i < cnt ? sort_key(sorted_id[start + i], shuffle, r) : ~0ull;
+    __syncthreads();
+    for (size_t k = 2; k <= P; k <<= 1)
+      for (size_t j = k >> 1; j > 0; j >>= 1) {
+        for (size_t i = threadIdx.x; i < P; i += blockDim.x) {
+          const size_t p = i ^ j;
+          if (p > i) {
+            const uint64_t u = a[i], v = a[p];
+            const bool up = (i & k) == 0;
+            if ((u > v) == up) { a[i] = v; a[p] = u; }
+          }
+        }
+        __syncthreads();
+      }
+    for (size_t i = threadIdx.x; i < cnt; i += blockDim.x) sorted_id[start + i] = uint32_t(a[i]);
+    __syncthreads();
+  }
+}
+
+// ============================================================================================
+// terminal velocity (hskpng_vterm.ipp:15-342, init_vterm.ipp:36-59)
+// ============================================================================================
+struct vt_cfg { int formula; double ln_r_min, ln_r_max; int n_bin; };
+
+template <class T>
+__global__ void k_init_vt0(T *vt_0, vt_cfg v)
+{
+  const size_t it = gid(); if (it >= size_t(v.n_bin)) return;
+  const T lnmin = T(v.ln_r_min), dlnr = (T(v.ln_r_max) - T(v.ln_r_min)) / v.n_bin;
+  const T r = exp(lnmin + (int(it) + 0.5) * dlnr);         // bin_mid: exp(real + double*real) as in the reference
+  vt_0[it] = T(vt_beard77_v0(double(r)));
+}
+template <class T>
+__device__ __forceinline__ T vt_eval(const vt_cfg &v, T rw2, T Tk, T p, T rhod, T eta, const T *vt_0)
+{
+  const T r = sqrt(rw2);
+  switch (v.formula) {
+    case LCX_VT_BEARD76: return vt_beard76(r, Tk, p, rhod, eta);
+    case LCX_VT_BEARD77: return vt_beard77_fact(r, p, rhod, eta) * T(vt_beard77_v0(double(r)));
+    case LCX_VT_BEARD77FAST: {
+      const T lnmin = T(v.ln_r_min), lnmax = T(v.ln_r_max), dlnr = (lnmax - lnmin) / v.n_bin;
+      const T lnr = .5 * log(rw2);
+      const int bin = lnr <= lnmin ? 0 : lnr >= lnmax ? v.n_bin - 1 : int((lnr - lnmin) / dlnr);
+      return vt_beard77_fact(r, p, rhod, eta) * vt_0[bin];
+    }
+    case LCX_VT_KHVOROSTYANOV_SPHERICAL: return T(vt_khvorostyanov(double(r), double(rhod), double(eta), true));
+    case LCX_VT_KHVOROSTYANOV_NONSPHERICAL: return T(vt_khvorostyanov(double(r), double(rhod), double(eta), false));
+    default: return T(0);
+  }
+}
+template <class T>
+__global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const T *Tk, const T *p,
+                        const T *rhod, const T *eta, const T *vt_0, T *vt)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const T r2 = rw2[i];
+  if (!(r2 > T(0))) return;
+  if (only_invalid && !(vt[i] == T(-1))) return;
+  const uint32_t c = ijk[i];
+  vt[i] = vt_eval(v, r2, Tk[c], p[c], rhod[c], eta[c], vt_0);
+}
+
+// ============================================================================================
+// condensation (percell/particles_impl_cond.ipp:13-139 + moms.ipp:277-350 + update_th_rv.ipp:74-191)
+// ============================================================================================
+// One lane per position of the cell-sorted order.  Reads: sorted_id, sorted_ijk (coalesced), the SD's
+// rw2, rd3, kpa, vt, n (gathers, near-coalesced while storage order ~ cell order), 8 cell fields
+// (wave broadcast).  Writes rw2 and the SD's contribution(s) to the 3rd wet moment into position-ordered
+// scratch (coalesced) for the order-preserving per-cell sum of k_cond_cellfinish.
+template <class T>
+struct cond_args {
+  const uint32_t *sorted_id, *sorted_ijk;
+  const n_t *n; const T *rd3, *kpa, *vt; T *rw2;
+  const T *rhod, *rv, *Tk, *eta, *RH, *lambda_D, *lambda_K;
+  T *m3_before, *m3_after;
+  T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first;
+};
+template <class T>
+__global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  const T rw2_old = a.rw2[id];
+  const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
+  if (a.first) a.m3_before[pos] = nn * (rw2_old >= 0 ? rw2_old * T(sqrt(rw2_old)) : T(0));
+  const T rw2_new = advance_rw2(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
+                                a.lambda_D[c], a.lambda_K[c], a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
+  a.rw2[id] = rw2_new;
+  a.m3_after[pos] = nn * (rw2_new >= 0 ? rw2_new * T(sqrt(rw2_new)) : T(0));
+}
+// One lane per cell: sums the cell's contributions IN SORTED ORDER (same addition order as the reference's
+// serial reduce_by_key), converts to the specific moment and applies the condensational feedback.
+template <class T>
+__global__ void k_cond_cellfinish(size_t n_cell, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
+                                  const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3,
+                                  int step, int sstp, int ndims)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  const bool has = e > s;
+  T after = 0, drw;
+  if (has) {
+    after = m3_after[s];
+    for (uint32_t q = s + 1; q < e; ++q) after = after + m3_after[q];
+    if (ndims > 0) { after = after / dv[c]; after = after / rhod[c]; }
+  }
+  if (step == 0) {
+    drw = 0;
+    if (has) {
+      T before = m3_before[s];
+      for (uint32_t q = s + 1; q < e; ++q) before = before + m3_before[q];
+      if (ndims > 0) { before = before / dv[c]; before = before / rhod[c]; }
+      drw = -before;
+    }
+    if (!has) rw_mom3[c] = 0;
+  } else drw = -rw_mom3[c];
+  if (step < sstp - 1) {
+    if (has) rw_mom3[c] = after;
+    drw = rw_mom3[c] + drw;
+  } else if (has) drw = after + drw;
+  // update_th_rv
+  drw = drw * (cst<T>::rho_w * T(4. / 3) * cst<T>::pi);
+  rv[c] = rv[c] - drw;
+  th[c] = th[c] - drw * d_th_d_rv(Tk[c], th[c]);
+}
+
+// ============================================================================================
+// coalescence (particles_impl_coal.ipp:99-546, src/detail/kernels.hpp:38-202, kernel_interpolation.hpp:9-65)
+// ============================================================================================
+template <class T> struct coal_kernel_cfg { int kernel; int n_user_params; T r_max; const T *params; };
+
+__device__ __forceinline__ int kernel_index(n_t R) { return R <= 100. ? int(R) : int(100 + (R - 100.) / 10.); }
+__device__ __forceinline__ size_t kernel_vector_index(int i, int j, n_t nup)
+{
+  return i >= j ? size_t(0.5 * i * (i + 1) + j + nup) : size_t(0.5 * j * (j + 1) + i + nup);
+}
+template <class T>
+__device__ __forceinline__ T interpolated_efficiency(const coal_kernel_cfg<T> &k, T r1, T r2)
+{
+  r1 *= 1e6; r2 *= 1e6;
+  if (r1 >= k.r_max) r1 = k.r_max - 1e-6;
+  if (r2 >= k.r_max) r2 = k.r_max - 1e-6;
+  n_t dx, dy, x[4];
+  if (r1 >= 100.) { x[0] = n_t(floor(r1 / 10.) * 10); dx = 10; } else { x[0] = n_t(floor(r1)); dx = 1; }
+  if (r2 >= 100.) { x[2] = n_t(floor(r2 / 10.) * 10); dy = 10; } else { x[2] = n_t(floor(r2)); dy = 1; }
+  x[1] = x[0] + dx; x[3] = x[2] + dy;
+  const n_t nup = k.n_user_params;
+  const size_t iv0 = kernel_vector_index(kernel_index(x[0]), kernel_index(x[2]), nup),
+               iv1 = kernel_vector_index(kernel_index(x[1]), kernel_index(x[2]), nup),
+               iv2 = kernel_vector_index(kernel_index(x[0]), kernel_index(x[3]), nup),
+               iv3 = kernel_vector_index(kernel_index(x[1]), kernel_index(x[3]), nup);
+  const T w0 = r1 - x[0], w1 = x[1] - r1, w2 = r2 - x[2], w3 = x[3] - r2;
+  return (k.params[iv0] * w1 * w3 + k.params[iv1] * w0 * w3 + k.params[iv2] * w1 * w2 + k.params[iv3] * w0 * w2) / dx / dy;
+}
+template <class T>
+__device__ __forceinline__ T k_geometric(n_t na, n_t nb, T rw2a, T rw2b, T vta, T vtb)
+{
+  const n_t nmax = na < nb ? nb : na;
+  return cst<T>::pi * nmax * fabs(vta - vtb) * (rw2a + rw2b + 2. * sqrt(rw2a * rw2b));
+}
+template <class T>
+__device__ __forceinline__ T kernel_calc(const coal_kernel_cfg<T> &k, n_t na, n_t nb, T rw2a, T rw2b, T vta, T vtb)
+{
+  switch (k.kernel) {
+    case LCX_KERNEL_GOLOVIN: {
+      const n_t nmax = na < nb ? nb : na;
+      return T(cst<T>::pi * 4. / 3. * k.params[0] * nmax * (rw2a * sqrt(rw2a) + rw2b * sqrt(rw2b)));
+    }
+    case LCX_KERNEL_GEOMETRIC:
+      if (k.n_user_params == 1) return k_geometric(na, nb, rw2a, rw2b, vta, vtb) * k.params[0];
+      return k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+    case LCX_KERNEL_LONG: {
+      T res = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+      const T r_L = mx(T(sqrt(rw2a)), T(sqrt(rw2b)));
+      if (r_L < 50.e-6) {
+        const T r_s = mn(T(sqrt(rw2a)), T(sqrt(rw2b)));
+        if (r_s <= 3e-6) res = 0.; else res *= 4.5e8 * r_L * r_L * (1. - 3e-6 / r_s);
+      }
+      return res;
+    }
+    default:
+      return interpolated_efficiency(k, T(sqrt(rw2a)), T(sqrt(rw2b))) * k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+  }
+}
+template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
+
+// One lane per position p of the (shuffled) cell-sorted order; lanes at even in-cell offsets own the pair
+// (p, p+1).  Pairs are disjoint, so the read-modify-write of the two SDs needs no atomics.  The collision
+// count / who-was-bigger flags go to col[] exactly as in the reference (coal.ipp:209,233-267) because the
+// kappa update (and tests) read them.
+template <class T>
+__global__ void __launch_bounds__(BS)
+k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
+       n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
+       int pure_const_multi, int *increase_sstp_coal)
+{
+  const size_t p = gid(); if (p + 1 >= n_part) return;
+  const uint32_t ca = sorted_ijk[p];
+  const uint32_t off = cell_start[ca];
+  const uint32_t cix_a = uint32_t(p) - off;
+  if (cix_a & 1u) return;
+  if (sorted_ijk[p + 1] != ca) { col[p] = T(0); return; }
+  const uint32_t cnt = cell_start[ca + 1] - off;
+  const n_t nn = cnt;
+  const T scl = nn > 1 ? (T(nn * (nn - 1)) / 2) / (nn / 2) : T(0);           // scale_factor, coal.ipp:99-107
+  const uint32_t a = sorted_id[p], b = sorted_id[p + 1];
+  n_t na = n[a], nb = n[b];
+  const T rw2a = rw2[a], rw2b = rw2[b];
+  const T prob = dt / dv[ca] * scl * kernel_calc(kc, na, nb, rw2a, rw2b, vt[a], vt[b]);
+  n_t col_no = n_t(prob);
+  if (pure_const_multi && col_no >= 1) *increase_sstp_coal = 1;
+  const T u = rs.arr ? rs.arr[p] : philox::u01<T>(p, rs.call, rs.seed);
+  if (u < prob - col_no) ++col_no;
+  if (col_no == 0) { col[p] = T(0); col[p + 1] = T(0); return; }
+  if (na >= nb) {                                                            // collide<>, coal.ipp:110-143
+    if (nb > 0) { const n_t q = na / nb; if (q < col_no) col_no = q; }
+    n[a] = na - col_no * nb;
+    const T rw_b = cbrt(col_no * rw2a * sqrt(rw2a) + rw2b * sqrt(rw2b));
+    rw2[b] = rw_b * rw_b;
+    rd3[b] = col_no * rd3[a] + rd3[b];
+    vt[b] = T(-1);
+    col[p + 1] = T(-2);
+  } else {
+    if (na > 0) { const n_t q = nb / na; if (q < col_no) col_no = q; }
+    n[b] = nb - col_no * na;
+    const T rw_a = cbrt(col_no * rw2b * sqrt(rw2b) + rw2a * sqrt(rw2a));
+    rw2[a] = rw_a * rw_a;
+    rd3[a] = col_no * rd3[b] + rd3[a];
+    vt[a] = T(-1);
+    col[p + 1] = T(-1);
+  }
+  col[p] = T(col_no);
+}
+// weighted_summator, coal.ipp:57-97,458-480 (only with more than one kappa in the run)
+template <class T>
+__global__ void k_coal_kappa(size_t n_part, const uint32_t *sorted_id, const T *col, T *kpa, const T *rd3)
+{
+  const size_t p = gid(); if (p + 1 >= n_part) return;
+  const T cn = col[p];
+  if (cn <= 0) return;
+  const uint32_t a = sorted_id[p], b = sorted_id[p + 1];
+  const bool na_ge_nb = col[p + 1] == T(-2);
+  const T rd3a = rd3[a], rd3b = rd3[b];
+  T rd3_old = na_ge_nb ? rd3b - cn * rd3a : rd3a - cn * rd3b;
+  T ka = kpa[a], kb = kpa[b];
+  for (int ci = 0; ci < cn; ++ci) {
+    if (na_ge_nb) { kb = (ka * rd3a + kb * rd3_old) / (rd3a + rd3_old); rd3_old += rd3a; }
+    else          { ka = (kb * rd3b + ka * rd3_old) / (rd3b + rd3_old); rd3_old += rd3b; }
+  }
+  if (na_ge_nb) kpa[b] = kb; else kpa[a] = ka;
+}
+
+// ============================================================================================
+// advection + sedimentation + subsidence + boundary conditions in ONE pass
+// (adve.ipp:28-165,169-183; sedi.ipp:13-25; subs.ipp:13-25; bcnd.ipp:99-368)
+// ============================================================================================
+template <class T>
+struct move_args {
+  size_t n_part; grid_t g;
+  T dx, dy, dz, x0, y0, z0, x1, y1, z1, dt;
+  T *x, *y, *z; const T *vt, *rw2, *rd3; n_t *n; const uint32_t *ijk;
+  const T *courant_x, *courant_y, *courant_z, *w_LS;
+  int do_adve, scheme, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
+  double *puddle_partial;      // [gridDim][4]: liq_vol, dry_vol, liq_num, prtcl_num
+  uint8_t *mig;                // distmem: 1 = left the domain through the left face, 2 = right
+};
+template <class T>
+__device__ __forceinline__ T adve_1d(int scheme, T x, uint32_t fl, T C_l, T C_r, T dx)
+{
+  if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - size_t(fl) * (C_r - C_l))) / (1 - (C_r - C_l));
+  return 1 * x + (C_r - C_l) * (x - dx * size_t(fl)) + dx * C_l;
+}
+template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return a + fmod((x - a) + 10 * (b - a), b - a); }
+
+template <class T>
+__global__ void __launch_bounds__(BS) k_move(move_args<T> a)
+{
+  __shared__ double red[4][BS / WAVE];
+  const size_t i = gid();
+  double pl = 0, pd = 0, pn = 0, pp = 0;
+  if (i < a.n_part) {
+    const grid_t &g = a.g;
+    const size_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
+    const uint32_t c = a.ijk[i];
+    T x = g.nx ? a.x[i] : T(0), y = g.ny ? a.y[i] : T(0), z = g.nz ? a.z[i] : T(0);
+    if (a.do_adve && g.ndims > 0) {
+      uint32_t ci, cj = 0, ck = 0;
+      if (g.ndims == 1) ci = c; else if (g.ndims == 2) { ci = c / nz; ck = c % nz; } else { ci = c / (nz * ny); cj = (c / nz) % ny; ck = c % nz; }
+      const size_t rgt = size_t(c) + (g.ndims == 3 ? nz * ny : size_t(g.nz));           // init_grid.ipp:96-121
+      x = adve_1d(a.scheme, x, ci, a.courant_x[c], a.courant_x[rgt], a.dx);
+      if (g.ndims > 2) {
+        const size_t fre = size_t(c) + (c / (nz * ny)) * nz;
+        y = adve_1d(a.scheme, y, cj, a.courant_y[fre], a.courant_y[fre + nz], a.dy);
+      }
+      if (g.ndims > 1) {
+        const size_t blw = g.ndims == 2 ? size_t(c) + c / nz : size_t(c) + ny * (c / (nz * ny)) + (c - (c / (nz * ny)) * (nz * ny)) / nz;
+        z = adve_1d(a.scheme, z, ck, a.courant_z[blw], a.courant_z[blw + 1], a.dz);
+      }
+    }
+    if (a.do_sedi) z = z - a.dt * a.vt[i];
+    if (a.do_subs) z = z - a.dt * a.w_LS[c % nz];
+    bool kill = false;
+    if (a.do_bcnd && g.ndims > 0) {
+      if (!a.distmem) {
+        if (!a.open_side_walls) x = periodic(x, a.x0, a.x1);
+        else if (x >= a.x1 || x < a.x0) kill = true;
+      } else {
+        uint8_t m = 0;
+        if (x < a.x0) { m = 1; if (a.bcond_lft == 3) kill = true; }
+        if (x >= a.x1) { m = 2; if (a.bcond_rgt == 3) kill = true; }
+        a.mig[i] = m;
+      }
+      if (g.ndims == 3) {
+        if (!a.open_side_walls) y = periodic(y, a.y0, a.y1);
+        else if (y >= a.y1 || y < a.y0) kill = true;
+      }
+      if (g.ndims > 1) {
+        if (!a.periodic_topbot) {
+          if (z >= a.z1) kill = true;
+          if (z < a.z0) {
+            // precipitation: the SD's multiplicity as it is AFTER the side-wall / top flags (bcnd.ipp:219-232)
+            const double nf = kill ? 0. : double(T(a.n[i]));
+            const T r2 = a.rw2[i];
+            pl = 4. / 3. * cst<T>::pi * nf * pow(r2, T(3. / 2.));
+            pd = 4. / 3. * cst<T>::pi * nf * a.rd3[i];
+            pn = (r2 == T(0)) ? 0. : nf;
+            pp = nf;
+            kill = true;
+          }
+        } else z = periodic(z, a.z0, a.z1);
+      }
+    }
+    if (g.nx) a.x[i] = x;
+    if (g.ny) a.y[i] = y;
+    if (g.nz) a.z[i] = z;
+    if (kill) a.n[i] = 0;
+  }
+  if (a.puddle_partial) {
+    // deterministic block reduction (fixed shuffle tree), one partial per workgroup, summed by the host in order
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { pl += __shfl_down(pl, d); pd += __shfl_down(pd, d); pn += __shfl_down(pn, d); pp += __shfl_down(pp, d); }
+    if (lane_id() == 0) { red[0][wave_id()] = pl; red[1][wave_id()] = pd; red[2][wave_id()] = pn; red[3][wave_id()] = pp; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double s = 0;
+      for (int w = 0; w < BS / WAVE; ++w) s += red[threadIdx.x][w];
+      a.puddle_partial[size_t(blockIdx.x) * 4 + threadIdx.x] = s;
+    }
+  }
+}
+
+// ============================================================================================
+// stable removal of SDs with n == 0 (hskpng_remove.ipp:20-76), fused with the re-indexing of
+// post_copy (post_copy.ipp:18-35): survivors are written to the second buffer set in order, and their
+// new cell index and histogram rank are produced in the same pass.
+// ============================================================================================
+__global__ void __launch_bounds__(BS) k_alive_tiles(const n_t *n, size_t n_part, uint32_t *tile_sums)
+{
+  __shared__ uint32_t lds[BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t cnt = 0;
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    const bool alive = i < n_part && n[i] != 0;
+    cnt += __popcll(__ballot(alive));
+  }
+  if (lane_id() == 0) lds[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[w]; tile_sums[blockIdx.x] = s; }
+}
+template <class T> struct attr_set { n_t *n; T *rd3, *rw2, *kpa, *vt, *x, *y, *z; };
+
+template <class T>
+__global__ void __launch_bounds__(BS)
+k_compact(size_t n_part, attr_set<T> src, attr_set<T> dst, const uint32_t *tile_offs, grid_t g,
+          uint32_t *ijk, uint32_t *cnt, uint32_t *rank)
+{
+  __shared__ uint32_t lds[BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t run = tile_offs[blockIdx.x];
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    n_t nn = 0;
+    if (i < n_part) nn = src.n[i];
+    const bool alive = nn != 0;
+    const unsigned long long bal = __ballot(alive);
+    const uint32_t in_wave = __popcll(bal & ((1ull << lane_id()) - 1ull));
+    if (lane_id() == 0) lds[wave_id()] = __popcll(bal);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (unsigned w = 0; w < BS / WAVE; ++w) { const uint32_t s = lds[w]; if (w < wave_id()) woff += s; tot += s; }
+    __syncthreads();
+    if (alive) {
+      const size_t d = size_t(run) + woff + in_wave;
+      dst.n[d] = nn; dst.rd3[d] = src.rd3[i]; dst.rw2[d] = src.rw2[i]; dst.kpa[d] = src.kpa[i]; dst.vt[d] = src.vt[i];
+      T x = 0, y = 0, z = 0;
+      if (g.nx) { x = src.x[i]; dst.x[d] = x; }
+      if (g.ny) { y = src.y[i]; dst.y[d] = y; }
+      if (g.nz) { z = src.z[i]; dst.z[d] = z; }
+      const uint32_t c = cell_of(g, x, y, z);
+      ijk[d] = c;
+      rank[d] = atomicAdd(&cnt[c], 1u);
+    }
+    run += tot;
+  }
+}
+
+// ============================================================================================
+// moments / diagnostics (moms.ipp:50-387, particles_diag.ipp)
+// ============================================================================================
+// n_filtered = f(n or n_filtered, vec)  mode: 0 all, 1 range [mn,mx), 2 vec > 0
+template <class T>
+__global__ void k_nfilt(size_t n_part, int mode, int cons, const n_t *n, const T *vec, T vmin, T vmax, T *nf)
+{
+  const size_t i = gid(); if (i >= n_part) return;
+  const T y = cons ? nf[i] : T(n[i]);
+  if (mode == 0) nf[i] = y;
+  else if (mode == 1) { const T v = vec[i]; nf[i] = (v >= vmin && v < vmax) ? y : T(0); }
+  else nf[i] = y * (vec[i] > 0);
+}
+// per sorted position: value to be summed.  kind 0: n_f * vec^power (moment_counter, moms.ipp:243-275), 1: n_f > 0
+template <class T>
+__global__ void k_mom_vals(size_t n_part, const uint32_t *sorted_id, const T *nf, const T *vec, T power, int kind, T *out)
+{
+  const size_t p = gid(); if (p >= n_part) return;
+  const uint32_t id = sorted_id[p];
+  if (kind == 1) { out[p] = nf[id] > T(0) ? T(1) : T(0); return; }
+  const T x = vec[id];
+  out[p] = x >= 0 ? nf[id] * pow(x, power) : nf[id] * pow(x, T(int(power)));
+}
+template <class T>
+__global__ void k_cell_seqsum(size_t n_cell, const uint32_t *cell_start, const T *vals, const T *dv, const T *rhod, int specific, T *out)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  T acc = 0;
+  if (e > s) {
+    acc = vals[s];
+    for (uint32_t q = s + 1; q < e; ++q) acc = acc + vals[q];
+    if (specific) { acc = acc / dv[c]; acc = acc / rhod[c]; }
+  }
+  out[c] = acc;
+}
+// max over a cell of vec (diag_max_rw)
+template <class T>
+__global__ void k_cell_max(size_t n_cell, const uint32_t *cell_start, const uint32_t *sorted_id, const T *vec, T *out)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  T acc = 0;
+  for (uint32_t q = s; q < e; ++q) { const T v = vec[sorted_id[q]]; if (q == s || v > acc) acc = v; }
+  out[c] = acc;
+}
+
+// ============================================================================================
+// initialisation of super-droplets, sd_conc mode (src/impl/initialization/)
+// ============================================================================================
+template <class T>
+__global__ void k_init_dry(size_t n_new, size_t n_old, n_t per_cell, T log_rd_min, T log_rd_max, u01_src<T> rs,
+                           uint32_t *ijk, T *rd3, T *kpa, T kappa, T *vt)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  const size_t c = gI / per_cell;                                            // init_ijk.ipp:36-52 (cell-major)
+  const size_t ptr = size_t(per_cell) * c;
+  const T u = rs.arr ? rs.arr[gI] : philox::u01<T>(gI, rs.call, rs.seed);
+  const T lnrd = log_rd_min + T(T(gI - ptr) + u) * (log_rd_max - log_rd_min) / T(per_cell);   // init_dry_sd_conc.ipp:26-34
+  ijk[n_old + gI] = uint32_t(c);
+  rd3[n_old + gI] = exp(3 * lnrd);
+  kpa[n_old + gI] = kappa;
+  vt[n_old + gI] = T(-1);                                                    // resize fills vt with `invalid`
+}
+struct lognormal_modes { int n; double mean_rd[4], sdev[4], n_stp[4]; };
+// init_n.ipp:48-143 with the built-in lognormal spectrum evaluated on the device
+template <class T>
+__global__ void k_init_n(size_t n_new, size_t n_old, const T *rd3, const uint32_t *ijk, const T *fvals, lognormal_modes lm,
+                         T multiplier, const T *rhod, const T *dv, const T *conc_factor, int nz, int indep_rhod, int ndims,
+                         T cellvol, n_t *n)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  const size_t p = n_old + gI;
+  const uint32_t c = ijk[p];
+  T f;
+  if (fvals) f = fvals[gI];
+  else {
+    const T lnrd = log(rd3[p]) / 3.;
+    f = 0;
+    for (int m = 0; m < lm.n; ++m)
+      f += T(lm.n_stp[m]) / sqrt(2 * cst<T>::pi) / log(T(lm.sdev[m])) *
+           exp(-pow((lnrd - log(T(lm.mean_rd[m]))), T(2)) / T(2.) / pow(log(T(lm.sdev[m])), T(2)));
+  }
+  T v = multiplier * f;
+  if (!indep_rhod) v = v * rhod[c] / cst<T>::rho_stp;
+  if (conc_factor) v = v * conc_factor[c % nz];
+  if (ndims > 0) v = v * dv[c] / cellvol;
+  n[p] = n_t(v + T(0.5));
+}
+// init_wet.ipp:17-78
+template <class T>
+__global__ void k_init_wet(size_t n_new, size_t n_old, const T *rd3, const T *kpa, const uint32_t *ijk, const T *RH, const T *Tk, T RH_max, T *rw2)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  const size_t p = n_old + gI;
+  const uint32_t c = ijk[p];
+  rw2[p] = pow(rw3_eq(rd3[p], kpa[p], mn(RH[c], RH_max), Tk[c]), T(2. / 3));
+}
+// init_xyz.ipp:40-74 for one dimension (dim: 0 x, 1 y, 2 z)
+template <class T>
+__global__ void k_init_pos(size_t n_new, size_t n_old, int dim, grid_t g, const uint32_t *ijk, u01_src<T> rs, T p0, T p1, T dp, T *pos)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  const size_t p = n_old + gI;
+  const size_t c = ijk[p], nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
+  size_t ii;
+  if (g.ndims == 1) ii = c;
+  else if (g.ndims == 2) ii = dim == 0 ? c / nz : c % nz;
+  else ii = dim == 0 ? c / (nz * ny) : dim == 1 ? (c / nz) % ny : c % nz;
+  const T u = rs.arr ? rs.arr[gI] : philox::u01<T>(gI, rs.call, rs.seed);
+  pos[p] = u * mn(p1, T((ii + 1) * dp)) + (1. - u) * mx(p0, T(ii * dp));
+}
+
+// ============================================================================================
+// 1-D domain decomposition: migrant lists, pack, unpack (bcnd.ipp:160-205, pack.ipp:14-133, unpack.ipp:14-143)
+// ============================================================================================
+// stable list of ids with mig[i] == side (copy_if order): flags -> tile sums -> scan -> ids
+__global__ void __launch_bounds__(BS) k_mig_tiles(const uint8_t *mig, size_t n_part, uint8_t side, uint32_t *tile_sums)
+{
+  __shared__ uint32_t lds[BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t cnt = 0;
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    cnt += __popcll(__ballot(i < n_part && mig[i] == side));
+  }
+  if (lane_id() == 0) lds[wave_id()] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[w]; tile_sums[blockIdx.x] = s; }
+}
+__global__ void __launch_bounds__(BS) k_mig_ids(const uint8_t *mig, size_t n_part, uint8_t side, const uint32_t *tile_offs, uint32_t *ids)
+{
+  __shared__ uint32_t lds[BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t run = tile_offs[blockIdx.x];
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    const bool sel = i < n_part && mig[i] == side;
+    const unsigned long long bal = __ballot(sel);
+    const uint32_t in_wave = __popcll(bal & ((1ull << lane_id()) - 1ull));
+    if (lane_id() == 0) lds[wave_id()] = __popcll(bal);
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (unsigned w = 0; w < BS / WAVE; ++w) { const uint32_t s = lds[w]; if (w < wave_id()) woff += s; tot += s; }
+    __syncthreads();
+    if (sel) ids[size_t(run) + woff + in_wave] = uint32_t(i);
+    run += tot;
+  }
+}
+// attribute-major record: n[count] | rd3,rw2,kpa,vt,x,(y),(z)[count] ; x re-based to the receiver's frame
+template <class T>
+__global__ void k_pack(size_t count, const uint32_t *ids, attr_set<T> s, grid_t g, T x_rmt, T x_lcl, n_t *nb, T *rb)
+{
+  const size_t i = gid(); if (i >= count) return;
+  const uint32_t id = ids[i];
+  nb[i] = s.n[id];
+  size_t slab = 0;
+  rb[slab++ * count + i] = s.rd3[id]; rb[slab++ * count + i] = s.rw2[id]; rb[slab++ * count + i] = s.kpa[id]; rb[slab++ * count + i] = s.vt[id];
+  if (g.nx) { const T xn = x_rmt + s.x[id] - x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
+  if (g.ny) rb[slab++ * count + i] = s.y[id];
+  if (g.nz) rb[slab++ * count + i] = s.z[id];
+}
+template <class T>
+__global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, const T *rb, T x0, T x1, T tol)
+{
+  const size_t i = gid(); if (i >= count) return;
+  const size_t d = n_old + i;
+  s.n[d] = nb[i];
+  size_t slab = 0;
+  s.rd3[d] = rb[slab++ * count + i]; s.rw2[d] = rb[slab++ * count + i]; s.kpa[d] = rb[slab++ * count + i]; s.vt[d] = rb[slab++ * count + i];
+  if (g.nx) { const T x = rb[slab++ * count + i]; s.x[d] = x >= x1 ? x - tol : x < x0 ? x + tol : x; }   // tolerance_away_from_bcond
+  if (g.ny) s.y[d] = rb[slab++ * count + i];
+  if (g.nz) s.z[d] = rb[slab++ * count + i];
+}
+__global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
+
+} // namespace lcx

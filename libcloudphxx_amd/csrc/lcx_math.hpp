@@ -1,0 +1,409 @@
+// lcx_math.hpp -- device/host formula library of the lgrngn hot path (HIP, gfx950).
+//
+// Templated on real_t (float | double).  Expressions keep the operator order of the reference
+// formulas they implement (cited per function, paths relative to the reference checkout) and the
+// library is compiled with -ffp-contract=off, so that +,-,*,/,sqrt results are IEEE-identical to the
+// reference's CPU backends; only libm calls (exp, log, pow, cbrt) may differ in the last ulp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+#define LCX_HD __host__ __device__ __forceinline__
+
+namespace lcx {
+
+using n_t = unsigned long long;   // src/impl/particles_impl.ipp:29
+
+template <class T> struct lim;
+template <> struct lim<float>  { static constexpr float  eps = FLT_EPSILON, max = FLT_MAX, min = FLT_MIN; };
+template <> struct lim<double> { static constexpr double eps = DBL_EPSILON, max = DBL_MAX, min = DBL_MIN; };
+
+// std::min / std::max semantics (first argument wins on ties / NaN in the second)
+template <class T> LCX_HD T mn(T a, T b) { return b < a ? b : a; }
+template <class T> LCX_HD T mx(T a, T b) { return a < b ? b : a; }
+
+// ---- constants: common/moist_air.hpp:26-112, const_cp.hpp:22-26, earth.hpp:16-22, theta_std.hpp:20
+template <class T> struct cst {
+  static constexpr T c_pd = T(1005), c_pv = T(1850), c_pw = T(4218);
+  static constexpr T M_d = T(0.02897);
+  static constexpr T M_v = T(1 * 1e-3) + T(17 * 1e-3);       // molar_mass.hpp:23-24, moist_air.hpp:36
+  static constexpr T kaBoNA = T(8.3144621);
+  static constexpr T R_d = kaBoNA / M_d, R_v = kaBoNA / M_v, eps = M_v / M_d;
+  static constexpr T rho_w = T(1e3), D_0 = T(2.26e-5), K_0 = T(2.4e-2);
+  static constexpr T p_tri = T(611.73), T_tri = T(273.16), l_tri = T(2.5e6);
+  static constexpr T p_1000 = T(100000), g = T(9.81), p_stp = T(101325), T_stp = T(273.15 + 15);
+  static constexpr T rho_stp = p_stp / T_stp / R_d;
+  static constexpr T pi = T(3.141592653589793238462643383279502884L);
+};
+
+// theta_dry.hpp:24-55
+template <class T> LCX_HD T theta_dry_T(T th, T rhod)
+{
+  using c = cst<T>;
+  return pow(th * pow(rhod * c::R_d / c::p_1000, c::R_d / c::c_pd), c::c_pd / (c::c_pd - c::R_d));
+}
+template <class T> LCX_HD T theta_dry_p(T rhod, T r, T Tk) { using c = cst<T>; return rhod * (c::R_d + r * c::R_v) * Tk; }
+// theta_std.hpp:35-41
+template <class T> LCX_HD T exner(T p) { using c = cst<T>; return pow(p / c::p_1000, c::R_d / c::c_pd); }
+// const_cp.hpp:82-86
+template <class T> LCX_HD T l_v(T Tk) { using c = cst<T>; return c::l_tri + (c::c_pv - c::c_pw) * (Tk - c::T_tri); }
+// theta_dry.hpp:60-65
+template <class T> LCX_HD T d_th_d_rv(T Tk, T th) { return -th / Tk * l_v(Tk) / cst<T>::c_pd; }
+// moist_air.hpp:77-83
+template <class T> LCX_HD T p_v(T p, T r) { return p * r / (r + cst<T>::eps); }
+// const_cp.hpp:34-43
+template <class T> LCX_HD T p_vs(T Tk)
+{
+  using c = cst<T>;
+  return c::p_tri * exp(
+    (c::l_tri + (c::c_pw - c::c_pv) * c::T_tri) / c::R_v * (T(1) / c::T_tri - T(1) / Tk)
+    - (c::c_pw - c::c_pv) / c::R_v * log(Tk / c::T_tri));
+}
+// const_cp.hpp:58-64
+template <class T> LCX_HD T r_vs(T Tk, T p) { return cst<T>::eps / (p / p_vs(Tk) - 1); }
+// tetens.hpp:12-37
+template <class T> LCX_HD T tet_p_vs(T Tk)
+{
+  const T Tc = T(Tk - 273.15);
+  return T(T(6.1078e2) * exp((T(17.27) * Tc) / (Tc + T(237.3))));
+}
+template <class T> LCX_HD T tet_r_vs(T Tk, T p)
+{
+  const T Tc = Tk - T(273.15);
+  return T(T(380) / (p * exp(T(-17.2693882) * Tc / (Tk - T(35.86))) - T(610.9)));
+}
+// hskpng_Tpr.ipp:64-97,146-165
+template <class T> LCX_HD T RH_of(int formula, T p, T rv, T Tk)
+{
+  switch (formula) {
+    case 0: return p_v(p, rv) / p_vs(Tk);
+    case 1: return rv / r_vs(Tk, p);
+    case 2: return p_v(p, rv) / tet_p_vs(Tk);
+    default: return rv / tet_r_vs(Tk, p);
+  }
+}
+// vterm.hpp:22-31
+template <class T> LCX_HD T visc(T Tk)
+{
+  const T tt = Tk / cst<T>::T_tri;
+  return T(1.72 * 1e-5) * (T(393) / (Tk + T(120))) * T(tt * sqrt(tt));
+}
+// mean_free_path.hpp:16-51
+template <class T> LCX_HD T lambda_D_of(T Tk) { using c = cst<T>; return T(2) * c::D_0 / T(sqrt(T(2) * T(c::R_v * Tk))); }
+template <class T> LCX_HD T lambda_K_of(T Tk, T p) { using c = cst<T>; return T(.8) * (c::K_0 * Tk / p) / T(sqrt(T(2) * T(c::R_d * Tk))); }
+// kelvin_term.hpp:25-50
+template <class T> LCX_HD T sg_surf(T Tk) { return T(0.07275) * (T(1.) - T(0.002) * (Tk - T(291.))); }
+template <class T> LCX_HD T kelvin_A(T Tk) { using c = cst<T>; return T(2) * sg_surf(Tk) / c::R_v / Tk / c::rho_w; }
+// kappa_koehler.hpp:31-54
+template <class T> LCX_HD T rw3_eq_nokelvin(T rd3, T kappa, T RH) { return rd3 * (1 - RH * (1 - kappa)) / (1 - RH); }
+template <class T> LCX_HD T a_w(T rw3, T rd3, T kappa) { return (rw3 - rd3) / (rw3 - rd3 * (T(1) - kappa)); }
+// transition_regime.hpp:15-20
+template <class T> LCX_HD T trans_beta(T Kn) { return (1 + Kn) / (1 + T(1.71) * Kn + T(1.33) * Kn * Kn); }
+
+// ---------------------------------------------------------------------------------------------
+// TOMS 748 bracketing root finder in the form the reference vendors it
+// (common/detail/toms748.hpp:60-454): same steps, same safeguards, same termination test, because
+// the returned value is the midpoint of the LAST bracket and therefore depends on the iteration path.
+// F: functor with T operator()(T) const.
+template <class T> LCX_HD T eps_tolerance(unsigned bits)
+{                                                                  // toms748.hpp:267-282
+  return mx(T(ldexpf(1.0f, 1 - int(bits))), T(4 * lim<T>::eps));
+}
+template <class T> LCX_HD bool tol_reached(T eps, T a, T b) { return fabs(a - b) <= eps * mn(fabs(a), fabs(b)); }
+
+namespace t748 {
+template <class T> struct st { T a, b, fa, fb, d, fd; };
+
+template <class T> LCX_HD T safe_div(T num, T den, T r)
+{                                                                  // :124-138
+  if (fabs(den) < 1 && fabs(den * lim<T>::max) <= fabs(num)) return r;
+  return num / den;
+}
+template <class T> LCX_HD T secant(T a, T b, T fa, T fb)
+{                                                                  // :140-160
+  const T tol = lim<T>::eps * 5;
+  const T c = a - (fa / (fb - fa)) * (b - a);
+  if (c <= a + fabs(a) * tol || c >= b - fabs(b) * tol) return (a + b) / 2;
+  return c;
+}
+template <class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb, T fd, unsigned count)
+{                                                                  // :162-222
+  T B = safe_div(T(fb - fa), T(b - a), lim<T>::max);
+  T A = safe_div(T(fd - fb), T(d - b), lim<T>::max);
+  A = safe_div(T(A - B), T(d - a), T(0));
+  if (A == 0) return secant(a, b, fa, fb);
+  T c = copysign(T(1), A * fa) > 0 ? a : b;
+  for (unsigned i = 1; i <= count; ++i)
+    c -= safe_div(T(fa + (B + A * (c - b)) * (c - a)), T(B + A * (2 * c - a - b)), T(1 + c - a));
+  if (c <= a || c >= b) c = secant(a, b, fa, fb);
+  return c;
+}
+template <class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T fd, T fe)
+{                                                                  // :224-262
+  const T q11 = (d - e) * fd / (fe - fd);
+  const T q21 = (b - d) * fb / (fd - fb);
+  const T q31 = (a - b) * fa / (fb - fa);
+  const T d21 = (b - d) * fd / (fd - fb);
+  const T d31 = (a - b) * fb / (fb - fa);
+  const T q22 = (d21 - q11) * fb / (fe - fb);
+  const T q32 = (d31 - q21) * fa / (fd - fa);
+  const T d32 = (d31 - q21) * fd / (fd - fa);
+  const T q33 = (d32 - q22) * fa / (fe - fa);
+  T c = q31 + q32 + q33 + a;
+  if (c <= a || c >= b) c = quadratic(a, b, d, fa, fb, fd, 3);
+  return c;
+}
+template <class T, class F> LCX_HD void bracket(const F &f, st<T> &s, T c)
+{                                                                  // :60-122
+  const T tol = lim<T>::eps * 2;
+  if ((s.b - s.a) < 2 * tol * s.a) c = s.a + (s.b - s.a) / 2;
+  else if (c <= s.a + fabs(s.a) * tol) c = s.a + fabs(s.a) * tol;
+  else if (c >= s.b - fabs(s.b) * tol) c = s.b - fabs(s.a) * tol;
+  const T fc = f(c);
+  if (fc == 0) { s.a = c; s.fa = 0; s.d = 0; s.fd = 0; return; }
+  if (copysign(T(1), s.fa * fc) < 0) { s.d = s.b; s.fd = s.fb; s.b = c; s.fb = fc; }
+  else                               { s.d = s.a; s.fd = s.fa; s.a = c; s.fa = fc; }
+}
+template <class T> LCX_HD bool prof(const st<T> &s, T fe)
+{
+  const T md = lim<T>::min * 32;
+  return fabs(s.fa - s.fb) < md || fabs(s.fa - s.fd) < md || fabs(s.fa - fe) < md ||
+         fabs(s.fb - s.fd) < md || fabs(s.fb - fe) < md || fabs(s.fd - fe) < md;
+}
+} // namespace t748
+
+template <class T, class F>
+LCX_HD T toms748_solve(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter)
+{                                                                  // toms748.hpp:289-431
+  using namespace t748;
+  unsigned count = max_iter;
+  st<T> s{ax, bx, fax, fbx, T(0), T(0)};
+  T c, u, fu, a0, b0, e, fe;
+  const T mu = 0.5f;
+  if (tol_reached(eps, s.a, s.b) || s.fa == 0 || s.fb == 0) {
+    if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
+    return (s.a + s.b) / 2;
+  }
+  fe = e = s.fd = 1e5f;
+  if (s.fa != 0) {
+    c = secant(s.a, s.b, s.fa, s.fb);
+    bracket(f, s, c);
+    --count;
+    if (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
+      c = quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
+      e = s.d; fe = s.fd;
+      bracket(f, s, c);
+      --count;
+    }
+  }
+  while (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
+    a0 = s.a; b0 = s.b;
+    c = prof(s, fe) ? quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2) : cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
+    e = s.d; fe = s.fd;
+    bracket(f, s, c);
+    if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
+    c = prof(s, fe) ? quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 3) : cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
+    bracket(f, s, c);
+    if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
+    if (fabs(s.fa) < fabs(s.fb)) { u = s.a; fu = s.fa; } else { u = s.b; fu = s.fb; }
+    c = u - 2 * (fu / (s.fb - s.fa)) * (s.b - s.a);
+    if (fabs(c - u) > (s.b - s.a) / 2) c = s.a + (s.b - s.a) / 2;
+    e = s.d; fe = s.fd;
+    bracket(f, s, c);
+    if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
+    if ((s.b - s.a) < mu * (b0 - a0)) continue;
+    e = s.d; fe = s.fd;
+    bracket(f, s, T(s.a + (s.b - s.a) / 2));
+    --count;
+  }
+  if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
+  return (s.a + s.b) / 2;
+}
+
+// ---- equilibrium wet radius at init: kappa_koehler.hpp:58-146, init_wet.ipp:17-38
+template <class T> struct rw3_eq_minfun {
+  T RH, rd3, kappa, A;   // A = kelvin::A(T): hoisted (same value every evaluation)
+  LCX_HD T operator()(T rw3) const { return RH - a_w(rw3, rd3, kappa) * exp(A / T(cbrt(rw3))); }
+};
+template <class T> LCX_HD T rw3_eq(T rd3, T kappa, T RH, T Tk)
+{
+  if (kappa == 0) return rd3;
+  const rw3_eq_minfun<T> f{RH, rd3, kappa, kelvin_A(Tk)};
+  const T a = rd3, b = rw3_eq_nokelvin(rd3, kappa, RH);
+  return toms748_solve(f, a, b, f(a), f(b), eps_tolerance<T>(sizeof(T) * 8 / 4), 100u);
+}
+
+// ---- condensational growth: condensation/common/particles_impl_cond_common.ipp:80-338,
+//      maxwell-mason.hpp:15-47, ventil.hpp:16-80
+// Everything that does not depend on the trial radius is evaluated ONCE per super-droplet
+// (the reference recomputes it in every drw2_dt call); each hoisted quantity is the same
+// expression, so the values entering the formulas are bit-identical.
+template <class T> struct cond_fun {
+  T rw2_old, dt, rd3, kpa;
+  T vt, rhod, eta;
+  T Sc, Pr;           // Sc = eta/rhod/D_0, Pr = c_pd*eta/K_0
+  T lambda_D, lambda_K;
+  T rho_v, Tk, RH_eff, lv, A;
+  T lv_term;          // (lv / R_v / T - 1)
+
+  LCX_HD T Nu(T X, T Re) const
+  {                                                                // ventil.hpp:30-44
+    // max(1, pow(Re, .077)) == 1 for Re <= 1 (pow is monotone, pow(1,.)=1; NaN for Re<0 loses in std::max)
+    const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+    return T(1) + T(cbrt(T(1) + Re * X)) * m;
+  }
+  LCX_HD T drw2_dt(T rw2) const
+  {
+    using c = cst<T>;
+    const T rw = sqrt(rw2);
+    const T rw3 = rw * rw * rw;
+    const T Re = vt * (T(2) * rw) * rhod / eta;
+    const T D = c::D_0 * trans_beta(lambda_D / rw) * (Nu(Sc, Re) / 2);
+    const T K = c::K_0 * trans_beta(lambda_K / rw) * (Nu(Pr, Re) / 2);
+    const T aw = a_w(rw3, rd3, kpa);
+    const T klv = exp(A / rw);
+    return T(2) * ((T(1) - aw * klv / RH_eff) / c::rho_w /
+                   (T(1) / D / rho_v + lv / K / RH_eff / Tk * lv_term));
+  }
+  LCX_HD T operator()(T rw2) const { return rw2_old + dt * drw2_dt(rw2) - rw2; }
+};
+
+template <class T>
+LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt,
+                     T lambda_D, T lambda_K, T RH, T RH_max, T eps, T cond_mlt, unsigned n_iter)
+{                                                                  // cond_common.ipp:187-337
+  using c = cst<T>;
+  if (rw2_old <= 0) return rw2_old;
+  cond_fun<T> f;
+  f.rw2_old = rw2_old; f.dt = dt; f.rd3 = rd3; f.kpa = kpa; f.vt = vt; f.rhod = rhod; f.eta = eta;
+  f.Sc = eta / rhod / c::D_0;
+  f.Pr = c::c_pd * eta / c::K_0;
+  f.lambda_D = lambda_D; f.lambda_K = lambda_K;
+  f.rho_v = rhod * rv; f.Tk = Tk; f.RH_eff = RH > RH_max ? RH_max : RH;
+  f.lv = l_v(Tk);
+  f.A = kelvin_A(Tk);
+  f.lv_term = f.lv / c::R_v / Tk - T(1);
+  const T drw2 = dt * f.drw2_dt(rw2_old);
+  if (drw2 == 0) return rw2_old;
+  const T rd = cbrt(rd3);
+  const T rd2 = rd * rd;
+  const T a = mx(rd2, rw2_old + mn(T(0), cond_mlt * drw2)),
+          b = rw2_old + mx(T(0), cond_mlt * drw2);
+  if (a == b) return rw2_old;
+  T fa, fb;
+  if (drw2 > 0) { fa = drw2; fb = f(b); }
+  else          { fa = f(a); fb = drw2; }
+  T rw2_new;
+  if (fa * fb > 0) rw2_new = rw2_old + drw2;
+  else rw2_new = toms748_solve(f, a, b, fa, fb, eps, n_iter);
+  if (rw2_new < rd2) rw2_new = rd2;
+  return rw2_new;
+}
+
+// ---- terminal velocities: common/vterm.hpp:33-220 (khvorostyanov and beard77_v0 in double whatever real_t)
+LCX_HD double vt_khvorostyanov(double r, double rhoa, double eta, bool spherical)
+{
+  using c = cst<double>;
+  const double X = double(32. / 3) * (c::rho_w - rhoa) / rhoa * c::g * r * r * r / eta / eta * rhoa * rhoa;
+  const double sX = sqrt(X);
+  const double b = double(.0902 / 2) * sX / ((sqrt(double(1) + double(.0902) * sX) - double(1)) * (sqrt(double(1) + double(.0902) * sX)));
+  const double pow_hlpr = sqrt(double(1) + double(.0902) * sX) - double(1);
+  const double a = double(9.06 * 9.06 / 4) * pow_hlpr * pow_hlpr / pow(X, b);
+  double Av;
+  if (spherical)
+    Av = a * pow(eta / rhoa * double(1e4), double(1) - double(2) * b) * pow(double(4. / 3) * c::rho_w / rhoa * c::g * double(1e2), b);
+  else {
+    const double lambda_half = 2.35e-3;
+    const double ksi = exp(-r / lambda_half) + (double(1) - exp(-r / lambda_half)) / (double(1) + r / lambda_half);
+    const double alfa = c::pi / double(6) * c::rho_w * ksi;
+    Av = a * pow(eta / rhoa * double(1e4), double(1) - double(2) * b) * pow(double(2.546479) * alfa / rhoa * c::g * double(1e2), b);
+  }
+  const double Bv = double(3) * b - double(1);
+  return (Av * double(pow(double(2 * 1e2) * r, Bv))) / double(1e2);
+}
+LCX_HD double vt_beard77_v0(double r)
+{
+  const double m_s[4] = {0.105035e2, 0.108750e1, -0.133245, -0.659969e-2};
+  const double m_l[8] = {0.65639e1, -0.10391e1, -0.14001e1, -0.82736e0, -0.34277e0, -0.83072e-1, -0.10583e-1, -0.54208e-3};
+  const double x = log(2 * 100 * r);
+  double y = 0;
+  if (r <= 20e-6) for (int i = 0; i < 4; ++i) y += m_s[i] * pow(x, double(i));
+  else            for (int i = 0; i < 8; ++i) y += m_l[i] * pow(x, double(i));
+  return exp(y) / 100.;
+}
+template <class T> LCX_HD T vt_beard77_fact(T r, T p, T rhoa, T eta)
+{
+  using c = cst<T>;
+  const T eta_0 = T(1.818e-5);
+  if (r <= T(20e-6)) {
+    const T l_0 = T(6.62e-8);
+    const T l = l_0 * (eta / eta_0) * sqrt(c::p_stp / p * c::rho_stp / rhoa);
+    return (eta_0 / eta) * (1 + T(1.255) * (l / r)) / (1 + T(1.255) * (l_0 / r));
+  } else {
+    const T eps_s = (eta_0 / eta) - 1;
+    const T eps_c = sqrt(c::rho_stp / rhoa) - 1;
+    return T(1.104) * eps_s + ((T(1.058) * eps_c - T(1.104) * eps_s) * (T(5.52) + log(2 * 100 * r)) / T(5.01)) + 1;
+  }
+}
+template <class T> LCX_HD T vt_beard76(T r, T Tk, T p, T rhoa, T eta)
+{
+  using c = cst<T>;
+  if (r <= T(9.5e-6)) {
+    const T l = T(6.62e-8) * (eta / T(1.818e-5)) * (c::p_stp / p) * sqrt(Tk / T(293.15));
+    const T C_ac = T(1.) + T(1.255) * l / r;
+    return (c::rho_w - rhoa) * c::g / (T(4.5) * eta) * C_ac * r * r;
+  } else if (r <= T(5.035e-4)) {
+    const double b[7] = {-0.318657e1, 0.992696, -0.153193e-2, -0.987059e-3, -0.578878e-3, 0.855176e-4, -0.327815e-5};
+    const T l = T(6.62e-8) * (eta / T(1.818e-5)) * (c::p_stp / p) * sqrt(Tk / T(293.15));
+    const T C_ac = T(1.) + T(1.255) * l / r;
+    const T log_N_Da = log(T(32. / 3.) * r * r * r * rhoa * (c::rho_w - rhoa) * c::g / eta / eta);
+    T Y = 0.;
+    for (int i = 0; i < 7; ++i) Y = T(double(Y) + b[i] * pow(double(log_N_Da), double(i)));
+    const T N_Re = T(C_ac * exp(double(Y)));
+    return eta * N_Re / rhoa / T(2.) / r;
+  } else {
+    const T b[6] = {T(-0.500015e1), T(0.523778e1), T(-0.204914e1), T(0.475294), T(-0.542819e-1), T(0.238449e-2)};
+    const T sg = sg_surf(Tk);
+    const T Bo = T(16. / 3.) * r * r * (c::rho_w - rhoa) * c::g / sg;
+    const T N_p = sg * sg * sg * rhoa * rhoa / eta / eta / eta / eta / c::g / (c::rho_w - rhoa);
+    const T X = log(Bo * pow(N_p, T(1. / 6.)));
+    T Y = 0.;
+    for (int i = 0; i < 6; ++i) Y = Y + b[i] * pow(X, T(i));
+    const T N_Re = pow(N_p, T(1. / 6.)) * exp(Y);
+    return eta * N_Re / rhoa / T(2.) / r;
+  }
+}
+
+// ---- Philox4x32-10 counter-based generator (Salmon et al. 2011): stateless, so every kernel draws
+//      the number it needs from (call counter, element index) with no HBM traffic.
+struct philox {
+  static LCX_HD void round(uint32_t (&c)[4], uint32_t (&k)[2])
+  {
+    const uint64_t p0 = uint64_t(0xD2511F53u) * c[0], p1 = uint64_t(0xCD9E8D57u) * c[2];
+    const uint32_t n0 = uint32_t(p1 >> 32) ^ c[1] ^ k[0], n2 = uint32_t(p0 >> 32) ^ c[3] ^ k[1];
+    c[1] = uint32_t(p1); c[3] = uint32_t(p0); c[0] = n0; c[2] = n2;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  static LCX_HD void gen(uint64_t idx, uint64_t call, uint64_t seed, uint32_t (&out)[4])
+  {
+    uint32_t c[4] = {uint32_t(idx), uint32_t(idx >> 32), uint32_t(call), uint32_t(call >> 32)};
+    uint32_t k[2] = {uint32_t(seed), uint32_t(seed >> 32)};
+    for (int i = 0; i < 10; ++i) round(c, k);
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+  }
+  // uniform in [0,1) with 53 (double) / 24 (float) random bits
+  template <class T> static LCX_HD T u01(uint64_t idx, uint64_t call, uint64_t seed)
+  {
+    uint32_t r[4]; gen(idx, call, seed, r);
+    if (sizeof(T) == 8) return T(double((uint64_t(r[0]) << 21) ^ (uint64_t(r[1]) >> 11)) * (1.0 / 9007199254740992.0));
+    return T(float(r[0] >> 8) * (1.0f / 16777216.0f));
+  }
+  static LCX_HD uint32_t un(uint64_t idx, uint64_t call, uint64_t seed)
+  {
+    uint32_t r[4]; gen(idx, call, seed, r);
+    return r[0];
+  }
+};
+
+} // namespace lcx

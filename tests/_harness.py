@@ -96,3 +96,93 @@ def lognormal_fn(mean_r, stdev, n_tot):
     def f(lnr):
         return n_tot * exp(-pow((lnr - log(mean_r)), 2) / 2 / pow(log(stdev), 2)) / log(stdev) / sqrt(2 * pi)
     return f
+
+
+# ------------------------------------------------------------------ oracle <-> HIP pairing helpers
+def box_opts(nx=4, ny=4, nz=4, sd_conc=64, dx=40., **kw):
+    """a small periodic 3-D (or 2-D if ny=0) box in the spirit of BASELINE config 3"""
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.ny, oi.nz = nx, ny, nz
+    oi.dx = oi.dy = oi.dz = dx
+    oi.x1, oi.y1, oi.z1 = max(nx, 1) * dx, max(ny, 1) * dx, max(nz, 1) * dx
+    if ny == 0:
+        oi.dy, oi.y1 = 1., 1.
+    oi.dt = 1.
+    oi.sd_conc = sd_conc
+    oi.n_sd_max = int(sd_conc * max(nx, 1) * max(ny, 1) * max(nz, 1) * 1.2) + 16
+    oi.dry_distros = {(.61, 0.): lgrngn_bimodal()}
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.terminal_velocity = lgrngn.vt_t.beard77fast
+    oi.adve_scheme = lgrngn.as_t.euler
+    for k, v in kw.items():
+        assert hasattr(oi, k), k
+        setattr(oi, k, v)
+    return oi
+
+
+def lgrngn_bimodal():
+    """icicle's bimodal lognormal aerosol (models/kinematic_2D/src/opts_common.hpp:56-62) as a python callable,
+    so that oracle and HIP evaluate the very same host function"""
+    f1 = lognormal_fn(.02e-6, 1.4, 60e6)
+    f2 = lognormal_fn(.075e-6, 1.6, 40e6)
+    return lambda lnr: f1(lnr) + f2(lnr)
+
+
+def box_fields(oi, seed=0, supersat=True):
+    """th, rv, rhod, Cx, Cy, Cz for a box: smooth, non-uniform, RH ~ 0.95..1.01; |C| <= 0.3"""
+    nx, ny, nz = max(oi.nx, 1), max(oi.ny, 1), max(oi.nz, 1)
+    shp = tuple(n for n, f in zip((oi.nx, oi.ny, oi.nz), (1, 1, 1)) if n > 0)
+    rng = np.random.default_rng(seed)
+    ii = np.indices(shp if shp else (1,)).astype(float)
+    th = 289. + 0.3 * rng.random(shp if shp else (1,))
+    rhod = 1.1 - 0.01 * (ii[-1] / max(1, shp[-1] if shp else 1))
+    rv = 8.0e-3 + (2.2e-3 if supersat else 0.) * (ii[-1] / max(1, shp[-1] if shp else 1)) + 1e-4 * rng.random(shp if shp else (1,))
+    C = {}
+    if oi.nx:
+        if oi.ny:
+            C["Cx"] = 0.3 * np.sin(2 * np.pi * np.indices((nx + 1, ny, nz))[1] / ny) + 0.05
+            C["Cy"] = 0.2 * np.cos(2 * np.pi * np.indices((nx, ny + 1, nz))[0] / nx)
+            C["Cz"] = 0.1 * np.sin(2 * np.pi * np.indices((nx, ny, nz + 1))[0] / nx) * np.sin(np.pi * np.indices((nx, ny, nz + 1))[2] / nz)
+        elif oi.nz:
+            C["Cx"] = 0.3 * np.sin(np.pi * (np.indices((nx + 1, nz))[1] + 0.5) / nz) + 0.05
+            C["Cz"] = 0.1 * np.sin(2 * np.pi * np.indices((nx, nz + 1))[0] / nx) * np.sin(np.pi * np.indices((nx, nz + 1))[1] / nz)
+        else:
+            C["Cx"] = 0.3 * np.ones((nx + 1,))
+    return (np.ascontiguousarray(th), np.ascontiguousarray(rv), np.ascontiguousarray(rhod),
+            {k: np.ascontiguousarray(v) for k, v in C.items()})
+
+
+def init_replay_calls(oi):
+    """random arrays consumed by init() for a single-distro sd_conc run"""
+    n_new = int(oi.sd_conc) * max(oi.nx, 1) * max(oi.ny, 1) * max(oi.nz, 1)
+    ndim = sum(1 for n in (oi.nx, oi.ny, oi.nz) if n > 0)
+    return [(0, n_new)] * (1 + ndim)
+
+
+def make_pair(oi, fields, force_state=True):
+    """oracle and HIP objects initialised from the same inputs and the same (oracle) random stream"""
+    th, rv, rhod, C = fields
+    orc = oracle_particles(oi)
+    hip = hip_particles(oi)
+    for arr in oracle_rng_preview(orc, init_replay_calls(oi)):
+        hip.rng_replay_push(0, arr)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    if force_state:
+        copy_state(orc, hip)
+    return orc, hip
+
+
+def copy_state(orc, hip):
+    """overwrite the device particle state with the oracle's (so later stages start bit-identical)"""
+    g = lambda nm: orc.state_real(nm)
+    oi = orc.opts_init
+    hip.set_particles(orc.state_u64("n"), g("rd3"), g("rw2"), g("kappa"), g("vt"),
+                      g("x") if oi.nx else None, g("y") if oi.ny else None, g("z") if oi.nz else None)
+
+
+def push_coal_replay(orc, hip, sstp_coal=1):
+    n = orc.n_part
+    calls = [(1, n), (0, n)] * sstp_coal
+    for (kind, _), arr in zip(calls, oracle_rng_preview(orc, calls)):
+        hip.rng_replay_push(kind, arr)

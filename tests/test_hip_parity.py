@@ -1,0 +1,365 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: integers (cell index, sort permutation, counts, multiplicities under a replayed random
+stream) bit-exact; cell thermodynamics rtol 1e-12; vt rtol 1e-12; positions rtol 1e-14; rw2 after a
+condensation substep rtol 1e-4 (the root finder stops at a 2^-15 bracket: a 1-ulp libm difference may move
+the stopping iteration) and exact for the overwhelming majority; th / rv after step_cond rtol 1e-7.
+"""
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+
+
+def exact(a, b, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a, b), (what, int(np.sum(a != b)), "mismatches of", a.size)
+
+
+def step_pair(orc, hip, opts, fields, coal_replay=True):
+    th, rv, rhod, C = fields
+    tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()
+    orc.step_sync(opts, tho, rvo, rhod, **C)
+    hip.step_sync(opts, thh, rvh, rhod, **C)
+    if opts.coal and coal_replay:
+        h.push_coal_replay(orc, hip, orc.opts_init.sstp_coal)
+    orc.step_async(opts)
+    hip.step_async(opts)
+    return (tho, rvo), (thh, rvh)
+
+
+# ------------------------------------------------------------------ cell thermodynamics (a5)
+@pytest.mark.parametrize("RH_formula", list(lgrngn.RH_formula_t))
+def test_cell_fields(RH_formula):
+    oi = h.box_opts(5, 3, 7, 8, RH_formula=RH_formula)
+    orc, hip = h.make_pair(oi, h.box_fields(oi, supersat=False))
+    for st in ("hskpng_Tpr", "hskpng_mfp"):
+        orc.stage(st)
+        hip.stage(st)
+    for f in ("T", "p", "RH", "eta", "dv", "lambda_D", "lambda_K"):
+        np.testing.assert_allclose(hip.state_real(f), orc.state_real(f), rtol=1e-12, err_msg=f)
+
+
+# ------------------------------------------------------------------ init with the oracle's random stream (a20)
+@pytest.mark.parametrize("dims", [(0, 0, 0), (6, 0, 0), (6, 0, 5), (4, 3, 5)])
+def test_init_replay(dims):
+    nx, ny, nz = dims
+    kw = dict(sedi_switch=False) if nz == 0 else {}
+    oi = h.box_opts(nx, ny, nz, 32, dx=25., **kw)
+    if nx == 0:
+        oi.dx = oi.dy = oi.dz = 1.
+        oi.x1 = oi.y1 = oi.z1 = 1.
+    fields = h.box_fields(oi, supersat=False)
+    orc, hip = h.make_pair(oi, fields, force_state=False)
+    assert hip.n_part == orc.n_part == 32 * max(nx, 1) * max(ny, 1) * max(nz, 1)
+    exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+    exact(hip.state_u64("count_num"), orc.state_u64("count_num"), "count_num")
+    exact(hip.state_u64("count_ijk"), orc.state_u64("count_ijk"), "count_ijk")
+    np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-14)
+    # multiplicities: n = floor(x + .5) of a value computed from rd3 -> at most a handful may differ by one
+    nh, no = hip.state_u64("n").astype(np.int64), orc.state_u64("n").astype(np.int64)
+    assert np.max(np.abs(nh - no)) <= 1 and np.mean(nh != no) < 1e-3
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)   # TOMS748 tolerance 2^-15
+    assert np.mean(hip.get_attr("rw2") != orc.get_attr("rw2")) < 0.5
+    for a, present in (("x", nx), ("y", ny), ("z", nz)):
+        if present:
+            np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14)
+    np.testing.assert_allclose(hip.state_real("vt"), orc.state_real("vt"), rtol=1e-4)
+
+
+# ------------------------------------------------------------------ sort (a2-a4)
+def test_sort_and_count_exact():
+    oi = h.box_opts(7, 5, 6, 40)
+    orc, hip = h.make_pair(oi, h.box_fields(oi))
+    # scramble cells: advect a few steps without anything else
+    opts = lgrngn.opts_t()
+    opts.cond = opts.coal = opts.sedi = False
+    for _ in range(3):
+        step_pair(orc, hip, opts, h.box_fields(oi))
+    for nm in ("ijk", "sorted_id", "sorted_ijk", "count_ijk", "count_num"):
+        exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+    # sortedness properties
+    sid, sijk, ijk = hip.state_u64("sorted_id"), hip.state_u64("sorted_ijk"), hip.state_u64("ijk")
+    assert np.all(np.diff(sijk.astype(np.int64)) >= 0)
+    exact(ijk[sid], sijk, "ijk[sorted_id]")
+    same = np.diff(sijk.astype(np.int64)) == 0
+    assert np.all(np.diff(sid.astype(np.int64))[same] > 0)      # stable: ids ascend inside a cell
+
+
+def test_shuffle_sort_replay_exact():
+    oi = h.box_opts(5, 4, 3, 70)            # > 64 SD per cell: segments span more than one wave
+    orc, hip = h.make_pair(oi, h.box_fields(oi))
+    n = orc.n_part
+    (un,) = h.oracle_rng_preview(orc, [(1, n)])
+    hip.rng_replay_push(1, un)
+    orc.stage("hskpng_shuffle_and_sort")
+    hip.stage("hskpng_shuffle_and_sort")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "shuffled sorted_id")
+    exact(hip.state_u64("sorted_ijk"), orc.state_u64("sorted_ijk"), "sorted_ijk")
+
+
+def test_big_segment_sort_0d():
+    """one cell with 5000 SDs: exercises the > LDS-segment path (bitonic in global scratch)"""
+    oi = h.box_opts(0, 0, 0, 5000, sedi_switch=False)
+    oi.dx = oi.dy = oi.dz = 1.
+    oi.x1 = oi.y1 = oi.z1 = 1.
+    orc, hip = h.make_pair(oi, h.box_fields(oi, supersat=False))
+    (un,) = h.oracle_rng_preview(orc, [(1, orc.n_part)])
+    hip.rng_replay_push(1, un)
+    orc.stage("hskpng_shuffle_and_sort")
+    hip.stage("hskpng_shuffle_and_sort")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "0-D shuffled sorted_id")
+
+
+# ------------------------------------------------------------------ terminal velocity (a6)
+@pytest.mark.parametrize("vt", [lgrngn.vt_t.beard76, lgrngn.vt_t.beard77, lgrngn.vt_t.beard77fast,
+                                lgrngn.vt_t.khvorostyanov_spherical, lgrngn.vt_t.khvorostyanov_nonspherical])
+def test_vterm(vt):
+    oi = h.box_opts(4, 3, 5, 32, terminal_velocity=vt)
+    orc, hip = h.make_pair(oi, h.box_fields(oi))
+    # spread radii over all regimes of the formulas (0.5 um .. 3 mm)
+    n = orc.n_part
+    rw2 = np.exp(np.linspace(np.log(0.5e-6), np.log(3e-3), n)) ** 2
+    g = lambda nm: orc.state_real(nm)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    orc.stage("hskpng_vterm_all")
+    hip.stage("hskpng_vterm_all")
+    vo, vh = orc.state_real("vt"), hip.state_real("vt")
+    np.testing.assert_allclose(vh, vo, rtol=1e-11)
+    if vt == lgrngn.vt_t.beard77fast:
+        np.testing.assert_allclose(hip.state_real("vt_0"), orc.state_real("vt_0"), rtol=1e-13)
+
+
+# ------------------------------------------------------------------ condensation (a7-a10)
+@pytest.mark.parametrize("sstp", [1, 4])
+def test_cond_step(sstp):
+    oi = h.box_opts(4, 4, 6, 64, sstp_cond=sstp)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+    for it in range(3):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
+        np.testing.assert_allclose(rh, ro, rtol=1e-4)
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        h.copy_state(orc, hip)      # keep later iterations comparable one step at a time
+    assert np.mean(rh != ro) < 0.5
+
+
+def test_cond_moment_feedback_conservation():
+    """size-independent property: d(rv) summed over cells == -4/3 pi rho_w d(sum n rw^3)/(dv rhod)"""
+    oi = h.box_opts(6, 5, 4, 64)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+
+    def m3():
+        hip.diag_all()
+        hip.diag_wet_mom(3)
+        return hip.outbuf_array().reshape(rv.shape)
+    before = m3()
+    thh, rvh = th.copy(), rv.copy()
+    hip.step_sync(opts, thh, rvh, rhod, **C)
+    hip.step_async(opts)
+    after = m3()
+    drv = -(after - before) * 4. / 3 * np.pi * 1e3
+    np.testing.assert_allclose(rvh - rv, drv, rtol=1e-9, atol=1e-16)
+
+
+# ------------------------------------------------------------------ coalescence (a11, a12)
+@pytest.mark.parametrize("kernel,params", [(lgrngn.kernel_t.geometric, []), (lgrngn.kernel_t.geometric, [0.5]),
+                                           (lgrngn.kernel_t.golovin, [1500.]), (lgrngn.kernel_t.Long, [])])
+def test_coal_replay(kernel, params):
+    oi = h.box_opts(3, 3, 3, 96, kernel=kernel, kernel_parameters=np.array(params), dx=1.)
+    oi.dt = 30.      # long step + small cells -> many collisions
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    # rain-sized droplets so that the collision probability is appreciable
+    n = orc.n_part
+    rng = np.random.default_rng(1)
+    rw2 = (10 ** rng.uniform(-5.3, -3.5, n)) ** 2
+    g = lambda nm: orc.state_real(nm)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    for st in ("hskpng_Tpr", "hskpng_vterm_all"):
+        orc.stage(st)
+        hip.stage(st)
+    np.testing.assert_allclose(hip.state_real("vt"), orc.state_real("vt"), rtol=1e-11)
+    hip.set_particles(orc.state_u64("n"), g("rd3"), g("rw2"), g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    h.push_coal_replay(orc, hip)
+    orc.stage("coal")
+    hip.stage("coal")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+    n_o, n_h = orc.state_u64("n"), hip.state_u64("n")
+    assert np.sum(n_o != args[0]) > 10, "test needs collisions to happen"
+    exact(n_h, n_o, "multiplicities after coalescence")
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-14)
+    np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-14)
+    exact(hip.state_real("vt") == -1, orc.state_real("vt") == -1, "invalidated vt flags")
+    np.testing.assert_allclose(hip.state_real("col")[:-1], orc.state_real("col")[:-1], rtol=0, atol=0)
+
+
+def test_coal_two_kappas_replay():
+    """kappa mixing (weighted_summator) with two aerosol modes"""
+    oi = h.box_opts(0, 0, 0, 2048, sedi_switch=False)
+    oi.dx = oi.dy = oi.dz = 1.
+    oi.x1 = oi.y1 = oi.z1 = 1.
+    oi.dt = 100.
+    f = h.lognormal_fn(20e-6, 1.5, 3e7)
+    oi.dry_distros = {(.1, 0.): f, (.9, 0.): f}
+    oi.n_sd_max = 2048
+    th, rv, rhod = np.array([300.]), np.array([.01]), np.array([1.])
+    orc, hip = h.oracle_particles(oi), h.hip_particles(oi)
+    for arr in h.oracle_rng_preview(orc, [(0, 1024)] * 2):
+        hip.rng_replay_push(0, arr)
+    orc.init(th, rv, rhod)
+    hip.init(th, rv, rhod)
+    h.copy_state(orc, hip)
+    for st in ("hskpng_Tpr", "hskpng_vterm_all"):
+        orc.stage(st)
+        hip.stage(st)
+    h.copy_state(orc, hip)
+    h.push_coal_replay(orc, hip)
+    orc.stage("coal")
+    hip.stage("coal")
+    exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+    assert np.sum(orc.state_real("col")[:-1] > 0) > 10
+    np.testing.assert_allclose(hip.get_attr("kappa"), orc.get_attr("kappa"), rtol=1e-13)
+
+
+# ------------------------------------------------------------------ advection / sedimentation / boundary (a13-a16)
+@pytest.mark.parametrize("scheme", [lgrngn.as_t.euler, lgrngn.as_t.implicit])
+@pytest.mark.parametrize("dims", [(6, 0, 5), (5, 4, 6)])
+def test_move_and_post_copy(scheme, dims):
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 48, adve_scheme=scheme, dx=30.)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    # make a good fraction of SDs rain-sized so that they fall through the bottom
+    n = orc.n_part
+    rw2 = orc.get_attr("rw2")
+    rw2[::3] = (1.5e-3) ** 2
+    g = lambda nm: orc.state_real(nm)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y") if ny else None, g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.cond = opts.coal = False
+    for it in range(4):
+        step_pair(orc, hip, opts, fields)
+        assert hip.n_part == orc.n_part
+        for a in ("x", "y", "z"):
+            if getattr(oi, "n" + a):
+                np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14, atol=1e-9, err_msg=a)
+        for nm in ("ijk", "sorted_id", "count_num", "n"):
+            exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+        h.copy_state(orc, hip)
+    assert orc.n_part < n, "test needs precipitation to happen"
+    po, ph = orc.diag_puddle(), hip.diag_puddle()
+    for k in po:
+        np.testing.assert_allclose(ph[k], po[k], rtol=1e-12, err_msg=k)
+
+
+def test_advection_shifts_by_one_cell():
+    """tests/python/unit/lgrngn_adve.py:97-105: C = +-1 moves the sd_conc field by exactly one cell"""
+    for Cx, roll in ((1., -1), (-1., 1)):
+        oi = lgrngn.opts_init_t()
+        oi.dry_distros = {(.61, 0.): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6)}
+        oi.coal_switch = oi.sedi_switch = False
+        oi.dt = 1
+        oi.nz, oi.nx, oi.dz, oi.dx = 5, 6, 1, 1
+        oi.z1, oi.x1 = oi.nz * oi.dz, oi.nx * oi.dx
+        oi.sd_conc = 10
+        oi.n_sd_max = 10 * oi.nx * oi.nz
+        opts = lgrngn.opts_t()
+        opts.sedi = opts.cond = opts.coal = False
+        rhod, th, rv = 1. * np.ones((oi.nx, oi.nz)), 300. * np.ones((oi.nx, oi.nz)), 0.01 * np.ones((oi.nx, oi.nz))
+        pr = h.hip_particles(oi)
+        pr.init(th, rv, rhod, Cx=Cx * np.ones((oi.nx + 1, oi.nz)), Cz=np.zeros((oi.nx, oi.nz + 1)))
+        pr.step_sync(opts, th, rv, rhod)
+        pr.diag_all()
+        pr.diag_sd_conc()
+        tab_in = np.frombuffer(pr.outbuf()).reshape(oi.nx, oi.nz).copy()
+        pr.step_async(opts)
+        pr.step_sync(opts, th, rv, rhod)
+        pr.diag_all()
+        pr.diag_sd_conc()
+        tab_out = np.frombuffer(pr.outbuf()).reshape(oi.nx, oi.nz).copy()
+        assert (tab_in == np.roll(tab_out, roll, 0)).all()
+        assert tab_in.sum() == oi.sd_conc * oi.nx * oi.nz
+
+
+# ------------------------------------------------------------------ full steps, everything on, replayed stream
+@pytest.mark.parametrize("dims,sstp", [((4, 4, 4), (1, 1)), ((8, 0, 8), (3, 2))])
+def test_full_steps_replay(dims, sstp):
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 64, sstp_cond=sstp[0], sstp_coal=sstp[1])
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    for it in range(3):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        assert hip.n_part == orc.n_part
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)
+        h.copy_state(orc, hip)
+
+
+# ------------------------------------------------------------------ API behaviour (api_lgrngn.py:123-133,166-170)
+def test_call_order_exceptions():
+    oi = h.box_opts(0, 0, 0, 64, sedi_switch=False)
+    oi.dx = oi.dy = oi.dz = 1.
+    oi.x1 = oi.y1 = oi.z1 = 1.
+    th, rv, rhod = np.array([300.]), np.array([.01]), np.array([1.])
+    pr = h.hip_particles(oi)
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.adve = False
+    with pytest.raises(RuntimeError):
+        pr.step_sync(opts, th, rv, rhod)          # before init
+    pr.init(th, rv, rhod)
+    with pytest.raises(RuntimeError):
+        pr.init(th, rv, rhod)                     # init twice
+    with pytest.raises(RuntimeError):
+        pr.step_async(opts)                       # async before sync
+    pr.step_sync(opts, th, rv, rhod)
+    with pytest.raises(RuntimeError):
+        pr.step_sync(opts, th, rv, rhod)          # sync twice
+    pr.step_async(opts)
+    with pytest.raises(RuntimeError):
+        pr.step_async(opts)                       # async twice
+    pr.diag_all()
+    pr.diag_sd_conc()
+    assert np.frombuffer(pr.outbuf())[0] == 64
+
+
+def test_float_build_runs_and_tracks_double():
+    oi = h.box_opts(4, 4, 4, 64)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = {}
+    for rt in (np.float64, np.float32):
+        pr = h.hip_particles(oi, rt)
+        f = lambda a: np.ascontiguousarray(a, dtype=rt)
+        tt, rr, dd = f(th), f(rv), f(rhod)
+        CC = {k: f(v) for k, v in C.items()}
+        pr.init(tt, rr, dd, **CC)
+        opts = lgrngn.opts_t()
+        for it in range(3):
+            pr.step_sync(opts, tt, rr, dd, **CC)
+            pr.step_async(opts)
+        res[rt] = (tt.astype(np.float64), rr.astype(np.float64), pr.n_part)
+    np.testing.assert_allclose(res[np.float32][0], res[np.float64][0], rtol=2e-5)
+    np.testing.assert_allclose(res[np.float32][1], res[np.float64][1], rtol=2e-3)
