@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- super-droplets/s of the lgrngn time step (step_sync + step_async: condensation,
+coalescence, advection, sedimentation, boundary, re-sort) on the BASELINE workload:
+3-D stratocumulus-like box 128^3 cells x 64 super-droplets per cell (BASELINE.json configs[2]).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pass of the hot path over all super-droplets.  Inputs (th, rv, rhod, Courant numbers) are
+device-resident when the timed region starts.  Rank 0 prints ONE JSON line.  N > 1: the SAME box is split into N
+slabs along x (strong scaling, as BASELINE.json's metric asks: one problem at 1/2/4/8 GPUs); migrating
+super-droplets are exchanged with the two neighbours over RCCL point-to-point (no collective).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
+def bimodal():
+    from libcloudphxx_amd import lgrngn
+    # icicle's aerosol, models/kinematic_2D/src/opts_common.hpp:56-62
+    return lgrngn.lognormal([.02e-6, .075e-6], [1.4, 1.6], [60e6, 40e6])
+
+
+def make_opts_init(nx, ny, nz, sd_conc, dx, sstp_cond, sstp_coal, seed):
+    from libcloudphxx_amd import lgrngn
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.ny, oi.nz = nx, ny, nz
+    oi.dx = oi.dy = oi.dz = dx
+    oi.x1, oi.y1, oi.z1 = nx * dx, ny * dx, nz * dx
+    oi.dt = 1.
+    oi.sd_conc = sd_conc
+    oi.n_sd_max = int(nx * ny * nz * sd_conc * 1.15) + 1024
+    oi.dry_distros = {(.61, 0.): bimodal()}
+    oi.kernel = lgrngn.kernel_t.hall_pinsky_stratocumulus if os.path.exists(
+        os.path.join(ROOT, "libcloudphxx_amd", "data", "kernel_eff_10.f64")) else lgrngn.kernel_t.Long
+    oi.terminal_velocity = lgrngn.vt_t.beard77fast
+    oi.adve_scheme = lgrngn.as_t.euler
+    oi.sstp_cond, oi.sstp_coal = sstp_cond, sstp_coal
+    oi.rng_seed = seed
+    return oi
+
+
+def make_fields(nx_loc, ny, nz, x_off, nx_tot, xp, dtype):
+    """th, rv, rhod and a smooth non-divergent-ish Courant field with |C| <= 0.3 for the slab of x-planes
+    [x_off, x_off + nx_loc).  xp is numpy (CPU sample) or torch-on-device."""
+    def idx(shape, axis, off=0.):
+        n = shape[axis]
+        v = xp.arange(n, dtype=dtype) + off
+        sh = [1, 1, 1]
+        sh[axis] = n
+        return v.reshape(sh)
+    two_pi = 2 * np.pi
+    s = (nx_loc, ny, nz)
+    z = idx(s, 2, .5) / nz
+    th = 289. + 0. * z + 0.2 * xp.sin(two_pi * (idx(s, 0, x_off) / nx_tot)) * xp.cos(two_pi * idx(s, 1) / ny)
+    rhod = 1.1 - 0.02 * z + 0. * th
+    # rv from a target relative humidity: 0.85 at the bottom rising to 1.015 in the upper third (activation + growth)
+    R_d, R_v, c_pd = 8.3144621 / 0.02897, 8.3144621 / 0.018, 1005.
+    T = (th * (rhod * R_d / 1e5) ** (R_d / c_pd)) ** (c_pd / (c_pd - R_d))
+    p_vs = 611.73 * xp.exp((2.5e6 + (4218. - 1850.) * 273.16) / R_v * (1. / 273.16 - 1. / T) - (4218. - 1850.) / R_v * xp.log(T / 273.16))
+    RH_t = 0.85 + 0.25 * z
+    RH_t = RH_t - (RH_t - 1.015) * (RH_t > 1.015)
+    rv = RH_t * p_vs / (rhod * R_v * T)
+    sx, sy, sz = (nx_loc + 1, ny, nz), (nx_loc, ny + 1, nz), (nx_loc, ny, nz + 1)
+    Cx = 0.3 * xp.sin(two_pi * idx(sx, 1, .5) / ny) * xp.cos(np.pi * idx(sx, 2, .5) / nz) + 0. * idx(sx, 0)
+    Cy = 0.2 * xp.sin(two_pi * (idx(sy, 0, x_off + .5) / nx_tot)) + 0. * idx(sy, 1) + 0. * idx(sy, 2)
+    Cz = 0.1 * xp.sin(two_pi * (idx(sz, 0, x_off + .5) / nx_tot)) * xp.sin(np.pi * idx(sz, 2) / nz) + 0. * idx(sz, 1)
+    return [a.contiguous() if hasattr(a, "contiguous") else np.ascontiguousarray(a) for a in (th, rv, rhod, Cx, Cy, Cz)]
+
+
+def cpu_baseline(args):
+    """the CPU oracle (a serial port of the reference path) timed on a bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _harness as h
+    from libcloudphxx_amd import lgrngn
+    n = args.cpu_sample_n
+    oi = make_opts_init(n, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44)
+    th, rv, rhod, Cx, Cy, Cz = make_fields(n, n, n, 0, n, np, np.float64)
+    pr = h.oracle_particles(oi)
+    pr.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
+    opts = lgrngn.opts_t()
+    pr.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+    pr.step_async(opts)
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(args.cpu_sample_steps):
+        pr.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        pr.step_async(opts)
+        done += pr.n_part
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "super-droplets/s", "cores": 1, "kind": "port",
+            "sample": "%d^3 cells x %d SD/cell, %d full steps (cond+coal+adve+sedi), serial C oracle, %.1f s" % (n, args.sd_conc, args.cpu_sample_steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=128, help="cells per dimension (BASELINE: 128)")
+    ap.add_argument("--sd-conc", type=int, default=64)
+    ap.add_argument("--dx", type=float, default=40.)
+    ap.add_argument("--sstp-cond", type=int, default=1)
+    ap.add_argument("--sstp-coal", type=int, default=1)
+    ap.add_argument("--real", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=24)
+    ap.add_argument("--cpu-sample-steps", type=int, default=6)
+    ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from libcloudphxx_amd import lgrngn, multi
+    real_t = np.float64 if args.real == "f64" else np.float32
+    tdtype = torch.float64 if args.real == "f64" else torch.float32
+    n = args.n
+    nx_tot = n * world if args.scaling == "weak" else n
+    oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
+    oi.dev_id = local_rank
+    if world > 1:
+        prt = multi.particles_multi_t(oi, real_t, device=dev)
+        nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
+    else:
+        prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
+        nx_loc, x_off = nx_tot, 0
+
+    class TorchXP:                      # the tiny subset of the numpy namespace make_fields uses, on the device
+        @staticmethod
+        def arange(m, dtype=None):
+            return torch.arange(m, dtype=tdtype, device=dev)
+        sin, cos, exp, log = staticmethod(torch.sin), staticmethod(torch.cos), staticmethod(torch.exp), staticmethod(torch.log)
+    fields_t = make_fields(nx_loc, n, n, x_off, nx_tot, TorchXP, tdtype)
+    shapes = [(nx_loc, n, n)] * 3 + [(nx_loc + 1, n, n), (nx_loc, n + 1, n), (nx_loc, n, n + 1)]
+    fields_t = [f.expand(s).contiguous() for f, s in zip(fields_t, shapes)]
+    th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in fields_t]
+    torch.cuda.synchronize()
+
+    t_init = time.perf_counter()
+    prt.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
+    opts = lgrngn.opts_t()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        prt.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        prt.step_async(opts)
+
+    for _ in range(args.warmup):
+        one_step()
+    p1 = prt.prt if world > 1 else prt
+    if not args.no_stage_timers:
+        p1.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    sd_done = 0
+    for _ in range(args.steps):
+        one_step()
+        sd_done += p1.n_part
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_ms = p1.timings() if not args.no_stage_timers else {}
+    tt = torch.tensor([elapsed, float(sd_done)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, sd_total = float(tmax[0]), float(tsum[1])
+    else:
+        sd_total = float(sd_done)
+
+    if rank == 0:
+        R = 8 if args.real == "f64" else 4
+        # ALGORITHMIC bytes of the dominant kernel (k_cond), SURVEY 8(d): 5R (rw2,rd3,kpa,vt read + rw2 write)
+        # + I (sorted_id + sorted_ijk, two u32 = 8 B) + N (multiplicity, 8 B) per super-droplet per substep
+        cond_bytes_per_sd = 5 * R + 8 + 8
+        n_local = sd_done / max(args.steps, 1)
+        roof = None
+        if "cond" in stage_ms:
+            launches = args.steps * args.sstp_cond
+            avg_ms = stage_ms["cond"] / launches
+            ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_sd": cond_bytes_per_sd}
+        out = {
+            "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
+            "value": sd_total / elapsed,
+            "unit": "super-droplets/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.scaling,
+            "vs_baseline": None,
+            "dtype": args.real,
+            "data": "synthetic",
+            "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
+                                   % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
+                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d" % world,
+                       "init_s": t_init},
+            "roofline": roof,
+            "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
