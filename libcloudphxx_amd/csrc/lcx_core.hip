@@ -359,8 +359,14 @@ struct Particles : IParticles {
   void sort_from_hist(bool shuffle)
   {
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell);
-    if (npart) {
+    if (npart)
       hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(npart)), dim3(BS), 0, st, npart, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
+    order_cells(shuffle);
+  }
+  // puts every cell segment of sorted_id into the reference's order: ascending id, or ascending (un[id], id)
+  void order_cells(bool shuffle)
+  {
+    if (npart) {
       rng_src rs{nullptr, 0, 0};
       if (shuffle) rs = rand_un(npart);
       if (ncell == 1 && !shuffle) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
@@ -386,6 +392,7 @@ struct Particles : IParticles {
   void hskpng_sort_helper(bool shuffle)
   {
     Range r(this, shuffle ? "hskpng_shuffle_and_sort" : "hskpng_sort");
+    if (sorted && shuffle) { order_cells(true); return; }   // cells unchanged since the last sort: re-order the segments only
     ijk_and_hist(false, true);
     sort_from_hist(shuffle);
   }
@@ -454,7 +461,7 @@ struct Particles : IParticles {
     }
     {
       Range r(this, "cond_cellfinish");
-      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, CF_CELLS)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
                          rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
     }
   }
@@ -800,7 +807,7 @@ struct Particles : IParticles {
     hskpng_sort();
     if (npart)
       hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, power, kind, m3_after.p);
-    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p,
+    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, CF_CELLS)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p,
                        int(specific && n_dims > 0), count_mom.p);
     sync();
   }
