@@ -372,9 +372,9 @@ struct Particles : IParticles {
       if (ncell == 1 && !shuffle) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
         HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
-        const unsigned blocks = unsigned(std::min<size_t>((ncell + 3) / 4, 4096));
-        hipLaunchKernelGGL(k_cellsort, dim3(blocks), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, int(shuffle), rs,
-                           big_list.p, big_meta.p, big_meta.p + 1);
+        hipLaunchKernelGGL(k_cellrank, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
+                           int(shuffle), rs, big_list.p, big_meta.p, big_meta.p + 1);
+        sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         uint32_t meta[2];
         HIPCHK(hipMemcpyAsync(meta, big_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
         sync();

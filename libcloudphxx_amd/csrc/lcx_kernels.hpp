@@ -221,10 +221,13 @@ __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *
 
 // Per-cell ordering.  Reference semantics (hskpng_sort.ipp:15-57): sorted_id = stable_sort_by_key(ijk) of the
 // sequence 0..n-1  => inside a cell ids ascend; shuffled variant: first stable sort by the random key un[id],
-// then stable sort by cell => inside a cell (un[id], id) ascends.  Each wave owns one cell segment staged in
-// LDS and ranks every element by counting smaller keys (keys are unique): O(count^2/64) LDS broadcast reads
-// per lane, no data-dependent branching, no inter-wave traffic.
-constexpr int CELLSORT_MAX = 1024;      // largest segment handled in LDS by one wave (8 KiB of u64 keys)
+// then stable sort by cell => inside a cell (un[id], id) ascends.
+// One lane per position of the cell-grouped order (dense, coalesced).  A workgroup stages the keys of all cells
+// its 256 positions touch (its own range plus the overhang of the first and last cell) in LDS; every lane then
+// ranks its key inside its cell by counting smaller keys (keys are unique) with LDS broadcast reads and writes
+// its id to `out` at cell_start + rank.  O(count) reads per lane, no data-dependent branching, no atomics.
+constexpr int CELLSORT_MAX = 1024;      // cells with more SDs go to k_cellsort_big
+constexpr int CR_CAP = 1024;            // keys staged per workgroup (8 KiB)
 struct rng_src { const uint32_t *un; uint64_t call, seed; };
 
 __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng_src &r)
@@ -234,33 +237,34 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
   return (uint64_t(u) << 32) | id;
 }
 __global__ void __launch_bounds__(BS)
-k_cellsort(size_t n_cell, const uint32_t *cell_start, uint32_t *sorted_id, int shuffle, rng_src r,
-           uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out,
+           int shuffle, rng_src r, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
 {
-  __shared__ uint64_t keys[BS / WAVE][CELLSORT_MAX];
-  const unsigned w = wave_id(), l = lane_id(), wpb = BS / WAVE;
-  const size_t waves_total = size_t(gridDim.x) * wpb;
-  const size_t iters = (n_cell + waves_total - 1) / waves_total;      // uniform trip count: barriers are legal
-  for (size_t it = 0; it < iters; ++it) {
-    const size_t c = it * waves_total + size_t(blockIdx.x) * wpb + w;
-    uint32_t start = 0, cnt = 0;
-    if (c < n_cell) { start = cell_start[c]; cnt = cell_start[c + 1] - start; }
-    if (cnt > CELLSORT_MAX) {
-      if (l == 0) { const uint32_t k = atomicAdd(big_count, 1u); big_list[k] = uint32_t(c); atomicMax(big_max, cnt); }
-      cnt = 0;
-    }
-    const bool active = cnt > 1;
-    if (active) for (uint32_t j = l; j < cnt; j += WAVE) keys[w][j] = sort_key(sorted_id[start + j], shuffle, r);
-    __syncthreads();
-    if (active)
-      for (uint32_t m = l; m < cnt; m += WAVE) {
-        const uint64_t mine = keys[w][m];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < cnt; ++j) rank += keys[w][j] < mine;
-        sorted_id[start + rank] = uint32_t(mine);
-      }
-    __syncthreads();
+  __shared__ uint64_t lds[CR_CAP];
+  const size_t p0 = size_t(blockIdx.x) * BS;
+  const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
+  const uint32_t lo = cell_start[sorted_ijk[p0]], hi = cell_start[sorted_ijk[plast] + 1];
+  const bool staged = (hi - lo) <= uint32_t(CR_CAP);
+  if (staged) for (uint32_t q = lo + threadIdx.x; q < hi; q += BS) lds[q - lo] = sort_key(in[q], shuffle, r);
+  __syncthreads();
+  const size_t p = p0 + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t c = sorted_ijk[p], s = cell_start[c], e = cell_start[c + 1], cnt = e - s;
+  if (cnt > uint32_t(CELLSORT_MAX)) {
+    if (p == s) { const uint32_t k = atomicAdd(big_count, 1u); big_list[k] = c; atomicMax(big_max, cnt); }
+    out[p] = in[p];
+    return;
   }
+  uint32_t rank = 0;
+  uint64_t mine;
+  if (staged) {
+    mine = lds[p - lo];
+    for (uint32_t q = s; q < e; ++q) rank += lds[q - lo] < mine;
+  } else {
+    mine = sort_key(in[p], shuffle, r);
+    for (uint32_t q = s; q < e; ++q) rank += sort_key(in[q], shuffle, r) < mine;
+  }
+  out[s + rank] = uint32_t(mine);
 }
 // segments larger than CELLSORT_MAX (e.g. a 0-D parcel): one workgroup per segment, bitonic network on a
 // power-of-two padded scratch copy in global memory
@@ -356,11 +360,11 @@ __global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
   const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
   const T rw2_old = a.rw2[id];
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
-  if (a.first) a.m3_before[pos] = nn * (rw2_old >= 0 ? rw2_old * T(sqrt(rw2_old)) : T(0));
-  const T rw2_new = advance_rw2(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
-                                a.lambda_D[c], a.lambda_K[c], a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
-  a.rw2[id] = rw2_new;
-  a.m3_after[pos] = nn * (rw2_new >= 0 ? rw2_new * T(sqrt(rw2_new)) : T(0));
+  if (a.first) a.m3_before[pos] = rw2_old >= 0 ? nn * (rw2_old * T(sqrt(rw2_old))) : nn * rw2_old;
+  const T r = advance_rw2(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
+                          a.lambda_D[c], a.lambda_K[c], a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
+  a.rw2[id] = r;
+  a.m3_after[pos] = r >= 0 ? nn * (r * T(sqrt(r))) : nn * r;
 }
 // Per-cell finish: sums the cell's contributions IN SORTED ORDER (the same addition order as the reference's
 // serial reduce_by_key), converts to the specific moment and applies the condensational feedback.
