@@ -1,0 +1,16 @@
+// backend_t with the reference's enumerators (reference: lgrngn/backend.hpp:8) plus the two HIP slots.
+// CUDA / multi_CUDA are accepted as aliases of HIP / multi_HIP by factory() so that a driver that asks for
+// "the GPU backend" keeps working; serial / OpenMP are not part of this library.
+#pragma once
+#include <string>
+#include <unordered_map>
+namespace libcloudphxx { namespace lgrngn {
+  enum backend_t { undefined, serial, OpenMP, CUDA, multi_CUDA, HIP, multi_HIP };
+  inline const char *backend_str(backend_t b)
+  {
+    switch (b) { case serial: return "serial"; case OpenMP: return "OpenMP"; case CUDA: return "CUDA"; case multi_CUDA: return "multi_CUDA";
+                 case HIP: return "HIP"; case multi_HIP: return "multi_HIP"; default: return "undefined"; }
+  }
+  static const std::unordered_map<int, std::string> backend_name = {
+    {undefined, "undefined"}, {serial, "serial"}, {OpenMP, "OpenMP"}, {CUDA, "CUDA"}, {multi_CUDA, "multi_CUDA"}, {HIP, "HIP"}, {multi_HIP, "multi_HIP"}};
+} }

@@ -1,0 +1,21 @@
+// factory<real_t>(backend, opts_init): same signature and failure mode as the reference
+// (reference: lgrngn/factory.hpp:12-15, src/lib.cpp:13-40 -- std::runtime_error for a backend that is not built in).
+#pragma once
+#include "particles.hpp"
+namespace libcloudphxx { namespace lgrngn {
+  template <typename real_t>
+  inline particles_proto_t<real_t> *factory(const backend_t backend, opts_init_t<real_t> opts_init)
+  {
+    switch (backend) {
+      case HIP:
+      case CUDA:              // "the GPU backend" of a driver written for the reference
+        return new particles_t<real_t, HIP>(opts_init);
+      case multi_HIP:
+      case multi_CUDA:
+        throw std::runtime_error("libcloudph++: the multi-GPU backend of this library is one process per GPU "
+                                 "(libcloudphxx_amd.multi + torch.distributed/RCCL); see INTEGRATION.md");
+      default:
+        throw std::runtime_error(std::string("libcloudph++: backend ") + backend_str(backend) + " is not part of the HIP library (available: HIP)");
+    }
+  }
+} }

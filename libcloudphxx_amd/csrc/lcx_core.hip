@@ -117,7 +117,7 @@ struct Particles : IParticles {
   DevBuf<T> courant_x, courant_y, courant_z, w_LS, conc_factor, vt_0, kparams;
   size_t n_cx = 0, n_cy = 0, n_cz = 0;
   DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
-  DevBuf<double> puddle_partial; std::vector<double> puddle_partial_h;
+  DevBuf<double> puddle_partial, puddle_sum;
   DevBuf<int> d_flag;
   double puddle[LCX_OUT_COUNT];
   bool count_mom_valid_all = true;
@@ -181,7 +181,7 @@ struct Particles : IParticles {
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
       b->alloc_zero(ncell, st);
     d_flag.alloc_zero(1, st);
-    puddle_partial.alloc(size_t(nblk(cap)) * 4);
+    puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4);
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
   }
@@ -456,7 +456,7 @@ struct Particles : IParticles {
     if (npart) {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
-                     lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0};
+                     lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell};
       hipLaunchKernelGGL(k_cond<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
     }
     {
@@ -511,12 +511,11 @@ struct Particles : IParticles {
     a.mig = mig.p;
     hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
     if (want_puddle) {
-      puddle_partial_h.resize(size_t(blocks) * 4);
-      HIPCHK(hipMemcpyAsync(puddle_partial_h.data(), puddle_partial.p, puddle_partial_h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), puddle_sum.p);
+      double s4[4];
+      HIPCHK(hipMemcpyAsync(s4, puddle_sum.p, sizeof s4, hipMemcpyDeviceToHost, st));
       sync();
-      double s[4] = {0, 0, 0, 0};
-      for (unsigned b = 0; b < blocks; ++b) for (int k = 0; k < 4; ++k) s[k] += puddle_partial_h[size_t(b) * 4 + k];
-      puddle[LCX_OUT_LIQ_VOL] += s[0]; puddle[LCX_OUT_DRY_VOL] += s[1]; puddle[LCX_OUT_LIQ_NUM] += s[2]; puddle[LCX_OUT_PRTCL_NUM] += s[3];
+      puddle[LCX_OUT_LIQ_VOL] += s4[0]; puddle[LCX_OUT_DRY_VOL] += s4[1]; puddle[LCX_OUT_LIQ_NUM] += s4[2]; puddle[LCX_OUT_PRTCL_NUM] += s4[3];
     }
     if (do_bcnd && distmem()) build_migrant_lists();
   }

@@ -351,7 +351,7 @@ struct cond_args {
   const n_t *n; const T *rd3, *kpa, *vt; T *rw2;
   const T *rhod, *rv, *Tk, *eta, *RH, *lambda_D, *lambda_K;
   T *m3_before, *m3_after;
-  T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first;
+  T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
 };
 template <class T>
 __global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
@@ -650,6 +650,22 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
       a.puddle_partial[size_t(blockIdx.x) * 4 + threadIdx.x] = s;
     }
   }
+}
+
+// fixed-order reduction of the per-workgroup precipitation partials (deterministic for a given launch geometry)
+__global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, double *out4)
+{
+  __shared__ double red[4][BS];
+  double acc[4] = {0, 0, 0, 0};
+  for (size_t b = threadIdx.x; b < nblocks; b += BS)
+    for (int k = 0; k < 4; ++k) acc[k] += partials[b * 4 + k];
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int d = BS / 2; d > 0; d >>= 1) {
+    if (int(threadIdx.x) < d) for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) out4[threadIdx.x] = red[threadIdx.x][0];
 }
 
 // ============================================================================================

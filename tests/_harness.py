@@ -186,3 +186,77 @@ def push_coal_replay(orc, hip, sstp_coal=1):
     calls = [(1, n), (0, n)] * sstp_coal
     for (kind, _), arr in zip(calls, oracle_rng_preview(orc, calls)):
         hip.rng_replay_push(kind, arr)
+
+
+# ------------------------------------------------------------------ in-process ring of slabs (drives the migration primitives)
+class LocalRing:
+    """N slabs of one periodic domain held by N particle objects in ONE process; migrants are moved with the same
+    pack / unpack / finish primitives the multi-process wrapper (libcloudphxx_amd/multi.py) uses, without
+    torch.distributed.  make(oi) -> particles object; alloc(nbytes) -> (keepalive, address)."""
+
+    def __init__(self, oi_global, size, make, alloc):
+        from libcloudphxx_amd import multi
+        self.size, self.alloc, self.oi = size, alloc, oi_global
+        self.prts, self.bfr, self.nxl = [], [], []
+        for r in range(size):
+            o, b = multi.distmem_opts(oi_global, r, size)
+            o.n_x_bfr = 0
+            o.rng_seed = oi_global.rng_seed + r
+            self.prts.append(make(o))
+            self.bfr.append(b)
+            self.nxl.append(o.nx)
+
+    def slab(self, arr, r, ext=0):
+        return np.ascontiguousarray(arr[self.bfr[r]:self.bfr[r] + self.nxl[r] + ext])
+
+    def init(self, th, rv, rhod, Cx=None, Cy=None, Cz=None):
+        for r, p in enumerate(self.prts):
+            kw = {}
+            if Cx is not None: kw["Cx"] = self.slab(Cx, r, 1)
+            if Cy is not None: kw["Cy"] = self.slab(Cy, r)
+            if Cz is not None: kw["Cz"] = self.slab(Cz, r)
+            p.init(self.slab(th, r), self.slab(rv, r), self.slab(rhod, r), **kw)
+
+    def step(self, opts, th, rv, rhod, Cx=None, Cy=None, Cz=None):
+        for r, p in enumerate(self.prts):
+            a = [self.slab(th, r), self.slab(rv, r), self.slab(rhod, r),
+                 None if Cx is None else self.slab(Cx, r, 1), None if Cy is None else self.slab(Cy, r), None if Cz is None else self.slab(Cz, r)]
+            p.step_sync(opts, *a)
+            th[self.bfr[r]:self.bfr[r] + self.nxl[r]] = a[0]
+            rv[self.bfr[r]:self.bfr[r] + self.nxl[r]] = a[1]
+            p.step_async(opts)
+        n = self.size
+        packs = []
+        for r, p in enumerate(self.prts):
+            nl, nr = p.migrate_counts()
+            rec = p.migrate_record_bytes()
+            lft, rgt = (r - 1) % n, (r + 1) % n
+            lft_x1 = self.prts[lft].opts_init.x1
+            rgt_x0 = self.prts[rgt].opts_init.x0
+            kl, pl = self.alloc(max(nl * rec, 8))
+            kr, pr_ = self.alloc(max(nr * rec, 8))
+            if nl: p.migrate_pack(0, lft_x1, pl, nl * rec)
+            if nr: p.migrate_pack(1, rgt_x0, pr_, nr * rec)
+            packs.append((nl, pl, kl, nr, pr_, kr))
+        for r, p in enumerate(self.prts):
+            lft, rgt = (r - 1) % n, (r + 1) % n
+            n_from_l, p_from_l = packs[lft][3], packs[lft][4]      # left neighbour's right-going
+            n_from_r, p_from_r = packs[rgt][0], packs[rgt][1]      # right neighbour's left-going
+            if n_from_l: p.migrate_unpack(p_from_l, n_from_l)
+            if n_from_r: p.migrate_unpack(p_from_r, n_from_r)
+        for p in self.prts:
+            p.migrate_finish(opts)
+
+    def gather(self, fn):
+        return np.concatenate([fn(p) for p in self.prts])
+
+
+def host_alloc(nbytes):
+    a = np.zeros(nbytes, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+def dev_alloc(nbytes):
+    import torch
+    t = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    return t, t.data_ptr()

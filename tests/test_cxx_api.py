@@ -1,0 +1,26 @@
+"""The C++ host mirror (include/libcloudph++/lgrngn/*.hpp over the C ABI): a driver written against the
+reference's C++ interface, built by examples/Makefile, run on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "parcel_cxx")
+
+
+def test_cxx_example_builds():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    assert os.path.exists(EXE)
+
+
+@pytest.mark.gpu
+def test_cxx_example_runs():
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    out = subprocess.check_output([EXE], env=dict(os.environ, LCX_DATA_DIR=os.path.join(ROOT, "libcloudphxx_amd", "data"))).decode()
+    vals = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
+    assert vals["call_order_exception"] == ["1"]
+    th, rv, sd = float(vals["parcel"][1]), float(vals["parcel"][3]), float(vals["parcel"][5])
+    assert abs(th - 307.78) < 1e-4 * 307.78 and abs(rv - 1.7e-2) < 1e-3 * 1.7e-2 and sd == 100   # lgrngn_cond.py:52-56
+    assert float(vals["box"][1]) == 300 and int(vals["box"][3]) == 300

@@ -1,0 +1,88 @@
+"""GPU tests of the 1-D decomposition primitives (migrant lists, pack, unpack, finish): a ring of slabs driven
+in one process on one GPU, compared slab by slab with the oracle running the identical protocol."""
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+
+
+def ring_pair(oi, size, fields):
+    th, rv, rhod, C = fields
+    rings = []
+    for make, alloc in ((h.oracle_particles, h.host_alloc), (h.hip_particles, h.dev_alloc)):
+        rings.append(h.LocalRing(oi, size, make, alloc))
+    orc, hip = rings
+    # same random stream for both: replay the oracle's init draws slab by slab
+    for po, ph in zip(orc.prts, hip.prts):
+        for arr in h.oracle_rng_preview(po, h.init_replay_calls(po.opts_init)):
+            ph.rng_replay_push(0, arr)
+    for ring in rings:
+        ring.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    for po, ph in zip(orc.prts, hip.prts):
+        h.copy_state(po, ph)
+    return orc, hip
+
+
+@pytest.mark.parametrize("dims,size", [((6, 0, 5), 2), ((7, 3, 4), 3)])
+def test_migration_matches_oracle(dims, size):
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False)
+    oi.n_sd_max = 24 * max(nx, 1) * max(ny, 1) * nz * 3
+    fields = h.box_fields(oi)
+    orc, hip = ring_pair(oi, size, fields)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    moved = 0
+    for it in range(4):
+        a = [x.copy() for x in (th, rv, rhod)]
+        b = [x.copy() for x in (th, rv, rhod)]
+        orc.step(opts, *a, **C)
+        hip.step(opts, *b, **C)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            for a_ in ("x", "y", "z", "rw2", "rd3", "kappa"):
+                if a_ in ("x", "y", "z") and not getattr(oi, "n" + a_):
+                    continue
+                np.testing.assert_allclose(ph.get_attr(a_), po.get_attr(a_), rtol=1e-14, atol=1e-9, err_msg="%s slab %d" % (a_, r))
+    tot0 = 24 * max(nx, 1) * max(ny, 1) * nz
+    assert sum(p.n_part for p in hip.prts) <= tot0
+
+
+def test_ring_round_trip_bit_identical_hip():
+    """tests/mpi/mpi_adve_test.cpp:196-255 on the GPU: nx steps with C = 1 bring every SD back to its cell"""
+    oi = lgrngn.opts_init_t()
+    oi.dry_distros = {(.61, 0.): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6)}
+    oi.coal_switch = oi.sedi_switch = False
+    oi.dt = 1
+    oi.nx, oi.nz, oi.dx, oi.dz = 7, 4, 1, 1
+    oi.x1, oi.z1 = 7., 4.
+    oi.sd_conc = 8
+    oi.n_sd_max = 8 * 7 * 4 * 3
+    oi.adve_scheme = lgrngn.as_t.euler
+    ring = h.LocalRing(oi, 3, h.hip_particles, h.dev_alloc)
+    th, rv, rhod = 300. * np.ones((7, 4)), .01 * np.ones((7, 4)), np.ones((7, 4))
+    Cx, Cz = np.ones((8, 4)), np.zeros((7, 5))
+    ring.init(th, rv, rhod, Cx=Cx, Cz=Cz)
+    opts = lgrngn.opts_t()
+    opts.cond = opts.coal = opts.sedi = False
+
+    def diags():
+        out = []
+        for fn, k in (("diag_sd_conc", None), ("diag_dry_mom", 1), ("diag_wet_mom", 1), ("diag_kappa_mom", 1)):
+            def one(p):
+                p.diag_all()
+                getattr(p, fn)(*([k] if k is not None else []))
+                return p.outbuf_array()
+            out.append(ring.gather(one))
+        return np.stack(out)
+    before = diags()
+    for step in range(oi.nx):
+        ring.step(opts, th, rv, rhod, Cx=Cx, Cz=Cz)
+    after = diags()
+    assert np.array_equal(before, after)
