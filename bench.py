@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--sstp-coal", type=int, default=1)
     ap.add_argument("--real", choices=["f64", "f32"], default="f64")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--strict-fp", action="store_true",
+                    help="IEEE operation order in the condensation kernel (bit-faithful to the reference's formulas); default: "
+                         "the collected one-division form with FMA contraction, parity-tested at the same tolerances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=24)
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
@@ -144,6 +147,7 @@ def main():
     nx_tot = n * world if args.scaling == "weak" else n
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = local_rank
+    oi.strict_fp = args.strict_fp
     if world > 1:
         prt = multi.particles_multi_t(oi, real_t, device=dev)
         nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
@@ -229,6 +233,7 @@ def main():
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
                                    % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
                        "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d" % world,
+                       "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
                        "init_s": t_init},
             "roofline": roof,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},

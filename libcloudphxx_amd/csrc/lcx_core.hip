@@ -457,7 +457,8 @@ struct Particles : IParticles {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell};
-      hipLaunchKernelGGL(k_cond<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
+      if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
+      else hipLaunchKernelGGL((k_cond<T, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
     }
     {
       Range r(this, "cond_cellfinish");

@@ -353,7 +353,7 @@ struct cond_args {
   T *m3_before, *m3_after;
   T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
 };
-template <class T>
+template <class T, bool FAST>
 __global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
 {
   const size_t pos = gid(); if (pos >= n_part) return;
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
   const T rw2_old = a.rw2[id];
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
   if (a.first) a.m3_before[pos] = rw2_old >= 0 ? nn * (rw2_old * T(sqrt(rw2_old))) : nn * rw2_old;
-  const T r = advance_rw2(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
+  const T r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
                           a.lambda_D[c], a.lambda_K[c], a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
   a.rw2[id] = r;
   a.m3_after[pos] = r >= 0 ? nn * (r * T(sqrt(r))) : nn * r;

@@ -269,27 +269,61 @@ template <class T> struct cond_fun {
   LCX_HD T operator()(T rw2) const { return rw2_old + dt * drw2_dt(rw2) - rw2; }
 };
 
+// The same growth rate as cond_fun, algebraically collected into ONE rational expression (one IEEE division
+// instead of fifteen) with FMA contraction allowed.  Selected by opts_init.strict_fp = 0.  It is the counterpart
+// of how the reference itself is built for production (-Ofast: reassociation + contraction, CMakeLists.txt:124):
+// values differ from the strict form by a few ulp per evaluation, i.e. far inside the root finder's 2^-15
+// tolerance; the parity tests hold it to the same bars as the strict form.
+//   r dr/dt = (da RH - na klv) nD Sh nK Nu / ( da RH rho_w (c1 dD nK Nu + c2 dK nD Sh) )
+// with beta(Kn) = n/d, a_w = na/da, c1 = 2/(D_0 rho_v), c2 = 2 l_v (l_v/(R_v T) - 1)/(K_0 RH T).
+template <class T> struct cond_fun_fast {
+  T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
+  LCX_HD void setup(const cond_fun<T> &f)
+  {
+    using c = cst<T>;
+    rw2_old = f.rw2_old; dt = f.dt; rd3 = f.rd3; rd3_1mk = f.rd3 * (T(1) - f.kpa);
+    c_Re = f.vt * T(2) * f.rhod / f.eta;
+    Sc = f.Sc; Pr = f.Pr; lambda_D = f.lambda_D; lambda_K = f.lambda_K; A = f.A; RH_eff = f.RH_eff;
+    c1 = T(2) / (c::D_0 * f.rho_v);
+    c2_rho = T(2) * f.lv * f.lv_term / (c::K_0 * f.RH_eff * f.Tk);
+    RH_rho_w = f.RH_eff * c::rho_w;
+  }
+  LCX_HD T drw2_dt(T rw2) const
+  {
+#pragma clang fp contract(fast)
+    const T rw = sqrt(rw2);
+    const T irw = T(1) / rw;
+    const T rw3 = rw2 * rw;
+    const T Re = c_Re * rw;
+    const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+    const T Sh = T(1) + T(cbrt(T(1) + Re * Sc)) * m;
+    const T Nu = T(1) + T(cbrt(T(1) + Re * Pr)) * m;
+    const T KnD = lambda_D * irw, KnK = lambda_K * irw;
+    const T nD = T(1) + KnD, dD = T(1) + KnD * (T(1.71) + T(1.33) * KnD);
+    const T nK = T(1) + KnK, dK = T(1) + KnK * (T(1.71) + T(1.33) * KnK);
+    const T na = rw3 - rd3, da = rw3 - rd3_1mk;
+    const T klv = exp(A * irw);
+    const T nDSh = nD * Sh, nKNu = nK * Nu;
+    const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
+    const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);
+    return T(2) * (num / den);
+  }
+  LCX_HD T operator()(T rw2) const
+  {
+#pragma clang fp contract(fast)
+    return rw2_old + dt * drw2_dt(rw2) - rw2;
+  }
+};
+
 // NOTE (measured on MI355X, 128^3 x 64 SDs, fp64): three forms of this routine were timed --
 //   nested calls as below (growth rate inlined at ~10 sites, 128 VGPRs, 4 waves/SIMD)        17.1 ms
 //   one-loop state machine with a single evaluation site (160 VGPRs, 3 waves/SIMD)            18.3 ms
 //   persistent lanes refilled from an LDS-staged chunk (mean instead of max iterations/wave)  22.0 ms
 // The kernel is bound by fp64 VALU issue (~500 instructions per evaluation, ~15 IEEE divisions), not by
 // divergence or instruction fetch, so the plain form with the lowest register count wins.
-template <class T>
-LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt,
-                     T lambda_D, T lambda_K, T RH, T RH_max, T eps, T cond_mlt, unsigned n_iter)
-{                                                                  // cond_common.ipp:187-337
-  using c = cst<T>;
-  if (rw2_old <= 0) return rw2_old;
-  cond_fun<T> f;
-  f.rw2_old = rw2_old; f.dt = dt; f.rd3 = rd3; f.kpa = kpa; f.vt = vt; f.rhod = rhod; f.eta = eta;
-  f.Sc = eta / rhod / c::D_0;
-  f.Pr = c::c_pd * eta / c::K_0;
-  f.lambda_D = lambda_D; f.lambda_K = lambda_K;
-  f.rho_v = rhod * rv; f.Tk = Tk; f.RH_eff = RH > RH_max ? RH_max : RH;
-  f.lv = l_v(Tk);
-  f.A = kelvin_A(Tk);
-  f.lv_term = f.lv / c::R_v / Tk - T(1);
+template <class T, class F>
+LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+{                                                                  // cond_common.ipp:197-337
   const T drw2 = dt * f.drw2_dt(rw2_old);
   if (drw2 == 0) return rw2_old;
   const T rd = cbrt(rd3);
@@ -305,6 +339,24 @@ LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T
   else rw2_new = toms748_solve(f, a, b, fa, fb, eps, n_iter);
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
+}
+template <class T, bool FAST = false>
+LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt,
+                     T lambda_D, T lambda_K, T RH, T RH_max, T eps, T cond_mlt, unsigned n_iter)
+{                                                                  // cond_common.ipp:187-337
+  using c = cst<T>;
+  if (rw2_old <= 0) return rw2_old;
+  cond_fun<T> f;
+  f.rw2_old = rw2_old; f.dt = dt; f.rd3 = rd3; f.kpa = kpa; f.vt = vt; f.rhod = rhod; f.eta = eta;
+  f.Sc = eta / rhod / c::D_0;
+  f.Pr = c::c_pd * eta / c::K_0;
+  f.lambda_D = lambda_D; f.lambda_K = lambda_K;
+  f.rho_v = rhod * rv; f.Tk = Tk; f.RH_eff = RH > RH_max ? RH_max : RH;
+  f.lv = l_v(Tk);
+  f.A = kelvin_A(Tk);
+  f.lv_term = f.lv / c::R_v / Tk - T(1);
+  if (FAST) { cond_fun_fast<T> ff; ff.setup(f); return advance_rw2_with(ff, rw2_old, rd3, dt, eps, cond_mlt, n_iter); }
+  return advance_rw2_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter);
 }
 
 // ---- terminal velocities: common/vterm.hpp:33-220 (khvorostyanov and beard77_v0 in double whatever real_t)

@@ -139,9 +139,12 @@ def test_vterm(vt):
 
 
 # ------------------------------------------------------------------ condensation (a7-a10)
+@pytest.mark.parametrize("strict_fp", [True, False])
 @pytest.mark.parametrize("sstp", [1, 4])
-def test_cond_step(sstp):
-    oi = h.box_opts(4, 4, 6, 64, sstp_cond=sstp)
+def test_cond_step(sstp, strict_fp):
+    """strict_fp=False: the growth rate collected into one rational expression + FMA contraction (lcx_math.hpp,
+    cond_fun_fast) -- held to the SAME bars as the IEEE-order form"""
+    oi = h.box_opts(4, 4, 6, 64, sstp_cond=sstp, strict_fp=strict_fp)
     fields = h.box_fields(oi)
     orc, hip = h.make_pair(oi, fields)
     opts = lgrngn.opts_t()
@@ -303,10 +306,11 @@ def test_advection_shifts_by_one_cell():
 
 
 # ------------------------------------------------------------------ full steps, everything on, replayed stream
+@pytest.mark.parametrize("strict_fp", [True, False])
 @pytest.mark.parametrize("dims,sstp", [((4, 4, 4), (1, 1)), ((8, 0, 8), (3, 2))])
-def test_full_steps_replay(dims, sstp):
+def test_full_steps_replay(dims, sstp, strict_fp):
     nx, ny, nz = dims
-    oi = h.box_opts(nx, ny, nz, 64, sstp_cond=sstp[0], sstp_coal=sstp[1])
+    oi = h.box_opts(nx, ny, nz, 64, sstp_cond=sstp[0], sstp_coal=sstp[1], strict_fp=strict_fp)
     fields = h.box_fields(oi)
     orc, hip = h.make_pair(oi, fields)
     opts = lgrngn.opts_t()

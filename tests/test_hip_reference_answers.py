@@ -11,31 +11,16 @@ from libcloudphxx_amd import lgrngn
 pytestmark = pytest.mark.gpu
 
 
-def hip_with_oracle_init_stream(n_calls_of):
-    """factory for run_* helpers: HIP object whose init() consumes the oracle's random stream"""
-    def make(oi):
-        orc = h.oracle_particles(oi)
-        hip = h.hip_particles(oi)
-        for arr in h.oracle_rng_preview(orc, n_calls_of(oi)):
-            hip.rng_replay_push(0, arr)
-        return hip
-    return make
-
-
-def _two_distro_calls(oi):
-    # two distros, 0-D: each consumes one u01 array of its share of sd_conc (init_SD_with_distros_sd_conc.ipp:23-35)
-    orc = h.oracle_particles(oi)
-    return None
-
-
 ROWS = [r for r in pins._rows() if r["sstp_cond"] in ("1", "3", "8", "32") and r["RH_formula"] in ("pv_cc", "rv_tet")]
 
 
+@pytest.mark.parametrize("strict_fp", [True, False])
 @pytest.mark.parametrize("row", ROWS, ids=lambda r: "%s-%s-sstp%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"]))
-def test_cond_substepping_refdata_hip(row):
+def test_cond_substepping_refdata_hip(row, strict_fp):
     """tests/python/physics/refdata/lgrngn_cond_substepping_refdata.csv through the GPU.  The run needs the CPU random
     stream to reproduce the sampled aerosol (1000 SDs in two modes): the dry radii of both distros are replayed."""
     def make(oi):
+        oi.strict_fp = strict_fp
         orc = h.oracle_particles(oi)
         # fraction of sd_conc per distro is decided inside init; query the oracle for the split by running its init
         th, rv, rhod = np.array([305.]), np.array([0.0085]), np.array([1.1])
