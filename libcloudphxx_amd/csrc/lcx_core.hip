@@ -98,7 +98,8 @@ struct Particles : IParticles {
   lcx_opts_init_t o;
   std::vector<lcx_distro_t> distros;
   std::vector<double> kernel_parameters_h, w_LS_h, conc_factor_h;
-  int n_dims; size_t ncell, npart = 0, cap;
+  int n_dims; size_t ncell, npart = 0, nphys = 0, cap;   // npart: living SDs (API); nphys: storage extent incl. not yet compacted dead SDs
+  bool eager_compact = false;
   grid_t g;
   // ---- order-of-operation flags (particles_impl.ipp:32) ----
   bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
@@ -168,6 +169,7 @@ struct Particles : IParticles {
     eps_tol = eps_tolerance<T>(sizeof(T) * 8 / 4);                                   // src/detail/config.hpp:39
     vtc = vt_cfg{oi.terminal_velocity, double(T(std::log(5e-7))), double(T(std::log(3e-3))), 10000};   // config.hpp:27-38
     cap = size_t(oi.n_sd_max);
+    eager_compact = getenv("LCX_EAGER_COMPACT") != nullptr;
     for (double &v : puddle) v = 0;
     if (oi.dev_id >= 0) HIPCHK(hipSetDevice(oi.dev_id));                             // particles_ctor.ipp:60-63
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -350,8 +352,8 @@ struct Particles : IParticles {
   void ijk_and_hist(bool do_ijk, bool do_hist)
   {
     if (do_hist) HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
-    if (npart)
-      hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, g, A.x.p, A.y.p, A.z.p, ijk.p,
+    if (nphys)
+      hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
                          do_hist ? cell_cnt.p : nullptr, rank.p, int(do_ijk));
   }
   void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(true, false); sorted = false; }
@@ -359,8 +361,8 @@ struct Particles : IParticles {
   void sort_from_hist(bool shuffle)
   {
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell);
-    if (npart)
-      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(npart)), dim3(BS), 0, st, npart, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
+    if (nphys)
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
     order_cells(shuffle);
   }
   // puts every cell segment of sorted_id into the reference's order: ascending id, or ascending (un[id], id)
@@ -368,8 +370,8 @@ struct Particles : IParticles {
   {
     if (npart) {
       rng_src rs{nullptr, 0, 0};
-      if (shuffle) rs = rand_un(npart);
-      if (ncell == 1 && !shuffle) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
+      if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
+      if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
         HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
         hipLaunchKernelGGL(k_cellrank, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
@@ -401,36 +403,50 @@ struct Particles : IParticles {
   void hskpng_vterm(bool only_invalid)
   {
     Range r(this, only_invalid ? "hskpng_vterm_invalid" : "hskpng_vterm_all");
-    if (npart)
-      hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
+    if (nphys)
+      hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
   }
   void check_npart(size_t n) const
   {                                                                                      // hskpng_resize.ipp:9
     if (n > o.n_sd_max) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part (" + std::to_string(n) + ")");
   }
 
-  // post_copy.ipp:18-35: remove n==0 (stable) -> ijk -> count(sort), fused into one pass over the attributes
-  void post_copy(const lcx_opts_t &opts)
+  // post_copy.ipp:18-35: remove n==0 (stable) -> ijk -> count(sort).
+  // The removal is LAZY: a dead SD (n == 0) is excluded from the cell histogram at once (so no kernel that walks the
+  // sorted order ever sees it and n_part() reports living SDs only), but the stable compaction of the storage --
+  // 2 x 64 B per SD of traffic for typically a handful of deaths per step -- is deferred until dead SDs exceed 1/32 of
+  // the storage, or until something observes storage order (get_attr / state getters, a replayed random stream,
+  // set_particles, capacity pressure).  Relative order of the living SDs, hence every tie-break of the stable sort, is
+  // the same as after the reference's eager remove_if.  LCX_EAGER_COMPACT=1 forces a compaction every step.
+  void post_copy(const lcx_opts_t &opts, bool force_compact = false)
   {
     if (opts.rcyc) throw lcx_error("libcloudph++: rcyc not supported by this backend");
     Range r(this, "post_copy");
-    const size_t tiles = (npart + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t alive = 0;
     if (tiles) {
-      hipLaunchKernelGGL(k_alive_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, A.n.p, npart, tile_sums.p);
+      hipLaunchKernelGGL(k_alive_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, A.n.p, nphys, tile_sums.p);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
       HIPCHK(hipMemcpyAsync(&alive, scan_total.p, sizeof alive, hipMemcpyDeviceToHost, st));
       sync();
     }
-    if (alive == npart) ijk_and_hist(true, true);                  // nobody died: re-index in place
-    else {
+    const size_t dead = nphys - alive;
+    if (dead && (force_compact || eager_compact || dead * 32 > nphys)) {
       if (!B.n.p) alloc_attrs(B);
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
-      hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, npart, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
+      hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, nphys, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
       A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
-      npart = alive;
-    }
+      nphys = alive;
+    } else ijk_and_hist(true, true);                 // re-index in place (dead SDs get DEAD_CELL)
+    npart = alive;
     sort_from_hist(false);
+  }
+  // make storage order == the reference's (no dead SDs in it) before anything that exposes storage order
+  void ensure_compact()
+  {
+    if (nphys == npart) return;
+    lcx_opts_t od; lcx_opts_default(&od);
+    post_copy(od, true);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -479,6 +495,7 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   void coal(double dt_sub)
   {
+    if (!replay.empty()) ensure_compact();     // un[id] of a replayed CPU stream is indexed by the reference's (compact) ids
     hskpng_sort_helper(true);
     if (npart < 2) { if (npart) (void)rand_u01(npart); return; }
     Range r(this, "coal");
@@ -495,10 +512,10 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   void move(bool do_adve, bool do_sedi, bool do_subs, bool do_bcnd)
   {
-    if (n_dims == 0 || npart == 0) { if (do_bcnd) { lft_count = rgt_count = 0; } return; }
+    if (n_dims == 0 || nphys == 0) { if (do_bcnd) { lft_count = rgt_count = 0; } return; }
     Range r(this, "move(adve+sedi+bcnd)");
     move_args<T> a;
-    a.n_part = npart; a.g = g;
+    a.n_part = nphys; a.g = g;
     a.dx = T(o.dx); a.dy = T(o.dy); a.dz = T(o.dz); a.x0 = T(o.x0); a.y0 = T(o.y0); a.z0 = T(o.z0); a.x1 = T(o.x1); a.y1 = T(o.y1); a.z1 = T(o.z1);
     a.dt = T(dt);
     a.x = A.x.p; a.y = A.y.p; a.z = A.z.p; a.vt = A.vt.p; a.rw2 = A.rw2.p; a.rd3 = A.rd3.p; a.n = A.n.p; a.ijk = ijk.p;
@@ -507,7 +524,7 @@ struct Particles : IParticles {
     a.distmem = distmem(); a.bcond_lft = o.bcond_lft; a.bcond_rgt = o.bcond_rgt;
     a.open_side_walls = o.open_side_walls; a.periodic_topbot = o.periodic_topbot_walls;
     const bool want_puddle = do_bcnd && n_dims > 1 && !o.periodic_topbot_walls;
-    const unsigned blocks = nblk(npart);
+    const unsigned blocks = nblk(nphys);
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
     a.mig = mig.p;
     hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
@@ -522,13 +539,13 @@ struct Particles : IParticles {
   }
   void build_migrant_lists()
   {
-    const size_t tiles = (npart + SCAN_TILE - 1) / SCAN_TILE;
+    const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     size_t *cnt[2] = {&lft_count, &rgt_count};
     for (int side = 0; side < 2; ++side) {
       uint32_t tot = 0;
-      hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, npart, uint8_t(side + 1), tile_sums.p);
+      hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
-      hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, npart, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
+      hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
       HIPCHK(hipMemcpyAsync(&tot, scan_total.p, sizeof tot, hipMemcpyDeviceToHost, st));
       sync();
       *cnt[side] = tot;
@@ -580,7 +597,7 @@ struct Particles : IParticles {
       const n_t per_cell = n_t(fraction * o.sd_conc);                                    // init_count_num.ipp:32-35
       const size_t n_old = npart, n_new = size_t(per_cell) * ncell;
       check_npart(n_old + n_new);
-      npart = n_old + n_new;
+      npart = nphys = n_old + n_new;
       if (n_new == 0) continue;
       const unsigned nb = nblk(n_new);
       {
@@ -796,8 +813,8 @@ struct Particles : IParticles {
     hskpng_sort();
     need_nfiltered();
     if (cons && !selected_before_counting) throw lcx_error("libcloudph++: consecutive selection without a previous selection");
-    if (npart)
-      hipLaunchKernelGGL(k_nfilt<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, mode, cons, A.n.p, attr_ptr(attr), T(a), T(b), n_filtered.p);
+    if (nphys)
+      hipLaunchKernelGGL(k_nfilt<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, mode, cons, A.n.p, attr_ptr(attr), T(a), T(b), n_filtered.p);
     selected_before_counting = true;
     sync();
   }
@@ -832,6 +849,7 @@ struct Particles : IParticles {
   }
   void get_attr(const char *name, void *out, size_t capn, size_t *n) override
   {
+    ensure_compact();
     const std::string s(name);
     const T *v = s == "rw2" ? A.rw2.p : s == "rd3" ? A.rd3.p : s == "kappa" ? A.kpa.p : s == "x" ? A.x.p : s == "y" ? A.y.p : s == "z" ? A.z.p : nullptr;
     if (s != "rw2" && s != "rd3" && s != "kappa" && s != "x" && s != "y" && s != "z") throw lcx_error("Unknown attribute name passed to get_attr.");
@@ -851,6 +869,7 @@ struct Particles : IParticles {
   template <class S> std::vector<S> d2h(const S *p_, size_t n) { std::vector<S> h(n); if (n) { HIPCHK(hipMemcpyAsync(h.data(), p_, n * sizeof(S), hipMemcpyDeviceToHost, st)); sync(); } return h; }
   void get_state_u64(const char *name, unsigned long long *out, size_t capn, size_t *n) override
   {
+    ensure_compact();
     const std::string s(name);
     std::vector<unsigned long long> v;
     if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
@@ -870,6 +889,7 @@ struct Particles : IParticles {
   }
   void get_state_real(const char *name, double *out, size_t capn, size_t *n) override
   {
+    ensure_compact();
     const std::string s(name);
     struct E { const char *nm; const T *p; size_t len; };
     const E tab[] = {{"vt", A.vt.p, npart}, {"T", Tk.p, ncell}, {"p", p.p, ncell}, {"RH", RH.p, ncell}, {"eta", eta.p, ncell}, {"th", th.p, ncell},
@@ -893,7 +913,7 @@ struct Particles : IParticles {
                      const double *x_, const double *y_, const double *z_) override
   {
     check_npart(n);
-    npart = n;
+    npart = nphys = n;
     auto up = [&](DevBuf<T> &b, const double *src) {
       if (!src || !b.p || !n) return;
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(src[i]);
@@ -944,11 +964,12 @@ struct Particles : IParticles {
   void migrate_unpack(const void *buf, size_t cnt) override
   {
     if (!cnt) return;
-    check_npart(npart + cnt);
+    if (nphys + cnt > cap) ensure_compact();
+    check_npart(nphys + cnt);
     Range r(this, "migrate_unpack");
     const n_t *nb = (const n_t *)buf; const T *rb = (const T *)((const n_t *)buf + cnt);
-    hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, npart, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4));
-    npart += cnt;
+    hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, nphys, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4));
+    nphys += cnt;
     sync();
   }
   void migrate_finish(const lcx_opts_t &opts) override

@@ -160,6 +160,7 @@ __global__ void k_init_dv(size_t n_cell, T *dv, int ny, int nz, T dx, T dy, T dz
 // housekeeping: cell index, sort
 // ============================================================================================
 struct grid_t { int nx, ny, nz, ndims; double dx, dy, dz; };
+constexpr uint32_t DEAD_CELL = 0xFFFFFFFFu;   // ijk of a super-droplet with n == 0 that has not been compacted away yet
 
 // hskpng_ijk.ipp:159-200,33-82: size_t(double(x)/double(dx)), z fastest
 template <class T>
@@ -195,17 +196,23 @@ __device__ __forceinline__ uint32_t wave_hist_rank(uint32_t *cnt, uint32_t c, bo
   }
   return rank;
 }
-// ijk (optional) + histogram/rank in one pass over the positions
+// ijk (optional) + histogram/rank in one pass over the storage.  SDs with n == 0 ("dead": removed by the
+// reference's hskpng_remove_n0, here possibly still in storage until the next compaction) get ijk = DEAD_CELL
+// and take no part in the histogram, so they never enter the sorted order.
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_ijk_hist(size_t n, grid_t g, const T *x, const T *y, const T *z, uint32_t *ijk, uint32_t *cnt, uint32_t *rank, int do_ijk)
+k_ijk_hist(size_t n, grid_t g, const n_t *mult, const T *x, const T *y, const T *z, uint32_t *ijk, uint32_t *cnt, uint32_t *rank, int do_ijk)
 {
   const size_t i = gid();
-  const bool active = i < n;
+  bool active = i < n;
   uint32_t c = 0;
   if (active) {
-    if (do_ijk) { c = cell_of(g, g.nx ? x[i] : T(0), g.ny ? y[i] : T(0), g.nz ? z[i] : T(0)); ijk[i] = c; }
-    else c = ijk[i];
+    if (do_ijk) {
+      if (mult[i] == 0) c = DEAD_CELL;
+      else c = cell_of(g, g.nx ? x[i] : T(0), g.ny ? y[i] : T(0), g.nz ? z[i] : T(0));
+      ijk[i] = c;
+    } else c = ijk[i];
+    active = c != DEAD_CELL;
   }
   if (cnt) { const uint32_t r = wave_hist_rank(cnt, c, active); if (active) rank[i] = r; }
 }
@@ -214,6 +221,7 @@ __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *
 {
   const size_t i = gid(); if (i >= n) return;
   const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
   const uint32_t pos = cell_start[c] + rank[i];
   sorted_id[pos] = uint32_t(i);
   sorted_ijk[pos] = c;
@@ -335,6 +343,7 @@ __global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, cons
   if (!(r2 > T(0))) return;
   if (only_invalid && !(vt[i] == T(-1))) return;
   const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
   vt[i] = vt_eval(v, r2, Tk[c], p[c], rhod[c], eta[c], vt_0);
 }
 
@@ -581,10 +590,11 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   __shared__ double red[4][BS / WAVE];
   const size_t i = gid();
   double pl = 0, pd = 0, pn = 0, pp = 0;
-  if (i < a.n_part) {
+  const uint32_t c = i < a.n_part ? a.ijk[i] : DEAD_CELL;
+  if (c == DEAD_CELL && i < a.n_part && a.mig) a.mig[i] = 0;
+  if (c != DEAD_CELL) {
     const grid_t &g = a.g;
     const size_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
-    const uint32_t c = a.ijk[i];
     T x = g.nx ? a.x[i] : T(0), y = g.ny ? a.y[i] : T(0), z = g.nz ? a.z[i] : T(0);
     if (a.do_adve && g.ndims > 0) {
       uint32_t ci, cj = 0, ck = 0;

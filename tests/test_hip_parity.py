@@ -276,6 +276,49 @@ def test_move_and_post_copy(scheme, dims):
         np.testing.assert_allclose(ph[k], po[k], rtol=1e-12, err_msg=k)
 
 
+@pytest.mark.parametrize("eager", [False, True])
+def test_lazy_compaction_is_unobservable(eager, monkeypatch):
+    """Dead SDs stay in storage until a compaction is due (post_copy in lcx_core.hip); nothing observable may depend on
+    that: run several precipitating steps WITHOUT touching any getter, then compare everything with the oracle."""
+    if eager:
+        monkeypatch.setenv("LCX_EAGER_COMPACT", "1")
+    else:
+        monkeypatch.delenv("LCX_EAGER_COMPACT", raising=False)
+    oi = h.box_opts(5, 4, 6, 48, dx=30., coal_switch=False)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    n0 = orc.n_part
+    rw2 = orc.get_attr("rw2")
+    rw2[::5] = (1.2e-3) ** 2
+    g = lambda nm: orc.state_real(nm)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False         # (mm-sized drops with aerosol multiplicities are not a state to condense on)
+    th, rv, rhod, C = fields
+    tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()
+    for it in range(6):
+        orc.step_sync(opts, tho, rvo, rhod, **C)
+        orc.step_async(opts)
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        hip.step_async(opts)
+        assert hip.n_part == orc.n_part          # n_part() itself must already report living SDs only
+    assert orc.n_part < n0
+    # diagnostics walk the sorted order: they must not see dead SDs either (still no storage getter called)
+    for prt in (orc, hip):
+        prt.diag_all()
+        prt.diag_sd_conc()
+    exact(hip.outbuf_array(), orc.outbuf_array(), "sd_conc")
+    for nm in ("n", "ijk", "sorted_id", "count_num"):
+        exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+    for a in ("x", "y", "z"):
+        np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-13, atol=1e-9)
+    exact(hip.get_attr("rw2"), orc.get_attr("rw2"), "rw2")
+    po, ph = orc.diag_puddle(), hip.diag_puddle()
+    np.testing.assert_allclose(ph["particle_number"], po["particle_number"], rtol=1e-12)
+
+
 def test_advection_shifts_by_one_cell():
     """tests/python/unit/lgrngn_adve.py:97-105: C = +-1 moves the sd_conc field by exactly one cell"""
     for Cx, roll in ((1., -1), (-1., 1)):
