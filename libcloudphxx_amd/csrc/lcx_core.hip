@@ -120,6 +120,7 @@ struct Particles : IParticles {
   DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
   DevBuf<double> puddle_partial, puddle_sum;
   DevBuf<int> d_flag;
+  void *pinned = nullptr;      // 256 B of page-locked host memory for the small per-step read-backs (counts, sums)
   double puddle[LCX_OUT_COUNT];
   bool count_mom_valid_all = true;
   double kernel_r_max = 0; int n_user_params = 0;
@@ -173,6 +174,7 @@ struct Particles : IParticles {
     for (double &v : puddle) v = 0;
     if (oi.dev_id >= 0) HIPCHK(hipSetDevice(oi.dev_id));                             // particles_ctor.ipp:60-63
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIPCHK(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
     alloc_attrs(A);
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
@@ -187,7 +189,14 @@ struct Particles : IParticles {
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
   }
-  ~Particles() override { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } }
+  ~Particles() override { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (pinned) (void)hipHostFree(pinned); }
+  // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
+  template <class S> void read_back(S *dst, const S *src, size_t n)
+  {
+    HIPCHK(hipMemcpyAsync(pinned, src, n * sizeof(S), hipMemcpyDeviceToHost, st));
+    sync();
+    memcpy(dst, pinned, n * sizeof(S));
+  }
 
   void alloc_attrs(Attrs &a)
   {
@@ -378,8 +387,7 @@ struct Particles : IParticles {
                            int(shuffle), rs, big_list.p, big_meta.p, big_meta.p + 1);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         uint32_t meta[2];
-        HIPCHK(hipMemcpyAsync(meta, big_meta.p, sizeof meta, hipMemcpyDeviceToHost, st));
-        sync();
+        read_back(meta, big_meta.p, 2);
         if (meta[0]) {
           size_t P = 1; while (P < meta[1]) P <<= 1;
           const unsigned nb = std::min<unsigned>(meta[0], 64u);
@@ -427,8 +435,7 @@ struct Particles : IParticles {
     if (tiles) {
       hipLaunchKernelGGL(k_alive_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, A.n.p, nphys, tile_sums.p);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
-      HIPCHK(hipMemcpyAsync(&alive, scan_total.p, sizeof alive, hipMemcpyDeviceToHost, st));
-      sync();
+      read_back(&alive, scan_total.p, 1);
     }
     const size_t dead = nphys - alive;
     if (dead && (force_compact || eager_compact || dead * 32 > nphys)) {
@@ -501,7 +508,7 @@ struct Particles : IParticles {
     Range r(this, "coal");
     const u01_src<T> rs = rand_u01(npart);
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p};
-    hipLaunchKernelGGL(k_coal<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
+    hipLaunchKernelGGL(k_coal<T>, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
                        A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p);
     if (o.n_dry_distros + o.n_dry_sizes > 1)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
@@ -531,8 +538,7 @@ struct Particles : IParticles {
     if (want_puddle) {
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), puddle_sum.p);
       double s4[4];
-      HIPCHK(hipMemcpyAsync(s4, puddle_sum.p, sizeof s4, hipMemcpyDeviceToHost, st));
-      sync();
+      read_back(s4, puddle_sum.p, 4);
       puddle[LCX_OUT_LIQ_VOL] += s4[0]; puddle[LCX_OUT_DRY_VOL] += s4[1]; puddle[LCX_OUT_LIQ_NUM] += s4[2]; puddle[LCX_OUT_PRTCL_NUM] += s4[3];
     }
     if (do_bcnd && distmem()) build_migrant_lists();
@@ -546,8 +552,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p);
       hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
       hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
-      HIPCHK(hipMemcpyAsync(&tot, scan_total.p, sizeof tot, hipMemcpyDeviceToHost, st));
-      sync();
+      read_back(&tot, scan_total.p, 1);
       *cnt[side] = tot;
     }
   }
@@ -784,7 +789,7 @@ struct Particles : IParticles {
       }
       if (pure_const_multi) {
         int flag = 0;
-        HIPCHK(hipMemcpyAsync(&flag, d_flag.p, sizeof flag, hipMemcpyDeviceToHost, st)); sync();
+        read_back(&flag, d_flag.p, 1);
         if (flag) { ++sstp_coal; HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st)); }
       }
       release_replay_keep();

@@ -496,22 +496,35 @@ __device__ __forceinline__ T kernel_calc(const coal_kernel_cfg<T> &k, n_t na, n_
 }
 template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 
-// One lane per position p of the (shuffled) cell-sorted order; lanes at even in-cell offsets own the pair
-// (p, p+1).  Pairs are disjoint, so the read-modify-write of the two SDs needs no atomics.  The collision
-// count / who-was-bigger flags go to col[] exactly as in the reference (coal.ipp:209,233-267) because the
-// kappa update (and tests) read them.
+// One lane per CANDIDATE PAIR: lane t looks at position 2t of the (shuffled) cell-sorted order and owns the pair
+// (p, p+1) that starts at 2t if 2t sits at an even in-cell offset with a cell-mate behind it, else the one that may
+// start at 2t+1.  Every pair of the reference (even in-cell offset a, b = a+1 in the same cell, coal.ipp:198-212) is
+// owned by exactly one lane and all 64 lanes of a wave carry work.  Pairs are disjoint, so the read-modify-write
+// of the two SDs needs no atomics.  The collision count / who-was-bigger flags go to col[] exactly as in the
+// reference (coal.ipp:209,233-267) because the kappa update (and tests) read them.
 template <class T>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
        int pure_const_multi, int *increase_sstp_coal)
 {
-  const size_t p = gid(); if (p + 1 >= n_part) return;
-  const uint32_t ca = sorted_ijk[p];
-  const uint32_t off = cell_start[ca];
-  const uint32_t cix_a = uint32_t(p) - off;
-  if (cix_a & 1u) return;
-  if (sorted_ijk[p + 1] != ca) { col[p] = T(0); return; }
+  const size_t p0 = 2 * gid();
+  if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
+  size_t p = p0;
+  uint32_t ca = sorted_ijk[p];
+  uint32_t off = cell_start[ca];
+  {
+    const bool even0 = ((uint32_t(p) - off) & 1u) == 0;
+    const uint32_t cb = sorted_ijk[p + 1];
+    if (!(even0 && cb == ca)) {
+      if (even0) col[p] = T(0);                        // last SD of a cell with an odd count: no partner
+      p = p0 + 1;
+      if (p + 1 >= n_part) return;
+      if (cb != ca) { ca = cb; off = cell_start[ca]; }
+      if ((uint32_t(p) - off) & 1u) return;            // odd offset: this SD is the b of the previous lane's pair
+      if (sorted_ijk[p + 1] != ca) { col[p] = T(0); return; }
+    }
+  }
   const uint32_t cnt = cell_start[ca + 1] - off;
   const n_t nn = cnt;
   const T scl = nn > 1 ? (T(nn * (nn - 1)) / 2) / (nn / 2) : T(0);           // scale_factor, coal.ipp:99-107
