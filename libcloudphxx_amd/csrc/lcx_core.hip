@@ -185,7 +185,7 @@ struct Particles : IParticles {
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
       b->alloc_zero(ncell, st);
     d_flag.alloc_zero(1, st);
-    puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4);
+    puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4);
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
   }
@@ -383,8 +383,10 @@ struct Particles : IParticles {
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
         HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_cellrank, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
-                           int(shuffle), rs, big_list.p, big_meta.p, big_meta.p + 1);
+        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
+                                        rs, big_list.p, big_meta.p, big_meta.p + 1);
+        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
+                                rs, big_list.p, big_meta.p, big_meta.p + 1);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         uint32_t meta[2];
         read_back(meta, big_meta.p, 2);
@@ -536,7 +538,9 @@ struct Particles : IParticles {
     a.mig = mig.p;
     hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
     if (want_puddle) {
-      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), puddle_sum.p);
+      const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
+      hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_sum.p + 4, slices, slices, puddle_sum.p);
       double s4[4];
       read_back(s4, puddle_sum.p, 4);
       puddle[LCX_OUT_LIQ_VOL] += s4[0]; puddle[LCX_OUT_DRY_VOL] += s4[1]; puddle[LCX_OUT_LIQ_NUM] += s4[2]; puddle[LCX_OUT_PRTCL_NUM] += s4[3];

@@ -181,20 +181,27 @@ __device__ __forceinline__ uint32_t cell_of(const grid_t &g, T x, T y, T z)
 // deterministic and equal to the stable sort of the reference.  Must be called by ALL lanes of the wave.
 __device__ __forceinline__ uint32_t wave_hist_rank(uint32_t *cnt, uint32_t c, bool active)
 {
-  uint32_t rank = 0;
-  unsigned long long todo = __ballot(active);
+  // 1) group the lanes by cell with ballots/shuffles only (no memory traffic inside the loop)
   const unsigned l = lane_id();
+  unsigned my_leader = l;
+  uint32_t my_rank = 0, my_size = 0;
+  unsigned long long todo = __ballot(active);
   while (todo) {
     const int leader = __ffsll((long long)todo) - 1;
     const uint32_t lc = __shfl(c, leader);
     const unsigned long long same = __ballot(active && c == lc) & todo;
-    uint32_t base = 0;
-    if (int(l) == leader) base = atomicAdd(&cnt[lc], uint32_t(__popcll(same)));
-    base = __shfl(base, leader);
-    if ((same >> l) & 1ull) rank = base + uint32_t(__popcll(same & ((1ull << l) - 1ull)));
+    if ((same >> l) & 1ull) {
+      my_leader = unsigned(leader);
+      my_rank = uint32_t(__popcll(same & ((1ull << l) - 1ull)));
+      my_size = uint32_t(__popcll(same));
+    }
     todo &= ~same;
   }
-  return rank;
+  // 2) ONE atomic instruction per wave: every group leader reserves its group's slots at once
+  uint32_t base = 0;
+  if (active && l == my_leader) base = atomicAdd(&cnt[c], my_size);
+  base = __shfl(base, int(my_leader));
+  return base + my_rank;
 }
 // ijk (optional) + histogram/rank in one pass over the storage.  SDs with n == 0 ("dead": removed by the
 // reference's hskpng_remove_n0, here possibly still in storage until the next compaction) get ijk = DEAD_CELL
@@ -244,16 +251,19 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
   const uint32_t u = r.un ? r.un[id] : philox::un(id, r.call, r.seed);
   return (uint64_t(u) << 32) | id;
 }
+// KEY = uint32_t for the plain order (key == id), uint64_t for the shuffled order ((un << 32) | id)
+template <class KEY>
 __global__ void __launch_bounds__(BS)
 k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out,
-           int shuffle, rng_src r, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+           rng_src r, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
 {
-  __shared__ uint64_t lds[CR_CAP];
+  constexpr int shuffle = sizeof(KEY) == 8;
+  __shared__ KEY lds[CR_CAP];
   const size_t p0 = size_t(blockIdx.x) * BS;
   const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
   const uint32_t lo = cell_start[sorted_ijk[p0]], hi = cell_start[sorted_ijk[plast] + 1];
   const bool staged = (hi - lo) <= uint32_t(CR_CAP);
-  if (staged) for (uint32_t q = lo + threadIdx.x; q < hi; q += BS) lds[q - lo] = sort_key(in[q], shuffle, r);
+  if (staged) for (uint32_t q = lo + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));
   __syncthreads();
   const size_t p = p0 + threadIdx.x;
   if (p >= n) return;
@@ -264,13 +274,14 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
     return;
   }
   uint32_t rank = 0;
-  uint64_t mine;
+  KEY mine;
   if (staged) {
     mine = lds[p - lo];
-    for (uint32_t q = s; q < e; ++q) rank += lds[q - lo] < mine;
+    const KEY *seg = lds + (s - lo);
+    for (uint32_t q = 0; q < cnt; ++q) rank += seg[q] < mine;
   } else {
-    mine = sort_key(in[p], shuffle, r);
-    for (uint32_t q = s; q < e; ++q) rank += sort_key(in[q], shuffle, r) < mine;
+    mine = KEY(sort_key(in[p], shuffle, r));
+    for (uint32_t q = s; q < e; ++q) rank += KEY(sort_key(in[q], shuffle, r)) < mine;
   }
   out[s + rank] = uint32_t(mine);
 }
@@ -675,12 +686,15 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   }
 }
 
-// fixed-order reduction of the per-workgroup precipitation partials (deterministic for a given launch geometry)
-__global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, double *out4)
+// fixed-order reduction of the per-workgroup precipitation partials (deterministic for a given launch geometry):
+// workgroup g of the first launch reduces the contiguous slice [g*per, (g+1)*per) of the partials into out[g][4];
+// the second launch (one workgroup, nblocks = number of slices, per = 1) reduces those.
+__global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, size_t per, double *out)
 {
   __shared__ double red[4][BS];
+  const size_t b0 = size_t(blockIdx.x) * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
   double acc[4] = {0, 0, 0, 0};
-  for (size_t b = threadIdx.x; b < nblocks; b += BS)
+  for (size_t b = b0 + threadIdx.x; b < b1; b += BS)
     for (int k = 0; k < 4; ++k) acc[k] += partials[b * 4 + k];
   for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
   __syncthreads();
@@ -688,7 +702,7 @@ __global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, siz
     if (int(threadIdx.x) < d) for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
     __syncthreads();
   }
-  if (threadIdx.x < 4) out4[threadIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < 4) out[size_t(blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 // ============================================================================================
