@@ -97,6 +97,7 @@ struct Particles : IParticles {
   // ---- options (deep copies) ----
   lcx_opts_init_t o;
   std::vector<lcx_distro_t> distros;
+  std::vector<lcx_dry_size_t> sizes; int n_size_keys = 0;   // dry_sizes.size() of the reference = number of (kappa, rd_insol) keys
   std::vector<double> kernel_parameters_h, w_LS_h, conc_factor_h;
   int n_dims; size_t ncell, npart = 0, nphys = 0, cap;   // npart: living SDs (API); nphys: storage extent incl. not yet compacted dead SDs
   bool eager_compact = false;
@@ -152,6 +153,9 @@ struct Particles : IParticles {
     if (oi.adve_scheme == LCX_ADVE_PRED_CORR) throw lcx_error("libcloudph++: pred_corr advection not supported by this backend");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
+    sizes.assign(oi.dry_sizes, oi.dry_sizes + oi.n_dry_sizes);
+    for (size_t d = 0; d < sizes.size(); ++d)
+      if (d == 0 || sizes[d].kappa != sizes[d - 1].kappa || sizes[d].rd_insol != sizes[d - 1].rd_insol) ++n_size_keys;
     kernel_parameters_h.assign(oi.kernel_parameters, oi.kernel_parameters + oi.n_kernel_parameters);
     w_LS_h.assign(oi.w_LS, oi.w_LS + oi.n_w_LS);
     conc_factor_h.assign(oi.aerosol_conc_factor, oi.aerosol_conc_factor + oi.n_aerosol_conc_factor);
@@ -512,7 +516,7 @@ struct Particles : IParticles {
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p};
     hipLaunchKernelGGL(k_coal<T>, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
                        A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p);
-    if (o.n_dry_distros + o.n_dry_sizes > 1)
+    if (o.n_dry_distros + n_size_keys > 1)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
   }
 
@@ -630,14 +634,34 @@ struct Particles : IParticles {
                          conc_factor_h.empty() ? (const T *)nullptr : conc_factor.p, m1(o.nz), o.aerosol_independent_of_rhod, n_dims,
                          T(T(o.dx) * T(o.dy) * T(o.dz)), A.n.p);
       hipLaunchKernelGGL(k_init_wet<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, A.rd3.p, A.kpa.p, ijk.p, RH.p, Tk.p, T(o.RH_max), A.rw2.p);
-      const int nn[3] = {o.nx, o.ny, o.nz};
-      const T a0[3] = {T(o.x0), T(o.y0), T(o.z0)}, b1[3] = {T(o.x1), T(o.y1), T(o.z1)}, dd[3] = {T(o.dx), T(o.dy), T(o.dz)};
-      T *pos[3] = {A.x.p, A.y.p, A.z.p};
-      for (int ix = 0; ix < 3; ++ix) {
-        if (!nn[ix]) continue;
-        const u01_src<T> rs = rand_u01(n_new);
-        hipLaunchKernelGGL(k_init_pos<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, ix, g, ijk.p, rs, a0[ix], b1[ix], dd[ix], pos[ix]);
-      }
+      init_positions(n_new, n_old);
+    }
+    release_replay_keep();
+  }
+  void init_positions(size_t n_new, size_t n_old)
+  {                                                                                      // init_xyz.ipp:40-74
+    const int nn[3] = {o.nx, o.ny, o.nz};
+    const T a0[3] = {T(o.x0), T(o.y0), T(o.z0)}, b1[3] = {T(o.x1), T(o.y1), T(o.z1)}, dd[3] = {T(o.dx), T(o.dy), T(o.dz)};
+    T *pos[3] = {A.x.p, A.y.p, A.z.p};
+    for (int ix = 0; ix < 3; ++ix) {
+      if (!nn[ix]) continue;
+      const u01_src<T> rs = rand_u01(n_new);
+      hipLaunchKernelGGL(k_init_pos<T>, dim3(nblk(n_new)), dim3(BS), 0, st, n_new, n_old, ix, g, ijk.p, rs, a0[ix], b1[ix], dd[ix], pos[ix]);
+    }
+  }
+  void init_SD_with_sizes()
+  {                                                                                      // init_SD_with_sizes.ipp:14-77
+    for (const auto &ds : sizes) {
+      const n_t per_cell = n_t(ds.sd_count);
+      const size_t n_old = npart, n_new = size_t(per_cell) * ncell;
+      check_npart(n_old + n_new);
+      npart = nphys = n_old + n_new;
+      if (n_new == 0) continue;
+      const T r = T(ds.radius);
+      hipLaunchKernelGGL(k_init_sizes<T>, dim3(nblk(n_new)), dim3(BS), 0, st, n_new, n_old, per_cell, T(r * r * r), T(ds.kappa), T(ds.conc), dv.p, rhod.p,
+                         conc_factor_h.empty() ? (const T *)nullptr : conc_factor.p, m1(o.nz), o.aerosol_independent_of_rhod, ijk.p, A.rd3.p, A.kpa.p, A.vt.p, A.n.p);
+      hipLaunchKernelGGL(k_init_wet<T>, dim3(nblk(n_new)), dim3(BS), 0, st, n_new, n_old, A.rd3.p, A.kpa.p, ijk.p, RH.p, Tk.p, T(o.RH_max), A.rw2.p);
+      init_positions(n_new, n_old);
     }
     release_replay_keep();
   }
@@ -664,7 +688,7 @@ struct Particles : IParticles {
     init_called = true;
     if (is_null(th_) || is_null(rv_) || is_null(rhod_)) throw lcx_error("libcloudph++: passing th, rv and rhod is mandatory");
     courant_checks(cx, cy, cz);
-    if (distros.empty() && o.n_dry_sizes == 0) throw lcx_error("libcloudph++: Both dry_distros and dry_sizes are undefined");
+    if (distros.empty() && sizes.empty()) throw lcx_error("libcloudph++: Both dry_distros and dry_sizes are undefined");
     if (n_dims > 0) {
       if (!(o.x0 >= 0 && o.x0 < m1(o.nx) * o.dx)) throw lcx_error("libcloudph++: !(x0 >= 0 & x0 < min(1,nx)*dz)");
       if (!(o.y0 >= 0 && o.y0 < m1(o.ny) * o.dy)) throw lcx_error("libcloudph++: !(y0 >= 0 & y0 < min(1,ny)*dy)");
@@ -690,7 +714,6 @@ struct Particles : IParticles {
     if (!o.const_p && !is_null(p_)) throw lcx_error("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
     if (o.sstp_cond < 1) throw lcx_error("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
     if (!o.sstp_cond_mix && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
-    if (o.n_dry_sizes > 0) throw lcx_error("libcloudph++: dry_sizes initialisation not supported by this backend yet");
   }
   void courant_checks(const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) const
   {
@@ -721,7 +744,8 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
                          T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
     hskpng_Tpr();
-    if (!o.no_ccn_at_init && !distros.empty()) init_SD_with_distros();
+    if (!o.no_ccn_at_init && !distros.empty() && o.sd_conc > 0) init_SD_with_distros();
+    if (!o.no_ccn_at_init && !sizes.empty()) init_SD_with_sizes();
     if (o.coal_switch) init_kernel();
     if (o.terminal_velocity == LCX_VT_BEARD77FAST) {
       vt_0.alloc(size_t(vtc.n_bin));
@@ -827,12 +851,12 @@ struct Particles : IParticles {
     selected_before_counting = true;
     sync();
   }
-  void moms_sum(const T *vec, T power, int kind, bool specific)
+  void moms_sum(const T *vec, T power, int kind, bool specific, const T *vec2 = nullptr)
   {
     if (!selected_before_counting) throw lcx_error("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
     hskpng_sort();
     if (npart)
-      hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, power, kind, m3_after.p);
+      hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, vec2, power, kind, m3_after.p);
     hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, CF_CELLS)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p,
                        int(specific && n_dims > 0), count_mom.p);
     sync();
@@ -841,7 +865,8 @@ struct Particles : IParticles {
   void diag_mom(int attr, double power) override { moms_sum(attr_ptr(attr), T(power), 0, true); }
   void diag_precip_rate() override
   {                                                                                      // particles_diag.ipp:529-547
-    throw lcx_error("libcloudph++: diag_precip_rate not supported by this backend yet");
+    hskpng_vterm(false);
+    moms_sum(A.rw2.p, T(1), 2, false, A.vt.p);
   }
   void diag_max_rw() override
   {

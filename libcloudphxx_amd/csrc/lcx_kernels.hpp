@@ -776,14 +776,15 @@ __global__ void k_nfilt(size_t n_part, int mode, int cons, const n_t *n, const T
   else if (mode == 1) { const T v = vec[i]; nf[i] = (v >= vmin && v < vmax) ? y : T(0); }
   else nf[i] = y * (vec[i] > 0);
 }
-// per sorted position: value to be summed.  kind 0: n_f * vec^power (moment_counter, moms.ipp:243-275), 1: n_f > 0
+// per sorted position: value to be summed.  kind 0: n_f * vec^power (moment_counter, moms.ipp:243-275), 1: n_f > 0,
+// 2: n_f * (rw2^(3/2) * vt)  (precip_rate, particles_diag.ipp:56-68 with power 1)
 template <class T>
-__global__ void k_mom_vals(size_t n_part, const uint32_t *sorted_id, const T *nf, const T *vec, T power, int kind, T *out)
+__global__ void k_mom_vals(size_t n_part, const uint32_t *sorted_id, const T *nf, const T *vec, const T *vec2, T power, int kind, T *out)
 {
   const size_t p = gid(); if (p >= n_part) return;
   const uint32_t id = sorted_id[p];
   if (kind == 1) { out[p] = nf[id] > T(0) ? T(1) : T(0); return; }
-  const T x = vec[id];
+  const T x = kind == 2 ? T(pow(vec[id], T(3. / 2)) * vec2[id]) : vec[id];
   out[p] = x >= 0 ? nf[id] * pow(x, power) : nf[id] * pow(x, T(int(power)));
 }
 template <class T>
@@ -814,7 +815,7 @@ __global__ void k_cell_max(size_t n_cell, const uint32_t *cell_start, const uint
   const size_t c = gid(); if (c >= n_cell) return;
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T acc = 0;
-  for (uint32_t q = s; q < e; ++q) { const T v = vec[sorted_id[q]]; if (q == s || v > acc) acc = v; }
+  for (uint32_t q = s; q < e; ++q) { const T v = sqrt(vec[sorted_id[q]]); if (q == s || acc < v) acc = v; }
   out[c] = acc;
 }
 
@@ -834,6 +835,21 @@ __global__ void k_init_dry(size_t n_new, size_t n_old, n_t per_cell, T log_rd_mi
   rd3[n_old + gI] = exp(3 * lnrd);
   kpa[n_old + gI] = kappa;
   vt[n_old + gI] = T(-1);                                                    // resize fills vt with `invalid`
+}
+// init_SD_with_sizes.ipp:14-77: `per_cell` SDs of one dry radius in every cell; multiplicity from the STP
+// concentration (conc_to_number, init_count_num.ipp:41-70, and init_n.ipp:130-143)
+template <class T>
+__global__ void k_init_sizes(size_t n_new, size_t n_old, n_t per_cell, T rad3, T kappa, T conc0, const T *dv, const T *rhod,
+                             const T *conc_factor, int nz, int indep_rhod, uint32_t *ijk, T *rd3, T *kpa, T *vt, n_t *n)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  const size_t c = gI / per_cell, p = n_old + gI;
+  ijk[p] = uint32_t(c); rd3[p] = rad3; kpa[p] = kappa; vt[p] = T(-1);
+  T conc = conc0;
+  conc = conc * dv[c];
+  if (!indep_rhod) conc = rhod[c] / cst<T>::rho_stp * conc;
+  if (conc_factor) conc = conc * conc_factor[c % nz];
+  n[p] = n_t(conc / size_t(per_cell) + T(.5));
 }
 struct lognormal_modes { int n; double mean_rd[4], sdev[4], n_stp[4]; };
 // init_n.ipp:48-143 with the built-in lognormal spectrum evaluated on the device

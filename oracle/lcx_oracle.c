@@ -72,7 +72,7 @@ typedef struct { double *q; sz len, pos; } fifo_arr;
 struct orc_particles {
   lcx_opts_init_t o;
   lcx_distro_t *distros; lcx_dry_size_t *sizes;
-  double *kernel_parameters; sz n_kernel_parameters; double kernel_r_max; int n_user_params;
+  double *kernel_parameters; sz n_kernel_parameters; double kernel_r_max; int n_user_params; int n_size_keys;
   double *w_LS, *aerosol_conc_factor;
   int n_dims; sz n_cell, n_part, n_part_old, n_part_to_init, cap;
   int init_called, should_now_run_async, should_now_run_cond, selected_before_counting, var_rho, sorted;
@@ -137,6 +137,8 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->sizes = NEW(lcx_dry_size_t, oi->n_dry_sizes);
   if (oi->n_dry_sizes) memcpy(s->sizes, oi->dry_sizes, sizeof(lcx_dry_size_t) * oi->n_dry_sizes);
   s->n_user_params = oi->n_kernel_parameters;
+  for (int d = 0; d < oi->n_dry_sizes; ++d)        /* dry_sizes.size() of the reference = number of (kappa, rd_insol) keys */
+    if (d == 0 || oi->dry_sizes[d].kappa != oi->dry_sizes[d - 1].kappa || oi->dry_sizes[d].rd_insol != oi->dry_sizes[d - 1].rd_insol) s->n_size_keys++;
   s->n_kernel_parameters = oi->n_kernel_parameters;
   s->kernel_parameters = NEW(double, oi->n_kernel_parameters);
   if (oi->n_kernel_parameters) memcpy(s->kernel_parameters, oi->kernel_parameters, sizeof(double) * oi->n_kernel_parameters);
@@ -571,7 +573,7 @@ static void coal(orc_particles *s, double dt)
     }
     s->col[p] = (double)col_no;
   }
-  if (s->o.n_dry_distros + s->o.n_dry_sizes > 1)           /* weighted_summator, coal.ipp:57-97,458-480 */
+  if (s->o.n_dry_distros + s->n_size_keys > 1)             /* weighted_summator, coal.ipp:57-97,458-480 */
     for (sz p = 0; p + 1 < s->n_part; ++p) {
       if (s->col[p] <= 0) continue;
       const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
@@ -770,6 +772,53 @@ static int init_SD_with_distros(orc_particles *s)
   }
   return 0;
 }
+/* init_SD_with_sizes.ipp:14-77, init_count_num.ipp:41-70,88-92 (conc_to_number), init_n.ipp:130-143, init_dry_dry_sizes.ipp:14-20 */
+static int init_SD_with_sizes(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  for (int d = 0; d < o->n_dry_sizes; ++d) {
+    const lcx_dry_size_t *ds = &s->sizes[d];
+    const n_t per_cell = (n_t)ds->sd_count;
+    for (sz c = 0; c < s->n_cell; ++c) s->count_num[c] = per_cell;
+    s->n_part_old = s->n_part;
+    s->n_part_to_init = (sz)per_cell * s->n_cell;
+    s->n_part += s->n_part_to_init;
+    if (resize_npart(s)) return 1;
+    { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
+    const double rad3 = ds->radius * ds->radius * ds->radius;
+    for (sz p = s->n_part_old; p < s->n_part; ++p) { s->rd3[p] = rad3; s->kpa[p] = ds->kappa; s->vt[p] = -1.; }
+    for (sz p = s->n_part_old; p < s->n_part; ++p) {
+      const sz c = s->ijk[p];
+      double conc = ds->conc;
+      conc = conc * s->dv[c];
+      if (!o->aerosol_independent_of_rhod) conc = s->rhod[c] / rho_stp * conc;
+      if (o->n_aerosol_conc_factor > 0) conc = conc * s->aerosol_conc_factor[c % o->nz];
+      s->n[p] = (n_t)(conc / (sz)ds->sd_count + .5);
+    }
+    for (sz p = s->n_part_old; p < s->n_part; ++p) {
+      const sz c = s->ijk[p];
+      s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
+    }
+    const int nn[3] = {o->nx, o->ny, o->nz};
+    const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
+    double *v[3] = {s->x, s->y, s->z};
+    const sz nz = m1(o->nz), ny = m1(o->ny);
+    for (int ix = 0; ix < 3; ++ix) {
+      if (nn[ix] == 0) continue;
+      for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+      for (sz g = 0; g < s->n_part_to_init; ++g) {
+        const sz p = s->n_part_old + g, c = s->ijk[p];
+        sz ii;
+        if (s->n_dims == 1) ii = c;
+        else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
+        else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
+        const double u = s->tmp_part[g];
+        v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
+      }
+    }
+  }
+  return 0;
+}
 /* init_grid.ipp:14-54 */
 static void init_grid(orc_particles *s)
 {
@@ -882,7 +931,7 @@ int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
   hskpng_Tpr(s);
   if (!s->o.no_ccn_at_init) {
     if (s->o.n_dry_distros > 0 && init_SD_with_distros(s)) return 1;
-    if (s->o.n_dry_sizes > 0) FAIL("libcloudph++: dry_sizes initialisation not supported by this backend yet");
+    if (s->o.n_dry_sizes > 0 && init_SD_with_sizes(s)) return 1;
   }
   if (s->o.coal_switch && init_kernel(s)) return 1;
   init_vterm(s);
@@ -992,6 +1041,7 @@ int orc_diag_temperature(orc_particles *s) { diag_cellfield(s, s->T); return 0; 
 int orc_diag_RH(orc_particles *s) { diag_cellfield(s, s->RH); return 0; }
 int orc_diag_sd_conc(orc_particles *s)
 {
+  if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
   hskpng_sort(s);
   sz cn = 0;
   for (sz p = 0; p < s->n_part; ++p) {
@@ -1010,9 +1060,32 @@ int orc_diag_kappa_rng(orc_particles *s, double a, double b) { moms_rng(s, a, b,
 int orc_diag_dry_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 1); return 0; }
 int orc_diag_wet_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 1); return 0; }
 int orc_diag_kappa_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 1); return 0; }
-int orc_diag_dry_mom(orc_particles *s, int k) { moms_calc(s, s->rd3, k / 3., 1); return 0; }
-int orc_diag_wet_mom(orc_particles *s, int k) { moms_calc(s, s->rw2, k / 2., 1); return 0; }
-int orc_diag_kappa_mom(orc_particles *s, int k) { moms_calc(s, s->kpa, k, 1); return 0; }
+#define NEED_SELECTION if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments")
+int orc_diag_dry_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rd3, k / 3., 1); return 0; }
+int orc_diag_wet_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rw2, k / 2., 1); return 0; }
+int orc_diag_kappa_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->kpa, k, 1); return 0; }
+/* particles_diag.ipp:555-584: sum of n_filtered * rw^3 * vt per cell (not specific); refreshes vt as a side effect */
+int orc_diag_precip_rate(orc_particles *s)
+{
+  if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
+  hskpng_vterm(s, 0);
+  for (sz p = 0; p < s->n_part; ++p) s->tmp_part[p] = pow(s->rw2[p], 3. / 2) * s->vt[p];
+  moms_calc(s, s->tmp_part, 1., 0);
+  return 0;
+}
+/* particles_diag.ipp:607-640: max wet radius per cell */
+int orc_diag_max_rw(orc_particles *s)
+{
+  hskpng_sort(s);
+  sz cn = 0;
+  for (sz p = 0; p < s->n_part; ++p) {
+    const double v = sqrt(s->rw2[s->sorted_id[p]]);
+    if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
+    else if (s->count_mom[cn - 1] < v) s->count_mom[cn - 1] = v;
+  }
+  s->count_n = cn;
+  return 0;
+}
 int orc_outbuf(orc_particles *s, const void **data, size_t *n)
 {
   for (sz c = 0; c < s->n_cell; ++c) s->outbuf[c] = 0;

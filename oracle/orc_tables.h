@@ -1,5 +1,5 @@
 /* orc_tables.h -- TEST INFRASTRUCTURE (oracle).  Collision-efficiency tables for the
- * "geometric x tabulated efficiency" kernels (reference: src/detail/kernel_definitions/*.hpp).
+ * "geometric x tabulated efficiency" kernels (reference: src/detail/kernel_definitions/, six *_efficiencies.hpp files).
  * The tables are numeric data loaded at run time from libcloudphxx_amd/data/kernel_eff_<id>.f64
  * (see tools/extract_efficiency_tables.py); LCX_DATA_DIR overrides the directory. */
 #ifndef ORC_TABLES_H

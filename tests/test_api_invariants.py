@@ -1,0 +1,132 @@
+"""Integer-exact API invariants of the reference's tests/python/unit/api_lgrngn.py, for the init modes this backend
+supports (sd_conc distros, dry_sizes, both together), in 0-D ... 3-D.  Run against the oracle on CPU and against the HIP
+backend on the GPU."""
+import numpy as np
+import pytest
+from numpy import frombuffer, isclose
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+rho_stp = 1.2248          # api_lgrngn.py:28
+kappa1, kappa2, kappa3, rd_insol = .61, 1.28, 0.8, 0.
+
+
+def base_opts():
+    oi = lgrngn.opts_init_t()
+    oi.dry_distros = {(kappa1, rd_insol): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6)}
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.terminal_velocity = lgrngn.vt_t.beard76
+    oi.dt = 1
+    oi.sd_conc = 64
+    oi.n_sd_max = int(1e6)
+    oi.sedi_switch = False
+    return oi
+
+
+MAKERS = [pytest.param(h.oracle_particles, id="oracle"), pytest.param(h.hip_particles, id="hip", marks=pytest.mark.gpu)]
+th0, rv0, rhod0 = np.array([300.]), np.array([.01]), np.array([1.])
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_0d_sd_conc_and_call_order(make):
+    """api_lgrngn.py:110-190"""
+    oi = base_opts()
+    pr = make(oi)
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.adve = False
+    with pytest.raises(RuntimeError):
+        pr.step_sync(opts, th0, rv0, rhod0)
+    pr.init(th0.copy(), rv0.copy(), rhod0.copy())
+    with pytest.raises(RuntimeError):
+        pr.step_async(opts)
+    th, rv = th0.copy(), rv0.copy()
+    pr.step_sync(opts, th, rv, rhod0)
+    with pytest.raises(RuntimeError):
+        pr.step_sync(opts, th, rv, rhod0)
+    pr.step_async(opts)
+    with pytest.raises(RuntimeError):
+        pr.step_async(opts)
+    pr.diag_all()
+    pr.diag_sd_conc()
+    assert len(frombuffer(pr.outbuf())) == 1
+    assert frombuffer(pr.outbuf())[0] == oi.sd_conc
+    with pytest.raises(RuntimeError):                 # Courant numbers in 0-D
+        pr2 = make(base_opts())
+        pr2.init(th0.copy(), rv0.copy(), rhod0.copy(), Cx=np.zeros(1))
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_0d_dry_sizes_two_kappas(make):
+    """api_lgrngn.py:243-301: exact counts 75 / 50 / 30 / 20 / 15 / 10 and kappa moments"""
+    oi = base_opts()
+    oi.dry_distros = dict()
+    oi.dry_sizes = {(kappa1, rd_insol): {1.e-6: [30. * rho_stp, 15], 15.e-6: [10. * rho_stp, 10]},
+                    (kappa2, rd_insol): {1.2e-6: [20. * rho_stp, 10], 12.e-6: [15. * rho_stp, 15]}}
+    oi.sd_conc = 0
+    pr = make(oi)
+    pr.init(th0.copy(), rv0.copy(), rhod0.copy())
+    pr.diag_all()
+    pr.diag_sd_conc()
+    sd_tot = frombuffer(pr.outbuf()).sum()
+    pr.diag_all()
+    pr.diag_wet_mom(0)
+    assert frombuffer(pr.outbuf()).sum() == 75.
+    assert sd_tot == 50.
+    for (lo, hi, n_exp, kap) in ((1e-6, 1.1e-6, 30, kappa1), (1.2e-6, 1.3e-6, 20, kappa2), (12e-6, 13e-6, 15, kappa2), (15e-6, 15.1e-6, 10, kappa1)):
+        pr.diag_dry_rng(lo, hi)
+        pr.diag_wet_mom(0)
+        n = frombuffer(pr.outbuf()).copy()
+        pr.diag_kappa_mom(1)
+        k = frombuffer(pr.outbuf())
+        assert (n == n_exp).all()
+        assert isclose(k, n * kap, rtol=1e-15)
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_0d_dry_sizes_plus_sd_conc(make):
+    """api_lgrngn.py:308-323, 683-697: 64 from the distro + 20 from sizes; attributes ordered distro first, then sizes"""
+    oi = base_opts()
+    oi.dry_sizes = {(kappa3, rd_insol): {1.e-6: [30. * rho_stp, 15], 15.e-6: [10. * rho_stp, 5]}}
+    pr = make(oi)
+    pr.init(th0.copy(), rv0.copy(), rhod0.copy())
+    pr.diag_all()
+    pr.diag_sd_conc()
+    assert frombuffer(pr.outbuf())[0] == 84
+    kap = pr.get_attr("kappa")
+    assert (kap[:64] == kappa1).all() and (kap[64:] == kappa3).all()
+    rd3 = pr.get_attr("rd3")
+    assert np.allclose(rd3[64:79], 1e-18, rtol=1e-15) and np.allclose(rd3[79:], (15e-6) ** 3, rtol=1e-15)
+
+
+@pytest.mark.parametrize("make", MAKERS)
+@pytest.mark.parametrize("dims", [(3, 0, 0), (2, 0, 2), (2, 2, 2)])
+def test_nd_sd_conc_is_conserved_by_advection(make, dims):
+    """api_lgrngn.py:400-565: sum of sd_conc == n_cell * 64 after steps with advection in 1-D / 2-D / 3-D"""
+    nx, ny, nz = dims
+    oi = base_opts()
+    oi.nx, oi.ny, oi.nz = nx, ny, nz
+    oi.dx = oi.dy = oi.dz = 10
+    oi.x1, oi.y1, oi.z1 = max(nx, 1) * 10, max(ny, 1) * 10, max(nz, 1) * 10
+    if ny == 0:
+        oi.dy, oi.y1 = 1, 1
+    if nz == 0:
+        oi.dz, oi.z1 = 1, 1
+    shp = tuple(n for n in (nx, ny, nz) if n > 0)
+    th, rv, rhod = 300. * np.ones(shp), .01 * np.ones(shp), np.ones(shp)
+    C = {}
+    C["Cx"] = 0.5 * np.ones((nx + 1,) + shp[1:])
+    if ny:
+        C["Cy"] = 0.2 * np.ones((nx, ny + 1, nz))
+    if nz:
+        C["Cz"] = np.zeros(shp[:-1] + (nz + 1,))
+    pr = make(oi)
+    pr.init(th, rv, rhod, **C)
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.coal = False
+    for _ in range(3):
+        pr.step_sync(opts, th, rv, rhod)
+        pr.step_async(opts)
+    pr.diag_all()
+    pr.diag_sd_conc()
+    assert frombuffer(pr.outbuf()).sum() == 64 * int(np.prod(shp))

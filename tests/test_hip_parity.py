@@ -367,6 +367,43 @@ def test_full_steps_replay(dims, sstp, strict_fp):
         h.copy_state(orc, hip)
 
 
+# ------------------------------------------------------------------ diagnostics (a21)
+def test_diagnostics_match_oracle():
+    oi = h.box_opts(4, 3, 5, 40)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    step_pair(orc, hip, opts, fields)
+    h.copy_state(orc, hip)
+
+    def both(fn):
+        out = []
+        for p in (orc, hip):
+            fn(p)
+            out.append(p.outbuf_array())
+        return out
+    checks = [
+        lambda p: (p.diag_all(), p.diag_sd_conc()),
+        lambda p: (p.diag_all(), p.diag_wet_mom(0)), lambda p: (p.diag_all(), p.diag_wet_mom(1)),
+        lambda p: (p.diag_all(), p.diag_wet_mom(3)), lambda p: (p.diag_all(), p.diag_dry_mom(3)),
+        lambda p: (p.diag_all(), p.diag_kappa_mom(1)),
+        lambda p: (p.diag_wet_rng(.5e-6, 25e-6), p.diag_wet_mom(3)),
+        lambda p: (p.diag_dry_rng(0, 5e-8), p.diag_wet_rng_cons(0, 1e-6), p.diag_sd_conc()),
+        lambda p: (p.diag_kappa_rng(.5, 1.), p.diag_dry_mom(0)),
+        lambda p: (p.diag_water(), p.diag_wet_mom(2)),
+        lambda p: (p.diag_all(), p.diag_precip_rate()),
+        lambda p: p.diag_max_rw(), lambda p: p.diag_RH(), lambda p: p.diag_temperature(), lambda p: p.diag_pressure(),
+    ]
+    for i, fn in enumerate(checks):
+        o, g_ = both(fn)
+        np.testing.assert_allclose(g_, o, rtol=1e-11, atol=0, err_msg="diag #%d" % i)
+    with pytest.raises(RuntimeError):
+        fresh = h.hip_particles(oi)
+        fresh.init(fields[0].copy(), fields[1].copy(), fields[2].copy(), **fields[3])
+        fresh.diag_wet_mom(1)            # counting before selecting
+
+
 # ------------------------------------------------------------------ API behaviour (api_lgrngn.py:123-133,166-170)
 def test_call_order_exceptions():
     oi = h.box_opts(0, 0, 0, 64, sedi_switch=False)
