@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=128, help="cells per dimension (BASELINE: 128)")
+    ap.add_argument("--nx", type=int, default=0, help="override the number of x-planes (emulates one slab of a decomposed run)")
     ap.add_argument("--sd-conc", type=int, default=64)
     ap.add_argument("--dx", type=float, default=40.)
     ap.add_argument("--sstp-cond", type=int, default=1)
@@ -145,6 +146,8 @@ def main():
     tdtype = torch.float64 if args.real == "f64" else torch.float32
     n = args.n
     nx_tot = n * world if args.scaling == "weak" else n
+    if args.nx:
+        nx_tot = args.nx
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = local_rank
     oi.strict_fp = args.strict_fp

@@ -120,7 +120,7 @@ struct Particles : IParticles {
   size_t n_cx = 0, n_cy = 0, n_cz = 0;
   DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
   DevBuf<double> puddle_partial, puddle_sum;
-  DevBuf<int> d_flag;
+  DevBuf<int> d_flag; DevBuf<unsigned int> d_dead;
   void *pinned = nullptr;      // 256 B of page-locked host memory for the small per-step read-backs (counts, sums)
   double puddle[LCX_OUT_COUNT];
   bool count_mom_valid_all = true;
@@ -188,7 +188,7 @@ struct Particles : IParticles {
     if (oi.coal_switch) col.alloc(cap);
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
       b->alloc_zero(ncell, st);
-    d_flag.alloc_zero(1, st);
+    d_flag.alloc_zero(1, st); d_dead.alloc_zero(1, st);
     puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4);
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
@@ -454,6 +454,16 @@ struct Particles : IParticles {
     npart = alive;
     sort_from_hist(false);
   }
+  // post_copy when k_move has already produced ijk / histogram / ranks / the dead count
+  void post_copy_after_fused_move(const lcx_opts_t &opts)
+  {
+    unsigned int dead = 0;
+    read_back(&dead, d_dead.p, 1);
+    if (dead && (eager_compact || size_t(dead) * 32 > nphys)) { post_copy(opts, true); return; }
+    Range r(this, "post_copy");
+    npart = nphys - dead;
+    sort_from_hist(false);
+  }
   // make storage order == the reference's (no dead SDs in it) before anything that exposes storage order
   void ensure_compact()
   {
@@ -523,7 +533,8 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   // adve + sedi + subs + bcnd in one pass
   // ------------------------------------------------------------------------------------------
-  void move(bool do_adve, bool do_sedi, bool do_subs, bool do_bcnd)
+  // reindex: also produce the new cell index / histogram / rank / dead count (single-device post_copy fused in)
+  void move(bool do_adve, bool do_sedi, bool do_subs, bool do_bcnd, bool reindex = false)
   {
     if (n_dims == 0 || nphys == 0) { if (do_bcnd) { lft_count = rgt_count = 0; } return; }
     Range r(this, "move(adve+sedi+bcnd)");
@@ -540,6 +551,11 @@ struct Particles : IParticles {
     const unsigned blocks = nblk(nphys);
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
     a.mig = mig.p;
+    a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead.p;
+    if (reindex) {
+      HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
+      HIPCHK(hipMemsetAsync(d_dead.p, 0, sizeof(unsigned int), st));
+    }
     hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
     if (want_puddle) {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
@@ -822,9 +838,12 @@ struct Particles : IParticles {
       }
       release_replay_keep();
     }
-    move(opts.adve, opts.sedi, opts.subs, true);
+    // single device, > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions
+    const bool fused = !distmem() && n_dims > 0 && nphys > 0 && !opts.rcyc;
+    move(opts.adve, opts.sedi, opts.subs, true, fused);
     adve_scheme = o.adve_scheme;
-    if (!distmem()) post_copy(opts);
+    if (fused) post_copy_after_fused_move(opts);
+    else if (!distmem()) post_copy(opts);
     sync();
     selected_before_counting = false;
   }

@@ -599,6 +599,9 @@ struct move_args {
   int do_adve, scheme, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
   double *puddle_partial;      // [gridDim][4]: liq_vol, dry_vol, liq_num, prtcl_num
   uint8_t *mig;                // distmem: 1 = left the domain through the left face, 2 = right
+  // fused re-indexing (single-device runs): the new cell index, the cell histogram with per-SD rank and the number of
+  // dead SDs come out of the same pass, so post_copy needs no further sweep over the positions
+  int reindex; uint32_t *ijk_out, *cnt, *rank; unsigned int *dead_count;
 };
 template <class T>
 __device__ __forceinline__ T adve_1d(int scheme, T x, uint32_t fl, T C_l, T C_r, T dx)
@@ -614,8 +617,14 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   __shared__ double red[4][BS / WAVE];
   const size_t i = gid();
   double pl = 0, pd = 0, pn = 0, pp = 0;
-  const uint32_t c = i < a.n_part ? a.ijk[i] : DEAD_CELL;
+  uint32_t c = i < a.n_part ? a.ijk[i] : DEAD_CELL;
   if (c == DEAD_CELL && i < a.n_part && a.mig) a.mig[i] = 0;
+  bool dead_now = false;         // counted in dead_count: was dead already, or dies in this pass
+  uint32_t c_new = DEAD_CELL;
+  if (a.reindex && i < a.n_part) {
+    if (c == DEAD_CELL) dead_now = true;
+    else if (a.n[i] == 0) { dead_now = true; c = DEAD_CELL; }          // multiplicity went to zero in coalescence
+  }
   if (c != DEAD_CELL) {
     const grid_t &g = a.g;
     const size_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
@@ -670,7 +679,15 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     if (g.nx) a.x[i] = x;
     if (g.ny) a.y[i] = y;
     if (g.nz) a.z[i] = z;
-    if (kill) a.n[i] = 0;
+    if (kill) { a.n[i] = 0; dead_now = true; }
+    else if (a.reindex) c_new = cell_of(g, x, y, z);
+  }
+  if (a.reindex) {                                    // every lane of the wave takes part (ballots inside)
+    const bool live = c_new != DEAD_CELL;
+    const uint32_t r = wave_hist_rank(a.cnt, c_new, live);
+    if (i < a.n_part) { a.ijk_out[i] = c_new; if (live) a.rank[i] = r; }
+    const unsigned long long db = __ballot(dead_now);
+    if (db && lane_id() == 0) atomicAdd(a.dead_count, (unsigned int)__popcll(db));
   }
   if (a.puddle_partial) {
     // deterministic block reduction (fixed shuffle tree), one partial per workgroup, summed by the host in order
