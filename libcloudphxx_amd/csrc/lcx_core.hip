@@ -1138,4 +1138,17 @@ int lcx_dev_copy(void *dst, const void *src, size_t bytes, int kind)
 }
 int lcx_dev_sync(void) { LCX_TRY({ if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): device synchronize failed"); }) }
 
+int lcx_math_probe(int which, const double *x, double *y, size_t n)
+{
+  LCX_TRY({
+    double *d = nullptr;
+    if (hipMalloc(&d, (n ? n : 1) * sizeof(double)) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed");
+    hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice);
+    if (n) hipLaunchKernelGGL(lcx::k_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, which, d, n);
+    const hipError_t e = hipMemcpy(y, d, n * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d);
+    if (e != hipSuccess) throw std::runtime_error(std::string("libcloudph++ (HIP): math probe failed: ") + hipGetErrorString(e));
+  })
+}
+
 } // extern "C"

@@ -980,4 +980,13 @@ __global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, co
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 
+// parity hook (lcx_math_probe): the device elementary functions on an array
+__global__ void k_math_probe(int which, double *v, size_t n)
+{
+  const size_t i = gid();
+  if (i >= n) return;
+  const double x = v[i];
+  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : exp(x);
+}
+
 } // namespace lcx

@@ -269,6 +269,57 @@ template <class T> struct cond_fun {
   LCX_HD T operator()(T rw2) const { return rw2_old + dt * drw2_dt(rw2) - rw2; }
 };
 
+// ---- lean fp64 elementary functions for the collected growth rate (fast mode only).
+// The library cbrt/exp cost ~34/~54 VALU instructions each and make up 85 % of one growth-rate evaluation; their
+// arguments here are confined (cbrt of 1 + Re*Sc >= 1, exp of the Kelvin term A/r_w in (0, a few)), so a single
+// precision hardware seed (v_log_f32 / v_exp_f32 / v_rcp_f32) refined in double does the same job in ~15/~20.
+// Both are accurate to <= 1 ulp on their domain (tests/test_hip_parity.py::test_fast_math_accuracy) and fall back
+// to the library call outside it.
+LCX_HD double cbrt_seeded(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x >= 0.125 && x < 1e30)) return cbrt(x);
+  const float xf = float(x);
+  const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.f / 3.f));      // ~1e-6 relative
+  const double inv = double(__builtin_amdgcn_rcpf(3.f * y0 * y0));                       // 1 / (3 y^2), ~1e-7
+  double y = double(y0);
+  y = __builtin_fma(-inv, __builtin_fma(y * y, y, -x), y);                               // Newton, error -> ~1e-13
+  y = __builtin_fma(-inv, __builtin_fma(y * y, y, -x), y);                               //          -> rounding
+  return y;
+#else
+  return cbrt(x);
+#endif
+}
+LCX_HD float cbrt_seeded(float x) { return cbrt(x); }
+
+LCX_HD double exp_reduced(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x > -700. && x < 700.)) return exp(x);
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);                           // ln2 hi / lo (fdlibm split)
+  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                                                     // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);
+  p = __builtin_fma(p, r, 2.505210838544172e-08);
+  p = __builtin_fma(p, r, 2.755731922398589e-07);
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);
+  p = __builtin_fma(p, r, 2.48015873015873e-05);
+  p = __builtin_fma(p, r, 1.984126984126984e-04);
+  p = __builtin_fma(p, r, 1.3888888888888889e-03);
+  p = __builtin_fma(p, r, 8.333333333333333e-03);
+  p = __builtin_fma(p, r, 4.1666666666666664e-02);
+  p = __builtin_fma(p, r, 1.6666666666666666e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, int(k));
+#else
+  return exp(x);
+#endif
+}
+LCX_HD float exp_reduced(float x) { return exp(x); }
+
 // The same growth rate as cond_fun, algebraically collected into ONE rational expression (one IEEE division
 // instead of fifteen) with FMA contraction allowed.  Selected by opts_init.strict_fp = 0.  It is the counterpart
 // of how the reference itself is built for production (-Ofast: reassociation + contraction, CMakeLists.txt:124):
@@ -291,18 +342,18 @@ template <class T> struct cond_fun_fast {
   LCX_HD T drw2_dt(T rw2) const
   {
 #pragma clang fp contract(fast)
-    const T rw = sqrt(rw2);
-    const T irw = T(1) / rw;
+    const T irw = rsqrt(rw2);         // one v_rsq + Newton step; rw = rw2 / sqrt(rw2) to ~1 ulp
+    const T rw = rw2 * irw;
     const T rw3 = rw2 * rw;
     const T Re = c_Re * rw;
     const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
-    const T Sh = T(1) + T(cbrt(T(1) + Re * Sc)) * m;
-    const T Nu = T(1) + T(cbrt(T(1) + Re * Pr)) * m;
+    const T Sh = T(1) + cbrt_seeded(T(1) + Re * Sc) * m;
+    const T Nu = T(1) + cbrt_seeded(T(1) + Re * Pr) * m;
     const T KnD = lambda_D * irw, KnK = lambda_K * irw;
     const T nD = T(1) + KnD, dD = T(1) + KnD * (T(1.71) + T(1.33) * KnD);
     const T nK = T(1) + KnK, dK = T(1) + KnK * (T(1.71) + T(1.33) * KnK);
     const T na = rw3 - rd3, da = rw3 - rd3_1mk;
-    const T klv = exp(A * irw);
+    const T klv = exp_reduced(A * irw);
     const T nDSh = nD * Sh, nKNu = nK * Nu;
     const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
     const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);
@@ -332,8 +383,11 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
           b = rw2_old + mx(T(0), cond_mlt * drw2);
   if (a == b) return rw2_old;
   T fa, fb;
-  if (drw2 > 0) { fa = drw2; fb = f(b); }
-  else          { fa = f(a); fb = drw2; }
+  // f at the old radius is (rw2_old + drw2) - rw2_old: the growth rate there is already known
+  const T f_old = (rw2_old + drw2) - rw2_old;
+  const T f_far = f(drw2 > 0 ? b : a);
+  if (drw2 > 0) { fb = f_far; fa = (a == rw2_old) ? f_old : f(a); }
+  else          { fa = f_far; fb = f_old; }
   T rw2_new;
   if (fa * fb > 0) rw2_new = rw2_old + drw2;
   else rw2_new = toms748_solve(f, a, b, fa, fb, eps, n_iter);

@@ -454,3 +454,39 @@ def test_float_build_runs_and_tracks_double():
     np.testing.assert_allclose(res[np.float32][0], res[np.float64][0], rtol=5e-3)
     np.testing.assert_allclose(res[np.float32][1], res[np.float64][1], rtol=0.15)
     assert res[np.float32][2] == res[np.float64][2]
+
+
+def test_fast_math_accuracy():
+    """the seeded cbrt / reduced exp of the fast-mode growth rate (csrc/lcx_math.hpp) against numpy in long double:
+    <= 1 ulp on their domains, library fallback outside"""
+    import ctypes
+    from libcloudphxx_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+
+    def probe(which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        rc = lib.lcx_math_probe(ctypes.c_int(which), x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+                                ctypes.c_size_t(x.size))
+        assert rc == 0
+        return y
+
+    # cbrt: arguments 1 + Re*Sc span [1, ~1e4] in practice; test the whole seeded domain and the fallback
+    x = np.concatenate([1 + 10 ** rng.uniform(-12, 5, 200000), 10 ** rng.uniform(-0.9, 29.9, 100000), [1., 8., 27., 0.125]])
+    ref = np.cbrt(x.astype(np.longdouble))
+    for which in (0, 2):
+        y = probe(which, x)
+        ulp = np.abs((y.astype(np.longdouble) - ref) / np.spacing(ref.astype(np.float64)))
+        assert float(ulp.max()) <= 1.0, (which, float(ulp.max()))
+    xf = np.array([0., -8., 1e-40, 1e300, 0.1, -1e-3, np.inf])
+    np.testing.assert_array_equal(probe(0, xf), probe(2, xf))
+    # exp: Kelvin term A / r_w in (0, ~2); test [-50, 50] and the fallback
+    x = np.concatenate([10 ** rng.uniform(-12, 0.5, 200000), rng.uniform(-50, 50, 100000), [0., 1., -1.]])
+    ref = np.exp(x.astype(np.longdouble))
+    for which in (1, 3):
+        y = probe(which, x)
+        ulp = np.abs((y.astype(np.longdouble) - ref) / np.spacing(ref.astype(np.float64)))
+        assert float(ulp.max()) <= 1.0, (which, float(ulp.max()))
+    xf = np.array([800., -800., 710., -745., np.inf, -np.inf])
+    np.testing.assert_array_equal(probe(1, xf), probe(3, xf))
