@@ -221,7 +221,18 @@ def main():
             ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_sd": cond_bytes_per_sd}
+                    "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
+            # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE, KiB; they
+            # cannot be collected inside a timed run): reported only for the configuration they were measured on
+            default_cfg = (world == 1 and n == 128 and not args.nx and args.sd_conc == 64 and args.real == "f64"
+                           and not args.strict_fp and args.sstp_cond == 1)
+            if default_cfg:
+                import glob
+                for tf in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))[-1:]:
+                    t = json.load(open(tf)).get("lcx::k_cond<double, true>")
+                    if t:
+                        roof["traffic"] = t["hbm_bytes"]
+                        roof["traffic_source"] = "profiles/" + os.path.basename(tf)
         out = {
             "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
             "value": sd_total / elapsed,

@@ -1,0 +1,53 @@
+"""Condenses a tools/profile_round.sh output directory into the text summary committed under profiles/."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+out = sys.argv[1]
+print("== rocprofv3 --kernel-trace --stats : python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline")
+for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    print("%-60s %8s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
+    for r in rows[:30]:
+        print("%-60s %8s %12.3f %12.2f %7.2f" % (r["Name"][:60], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                              float(r["AverageNs"]) / 1e3, float(r["Percentage"])))
+print()
+print("== same trace, TIMED REGION only (the last 10 launches of each per-step kernel; the first warm-up launch of k_cond")
+print("   starts from the un-equilibrated initial state and takes ~3x longer, which skews the all-calls average above)")
+for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        per[r["Kernel_Name"].replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, d in sorted(per.items(), key=lambda kv: -sum(kv[1][-10:])):
+        if len(d) >= 13 and k.startswith("lcx::") and sum(d[-10:]) > 1000:
+            print("%-60s avg_us(last 10) %10.2f   min %10.2f  max %10.2f" % (k[:60], sum(d[-10:]) / 10, min(d[-10:]), max(d[-10:])))
+try:
+    print("bench line under trace:", open(out + "/bench_under_trace.json").read().strip()[:400])
+except OSError:
+    pass
+print()
+print("== PMC passes (python3 bench.py --steps 2 --warmup 1): per-launch averages of the steady-state launches")
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].replace("void ", "").split("(")[0][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+for k, v in sorted(agg.items()):
+    if not k.startswith("lcx::") or k.startswith("lcx::k_init") or k.startswith("lcx::k_scan") or "strided" in k:
+        continue
+    n = len(next(iter(v.values())))
+    line = {c: "%.4g" % (sum(x[-2:]) / len(x[-2:])) for c, x in sorted(v.items())}      # last two launches = timed steps
+    print("%-48s n=%-4d %s" % (k, n, line))
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        # MI355X_MICROARCH.md: counters are in KiB; FETCH_SIZE under-reports by 2x on gfx950 (calibrated with the
+        # streaming k_move kernel whose reads are known exactly); WRITE_SIZE needs no correction
+        rd = sum(v["FETCH_SIZE"][-2:]) / len(v["FETCH_SIZE"][-2:]) * 1024 * 2
+        wr = sum(v["WRITE_SIZE"][-2:]) / len(v["WRITE_SIZE"][-2:]) * 1024
+        traffic[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr}
+print()
+print("== HBM traffic per launch (FETCH_SIZE*2 KiB + WRITE_SIZE KiB)")
+for k, t in traffic.items():
+    print("%-48s read %.3f GB  write %.3f GB  total %.3f GB" % (k, t["read_bytes"] / 1e9, t["write_bytes"] / 1e9, t["hbm_bytes"] / 1e9))
+json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
