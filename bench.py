@@ -233,6 +233,28 @@ def main():
                     if t:
                         roof["traffic"] = t["hbm_bytes"]
                         roof["traffic_source"] = "profiles/" + os.path.basename(tf)
+        # attainable HBM bandwidth on this device (device-to-device copy of 1 GiB, read + write), SURVEY 8(d)
+        a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev); b_ = torch.empty_like(a_)
+        b_.copy_(a_); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            b_.copy_(a_)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 10 * 2 * a_.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a_, b_
+        # per-stage achieved algorithmic bandwidth (bytes per SD from SURVEY 8(d) with 4-byte indices: I = 4)
+        I = 4
+        stage_bytes = {"cond": 5 * R + 2 * I + 8, "cond_cellfinish": 2 * R, "hskpng_vterm_all": 2 * R + I,
+                       "hskpng_shuffle_and_sort": 2 * I, "coal": 2 * I + R / 2 + 8 + 3 * R,
+                       "move(adve+sedi+bcnd)": 7 * R + 2 * I, "post_copy": 3 * I}
+        stage_roof = {}
+        for k_, bsd in stage_bytes.items():
+            if k_ in stage_ms and stage_ms[k_] > 0:
+                gbs = bsd * n_local / (stage_ms[k_] / args.steps * 1e-3) / 1e9
+                stage_roof[k_] = {"bytes_per_sd": bsd, "GB/s": gbs, "frac_of_8TB/s": gbs / HBM_PEAK_GBS}
+        if roof is not None:
+            roof["peak_measured_copy_GBs"] = copy_gbs
         out = {
             "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
             "value": sd_total / elapsed,
@@ -251,6 +273,7 @@ def main():
                        "init_s": t_init},
             "roofline": roof,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+            "stage_roofline": stage_roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -85,6 +85,7 @@ typedef struct {
       turb_adve_switch, turb_cond_switch, turb_coal_switch, ice_switch,
       exact_sstp_cond, sstp_cond_mix, adaptive_sstp_cond, time_dep_ice_nucl;
   double RH_max;
+  double sstp_cond_adapt_drw2_eps, sstp_cond_adapt_drw2_max, rc2_T;   /* opts_init.hpp:105-106,149 */
   int rng_seed, rng_seed_init, rng_seed_init_switch;
   int dev_count, dev_id;
   const double *w_LS; int n_w_LS;

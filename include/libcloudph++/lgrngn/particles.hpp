@@ -113,7 +113,8 @@ namespace libcloudphxx { namespace lgrngn {
       c.rlx_switch = o.rlx_switch; c.turb_adve_switch = o.turb_adve_switch; c.turb_cond_switch = o.turb_cond_switch;
       c.turb_coal_switch = o.turb_coal_switch; c.ice_switch = o.ice_switch; c.exact_sstp_cond = o.exact_sstp_cond;
       c.sstp_cond_mix = o.sstp_cond_mix; c.adaptive_sstp_cond = o.adaptive_sstp_cond; c.time_dep_ice_nucl = o.time_dep_ice_nucl;
-      c.RH_max = o.RH_max; c.rng_seed = o.rng_seed; c.rng_seed_init = o.rng_seed_init; c.rng_seed_init_switch = o.rng_seed_init_switch;
+      c.RH_max = o.RH_max; c.sstp_cond_adapt_drw2_eps = o.sstp_cond_adapt_drw2_eps; c.sstp_cond_adapt_drw2_max = o.sstp_cond_adapt_drw2_max; c.rc2_T = o.rc2_T;
+      c.rng_seed = o.rng_seed; c.rng_seed_init = o.rng_seed_init; c.rng_seed_init_switch = o.rng_seed_init_switch;
       c.dev_count = o.dev_count; c.dev_id = o.dev_id; c.rd_min = o.rd_min; c.rd_max = o.rd_max;
       c.no_ccn_at_init = o.no_ccn_at_init; c.open_side_walls = o.open_side_walls; c.periodic_topbot_walls = o.periodic_topbot_walls;
       c.src_type = int(o.src_type); c.th_dry = o.th_dry; c.const_p = o.const_p; c.diag_incloud_time = o.diag_incloud_time;

@@ -183,7 +183,7 @@ struct Particles : IParticles {
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
     tile_sums.alloc(std::max(cap, ncell) / SCAN_TILE + 2); scan_total.alloc(4);
-    big_list.alloc(std::min<size_t>(ncell, cap / CELLSORT_MAX + 1) + 1); big_meta.alloc(2);
+    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); big_meta.alloc(2);
     m3_before.alloc(cap); m3_after.alloc(cap);
     if (oi.coal_switch) col.alloc(cap);
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
@@ -395,6 +395,11 @@ struct Particles : IParticles {
         uint32_t meta[2];
         read_back(meta, big_meta.p, 2);
         if (meta[0]) {
+          const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
+          if (shuffle) hipLaunchKernelGGL(k_cellsort_lds<uint64_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
+          else         hipLaunchKernelGGL(k_cellsort_lds<uint32_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
+        }
+        if (meta[0] && meta[1] > uint32_t(CELLSORT_LDS_MAX)) {
           size_t P = 1; while (P < meta[1]) P <<= 1;
           const unsigned nb = std::min<unsigned>(meta[0], 64u);
           sort_scratch.alloc(P * nb);
@@ -419,6 +424,12 @@ struct Particles : IParticles {
     Range r(this, only_invalid ? "hskpng_vterm_invalid" : "hskpng_vterm_all");
     if (nphys)
       hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
+  }
+  // cells per workgroup of the LDS-staged per-cell walks: as many as fit the staging buffer at the mean occupancy (+25 %)
+  int cf_cells() const
+  {
+    const size_t mean = npart / std::max<size_t>(ncell, 1) + 1;
+    return int(std::max<size_t>(1, std::min<size_t>(CF_CELLS, size_t(CF_CAP) * 4 / 5 / mean)));
   }
   void check_npart(size_t n) const
   {                                                                                      // hskpng_resize.ipp:9
@@ -501,7 +512,7 @@ struct Particles : IParticles {
     }
     {
       Range r(this, "cond_cellfinish");
-      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, CF_CELLS)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
                          rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
     }
   }
@@ -876,7 +887,7 @@ struct Particles : IParticles {
     hskpng_sort();
     if (npart)
       hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, vec2, power, kind, m3_after.p);
-    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, CF_CELLS)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p,
+    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p,
                        int(specific && n_dims > 0), count_mom.p);
     sync();
   }
@@ -1059,6 +1070,7 @@ void lcx_opts_init_default(lcx_opts_init_t *o)
   o->sstp_cond = o->sstp_coal = o->sstp_chem = o->sstp_cond_act = 1;
   o->sedi_switch = 1; o->coal_switch = 1; o->sstp_cond_mix = 1;
   o->RH_max = .95; o->rng_seed = 44; o->rng_seed_init = 44;
+  o->sstp_cond_adapt_drw2_eps = 1e-4; o->sstp_cond_adapt_drw2_max = 4; o->rc2_T = 10;
   o->adve_scheme = LCX_ADVE_IMPLICIT; o->RH_formula = LCX_RH_PV_CC;
   o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 1;
 }

@@ -241,8 +241,12 @@ __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *
 // its 256 positions touch (its own range plus the overhang of the first and last cell) in LDS; every lane then
 // ranks its key inside its cell by counting smaller keys (keys are unique) with LDS broadcast reads and writes
 // its id to `out` at cell_start + rank.  O(count) reads per lane, no data-dependent branching, no atomics.
-constexpr int CELLSORT_MAX = 1024;      // cells with more SDs go to k_cellsort_big
-constexpr int CR_CAP = 1024;            // keys staged per workgroup (8 KiB)
+// cells with more SDs than cellrank_max are listed and sorted by a bitonic network instead (O(n log^2 n)); the
+// crossover is later for the 4-byte keys of the plain order (measured at 512 SDs per cell: 56 vs 74 ms)
+constexpr int CELLRANK_MAX = 256;
+template <class KEY> constexpr int cellrank_max = sizeof(KEY) == 8 ? CELLRANK_MAX : 1024;
+constexpr int CELLSORT_LDS_MAX = 2048;  // ... in LDS up to this size (k_cellsort_lds), in global scratch beyond (k_cellsort_big)
+template <class KEY> constexpr int cr_cap = sizeof(KEY) == 8 ? 1024 : 4096;   // keys staged per workgroup (8 / 16 KiB)
 struct rng_src { const uint32_t *un; uint64_t call, seed; };
 
 __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng_src &r)
@@ -258,17 +262,17 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
            rng_src r, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
-  __shared__ KEY lds[CR_CAP];
+  __shared__ KEY lds[cr_cap<KEY>];
   const size_t p0 = size_t(blockIdx.x) * BS;
   const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
   const uint32_t lo = cell_start[sorted_ijk[p0]], hi = cell_start[sorted_ijk[plast] + 1];
-  const bool staged = (hi - lo) <= uint32_t(CR_CAP);
+  const bool staged = (hi - lo) <= uint32_t(cr_cap<KEY>);
   if (staged) for (uint32_t q = lo + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));
   __syncthreads();
   const size_t p = p0 + threadIdx.x;
   if (p >= n) return;
   const uint32_t c = sorted_ijk[p], s = cell_start[c], e = cell_start[c + 1], cnt = e - s;
-  if (cnt > uint32_t(CELLSORT_MAX)) {
+  if (cnt > uint32_t(cellrank_max<KEY>)) {
     if (p == s) { const uint32_t k = atomicAdd(big_count, 1u); big_list[k] = c; atomicMax(big_max, cnt); }
     out[p] = in[p];
     return;
@@ -285,7 +289,34 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   }
   out[s + rank] = uint32_t(mine);
 }
-// segments larger than CELLSORT_MAX (e.g. a 0-D parcel): one workgroup per segment, bitonic network on a
+// listed segments of up to CELLSORT_LDS_MAX keys (e.g. 512 SDs per cell): one workgroup per segment, bitonic network
+// on a power-of-two padded copy in LDS; each thread does one compare-exchange per pass per 2*BS keys
+template <class KEY>
+__global__ void __launch_bounds__(BS)
+k_cellsort_lds(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r)
+{
+  constexpr int shuffle = sizeof(KEY) == 8;
+  __shared__ KEY a[CELLSORT_LDS_MAX];
+  for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
+    const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
+    if (cnt > uint32_t(CELLSORT_LDS_MAX)) continue;          // k_cellsort_big takes it
+    uint32_t P = 2; while (P < cnt) P <<= 1;
+    for (uint32_t i = threadIdx.x; i < P; i += BS) a[i] = i < cnt ? KEY(sort_key(sorted_id[start + i], shuffle, r)) : KEY(~KEY(0));
+    __syncthreads();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = threadIdx.x; t < (P >> 1); t += BS) {
+          const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+          const KEY u = a[lo], v = a[hi];
+          if ((u > v) == ((lo & k) == 0)) { a[lo] = v; a[hi] = u; }
+        }
+        __syncthreads();
+      }
+    for (uint32_t i = threadIdx.x; i < cnt; i += BS) sorted_id[start + i] = uint32_t(a[i]);
+    __syncthreads();
+  }
+}
+// still larger segments (e.g. a 0-D parcel): one workgroup per segment, bitonic network on a
 // power-of-two padded scratch copy in global memory
 __global__ void __launch_bounds__(1024)
 k_cellsort_big(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, int shuffle, rng_src r,
@@ -294,6 +325,7 @@ k_cellsort_big(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_st
   uint64_t *a = scratch + size_t(blockIdx.x) * scratch_stride;
   for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
     const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
+    if (cnt <= uint32_t(CELLSORT_LDS_MAX)) continue;         // done by k_cellsort_lds
     size_t P = 1; while (P < cnt) P <<= 1;
     for (size_t i = threadIdx.x; i < P; i += blockDim.x) a[i] = i < cnt ? sort_key(sorted_id[start + i], shuffle, r) : ~0ull;
     __syncthreads();
@@ -391,8 +423,8 @@ __global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
 // A workgroup owns CF_CELLS consecutive cells = one contiguous range of the position-ordered scratch, which it
 // stages in LDS with coalesced loads; then one lane per cell walks its segment in LDS.  (A lane-per-cell walk
 // straight from global memory touches 64 different cache lines per load instruction and ran 10x slower.)
-constexpr int CF_CELLS = 64;
-constexpr int CF_CAP = 6144;            // reals staged per workgroup (48 KiB of fp64): 96 SDs per cell on average
+constexpr int CF_CELLS = 64;            // cells per workgroup at most; the host lowers it (cf_cells) when cells hold many SDs
+constexpr int CF_CAP = 6144;            // reals staged per workgroup (48 KiB of fp64)
 template <class T>
 __device__ __forceinline__ T seg_sum(const T *lds, const T *glob, bool staged, uint32_t base, uint32_t s, uint32_t e)
 {
@@ -403,16 +435,16 @@ __device__ __forceinline__ T seg_sum(const T *lds, const T *glob, bool staged, u
 }
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_cond_cellfinish(size_t n_cell, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
+k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
                   const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims)
 {
   __shared__ T lds[CF_CAP];
-  const size_t c0 = size_t(blockIdx.x) * CF_CELLS;
-  const size_t c1 = c0 + CF_CELLS < n_cell ? c0 + CF_CELLS : n_cell;
+  const size_t c0 = size_t(blockIdx.x) * cfc;
+  const size_t c1 = c0 + cfc < n_cell ? c0 + cfc : n_cell;
   const uint32_t base = cell_start[c0], end = cell_start[c1];
   const bool staged = (end - base) <= uint32_t(CF_CAP);
   const size_t c = c0 + threadIdx.x;
-  const bool mine = threadIdx.x < CF_CELLS && c < n_cell;
+  const bool mine = threadIdx.x < cfc && c < n_cell;
   uint32_t s = 0, e = 0;
   if (mine) { s = cell_start[c]; e = cell_start[c + 1]; }
   const bool has = e > s;
@@ -806,17 +838,17 @@ __global__ void k_mom_vals(size_t n_part, const uint32_t *sorted_id, const T *nf
 }
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_cell_seqsum(size_t n_cell, const uint32_t *cell_start, const T *vals, const T *dv, const T *rhod, int specific, T *out)
+k_cell_seqsum(size_t n_cell, int cfc, const uint32_t *cell_start, const T *vals, const T *dv, const T *rhod, int specific, T *out)
 {
   __shared__ T lds[CF_CAP];
-  const size_t c0 = size_t(blockIdx.x) * CF_CELLS;
-  const size_t c1 = c0 + CF_CELLS < n_cell ? c0 + CF_CELLS : n_cell;
+  const size_t c0 = size_t(blockIdx.x) * cfc;
+  const size_t c1 = c0 + cfc < n_cell ? c0 + cfc : n_cell;
   const uint32_t base = cell_start[c0], end = cell_start[c1];
   const bool staged = (end - base) <= uint32_t(CF_CAP);
   if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = vals[q];
   __syncthreads();
   const size_t c = c0 + threadIdx.x;
-  if (threadIdx.x >= CF_CELLS || c >= n_cell) return;
+  if (threadIdx.x >= cfc || c >= n_cell) return;
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T acc = 0;
   if (e > s) {

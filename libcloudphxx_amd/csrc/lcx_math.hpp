@@ -383,11 +383,9 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
           b = rw2_old + mx(T(0), cond_mlt * drw2);
   if (a == b) return rw2_old;
   T fa, fb;
-  // f at the old radius is (rw2_old + drw2) - rw2_old: the growth rate there is already known
-  const T f_old = (rw2_old + drw2) - rw2_old;
-  const T f_far = f(drw2 > 0 ? b : a);
-  if (drw2 > 0) { fb = f_far; fa = (a == rw2_old) ? f_old : f(a); }
-  else          { fa = f_far; fb = f_old; }
+  // the reference takes f(rw2_old) == drw2 at the near end of the bracket (cond_common.ipp:296-305)
+  if (drw2 > 0) { fa = drw2; fb = f(b); }
+  else          { fa = f(a); fb = drw2; }
   T rw2_new;
   if (fa * fb > 0) rw2_new = rw2_old + drw2;
   else rw2_new = toms748_solve(f, a, b, fa, fb, eps, n_iter);

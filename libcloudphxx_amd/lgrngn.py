@@ -108,6 +108,7 @@ class _opts_init_c(C.Structure):
         ("ice_switch", C.c_int), ("exact_sstp_cond", C.c_int), ("sstp_cond_mix", C.c_int), ("adaptive_sstp_cond", C.c_int),
         ("time_dep_ice_nucl", C.c_int),
         ("RH_max", C.c_double),
+        ("sstp_cond_adapt_drw2_eps", C.c_double), ("sstp_cond_adapt_drw2_max", C.c_double), ("rc2_T", C.c_double),
         ("rng_seed", C.c_int), ("rng_seed_init", C.c_int), ("rng_seed_init_switch", C.c_int),
         ("dev_count", C.c_int), ("dev_id", C.c_int),
         ("w_LS", C.POINTER(C.c_double)), ("n_w_LS", C.c_int),
@@ -185,6 +186,7 @@ class opts_init_t:
         self.adaptive_sstp_cond = False
         self.time_dep_ice_nucl = False
         self.RH_max = .95
+        self.sstp_cond_adapt_drw2_eps, self.sstp_cond_adapt_drw2_max, self.rc2_T = 1e-4, 4., 10.
         self.rng_seed = 44
         self.rng_seed_init = 44
         self.rng_seed_init_switch = False

@@ -86,6 +86,11 @@ struct orc_particles {
   /* cell fields */
   double *rhod, *th, *rv, *p, *T, *RH, *eta, *dv, *lambda_D, *lambda_K;
   double *sstp_tmp_rv, *sstp_tmp_th, *sstp_tmp_rh, *drw_mom3, *rw_mom3, *scl;
+  /* per-particle substepping (exact_sstp_cond): the reference re-uses sstp_tmp_{rv,th,rh,p} as n_part-long attributes
+   * (particles_impl.ipp:452-459); rc2 only with sstp_cond_act > 1 (:488-491) */
+  int exact, use_rc2, sstp_cond_act;
+  double *pp_rv, *pp_th, *pp_rh, *pp_p, *rc2;
+  double *dlt_rv, *dlt_th, *dlt_rh, *dlt_p, *rwX, *drwX, *Tp; unsigned *pp_sstp;
   double *courant_x, *courant_y, *courant_z; sz n_cx, n_cy, n_cz;
   sz *count_ijk, *off; n_t *count_num; double *count_mom; sz count_n;
   double vt_0[10000]; double vt0_ln_r_min, vt0_ln_r_max;
@@ -111,6 +116,7 @@ void orc_opts_init_default(lcx_opts_init_t *o)
   o->sstp_cond = o->sstp_coal = o->sstp_chem = o->sstp_cond_act = 1;
   o->sedi_switch = 1; o->coal_switch = 1; o->sstp_cond_mix = 1;
   o->RH_max = .95; o->rng_seed = 44; o->rng_seed_init = 44;
+  o->sstp_cond_adapt_drw2_eps = 1e-4; o->sstp_cond_adapt_drw2_max = 4; o->rc2_T = 10;
   o->adve_scheme = LCX_ADVE_IMPLICIT; o->RH_formula = LCX_RH_PV_CC;
   o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 1;
 }
@@ -126,9 +132,9 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
   if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
   if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->turb_adve_switch ||
-      oi->turb_cond_switch || oi->turb_coal_switch || oi->exact_sstp_cond || oi->adaptive_sstp_cond ||
+      oi->turb_cond_switch || oi->turb_coal_switch ||
       oi->sd_const_multi || oi->sd_conc_large_tail || oi->diag_incloud_time)
-    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/exact_sstp/const_multi/tail)");
+    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/const_multi/tail)");
   if (oi->adve_scheme == LCX_ADVE_PRED_CORR) FAIL("libcloudph++: pred_corr advection not supported by this backend");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
@@ -151,6 +157,9 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->n_cell = (sz)m1(oi->nx) * m1(oi->ny) * m1(oi->nz);
   s->sstp_cond = oi->sstp_cond; s->sstp_coal = oi->sstp_coal;
   s->allow_sstp_cond = oi->sstp_cond > 1 || oi->sstp_cond_act > 1;
+  s->sstp_cond_act = oi->sstp_cond_act;
+  s->exact = s->allow_sstp_cond && oi->exact_sstp_cond;
+  s->use_rc2 = oi->sstp_cond_act > 1 && s->allow_sstp_cond;
   s->pure_const_multi = (oi->sd_conc == 0) && (oi->sd_const_multi > 0 || oi->n_dry_sizes > 0);
   s->adve_scheme = oi->adve_scheme;
   if (s->o.n_x_tot == 0) s->o.n_x_tot = oi->nx;
@@ -169,6 +178,12 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->lambda_D = NEW(double, nc); s->lambda_K = NEW(double, nc);
   s->sstp_tmp_rv = NEW(double, nc); s->sstp_tmp_th = NEW(double, nc); s->sstp_tmp_rh = NEW(double, nc);
   s->drw_mom3 = NEW(double, nc); s->rw_mom3 = NEW(double, nc); s->scl = NEW(double, nc);
+  if (s->exact) {
+    s->pp_rv = NEW(double, c); s->pp_th = NEW(double, c); s->pp_rh = NEW(double, c); s->pp_p = NEW(double, c);
+    s->dlt_rv = NEW(double, c); s->dlt_th = NEW(double, c); s->dlt_rh = NEW(double, c); s->dlt_p = NEW(double, c);
+    s->rwX = NEW(double, c); s->drwX = NEW(double, c); s->Tp = NEW(double, c); s->pp_sstp = NEW(unsigned, c);
+  }
+  if (s->use_rc2) s->rc2 = NEW(double, c);
   s->count_ijk = NEW(sz, nc); s->off = NEW(sz, nc + 1); s->count_num = NEW(n_t, nc); s->count_mom = NEW(double, nc);
   s->outbuf = NEW(double, nc);
   *out = s;
@@ -346,6 +361,8 @@ static int hskpng_remove_n0(orc_particles *s)
     if (w != p) {
       s->n[w] = s->n[p]; s->rd3[w] = s->rd3[p]; s->rw2[w] = s->rw2[p]; s->kpa[w] = s->kpa[p];
       s->vt[w] = s->vt[p]; s->x[w] = s->x[p]; s->y[w] = s->y[p]; s->z[w] = s->z[p];
+      if (s->exact) { s->pp_rv[w] = s->pp_rv[p]; s->pp_th[w] = s->pp_th[p]; s->pp_rh[w] = s->pp_rh[p]; s->pp_p[w] = s->pp_p[p]; }
+      if (s->use_rc2) s->rc2[w] = s->rc2[p];
     }
     ++w;
   }
@@ -404,6 +421,14 @@ static void moms_calc(orc_particles *s, const double *vec, double power, int spe
 static void sstp_save(orc_particles *s)
 {
   if (!s->allow_sstp_cond) return;
+  if (s->o.exact_sstp_cond) {                  /* per-particle version: copy through ijk (sstp_save.ipp:17-22) */
+    for (sz p = 0; p < s->n_part; ++p) {
+      const sz c = s->ijk[p];
+      s->pp_rv[p] = s->rv[c]; s->pp_th[p] = s->th[c]; s->pp_rh[p] = s->rhod[c];
+      if (s->o.const_p) s->pp_p[p] = s->p[c];
+    }
+    return;
+  }
   memcpy(s->sstp_tmp_rv, s->rv, s->n_cell * sizeof(double));
   memcpy(s->sstp_tmp_th, s->th, s->n_cell * sizeof(double));
   memcpy(s->sstp_tmp_rh, s->rhod, s->n_cell * sizeof(double));
@@ -459,11 +484,197 @@ static void update_th_rv(orc_particles *s)
   for (sz c = 0; c < s->n_cell; ++c) s->rv[c] = s->rv[c] - s->drw_mom3[c];
   for (sz c = 0; c < s->n_cell; ++c) s->th[c] = s->th[c] - s->drw_mom3[c] * d_th_d_rv(s->T[c], s->th[c]);
 }
+/* ---------------- per-particle condensation substepping (src/impl/condensation/perparticle/, particles_step.ipp:199-236) ---------------- */
+/* hskpng_rc2.ipp:14-32, particles_diag.ipp:41-62: rc2 = rw3_cr(rd3, kappa, rc2_T + 273.15)^(2/3) where rc2 == invalid */
+static void hskpng_approximate_rc2_invalid(orc_particles *s)
+{
+  if (s->sstp_cond_act == 1 || !s->allow_sstp_cond) return;
+  for (sz p = 0; p < s->n_part; ++p)
+    if (s->rc2[p] == -1.) s->rc2[p] = pow(rw3_cr(s->rd3[p], s->kpa[p], s->o.rc2_T + 273.15), 2. / 3);
+}
+/* calculate_noncond_perparticle_sstp_delta.ipp:13-43 */
+static void calculate_noncond_perparticle_sstp_delta(orc_particles *s)
+{
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    s->dlt_rv[p] = s->rv[c] - s->pp_rv[p];
+    s->dlt_th[p] = s->th[c] - s->pp_th[p];
+    s->dlt_rh[p] = s->rhod[c] - s->pp_rh[p];
+    if (s->o.const_p) s->dlt_p[p] = s->p[c] - s->pp_p[p];
+  }
+}
+/* apply_noncond_perparticle_sstp_delta.ipp:11-31 */
+static void apply_noncond_perparticle_sstp_delta(orc_particles *s)
+{
+  for (sz p = 0; p < s->n_part; ++p) {
+    s->pp_rv[p] = s->pp_rv[p] + s->dlt_rv[p] / s->sstp_cond;
+    s->pp_th[p] = s->pp_th[p] + s->dlt_th[p] / s->sstp_cond;
+    s->pp_rh[p] = s->pp_rh[p] + s->dlt_rh[p] / s->sstp_cond;
+    if (s->o.const_p) s->pp_p[p] = s->pp_p[p] + s->dlt_p[p] / s->sstp_cond;
+  }
+}
+static double rw2torw3(double rw2) { return rw2 * sqrt(rw2); }       /* cond_common.ipp:57-67 */
+/* cond_common.ipp:24-41 */
+static double rw3diff2drv(const orc_particles *s, double rw3diff, double rhod, n_t n, double dv)
+{
+  const double mlt = -rho_w * (4. / 3) * ORC_PI;
+  if (s->n_dims > 0) return mlt * rw3diff * (double)n / rhod / dv;
+  return mlt * rw3diff * (double)n;
+}
+static double pp_T(const orc_particles *s, double th, double rhod, double p)
+{ return s->o.th_dry ? theta_dry_T(th, rhod) : th * theta_std_exner(p); }     /* hskpng_Tpr.ipp:26-46 */
+/* cond_perparticle_advance_rw2.ipp:30-125 + perparticle_advance_rw2.ipp:8-43 */
+static void cond_perparticle_advance_rw2(orc_particles *s, double RH_max)
+{
+  for (sz p = 0; p < s->n_part; ++p) s->Tp[p] = pp_T(s, s->pp_th[p], s->pp_rh[p], s->pp_p[p]);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    const double pr = s->o.const_p ? s->pp_p[p] : theta_dry_p(s->pp_rh[p], s->pp_rv[p], s->Tp[p]);
+    const double RH = RH_of(s->o.RH_formula, pr, s->pp_rv[p], s->Tp[p]);
+    cond_ctx cc = {s->rw2[p], s->dt / s->sstp_cond, s->pp_rh[p], s->pp_rv[p], s->Tp[p], pr, RH, visc(s->Tp[p]),
+                   s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};
+    s->rw2[p] = advance_rw2(&cc, s->eps_tol, 2., 100);
+  }
+}
+/* update_th_rv.ipp:243-283: per-cell sum (sorted order) of a per-particle change, added to every particle of the cell */
+static void update_pstate(orc_particles *s, double *pstate, const double *pdstate)
+{
+  double *dstate = s->scl;
+  for (sz c = 0; c < s->n_cell; ++c) dstate[c] = 0.;
+  sz nseg = 0;
+  for (sz q = 0; q < s->n_part; ++q) {                     /* thrust::reduce_by_key over the sorted order */
+    const double v = pdstate[s->sorted_id[q]];
+    if (q == 0 || s->sorted_ijk[q] != s->sorted_ijk[q - 1]) { s->count_ijk[nseg] = s->sorted_ijk[q]; s->count_mom[nseg] = v; ++nseg; }
+    else s->count_mom[nseg - 1] = s->count_mom[nseg - 1] + v;
+  }
+  s->count_n = nseg;
+  for (sz i = 0; i < nseg; ++i) dstate[s->count_ijk[i]] = s->count_mom[i] + dstate[s->count_ijk[i]];
+  for (sz p = 0; p < s->n_part; ++p) pstate[p] = pstate[p] + dstate[s->ijk[p]];
+}
+/* apply_perparticle_drw3_to_perparticle_rv_and_th.ipp:13-60 */
+static void apply_perparticle_drw3_to_perparticle_rv_and_th(orc_particles *s)
+{
+  double *drw3 = s->drwX;
+  for (sz p = 0; p < s->n_part; ++p) drw3[p] = rw3diff2drv(s, drw3[p], s->pp_rh[p], s->n[p], s->dv[s->ijk[p]]);
+  if (s->o.sstp_cond_mix) update_pstate(s, s->pp_rv, drw3);
+  else for (sz p = 0; p < s->n_part; ++p) s->pp_rv[p] = drw3[p] + s->pp_rv[p];
+  for (sz p = 0; p < s->n_part; ++p) drw3[p] = drw3[p] * d_th_d_rv(s->Tp[p], s->pp_th[p]);
+  if (s->o.sstp_cond_mix) update_pstate(s, s->pp_th, drw3);
+  else for (sz p = 0; p < s->n_part; ++p) s->pp_th[p] = drw3[p] + s->pp_th[p];
+}
+/* calc_liq_ice_content_change.ipp:12-26 */
+static void calc_liq_content_change(orc_particles *s)
+{
+  moms_all(s);
+  moms_calc(s, s->rw2, 3. / 2., 1);
+  for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = s->count_mom[i] + s->drw_mom3[s->count_ijk[i]];
+}
+/* perparticle_nomixing_adaptive_sstp_cond.ipp:56-265, one super-droplet */
+static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max)
+{
+  const lcx_opts_init_t *o = &s->o;
+  const sz c = s->ijk[p];
+  const double dlt_rv = s->dlt_rv[p], dlt_th = s->dlt_th[p], dlt_rhod = s->dlt_rh[p], dlt_p = s->dlt_p[p];
+  const n_t n = s->n[p];
+  const double dv = s->dv[c], lambda_D = s->lambda_D[c], lambda_K = s->lambda_K[c], rd3 = s->rd3[p], kpa = s->kpa[p], vt = s->vt[p];
+  const int sstp_cond_max = s->sstp_cond, sstp_cond_act = s->sstp_cond_act;
+  unsigned sstp_cond;
+  double t_rv = s->pp_rv[p], t_th = s->pp_th[p], t_rh = s->pp_rh[p], t_p = o->const_p ? s->pp_p[p] : 0., rw2 = s->rw2[p];
+  double drw2 = 0, Tp = 0, RH = 0, delta_fraction_applied = 0;
+#define APPLY_DELTA(mult) do { const double m_ = (mult); t_rv += dlt_rv * m_; t_th += dlt_th * m_; t_rh += dlt_rhod * m_; \
+                               if (o->const_p) t_p += dlt_p * m_; } while (0)
+#define CALC_STATE() do { Tp = pp_T(s, t_th, t_rh, t_p); if (!o->const_p) t_p = theta_dry_p(t_rh, t_rv, Tp); \
+                          RH = RH_of(o->RH_formula, t_p, t_rv, Tp); } while (0)
+  int first_cond_step_done_in_adaptation = sstp_cond_max == 1 ? 1 : 0;
+  {
+    double drw2_new = 0;
+    sstp_cond = (unsigned)sstp_cond_max;
+    for (int sstp_cond_try = 1; sstp_cond_try <= sstp_cond_max; sstp_cond_try *= 2) {
+      delta_fraction_applied = sstp_cond_try == 1 ? 1 : -1. / sstp_cond_try;
+      APPLY_DELTA(delta_fraction_applied);
+      CALC_STATE();
+      cond_ctx cc = {rw2, s->dt / sstp_cond_try, t_rh, t_rv, Tp, t_p, RH, visc(Tp), rd3, kpa, vt, RH_max, lambda_D, lambda_K};
+      const double d = advance_rw2_apply(&cc, s->eps_tol, 2., 100, 0);
+      if (sstp_cond_try == 1) drw2 = d; else drw2_new = d;
+      if (sstp_cond_try > 1) {
+        if ((fabs(drw2_new * 2 - drw2) <= o->sstp_cond_adapt_drw2_eps * rw2) && (fabs(drw2) < o->sstp_cond_adapt_drw2_max * rw2)) {
+          sstp_cond = (unsigned)(sstp_cond_try / 2);
+          APPLY_DELTA(-delta_fraction_applied);
+          first_cond_step_done_in_adaptation = 1;
+          break;
+        }
+        drw2 = drw2_new;
+      }
+    }
+    if (sstp_cond_act > 1) {
+      const double rc2 = s->rc2[p];
+      if ((rw2 < rc2 && (rw2 + sstp_cond * drw2) > rc2) || (rw2 > rc2 && (rw2 + sstp_cond * drw2) < rc2)) {
+        sstp_cond = (unsigned)sstp_cond_act;
+        first_cond_step_done_in_adaptation = 0;
+      }
+    }
+    if (!first_cond_step_done_in_adaptation)
+      APPLY_DELTA(sstp_cond_max == 1 ? -delta_fraction_applied : delta_fraction_applied);
+  }
+  delta_fraction_applied = 1. / sstp_cond;
+  double rw3 = drw2, drw3;          /* `real_t &rw3 = drw2`: drw2 is only needed at the start of the first step */
+  for (unsigned step = 0; step < sstp_cond; ++step) {
+    drw3 = step > 0 ? -rw3 : -rw2torw3(rw2);
+    if (first_cond_step_done_in_adaptation && step == 0) rw2 += rw3;      /* rw3 aliases drw2 here */
+    else {
+      APPLY_DELTA(delta_fraction_applied);
+      CALC_STATE();
+      cond_ctx cc = {rw2, s->dt / sstp_cond, t_rh, t_rv, Tp, t_p, RH, visc(Tp), rd3, kpa, vt, RH_max, lambda_D, lambda_K};
+      rw2 = advance_rw2_apply(&cc, s->eps_tol, 2., 100, 1);
+    }
+    if (step < sstp_cond - 1) { rw3 = rw2torw3(rw2); drw3 += rw3; }
+    else drw3 += rw2torw3(rw2);
+    drw3 = rw3diff2drv(s, drw3, t_rh, n, dv);
+    t_rv += drw3;
+    drw3 = drw3 * d_th_d_rv(Tp, t_th);
+    t_th += drw3;
+  }
+#undef APPLY_DELTA
+#undef CALC_STATE
+  s->pp_sstp[p] = sstp_cond;
+  s->pp_rv[p] = t_rv; s->pp_th[p] = t_th; s->pp_rh[p] = t_rh;
+  if (o->const_p) s->pp_p[p] = t_p;
+  s->rw2[p] = rw2;
+}
+/* particles_step.ipp:199-236 */
+static void cond_perparticle(orc_particles *s, double RH_max)
+{
+  if (!s->o.sstp_cond_mix) save_liq_before(s);
+  calculate_noncond_perparticle_sstp_delta(s);
+  if (s->o.adaptive_sstp_cond) {
+    for (sz p = 0; p < s->n_part; ++p) adaptive_sstp_cond_one(s, p, RH_max);
+  } else {
+    for (int step = 0; step < s->sstp_cond; ++step) {
+      apply_noncond_perparticle_sstp_delta(s);
+      if (step == 0) for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = -rw2torw3(s->rw2[p]);   /* set_perparticle_drwX_to_minus_rwX */
+      else           for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = -s->rwX[p];
+      cond_perparticle_advance_rw2(s, RH_max);
+      if (step < s->sstp_cond - 1) for (sz p = 0; p < s->n_part; ++p) { s->rwX[p] = rw2torw3(s->rw2[p]); s->drwX[p] = s->rwX[p] + s->drwX[p]; }
+      else                         for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = rw2torw3(s->rw2[p]) + s->drwX[p];
+      apply_perparticle_drw3_to_perparticle_rv_and_th(s);
+    }
+  }
+  /* apply_perparticle_cond_change_to_percell_rv_and_th.ipp:11-24 */
+  if (s->o.sstp_cond_mix) {
+    for (sz p = 0; p < s->n_part; ++p) s->rv[s->ijk[p]] = s->pp_rv[p];      /* update_state: last particle of a cell wins */
+    for (sz p = 0; p < s->n_part; ++p) s->th[s->ijk[p]] = s->pp_th[p];
+  } else {
+    calc_liq_content_change(s);
+    update_th_rv(s);
+  }
+}
+
 /* particles_impl_adjust_timesteps.ipp:13-24 */
 static int adjust_timesteps(orc_particles *s, double dt)
 {
   if (dt > 0 && !s->o.variable_dt_switch) FAIL("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
   s->sstp_cond = dt > 0 && s->o.sstp_cond > 1 ? (int)ceil(s->o.sstp_cond * dt / s->o.dt) : s->o.sstp_cond;
+  s->sstp_cond_act = dt > 0 && s->o.sstp_cond_act > 1 ? (int)ceil(s->o.sstp_cond_act * dt / s->o.dt) : s->o.sstp_cond_act;
   s->sstp_coal = dt > 0 && s->o.sstp_coal > 1 ? (int)ceil(s->o.sstp_coal * dt / s->o.dt) : s->o.sstp_coal;
   s->dt = dt > 0 ? dt : s->o.dt;
   return 0;
@@ -530,6 +741,7 @@ static void collide(orc_particles *s, sz a, sz b, n_t col_no)
   s->rw2[b] = rw_b * rw_b;
   s->rd3[b] = col_no * s->rd3[a] + s->rd3[b];
   s->vt[b] = -1.;
+  if (s->use_rc2) s->rc2[b] = -1.;        /* invalidator, coal.ipp:33-44,527-545 */
 }
 static void coal(orc_particles *s, double dt)
 {
@@ -724,7 +936,7 @@ static int init_SD_with_distros(orc_particles *s)
     s->n_part_to_init = (sz)per_cell * s->n_cell;
     s->n_part += s->n_part_to_init;
     if (resize_npart(s)) return 1;
-    for (sz p = s->n_part_old; p < s->n_part; ++p) s->vt[p] = -1.;
+    for (sz p = s->n_part_old; p < s->n_part; ++p) { s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
     /* init_ijk.ipp:36-52 */
     { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
     /* init_dry_sd_conc.ipp:43-86 */
@@ -786,7 +998,7 @@ static int init_SD_with_sizes(orc_particles *s)
     if (resize_npart(s)) return 1;
     { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
     const double rad3 = ds->radius * ds->radius * ds->radius;
-    for (sz p = s->n_part_old; p < s->n_part; ++p) { s->rd3[p] = rad3; s->kpa[p] = ds->kappa; s->vt[p] = -1.; }
+    for (sz p = s->n_part_old; p < s->n_part; ++p) { s->rd3[p] = rad3; s->kpa[p] = ds->kappa; s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
     for (sz p = s->n_part_old; p < s->n_part; ++p) {
       const sz c = s->ijk[p];
       double conc = ds->conc;
@@ -900,7 +1112,10 @@ static int init_sanity_check(orc_particles *s, const lcx_arrinfo_t *th, const lc
   if (o->const_p && arr_null(p)) FAIL("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
   if (!o->const_p && !arr_null(p)) FAIL("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
   if (o->sstp_cond < 1) FAIL("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+  if (o->adaptive_sstp_cond && !o->exact_sstp_cond) FAIL("libcloudph++: Adaptive condensation substepping (opts_init.adaptive_sstp_cond) works oly for per-particle substepping (opts_init.exact_sstp_cond)");
   if (!o->sstp_cond_mix && !o->exact_sstp_cond) FAIL("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
+  if (o->sstp_cond_mix && o->adaptive_sstp_cond && o->exact_sstp_cond) FAIL("libcloudph++: Adaptive cond substepping (opts_init.adaptive_sstp_cond) with per-particle substepping (opts_init.exact_sstp_cond) requires mixing of th and rv between subteps (opts_init.sstp_cond_mix) to be disabled");
+  if (o->sstp_cond_act > 1 && (o->sstp_cond_mix || !o->exact_sstp_cond || !o->adaptive_sstp_cond)) FAIL("libcloudph++: number of substeps for activation (opts_init.sstp_cond_act) can be greater than 1 only if mixing of rv and th (opts_init.sstp_cond_mix) is disabled and if per-particle condensation substepping is used (opts_init.exact_sstp_cond) and if adaptive substepping is used (opts_init.adaptive_sstp_cond)");
   return 0;
 }
 static void alloc_courants(orc_particles *s)
@@ -936,6 +1151,7 @@ int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
   if (s->o.coal_switch && init_kernel(s)) return 1;
   init_vterm(s);
   hskpng_vterm(s, 1);
+  hskpng_approximate_rc2_invalid(s);         /* particles_init.ipp:116-117 */
   sstp_save(s);
   hskpng_count(s);
   mt_seed(&s->rng, (uint32_t)s->o.rng_seed);
@@ -975,7 +1191,8 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
   if (opts->cond) {
     hskpng_sort(s);
     hskpng_mfp(s);
-    for (int step = 0; step < s->sstp_cond; ++step) {
+    if (s->o.exact_sstp_cond && (s->sstp_cond > 1 || s->sstp_cond_act > 1)) cond_perparticle(s, opts->RH_max);
+    else for (int step = 0; step < s->sstp_cond; ++step) {
       sstp_percell_step(s, step);
       hskpng_Tpr(s);
       if (step == 0) save_liq_before(s);
@@ -1017,6 +1234,7 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
       if (step + 1 != s->sstp_coal) hskpng_vterm(s, 1);
     }
     if (s->increase_sstp_coal) { ++s->sstp_coal; s->increase_sstp_coal = 0; }
+    hskpng_approximate_rc2_invalid(s);       /* particles_step.ipp:402-403 */
   }
   if (opts->adve) adve(s);
   s->adve_scheme = s->o.adve_scheme;
@@ -1131,7 +1349,11 @@ int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t c
     {"courant_x", s->courant_x, s->n_cx}, {"courant_y", s->courant_y, s->n_cy}, {"courant_z", s->courant_z, s->n_cz},
     {"vt_0", s->vt_0, 10000}, {"count_mom", s->count_mom, s->count_n}, {"col", s->col, s->n_part},
     {"rw2", s->rw2, s->n_part}, {"rd3", s->rd3, s->n_part}, {"kappa", s->kpa, s->n_part},
-    {"x", s->x, s->n_part}, {"y", s->y, s->n_part}, {"z", s->z, s->n_part}};
+    {"x", s->x, s->n_part}, {"y", s->y, s->n_part}, {"z", s->z, s->n_part},
+    {"sstp_tmp_rv", s->exact ? s->pp_rv : s->sstp_tmp_rv, s->exact ? s->n_part : s->n_cell},
+    {"sstp_tmp_th", s->exact ? s->pp_th : s->sstp_tmp_th, s->exact ? s->n_part : s->n_cell},
+    {"sstp_tmp_rh", s->exact ? s->pp_rh : s->sstp_tmp_rh, s->exact ? s->n_part : s->n_cell},
+    {"sstp_tmp_p", s->pp_p, s->exact && s->o.const_p ? s->n_part : 0}, {"rc2", s->rc2, s->use_rc2 ? s->n_part : 0}};
   for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
     if (!strcmp(name, tab[i].nm)) {
       *n = tab[i].len;
@@ -1151,6 +1373,8 @@ int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult
   if (y) memcpy(s->y, y, n * 8);
   if (z) memcpy(s->z, z, n * 8);
   hskpng_ijk(s);
+  if (s->use_rc2) { for (sz p = 0; p < n; ++p) s->rc2[p] = -1.; hskpng_approximate_rc2_invalid(s); }
+  sstp_save(s);
   hskpng_count(s);
   return 0;
 }
@@ -1184,7 +1408,19 @@ int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
 
 /* ---------------- 1-D decomposition helpers (pack.ipp:14-133, unpack.ipp:14-143) ---------------- */
 int orc_migrate_counts(orc_particles *s, size_t *l, size_t *r) { *l = s->lft_count; *r = s->rgt_count; return 0; }
-size_t orc_migrate_record_bytes(orc_particles *s) { return 8 + 8 * (4 + (size_t)s->n_dims); }
+/* attributes that travel with a super-droplet: distmem_real_vctrs, particles_impl.ipp:440-491 */
+static int mig_attrs(orc_particles *s, double **a)
+{
+  int k = 0;
+  a[k++] = s->rd3; a[k++] = s->rw2; a[k++] = s->kpa; a[k++] = s->vt;
+  if (s->o.nx != 0) a[k++] = s->x;
+  if (s->o.ny != 0) a[k++] = s->y;
+  if (s->o.nz != 0) a[k++] = s->z;
+  if (s->exact) { a[k++] = s->pp_rv; a[k++] = s->pp_th; a[k++] = s->pp_rh; if (s->o.const_p) a[k++] = s->pp_p; }
+  if (s->use_rc2) a[k++] = s->rc2;
+  return k;
+}
+size_t orc_migrate_record_bytes(orc_particles *s) { double *a[16]; return 8 + 8 * (size_t)mig_attrs(s, a); }
 int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t cap_bytes)
 {
   const sz cnt = side == 0 ? s->lft_count : s->rgt_count;
@@ -1193,11 +1429,9 @@ int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t
   const double x_lcl = side == 0 ? s->o.x0 : s->o.x1;
   for (sz i = 0; i < cnt; ++i) s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;   /* detail::remote, pack.ipp:14-26 */
   n_t *nb = (n_t *)buf; double *rb = (double *)buf + cnt;
-  const double *attrs[7] = {s->rd3, s->rw2, s->kpa, s->vt, s->x, s->y, s->z};
-  const int use[7] = {1, 1, 1, 1, s->o.nx != 0, s->o.ny != 0, s->o.nz != 0};
+  double *attrs[16]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) nb[i] = s->n[id[i]];
-  sz slab = 0;
-  for (int a = 0; a < 7; ++a) { if (!use[a]) continue; for (sz i = 0; i < cnt; ++i) rb[slab * cnt + i] = attrs[a][id[i]]; ++slab; }
+  for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) rb[(sz)a * cnt + i] = attrs[a][id[i]];
   return 0;
 }
 int orc_migrate_unpack(orc_particles *s, const void *buf, size_t cnt)
@@ -1206,11 +1440,9 @@ int orc_migrate_unpack(orc_particles *s, const void *buf, size_t cnt)
   const sz old = s->n_part;
   if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
   const n_t *nb = (const n_t *)buf; const double *rb = (const double *)buf + cnt;
-  double *attrs[7] = {s->rd3, s->rw2, s->kpa, s->vt, s->x, s->y, s->z};
-  const int use[7] = {1, 1, 1, 1, s->o.nx != 0, s->o.ny != 0, s->o.nz != 0};
+  double *attrs[16]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) s->n[old + i] = nb[i];
-  sz slab = 0;
-  for (int a = 0; a < 7; ++a) { if (!use[a]) continue; for (sz i = 0; i < cnt; ++i) attrs[a][old + i] = rb[slab * cnt + i]; ++slab; }
+  for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) attrs[a][old + i] = rb[(sz)a * cnt + i];
   const double tol = 5e-4;                          /* config.hpp:31, tolerance_away_from_bcond */
   for (sz i = old; i < old + cnt; ++i) { const double x = s->x[i]; s->x[i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x; }
   s->n_part = old + cnt;

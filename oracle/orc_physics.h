@@ -251,6 +251,22 @@ static inline double rw3_eq(double rd3, double kappa, double RH, double T)
                      orc_eps_tolerance(sizeof(double) * 8 / 4), &it);
 }
 
+/* ---- critical radius, kappa_koehler.hpp:88-166 (always evaluated in double) ---- */
+typedef struct { double rd3, kappa, T; } rw3cr_ctx;
+static inline double rw3_cr_minfun(double rw3, void *vc)
+{
+  const rw3cr_ctx *c = (const rw3cr_ctx *)vc;
+  return kelvin_A(c->T) * (c->rd3 - rw3) * ((c->kappa - 1) * c->rd3 + rw3) + 3 * c->kappa * c->rd3 * rw3 * cbrt(rw3);
+}
+static inline double rw3_cr(double rd3, double kappa, double T)
+{
+  rw3cr_ctx c = {rd3, kappa, T};
+  const double a = 1e0 * rd3, b = 1e8 * rd3;
+  uintmax_t it = 100;
+  return orc_toms748(rw3_cr_minfun, &c, a, b, rw3_cr_minfun(a, &c), rw3_cr_minfun(b, &c),
+                     orc_eps_tolerance(sizeof(double) * 8 / 4), &it);
+}
+
 /* ---- condensation: src/impl/condensation/common/particles_impl_cond_common.ipp:80-338 ---- */
 typedef struct {
   double rw2_old, dt, rhod, rv, T, p, RH, eta, rd3, kpa, vt, RH_max, lambda_D, lambda_K;
@@ -272,17 +288,20 @@ static inline double cond_minfun(double rw2, void *vc)
   const cond_ctx *c = (const cond_ctx *)vc;
   return c->rw2_old + c->dt * drw2_dt(c, rw2) - rw2;
 }
+static inline double advance_rw2_apply(cond_ctx *c, double eps, double cond_mlt, uintmax_t n_iter, int apply);
 static inline double advance_rw2(cond_ctx *c, double eps, double cond_mlt, uintmax_t n_iter)
+{ return advance_rw2_apply(c, eps, cond_mlt, n_iter, 1); }
+static inline double advance_rw2_apply(cond_ctx *c, double eps, double cond_mlt, uintmax_t n_iter, int apply)
 {
   const double rw2_old = c->rw2_old;
   if (rw2_old <= 0) return rw2_old;
   const double drw2 = c->dt * drw2_dt(c, rw2_old);
-  if (drw2 == 0) return rw2_old;
+  if (drw2 == 0) return apply ? rw2_old : 0.;
   const double rd = cbrt(c->rd3);
   const double rd2 = rd * rd;
   const double a = dmax(rd2, rw2_old + dmin(0., cond_mlt * drw2)),
                b = rw2_old + dmax(0., cond_mlt * drw2);
-  if (a == b) return rw2_old;
+  if (a == b) return apply ? rw2_old : 0.;
   double fa, fb;
   if (drw2 > 0) { fa = drw2; fb = cond_minfun(b, c); }
   else          { fa = cond_minfun(a, c); fb = drw2; }
@@ -290,7 +309,7 @@ static inline double advance_rw2(cond_ctx *c, double eps, double cond_mlt, uintm
   if (fa * fb > 0) rw2_new = rw2_old + drw2;
   else { uintmax_t it = n_iter; rw2_new = orc_toms748(cond_minfun, c, a, b, fa, fb, eps, &it); }
   if (rw2_new < rd2) rw2_new = rd2;
-  return rw2_new;
+  return apply ? rw2_new : rw2_new - rw2_old;
 }
 
 /* ---- terminal velocities: include/libcloudph++/common/vterm.hpp:33-220 ---- */

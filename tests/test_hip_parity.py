@@ -104,6 +104,25 @@ def test_shuffle_sort_replay_exact():
     exact(hip.state_u64("sorted_ijk"), orc.state_u64("sorted_ijk"), "sorted_ijk")
 
 
+@pytest.mark.parametrize("sd_conc", [300, 700, 1500])
+def test_mid_segment_sort(sd_conc):
+    """cells of 257..2048 SDs take the per-cell LDS bitonic network (k_cellsort_lds) in both the plain and the
+    shuffled order; a few advection steps make the cell populations ragged"""
+    oi = h.box_opts(3, 2, 2, sd_conc)
+    orc, hip = h.make_pair(oi, h.box_fields(oi))
+    opts = lgrngn.opts_t()
+    opts.cond = opts.coal = opts.sedi = False
+    for _ in range(2):
+        step_pair(orc, hip, opts, h.box_fields(oi))
+    for nm in ("ijk", "sorted_id", "sorted_ijk", "count_ijk", "count_num"):
+        exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+    (un,) = h.oracle_rng_preview(orc, [(1, orc.n_part)])
+    hip.rng_replay_push(1, un)
+    orc.stage("hskpng_shuffle_and_sort")
+    hip.stage("hskpng_shuffle_and_sort")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "shuffled sorted_id")
+
+
 def test_big_segment_sort_0d():
     """one cell with 5000 SDs: exercises the > LDS-segment path (bitonic in global scratch)"""
     oi = h.box_opts(0, 0, 0, 5000, sedi_switch=False)

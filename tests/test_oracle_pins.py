@@ -28,8 +28,22 @@ def _rows():
     return rows
 
 
-def run_substepping_case(make, RH_formula, sstp_cond, constp, step_count=100):
-    """tests/python/physics/lgrngn_cond_substepping.py:143-240 (per-cell branch), verbatim procedure"""
+def _rows_exact():
+    with open(os.path.join(HERE, "golden", "lgrngn_cond_substepping_refdata.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if r["exact_sstp"] == "True"]
+    assert len(rows) == 224
+    return rows
+
+
+def _row_id(r):
+    return "%s-%s-sstp%s-%s%s-act%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"],
+                                         "mix" if r["mixing"] == "True" else "nomix", "-adaptive" if r["adaptive"] == "True" else "",
+                                         r["sstp_cond_act"])
+
+
+def run_substepping_case(make, RH_formula, sstp_cond, constp, step_count=100, exact=False, mixing=True, adaptive=False,
+                         sstp_cond_act=1):
+    """tests/python/physics/lgrngn_cond_substepping.py:60-240, verbatim procedure"""
     oi = lgrngn.opts_init_t()
     oi.dry_distros = {(.61, 0.): lognormal_fn(.04e-6 / 2, 1.4, 60e6), (1.28, 0.): lognormal_fn(4e-6 / 2, 1.2, 10e6)}
     oi.coal_switch = False
@@ -40,6 +54,8 @@ def run_substepping_case(make, RH_formula, sstp_cond, constp, step_count=100):
     oi.n_sd_max = 1000
     oi.sstp_cond = sstp_cond
     oi.RH_formula = RH_formula
+    oi.exact_sstp_cond, oi.sstp_cond_mix, oi.adaptive_sstp_cond, oi.sstp_cond_act = exact, mixing, adaptive, sstp_cond_act
+    oi.rc2_T, oi.sstp_cond_adapt_drw2_eps, oi.sstp_cond_adapt_drw2_max = 10, 1e-3, 2      # :62-64
     opts = lgrngn.opts_t()
     opts.adve = opts.sedi = opts.coal = False
     opts.RH_max = 1.005
@@ -132,16 +148,57 @@ def check_against_row(res, row, tols=STRICT_TOL, tight=None):
             assert abs(res[col] - ref) <= tol * abs(ref), ("tight", col, res[col], ref)
 
 
+def _run_row(make, row):
+    return run_substepping_case(make, lgrngn.RH_formula_t[row["RH_formula"]], int(row["sstp_cond"]), row["constp"] == "True",
+                                exact=row["exact_sstp"] == "True", mixing=row["mixing"] == "True", adaptive=row["adaptive"] == "True",
+                                sstp_cond_act=int(row["sstp_cond_act"]))
+
+
+# The 280 + 112 oracle runs (~0.6 s each) are farmed out once per session to a fork pool over the host cores; the
+# parametrised tests below only compare the pre-computed result of their row.
+_RESULTS = {}
+
+
+def _pool_job(job):
+    kind, row = job
+    try:
+        return _run_row(oracle_particles if kind == "strict" else oracle_fastmath_particles, row)
+    except Exception as e:                                              # delivered to the test that owns the row
+        return e
+
+
+def _result(kind, row):
+    if kind not in _RESULTS:
+        import multiprocessing as mp
+        rows = _rows() + _rows_exact() if kind == "strict" else _rows() + _rows_exact()[::4]
+        with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+            out = pool.map(_pool_job, [(kind, r) for r in rows], chunksize=4)
+        _RESULTS[kind] = {_row_id(r) + r["exact_sstp"]: o for r, o in zip(rows, out)}
+    res = _RESULTS[kind][_row_id(row) + row["exact_sstp"]]
+    if isinstance(res, Exception):
+        raise res
+    return res
+
+
 @pytest.mark.parametrize("row", _rows(), ids=lambda r: "%s-%s-sstp%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"]))
 def test_cond_substepping_refdata(row):
-    res = run_substepping_case(oracle_particles, lgrngn.RH_formula_t[row["RH_formula"]], int(row["sstp_cond"]), row["constp"] == "True")
-    check_against_row(res, row)
+    check_against_row(_result("strict", row), row)
 
 
 @pytest.mark.parametrize("row", _rows(), ids=lambda r: "%s-%s-sstp%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"]))
 def test_cond_substepping_refdata_fastmath_build(row):
-    res = run_substepping_case(oracle_fastmath_particles, lgrngn.RH_formula_t[row["RH_formula"]], int(row["sstp_cond"]), row["constp"] == "True")
-    check_against_row(res, row, REF_TOL, TIGHT_FASTMATH)
+    check_against_row(_result("fastmath", row), row, REF_TOL, TIGHT_FASTMATH)
+
+
+# per-particle substepping (exact_sstp_cond; with and without mixing; adaptive number of substeps; sstp_cond_act)
+@pytest.mark.parametrize("row", _rows_exact(), ids=_row_id)
+def test_perparticle_substepping_refdata(row):
+    check_against_row(_result("strict", row), row)
+
+
+@pytest.mark.parametrize("row", _rows_exact()[::4], ids=_row_id)
+def test_perparticle_substepping_refdata_fastmath_build(row):
+    check_against_row(_result("fastmath", row), row, REF_TOL, TIGHT_FASTMATH)
 
 
 # ---- tests/python/physics/lgrngn_cond.py:52-56,131-132,152-187
