@@ -109,7 +109,11 @@ struct Particles : IParticles {
   int adve_scheme;
   hipStream_t st = nullptr;
   // ---- particle attributes (two buffer sets: stable compaction writes from one into the other) ----
-  struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z; } A, B;
+  struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
+  // per-particle condensation substepping (exact_sstp_cond): the private rv, th, rhod(, p) of a super-droplet and rc2 are
+  // further attributes (ext[]) that are compacted and migrate with it
+  bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
+  DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
   DevBuf<uint8_t> mig;
   DevBuf<uint64_t> sort_scratch;
@@ -147,9 +151,8 @@ struct Particles : IParticles {
   explicit Particles(const lcx_opts_init_t &oi) : o(oi)
   {
     if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_adve_switch || oi.turb_cond_switch ||
-        oi.turb_coal_switch || oi.exact_sstp_cond || oi.adaptive_sstp_cond || oi.sd_const_multi || oi.sd_conc_large_tail ||
-        oi.diag_incloud_time)
-      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/exact_sstp/const_multi/tail)");
+        oi.turb_coal_switch || oi.sd_const_multi || oi.sd_conc_large_tail || oi.diag_incloud_time)
+      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/const_multi/tail)");
     if (oi.adve_scheme == LCX_ADVE_PRED_CORR) throw lcx_error("libcloudph++: pred_corr advection not supported by this backend");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
@@ -167,6 +170,11 @@ struct Particles : IParticles {
     g = grid_t{oi.nx, oi.ny, oi.nz, n_dims, double(T(oi.dx)), double(T(oi.dy)), double(T(oi.dz))};
     sstp_cond = oi.sstp_cond; sstp_coal = oi.sstp_coal;
     allow_sstp_cond = oi.sstp_cond > 1 || oi.sstp_cond_act > 1;
+    sstp_cond_act = oi.sstp_cond_act;
+    exact = allow_sstp_cond && oi.exact_sstp_cond;                                   // particles_impl.ipp:452-459
+    use_rc2 = oi.sstp_cond_act > 1 && allow_sstp_cond;                               // :488-491
+    if (exact) { ix_rv = n_ext++; ix_th = n_ext++; ix_rh = n_ext++; if (oi.const_p) ix_p = n_ext++; }
+    if (use_rc2) ix_rc2 = n_ext++;
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
     adve_scheme = oi.adve_scheme;
     if (o.n_x_tot == 0) o.n_x_tot = oi.nx;
@@ -180,6 +188,7 @@ struct Particles : IParticles {
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
     alloc_attrs(A);
+    if (use_rc2) hipLaunchKernelGGL(k_fill<T>, dim3(nblk(cap)), dim3(BS), 0, st, A.ext[ix_rc2].p, cap, T(-1));   // detail::invalid, particles_impl.ipp:490
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
     tile_sums.alloc(std::max(cap, ncell) / SCAN_TILE + 2); scan_total.alloc(4);
@@ -206,8 +215,14 @@ struct Particles : IParticles {
   {
     a.n.alloc(cap); a.rd3.alloc(cap); a.rw2.alloc(cap); a.kpa.alloc(cap); a.vt.alloc(cap);
     if (o.nx) a.x.alloc(cap); if (o.ny) a.y.alloc(cap); if (o.nz) a.z.alloc(cap);
+    for (int e = 0; e < n_ext; ++e) a.ext[e].alloc(cap);
   }
-  attr_set<T> aset(Attrs &a) { return attr_set<T>{a.n.p, a.rd3.p, a.rw2.p, a.kpa.p, a.vt.p, a.x.p, a.y.p, a.z.p}; }
+  attr_set<T> aset(Attrs &a)
+  {
+    attr_set<T> s{a.n.p, a.rd3.p, a.rw2.p, a.kpa.p, a.vt.p, a.x.p, a.y.p, a.z.p, {}, n_ext};
+    for (int e = 0; e < n_ext; ++e) s.ext[e] = a.ext[e].p;
+    return s;
+  }
   void sync() { HIPCHK(hipStreamSynchronize(st)); }
 
   // ---- profiling ranges (hipEvents on OUR stream) ----
@@ -489,6 +504,12 @@ struct Particles : IParticles {
   void sstp_save()
   {
     if (!allow_sstp_cond) return;
+    if (o.exact_sstp_cond) {                                  // per-particle version (sstp_save.ipp:17-22); ijk is valid here
+      if (nphys)
+        hipLaunchKernelGGL(k_pp_save<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rv.p, th.p, rhod.p, p.p,
+                           A.ext[ix_rv].p, A.ext[ix_th].p, A.ext[ix_rh].p, o.const_p ? A.ext[ix_p].p : nullptr);
+      return;
+    }
     HIPCHK(hipMemcpyAsync(sstp_tmp_rv.p, rv.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(sstp_tmp_th.p, th.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(sstp_tmp_rh.p, rhod.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
@@ -516,10 +537,65 @@ struct Particles : IParticles {
                          rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
     }
   }
+  // hskpng_rc2.ipp:14-32
+  void hskpng_approximate_rc2_invalid()
+  {
+    if (sstp_cond_act == 1 || !allow_sstp_cond || !nphys) return;
+    hipLaunchKernelGGL(k_rc2<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, A.rd3.p, A.kpa.p, T(T(o.rc2_T) + T(273.15)), A.ext[ix_rc2].p);
+  }
+  // particles_step.ipp:199-236: per-particle substepping; sorted (plain order) on entry
+  void cond_perparticle(double RH_max)
+  {
+    if (!npart) return;
+    pp_args<T> a{};
+    a.sorted_id = sorted_id.p; a.sorted_ijk = sorted_ijk.p;
+    a.n = A.n.p; a.rd3 = A.rd3.p; a.kpa = A.kpa.p; a.vt = A.vt.p; a.rw2 = A.rw2.p;
+    a.pp_rv = A.ext[ix_rv].p; a.pp_th = A.ext[ix_th].p; a.pp_rh = A.ext[ix_rh].p; a.pp_p = o.const_p ? A.ext[ix_p].p : nullptr;
+    a.rv = rv.p; a.th = th.p; a.rhod = rhod.p; a.p = p.p;
+    a.dv = dv.p; a.lambda_D = lambda_D.p; a.lambda_K = lambda_K.p; a.rc2 = use_rc2 ? A.ext[ix_rc2].p : nullptr;
+    a.m3_before = m3_before.p; a.m3_after = m3_after.p;
+    a.dt = T(dt); a.RH_max = T(RH_max); a.eps = eps_tol; a.cond_mlt = T(2.); a.n_iter = 100u;
+    a.adapt_eps = T(o.sstp_cond_adapt_drw2_eps); a.adapt_max = T(o.sstp_cond_adapt_drw2_max);
+    a.sstp_cond = sstp_cond; a.sstp_cond_act = sstp_cond_act; a.th_dry = o.th_dry; a.const_p = o.const_p; a.RH_formula = o.RH_formula;
+    a.n_dims = n_dims;
+    const dim3 grid(nblk(npart)), blk(BS);
+    if (!o.sstp_cond_mix) {
+      {
+        Range r(this, o.adaptive_sstp_cond ? "cond_perparticle_adaptive" : "cond_perparticle");
+        if (o.adaptive_sstp_cond) {
+          if (o.strict_fp) hipLaunchKernelGGL((k_pp_cond_adaptive<T, false>), grid, blk, 0, st, npart, a);
+          else             hipLaunchKernelGGL((k_pp_cond_adaptive<T, true>), grid, blk, 0, st, npart, a);
+        } else {
+          if (o.strict_fp) hipLaunchKernelGGL((k_pp_cond_nomix<T, false>), grid, blk, 0, st, npart, a);
+          else             hipLaunchKernelGGL((k_pp_cond_nomix<T, true>), grid, blk, 0, st, npart, a);
+        }
+      }
+      // save_liq_ice_content_before_change + calc_liq_ice_content_change + update_th_rv: ordered per-cell sums of n rw^3
+      Range r(this, "cond_cellfinish");
+      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p,
+                         dv.p, rhod.p, rv.p, th.p, Tk.p, rw_mom3.p, 0, 1, n_dims);
+      return;
+    }
+    Range r(this, "cond_perparticle_mix");
+    for (int k = 0; k < (o.const_p ? 4 : 3); ++k) pp_dlt[k].alloc(cap);
+    pp_rw3s.alloc(cap); pp_dst_rv.alloc(ncell); pp_dst_th.alloc(ncell);
+    a.dlt_rv = pp_dlt[0].p; a.dlt_th = pp_dlt[1].p; a.dlt_rh = pp_dlt[2].p; a.dlt_p = pp_dlt[3].p; a.rw3s = pp_rw3s.p;
+    a.drv = m3_before.p; a.dth = m3_after.p; a.dst_rv = pp_dst_rv.p; a.dst_th = pp_dst_th.p;
+    for (int step = 0; step < sstp_cond; ++step) {
+      a.step = step;
+      if (o.strict_fp) hipLaunchKernelGGL((k_pp_cond_mix<T, false>), grid, blk, 0, st, npart, a);
+      else             hipLaunchKernelGGL((k_pp_cond_mix<T, true>), grid, blk, 0, st, npart, a);
+      hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, dv.p, rhod.p, 0, pp_dst_rv.p);
+      hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p, 0, pp_dst_th.p);
+    }
+    hipLaunchKernelGGL(k_pp_mix_finish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, A.ext[ix_rv].p, A.ext[ix_th].p,
+                       pp_dst_rv.p, pp_dst_th.p, rv.p, th.p);
+  }
   void adjust_timesteps(double dt_)
   {                                                                                      // particles_impl_adjust_timesteps.ipp:13-24
     if (dt_ > 0 && !o.variable_dt_switch) throw lcx_error("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
     sstp_cond = dt_ > 0 && o.sstp_cond > 1 ? int(std::ceil(o.sstp_cond * dt_ / o.dt)) : o.sstp_cond;
+    sstp_cond_act = dt_ > 0 && o.sstp_cond_act > 1 ? int(std::ceil(o.sstp_cond_act * dt_ / o.dt)) : o.sstp_cond_act;
     sstp_coal = dt_ > 0 && o.sstp_coal > 1 ? int(std::ceil(o.sstp_coal * dt_ / o.dt)) : o.sstp_coal;
     dt = dt_ > 0 ? dt_ : o.dt;
   }
@@ -536,7 +612,7 @@ struct Particles : IParticles {
     const u01_src<T> rs = rand_u01(npart);
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p};
     hipLaunchKernelGGL(k_coal<T>, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
-                       A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p);
+                       A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr);
     if (o.n_dry_distros + n_size_keys > 1)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
   }
@@ -740,7 +816,10 @@ struct Particles : IParticles {
     if (o.const_p && is_null(p_)) throw lcx_error("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
     if (!o.const_p && !is_null(p_)) throw lcx_error("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
     if (o.sstp_cond < 1) throw lcx_error("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+    if (o.adaptive_sstp_cond && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Adaptive condensation substepping (opts_init.adaptive_sstp_cond) works oly for per-particle substepping (opts_init.exact_sstp_cond)");
     if (!o.sstp_cond_mix && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
+    if (o.sstp_cond_mix && o.adaptive_sstp_cond && o.exact_sstp_cond) throw lcx_error("libcloudph++: Adaptive cond substepping (opts_init.adaptive_sstp_cond) with per-particle substepping (opts_init.exact_sstp_cond) requires mixing of th and rv between subteps (opts_init.sstp_cond_mix) to be disabled");
+    if (o.sstp_cond_act > 1 && (o.sstp_cond_mix || !o.exact_sstp_cond || !o.adaptive_sstp_cond)) throw lcx_error("libcloudph++: number of substeps for activation (opts_init.sstp_cond_act) can be greater than 1 only if mixing of rv and th (opts_init.sstp_cond_mix) is disabled and if per-particle condensation substepping is used (opts_init.exact_sstp_cond) and if adaptive substepping is used (opts_init.adaptive_sstp_cond)");
   }
   void courant_checks(const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) const
   {
@@ -779,6 +858,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_init_vt0<T>, dim3(nblk(size_t(vtc.n_bin))), dim3(BS), 0, st, vt_0.p, vtc);
     }
     hskpng_vterm(true);
+    hskpng_approximate_rc2_invalid();                                                    // particles_init.ipp:116-117
     sstp_save();
     sorted = false;
     hskpng_count();
@@ -811,7 +891,8 @@ struct Particles : IParticles {
     if (opts.cond) {
       hskpng_sort();
       hskpng_mfp();
-      for (int step = 0; step < sstp_cond; ++step) {
+      if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) cond_perparticle(opts.RH_max);
+      else for (int step = 0; step < sstp_cond; ++step) {
         sstp_percell_step(step);
         hskpng_Tpr();
         cond_substep(opts.RH_max, step);
@@ -848,6 +929,7 @@ struct Particles : IParticles {
         if (flag) { ++sstp_coal; HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st)); }
       }
       release_replay_keep();
+      hskpng_approximate_rc2_invalid();                                                  // particles_step.ipp:402-403
     }
     // single device, > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions
     const bool fused = !distmem() && n_dims > 0 && nphys > 0 && !opts.rcyc;
@@ -961,7 +1043,12 @@ struct Particles : IParticles {
       {"courant_x", courant_x.p, n_cx}, {"courant_y", courant_y.p, n_cy}, {"courant_z", courant_z.p, n_cz},
       {"vt_0", vt_0.p, vt_0.p ? size_t(vtc.n_bin) : 0}, {"count_mom", count_mom.p, ncell}, {"col", col.p, col.p ? npart : 0},
       {"rw2", A.rw2.p, npart}, {"rd3", A.rd3.p, npart}, {"kappa", A.kpa.p, npart},
-      {"x", A.x.p, A.x.p ? npart : 0}, {"y", A.y.p, A.y.p ? npart : 0}, {"z", A.z.p, A.z.p ? npart : 0}};
+      {"x", A.x.p, A.x.p ? npart : 0}, {"y", A.y.p, A.y.p ? npart : 0}, {"z", A.z.p, A.z.p ? npart : 0},
+      {"sstp_tmp_rv", exact ? A.ext[ix_rv].p : sstp_tmp_rv.p, exact ? npart : ncell},
+      {"sstp_tmp_th", exact ? A.ext[ix_th].p : sstp_tmp_th.p, exact ? npart : ncell},
+      {"sstp_tmp_rh", exact ? A.ext[ix_rh].p : sstp_tmp_rh.p, exact ? npart : ncell},
+      {"sstp_tmp_p", exact && o.const_p ? A.ext[ix_p].p : nullptr, exact && o.const_p ? npart : 0},
+      {"rc2", use_rc2 ? A.ext[ix_rc2].p : nullptr, use_rc2 ? npart : 0}};
     for (const E &e : tab)
       if (s == e.nm) {
         *n = e.len;
@@ -986,6 +1073,8 @@ struct Particles : IParticles {
     if (n) HIPCHK(hipMemcpy(A.n.p, mult, n * sizeof(n_t), hipMemcpyHostToDevice));
     up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
     hskpng_ijk();
+    if (use_rc2 && n) { hipLaunchKernelGGL(k_fill<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_rc2].p, n, T(-1)); hskpng_approximate_rc2_invalid(); }
+    sstp_save();
     hskpng_count();
     sync();
   }
@@ -1014,7 +1103,7 @@ struct Particles : IParticles {
   // 1-D decomposition primitives
   // ------------------------------------------------------------------------------------------
   void migrate_counts(size_t *l, size_t *r) override { *l = lft_count; *r = rgt_count; }
-  size_t migrate_record_bytes() override { return sizeof(n_t) + sizeof(T) * (4 + size_t(n_dims)); }
+  size_t migrate_record_bytes() override { return sizeof(n_t) + sizeof(T) * (4 + size_t(n_dims) + size_t(n_ext)); }
   void migrate_pack(int side, double x_rmt, void *buf, size_t capb) override
   {
     const size_t cnt = side == 0 ? lft_count : rgt_count;
@@ -1155,10 +1244,10 @@ int lcx_math_probe(int which, const double *x, double *y, size_t n)
   LCX_TRY({
     double *d = nullptr;
     if (hipMalloc(&d, (n ? n : 1) * sizeof(double)) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed");
-    hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d, x, n * sizeof(double), hipMemcpyHostToDevice);
     if (n) hipLaunchKernelGGL(lcx::k_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, which, d, n);
     const hipError_t e = hipMemcpy(y, d, n * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(d);
+    (void)hipFree(d);
     if (e != hipSuccess) throw std::runtime_error(std::string("libcloudph++ (HIP): math probe failed: ") + hipGetErrorString(e));
   })
 }

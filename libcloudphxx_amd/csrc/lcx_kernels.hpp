@@ -480,6 +480,205 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
 }
 
 // ============================================================================================
+// per-particle condensation substepping (exact_sstp_cond): src/impl/condensation/perparticle/*.ipp,
+// particles_step.ipp:199-236.  The reference runs ~8 thrust passes per substep over n_part-long temporaries
+// (sstp_dlt_*, rwX, drwX, Tp); here a super-droplet keeps its private (rv, th, rhod, p) in registers:
+//   no mixing            : ONE launch does all substeps of a super-droplet (k_pp_cond_nomix)
+//   adaptive, no mixing  : ONE launch, the substep count is chosen per super-droplet (k_pp_cond_adaptive)
+//   mixing               : one launch per substep + the ordered per-cell sums that couple the droplets of a cell
+// ============================================================================================
+template <class T>
+struct pp_args {
+  const uint32_t *sorted_id, *sorted_ijk;
+  const n_t *n; const T *rd3, *kpa, *vt; T *rw2;
+  T *pp_rv, *pp_th, *pp_rh, *pp_p;            // per-particle "old" state (sstp_tmp_* of the reference)
+  const T *rv, *th, *rhod, *p;                // cell state after sync_in
+  const T *dv, *lambda_D, *lambda_K, *rc2;
+  T *m3_before, *m3_after;                    // position-ordered: n rw^3 before / after (no mixing)
+  T *dlt_rv, *dlt_th, *dlt_rh, *dlt_p, *rw3s; // mixing only: per-particle deltas and stored rw^3
+  T *drv, *dth;                               // mixing only, position-ordered: this substep's change of rv, th
+  const T *dst_rv, *dst_th;                   // mixing only: per-cell sums of the previous substep
+  T dt, RH_max, eps, cond_mlt, adapt_eps, adapt_max; unsigned n_iter;
+  int sstp_cond, sstp_cond_act, th_dry, const_p, RH_formula, n_dims, step;
+};
+template <class T> __device__ __forceinline__ T rw2torw3(T rw2) { return rw2 * T(sqrt(rw2)); }       // cond_common.ipp:57-67
+template <class T> __device__ __forceinline__ T rw3diff2drv(T d, T rhod, n_t n, T dv, int n_dims)
+{                                                                                                  // cond_common.ipp:24-41
+  const T mlt = -cst<T>::rho_w * T(4. / 3) * cst<T>::pi;
+  return n_dims > 0 ? mlt * d * T(n) / rhod / dv : mlt * d * T(n);
+}
+// temperature, pressure and RH of one super-droplet's private air (cond_perparticle_advance_rw2.ipp:30-125)
+template <class T> __device__ __forceinline__ void pp_state(const pp_args<T> &a, T t_th, T t_rv, T t_rh, T &t_p, T &Tp, T &RH)
+{
+  Tp = a.th_dry ? theta_dry_T(t_th, t_rh) : T(t_th * exner(t_p));
+  if (!a.const_p) t_p = theta_dry_p(t_rh, t_rv, Tp);
+  RH = RH_of(a.RH_formula, t_p, t_rv, Tp);
+}
+template <class T, bool FAST> __device__ __forceinline__ T pp_advance(const pp_args<T> &a, T rw2, T dt, T t_rh, T t_rv, T Tp, T RH,
+                                                                      T rd3, T kpa, T vt, T lD, T lK)
+{ return advance_rw2<T, FAST>(rw2, dt, t_rh, t_rv, Tp, visc(Tp), rd3, kpa, vt, lD, lK, RH, a.RH_max, a.eps, a.cond_mlt, a.n_iter); }
+
+// sstp_save.ipp:17-22 / init_perparticle_sstp.ipp: per-particle copy of the cell state
+template <class T>
+__global__ void k_pp_save(size_t n, const uint32_t *ijk, const T *rv, const T *th, const T *rhod, const T *p,
+                          T *pp_rv, T *pp_th, T *pp_rh, T *pp_p)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
+  pp_rv[i] = rv[c]; pp_th[i] = th[c]; pp_rh[i] = rhod[c];
+  if (pp_p) pp_p[i] = p[c];
+}
+// hskpng_rc2.ipp:14-32
+template <class T>
+__global__ void k_rc2(size_t n, const T *rd3, const T *kpa, T Tk, T *rc2)
+{
+  const size_t i = gid(); if (i >= n) return;
+  if (rc2[i] == T(-1)) rc2[i] = rc2_of(rd3[i], kpa[i], Tk);
+}
+
+template <class T, bool FAST>
+__global__ void __launch_bounds__(BS) k_pp_cond_nomix(size_t n_part, pp_args<T> a)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  const n_t n = a.n[id];
+  const T rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id], dv = a.dv[c], lD = a.lambda_D[c], lK = a.lambda_K[c];
+  T t_rv = a.pp_rv[id], t_th = a.pp_th[id], t_rh = a.pp_rh[id], t_p = a.const_p ? a.pp_p[id] : T(0);
+  const T d_rv = a.rv[c] - t_rv, d_th = a.th[c] - t_th, d_rh = a.rhod[c] - t_rh, d_p = a.const_p ? a.p[c] - t_p : T(0);
+  T rw2 = a.rw2[id], rw3 = 0, Tp, RH;
+  a.m3_before[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
+  for (int step = 0; step < a.sstp_cond; ++step) {
+    t_rv = t_rv + d_rv / a.sstp_cond; t_th = t_th + d_th / a.sstp_cond; t_rh = t_rh + d_rh / a.sstp_cond;      // apply_noncond_...ipp
+    if (a.const_p) t_p = t_p + d_p / a.sstp_cond;
+    T drw3 = step > 0 ? -rw3 : -rw2torw3(rw2);
+    pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+    rw2 = pp_advance<T, FAST>(a, rw2, a.dt / a.sstp_cond, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK);
+    rw3 = rw2torw3(rw2);
+    drw3 = rw3 + drw3;
+    drw3 = rw3diff2drv(drw3, t_rh, n, dv, a.n_dims);
+    t_rv = drw3 + t_rv;
+    drw3 = drw3 * d_th_d_rv(Tp, t_th);
+    t_th = drw3 + t_th;
+  }
+  a.rw2[id] = rw2;
+  a.m3_after[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
+}
+
+// perparticle_nomixing_adaptive_sstp_cond.ipp:56-265
+template <class T, bool FAST>
+__global__ void __launch_bounds__(BS) k_pp_cond_adaptive(size_t n_part, pp_args<T> a)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  const n_t n = a.n[id];
+  const T rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id], dv = a.dv[c], lD = a.lambda_D[c], lK = a.lambda_K[c];
+  T t_rv = a.pp_rv[id], t_th = a.pp_th[id], t_rh = a.pp_rh[id], t_p = a.const_p ? a.pp_p[id] : T(0);
+  const T d_rv = a.rv[c] - t_rv, d_th = a.th[c] - t_th, d_rh = a.rhod[c] - t_rh, d_p = a.const_p ? a.p[c] - t_p : T(0);
+  T rw2 = a.rw2[id], drw2 = 0, Tp = 0, RH = 0, frac = 0;
+  a.m3_before[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
+  auto apply_delta = [&](T m) { t_rv += d_rv * m; t_th += d_th * m; t_rh += d_rh * m; if (a.const_p) t_p += d_p * m; };
+  const int sstp_max = a.sstp_cond;
+  unsigned sstp = unsigned(sstp_max);
+  bool first_done = sstp_max == 1;
+  {
+    T drw2_new = 0;
+    for (int tr = 1; tr <= sstp_max; tr *= 2) {
+      frac = tr == 1 ? T(1) : -T(1) / tr;
+      apply_delta(frac);
+      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+      T d = rw2;                                                    // advance_rw2<real_t, false>: the increment (rw2 <= 0: rw2 itself)
+      if (rw2 > 0) d = pp_advance<T, FAST>(a, rw2, a.dt / tr, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK) - rw2;
+      if (tr == 1) drw2 = d; else drw2_new = d;
+      if (tr > 1) {
+        if (fabs(drw2_new * 2 - drw2) <= a.adapt_eps * rw2 && fabs(drw2) < a.adapt_max * rw2) {
+          sstp = unsigned(tr / 2);
+          apply_delta(-frac);
+          first_done = true;
+          break;
+        }
+        drw2 = drw2_new;
+      }
+    }
+    if (a.sstp_cond_act > 1) {
+      const T rc2 = a.rc2[id];
+      if ((rw2 < rc2 && (rw2 + sstp * drw2) > rc2) || (rw2 > rc2 && (rw2 + sstp * drw2) < rc2)) {
+        sstp = unsigned(a.sstp_cond_act);
+        first_done = false;
+      }
+    }
+    if (!first_done) apply_delta(sstp_max == 1 ? -frac : frac);
+  }
+  frac = T(1) / sstp;
+  T rw3 = drw2;                                                     // `real_t &rw3 = drw2` in the reference
+  for (unsigned step = 0; step < sstp; ++step) {
+    T drw3 = step > 0 ? -rw3 : -rw2torw3(rw2);
+    if (first_done && step == 0) rw2 += rw3;
+    else {
+      apply_delta(frac);
+      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+      rw2 = pp_advance<T, FAST>(a, rw2, a.dt / sstp, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK);
+    }
+    if (step < sstp - 1) { rw3 = rw2torw3(rw2); drw3 += rw3; }
+    else drw3 += rw2torw3(rw2);
+    drw3 = rw3diff2drv(drw3, t_rh, n, dv, a.n_dims);
+    t_rv += drw3;
+    drw3 = drw3 * d_th_d_rv(Tp, t_th);
+    t_th += drw3;
+  }
+  a.rw2[id] = rw2;
+  a.m3_after[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
+}
+
+// one substep with mixing (particles_step.ipp:221-232); the per-cell sums of drv / dth are taken by k_cell_seqsum and
+// added to every droplet of the cell at the start of the next substep (update_pstate, update_th_rv.ipp:243-283)
+template <class T, bool FAST>
+__global__ void __launch_bounds__(BS) k_pp_cond_mix(size_t n_part, pp_args<T> a)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  const n_t n = a.n[id];
+  T t_rv = a.pp_rv[id], t_th = a.pp_th[id], t_rh = a.pp_rh[id], t_p = a.const_p ? a.pp_p[id] : T(0);
+  T d_rv, d_th, d_rh, d_p = 0;
+  if (a.step == 0) {
+    d_rv = a.rv[c] - t_rv; d_th = a.th[c] - t_th; d_rh = a.rhod[c] - t_rh;
+    a.dlt_rv[id] = d_rv; a.dlt_th[id] = d_th; a.dlt_rh[id] = d_rh;
+    if (a.const_p) { d_p = a.p[c] - t_p; a.dlt_p[id] = d_p; }
+  } else {
+    t_rv = t_rv + a.dst_rv[c]; t_th = t_th + a.dst_th[c];
+    d_rv = a.dlt_rv[id]; d_th = a.dlt_th[id]; d_rh = a.dlt_rh[id];
+    if (a.const_p) d_p = a.dlt_p[id];
+  }
+  t_rv = t_rv + d_rv / a.sstp_cond; t_th = t_th + d_th / a.sstp_cond; t_rh = t_rh + d_rh / a.sstp_cond;
+  if (a.const_p) t_p = t_p + d_p / a.sstp_cond;
+  T rw2 = a.rw2[id], Tp, RH;
+  T drw3 = a.step > 0 ? -a.rw3s[id] : -rw2torw3(rw2);
+  pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+  rw2 = pp_advance<T, FAST>(a, rw2, a.dt / a.sstp_cond, t_rh, t_rv, Tp, RH, a.rd3[id], a.kpa[id], a.vt[id], a.lambda_D[c], a.lambda_K[c]);
+  const T rw3 = rw2torw3(rw2);
+  if (a.step < a.sstp_cond - 1) a.rw3s[id] = rw3;
+  drw3 = rw3 + drw3;
+  drw3 = rw3diff2drv(drw3, t_rh, n, a.dv[c], a.n_dims);
+  a.rw2[id] = rw2;
+  a.pp_rv[id] = t_rv; a.pp_th[id] = t_th; a.pp_rh[id] = t_rh;
+  if (a.const_p) a.pp_p[id] = t_p;
+  a.drv[pos] = drw3;
+  a.dth[pos] = drw3 * d_th_d_rv(Tp, t_th);
+}
+// update_state (update_th_rv.ipp:287-299) after the last substep: the cell takes the value of its last droplet
+template <class T>
+__global__ void k_pp_mix_finish(size_t n_cell, const uint32_t *cell_start, const uint32_t *sorted_id, const T *pp_rv, const T *pp_th,
+                                const T *dst_rv, const T *dst_th, T *rv, T *th)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const uint32_t s = cell_start[c], e = cell_start[c + 1];
+  if (e == s) return;
+  const uint32_t id = sorted_id[e - 1];
+  rv[c] = pp_rv[id] + dst_rv[c];
+  th[c] = pp_th[id] + dst_th[c];
+}
+
+// ============================================================================================
 // coalescence (particles_impl_coal.ipp:99-546, src/detail/kernels.hpp:38-202, kernel_interpolation.hpp:9-65)
 // ============================================================================================
 template <class T> struct coal_kernel_cfg { int kernel; int n_user_params; T r_max; const T *params; };
@@ -549,7 +748,7 @@ template <class T>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
-       int pure_const_multi, int *increase_sstp_coal)
+       int pure_const_multi, int *increase_sstp_coal, T *rc2)
 {
   const size_t p0 = 2 * gid();
   if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
@@ -587,6 +786,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     rw2[b] = rw_b * rw_b;
     rd3[b] = col_no * rd3[a] + rd3[b];
     vt[b] = T(-1);
+    if (rc2) rc2[b] = T(-1);                                                 // invalidator, coal.ipp:33-44,527-545
     col[p + 1] = T(-2);
   } else {
     if (na > 0) { const n_t q = nb / na; if (q < col_no) col_no = q; }
@@ -595,6 +795,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     rw2[a] = rw_a * rw_a;
     rd3[a] = col_no * rd3[b] + rd3[a];
     vt[a] = T(-1);
+    if (rc2) rc2[a] = T(-1);
     col[p + 1] = T(-1);
   }
   col[p] = T(col_no);
@@ -773,7 +974,9 @@ __global__ void __launch_bounds__(BS) k_alive_tiles(const n_t *n, size_t n_part,
   __syncthreads();
   if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[w]; tile_sums[blockIdx.x] = s; }
 }
-template <class T> struct attr_set { n_t *n; T *rd3, *rw2, *kpa, *vt, *x, *y, *z; };
+// ext[]: further real-valued attributes that travel with a super-droplet (per-particle substepping state, rc2)
+constexpr int MAX_EXT = 5;
+template <class T> struct attr_set { n_t *n; T *rd3, *rw2, *kpa, *vt, *x, *y, *z; T *ext[MAX_EXT]; int n_ext; };
 
 template <class T>
 __global__ void __launch_bounds__(BS)
@@ -803,6 +1006,7 @@ k_compact(size_t n_part, attr_set<T> src, attr_set<T> dst, const uint32_t *tile_
       if (g.nx) { x = src.x[i]; dst.x[d] = x; }
       if (g.ny) { y = src.y[i]; dst.y[d] = y; }
       if (g.nz) { z = src.z[i]; dst.z[d] = z; }
+      for (int e = 0; e < src.n_ext; ++e) dst.ext[e][d] = src.ext[e][i];
       c = cell_of(g, x, y, z);
       ijk[d] = c;
     }
@@ -997,6 +1201,7 @@ __global__ void k_pack(size_t count, const uint32_t *ids, attr_set<T> s, grid_t 
   if (g.nx) { const T xn = x_rmt + s.x[id] - x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
   if (g.ny) rb[slab++ * count + i] = s.y[id];
   if (g.nz) rb[slab++ * count + i] = s.z[id];
+  for (int e = 0; e < s.n_ext; ++e) rb[slab++ * count + i] = s.ext[e][id];
 }
 template <class T>
 __global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, const T *rb, T x0, T x1, T tol)
@@ -1009,6 +1214,7 @@ __global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, co
   if (g.nx) { const T x = rb[slab++ * count + i]; s.x[d] = x >= x1 ? x - tol : x < x0 ? x + tol : x; }   // tolerance_away_from_bcond
   if (g.ny) s.y[d] = rb[slab++ * count + i];
   if (g.nz) s.z[d] = rb[slab++ * count + i];
+  for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = rb[slab++ * count + i];
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 

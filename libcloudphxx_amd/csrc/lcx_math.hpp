@@ -234,6 +234,20 @@ template <class T> LCX_HD T rw3_eq(T rd3, T kappa, T RH, T Tk)
   return toms748_solve(f, a, b, f(a), f(b), eps_tolerance<T>(sizeof(T) * 8 / 4), 100u);
 }
 
+// ---- critical radius: kappa_koehler.hpp:88-166 (evaluated in double whatever real_t), particles_diag.ipp:41-62
+struct rw3_cr_minfun {
+  double rd3, kappa, A;
+  LCX_HD double operator()(double rw3) const
+  { return A * (rd3 - rw3) * ((kappa - 1) * rd3 + rw3) + 3 * kappa * rd3 * rw3 * cbrt(rw3); }
+};
+template <class T> LCX_HD T rc2_of(T rd3, T kappa, T Tk)
+{
+  const rw3_cr_minfun f{double(rd3), double(kappa), kelvin_A(double(Tk))};
+  const double a = 1e0 * double(rd3), b = 1e8 * double(rd3);
+  const T rw3 = T(toms748_solve(f, a, b, f(a), f(b), eps_tolerance<double>(sizeof(double) * 8 / 4), 100u));
+  return pow(rw3, T(2. / 3));
+}
+
 // ---- condensational growth: condensation/common/particles_impl_cond_common.ipp:80-338,
 //      maxwell-mason.hpp:15-47, ventil.hpp:16-80
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet

@@ -178,6 +178,42 @@ def test_cond_step(sstp, strict_fp):
     assert np.median(np.abs(rh / ro - 1)) < 1e-10     # ulp-level differences of the moment sums feed back through th/rv
 
 
+@pytest.mark.parametrize("strict_fp", [True, False])
+@pytest.mark.parametrize("mode", ["nomix", "mix", "adaptive", "adaptive_act"])
+def test_perparticle_cond_step(mode, strict_fp):
+    """per-particle substepping (exact_sstp_cond) on a 3-D box against the oracle, advection on so that droplets carry
+    their private (rv, th, rhod) across cells; rc2 invalidation through coalescence in the adaptive_act variant"""
+    kw = dict(sstp_cond=4, exact_sstp_cond=True, strict_fp=strict_fp)
+    if mode != "mix":
+        kw["sstp_cond_mix"] = False
+    if mode.startswith("adaptive"):
+        kw.update(adaptive_sstp_cond=True, sstp_cond_adapt_drw2_eps=1e-3, sstp_cond_adapt_drw2_max=2.)
+    if mode == "adaptive_act":
+        kw["sstp_cond_act"] = 8
+    oi = h.box_opts(4, 3, 5, 48, **kw)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    opts.coal = mode == "adaptive_act"
+    opts.sedi = False
+    for nm in ("sstp_tmp_rv", "sstp_tmp_th", "sstp_tmp_rh"):
+        np.testing.assert_allclose(hip.state_real(nm), orc.state_real(nm), rtol=1e-12, err_msg=nm)
+    if mode == "adaptive_act":       # rc2 is itself the result of a tolerance-terminated root search (2^-16 in rw3)
+        np.testing.assert_allclose(hip.state_real("rc2"), orc.state_real("rc2"), rtol=1e-5)
+    for it in range(3):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
+        np.testing.assert_allclose(rh, ro, rtol=2e-4)
+        assert np.median(np.abs(rh / ro - 1)) < 2e-9      # no state copy between the steps here: 12 substeps of drift
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        for nm in ("sstp_tmp_rv", "sstp_tmp_th", "sstp_tmp_rh"):
+            np.testing.assert_allclose(hip.state_real(nm), orc.state_real(nm), rtol=1e-6, err_msg=nm)
+        if mode == "adaptive_act":
+            np.testing.assert_allclose(hip.state_real("rc2"), orc.state_real("rc2"), rtol=1e-5)
+
+
 def test_cond_moment_feedback_conservation():
     """size-independent property: d(rv) summed over cells == -4/3 pi rho_w d(sum n rw^3)/(dv rhod)"""
     oi = h.box_opts(6, 5, 4, 64)

@@ -39,6 +39,38 @@ def test_cond_substepping_refdata_hip(row, strict_fp):
     pins.check_against_row(res, row)
 
 
+def _hip_maker(strict_fp):
+    def make(oi):
+        oi.strict_fp = strict_fp
+        orc = h.oracle_particles(oi)
+        th, rv, rhod = np.array([305.]), np.array([0.0085]), np.array([1.1])
+        tmp = h.oracle_particles(oi)
+        if oi.const_p:
+            tmp.init(np.array([pins.th_dry2std(305., .0085)]), rv, rhod, np.array([1e5]))
+        else:
+            tmp.init(th, rv, rhod)
+        kap = tmp.get_attr("kappa")
+        n1 = int(np.sum(kap == kap[0]))
+        hip = h.hip_particles(oi)
+        for arr in h.oracle_rng_preview(orc, [(0, n1), (0, len(kap) - n1)]):
+            hip.rng_replay_push(0, arr)
+        return hip
+    return make
+
+
+# per-particle substepping rows: every combination of (mixing, adaptive, sstp_cond_act, const_p) at a spread of
+# substep counts and RH formulas
+ROWS_EXACT = [r for i, r in enumerate(pins._rows_exact()) if r["sstp_cond"] in ("2", "6", "32") and r["RH_formula"] in ("pv_cc", "rv_tet")]
+
+
+@pytest.mark.parametrize("strict_fp", [True, False])
+@pytest.mark.parametrize("row", ROWS_EXACT, ids=pins._row_id)
+def test_perparticle_substepping_refdata_hip(row, strict_fp):
+    """the exact_sstp_cond rows of lgrngn_cond_substepping_refdata.csv (with / without mixing, adaptive, sstp_cond_act = 8)
+    through the GPU, held to the reference's own tolerances and exact activated-droplet counts"""
+    pins.check_against_row(pins._run_row(_hip_maker(strict_fp), row), row)
+
+
 @pytest.mark.parametrize("constp", [False, True])
 @pytest.mark.parametrize("RH_formula", [lgrngn.RH_formula_t.pv_cc, lgrngn.RH_formula_t.pv_tet])
 def test_lgrngn_cond_known_answers_hip(constp, RH_formula):
