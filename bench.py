@@ -121,7 +121,7 @@ def main():
                     help="IEEE operation order in the condensation kernel (bit-faithful to the reference's formulas); default: "
                          "the collected one-division form with FMA contraction, parity-tested at the same tolerances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=24)
+    ap.add_argument("--cpu-sample-n", type=int, default=40)
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
     args = ap.parse_args()

@@ -475,6 +475,7 @@ struct Particles : IParticles {
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
       hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, nphys, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
       A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
+      for (int e = 0; e < n_ext; ++e) A.ext[e].swap(B.ext[e]);
       nphys = alive;
     } else ijk_and_hist(true, true);                 // re-index in place (dead SDs get DEAD_CELL)
     npart = alive;

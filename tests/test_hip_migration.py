@@ -54,6 +54,36 @@ def test_migration_matches_oracle(dims, size):
     assert sum(p.n_part for p in hip.prts) <= tot0
 
 
+def test_migration_carries_perparticle_state():
+    """exact_sstp_cond + sstp_cond_act: the private (rv, th, rhod) of a droplet and rc2 are attributes that are packed,
+    unpacked and compacted with it (particles_impl.ipp:452-491); condensation on, so the carried values matter"""
+    nx, ny, nz, size = 6, 0, 5, 2
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False, sstp_cond=2, exact_sstp_cond=True, sstp_cond_mix=False,
+                    adaptive_sstp_cond=True, sstp_cond_act=4)
+    oi.n_sd_max = 24 * nx * nz * 3
+    fields = h.box_fields(oi)
+    orc, hip = ring_pair(oi, size, fields)
+    assert hip.prts[0].migrate_record_bytes() == 8 + 8 * (4 + 2 + 4)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    for it in range(3):
+        a = [x.copy() for x in (th, rv, rhod)]
+        b = [x.copy() for x in (th, rv, rhod)]
+        orc.step(opts, *a, **C)
+        hip.step(opts, *b, **C)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-7)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-6)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            for nm in ("sstp_tmp_rv", "sstp_tmp_th", "sstp_tmp_rh"):
+                np.testing.assert_allclose(ph.state_real(nm), po.state_real(nm), rtol=1e-6, err_msg="%s slab %d" % (nm, r))
+            np.testing.assert_allclose(ph.state_real("rc2"), po.state_real("rc2"), rtol=1e-5)
+            np.testing.assert_allclose(ph.get_attr("rw2"), po.get_attr("rw2"), rtol=2e-4)
+
+
 def test_ring_round_trip_bit_identical_hip():
     """tests/mpi/mpi_adve_test.cpp:196-255 on the GPU: nx steps with C = 1 bring every SD back to its cell"""
     oi = lgrngn.opts_init_t()
