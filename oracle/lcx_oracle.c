@@ -105,9 +105,20 @@ typedef struct orc_particles orc_particles;
 
 static int m1(int n) { return n == 0 ? 1 : n; }
 #define NEW(T, n) ((T *)calloc((n) ? (n) : 1, sizeof(T)))
+/* Elementwise loops carry this marker; it only has an effect in the -fopenmp build (liblcx_oracle_omp.so), which
+ * exists for bench.py's cpu_baseline leg (the counterpart of the reference's OpenMP backend, thrust::omp transforms).
+ * Reductions and scans stay serial so that every build sums in the same order. */
+#define OMP_FOR _Pragma("omp parallel for schedule(static)")
 
 const char *orc_last_error(void) { return orc_err; }
+#ifdef _OPENMP
+#include <omp.h>
+const char *orc_version(void) { return "lcx-oracle 1 (double, OpenMP elementwise loops)"; }
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
 const char *orc_version(void) { return "lcx-oracle 1 (double, serial)"; }
+int orc_num_threads(void) { return 1; }
+#endif
 
 void orc_opts_init_default(lcx_opts_init_t *o)
 {                                           /* opts_init.hpp:186-247 */
@@ -254,6 +265,7 @@ static void hskpng_mfp(orc_particles *s)
 static void hskpng_ijk(orc_particles *s)
 {
   const lcx_opts_init_t *o = &s->o;
+  OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
     sz i = o->nx ? (sz)(s->x[p] / o->dx) : 0, j = o->ny ? (sz)(s->y[p] / o->dy) : 0, k = o->nz ? (sz)(s->z[p] / o->dz) : 0;
     switch (s->n_dims) {
@@ -339,6 +351,7 @@ static double vt_of(const orc_particles *s, double rw2, sz c)
 }
 static void hskpng_vterm(orc_particles *s, int only_invalid)
 {
+  OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
     if (only_invalid ? (s->vt[p] == -1. && s->rw2[p] > 0) : (s->rw2[p] > 0))
       s->vt[p] = vt_of(s, s->rw2[p], s->ijk[p]);
@@ -402,9 +415,11 @@ static double moment_counter(double n, double x, double xp)
 static void moms_calc(orc_particles *s, const double *vec, double power, int specific)
 {
   sz cn = 0;
+  double *vals = s->tmp_part;
+  OMP_FOR
+  for (sz p = 0; p < s->n_part; ++p) { const sz id = s->sorted_id[p]; vals[p] = moment_counter(s->n_filtered[id], vec[id], power); }
   for (sz p = 0; p < s->n_part; ++p) {
-    const sz id = s->sorted_id[p];
-    const double v = moment_counter(s->n_filtered[id], vec[id], power);
+    const double v = vals[p];
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
     else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
   }
@@ -462,6 +477,7 @@ static void cond(orc_particles *s, double dt, double RH_max, int step)
   hskpng_sort(s);
   if (step == 0) { if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->rw_mom3[c] = 0.; }
   else for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = -s->rw_mom3[c];
+  OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
     cond_ctx cc = {s->rw2[p], dt / s->sstp_cond, s->rhod[c], s->rv[c], s->T[c], s->p[c], s->RH[c], s->eta[c],
@@ -762,7 +778,9 @@ static void coal(orc_particles *s, double dt)
   { sz acc = 0; for (sz c = 0; c < s->n_cell; ++c) { sz t = s->off[c]; s->off[c] = acc; acc += t; } }
   double *u01 = s->col;
   for (sz p = 0; p < s->n_part; ++p) u01[p] = rng_u01(&s->rng);
-  for (sz p = 0; p + 1 < s->n_part; ++p) {                 /* collider::operator(), coal.ipp:180-267 */
+  const sz n_pairs_end = s->n_part ? s->n_part - 1 : 0;
+  OMP_FOR
+  for (sz p = 0; p < n_pairs_end; ++p) {                   /* collider::operator(), coal.ipp:180-267 */
     const sz ca = s->sorted_ijk[p], cb = s->sorted_ijk[p + 1];
     const sz cix_a = p - s->off[ca];
     if (cix_a % 2 != 0) continue;
@@ -809,6 +827,7 @@ static void adve(orc_particles *s)
   if (s->n_dims == 0) return;
   const lcx_opts_init_t *o = &s->o;
   const sz nz = m1(o->nz), ny = m1(o->ny);
+  OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
     sz i, j = 0, k = 0;
@@ -826,7 +845,11 @@ static void adve(orc_particles *s)
     }
   }
 }
-static void sedi(orc_particles *s, double dt) { for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->vt[p]; }
+static void sedi(orc_particles *s, double dt)
+{
+  OMP_FOR
+  for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->vt[p];
+}
 static void subs(orc_particles *s, double dt)
 {
   const sz nz = m1(s->o.nz);
@@ -838,7 +861,7 @@ static void bcnd(orc_particles *s)
   if (s->n_dims == 0) return;
   const lcx_opts_init_t *o = &s->o;
   if (!distmem(s)) {
-    if (!o->open_side_walls) for (sz p = 0; p < s->n_part; ++p) s->x[p] = periodic(s->x[p], o->x0, o->x1);
+    if (!o->open_side_walls) { OMP_FOR for (sz p = 0; p < s->n_part; ++p) s->x[p] = periodic(s->x[p], o->x0, o->x1); }
     else for (sz p = 0; p < s->n_part; ++p) if (s->x[p] >= o->x1 || s->x[p] < o->x0) s->n[p] = 0;
   } else {
     s->lft_count = s->rgt_count = 0;
@@ -848,7 +871,7 @@ static void bcnd(orc_particles *s)
     if (o->bcond_rgt == 3) for (sz i = 0; i < s->rgt_count; ++i) s->n[s->rgt_id[i]] = 0;
   }
   if (s->n_dims == 3) {
-    if (!o->open_side_walls) for (sz p = 0; p < s->n_part; ++p) s->y[p] = periodic(s->y[p], o->y0, o->y1);
+    if (!o->open_side_walls) { OMP_FOR for (sz p = 0; p < s->n_part; ++p) s->y[p] = periodic(s->y[p], o->y0, o->y1); }
     else for (sz p = 0; p < s->n_part; ++p) if (s->y[p] >= o->y1 || s->y[p] < o->y0) s->n[p] = 0;
   }
   if (s->n_dims > 1) {

@@ -24,7 +24,8 @@ def oracle_lib():
     if _oracle is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("lcx_oracle.c", "orc_physics.h", "orc_tables.h")]
         fm = os.path.join(ORACLE_DIR, "liblcx_oracle_fastmath.so")
-        if (not os.path.exists(ORACLE_SO)) or (not os.path.exists(fm)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+        omp = os.path.join(ORACLE_DIR, "liblcx_oracle_omp.so")
+        if (not os.path.exists(ORACLE_SO)) or (not os.path.exists(fm)) or (not os.path.exists(omp)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
         os.environ.setdefault("LCX_DATA_DIR", os.path.join(ROOT, "libcloudphxx_amd", "data"))
         _oracle = ctypes.CDLL(ORACLE_SO)
@@ -46,6 +47,23 @@ def oracle_fastmath_particles(opts_init):
         oracle_lib()
         _oracle_fm = ctypes.CDLL(os.path.join(ORACLE_DIR, "liblcx_oracle_fastmath.so"))
     return lgrngn.particles_t(opts_init, np.float64, lib=_oracle_fm, prefix="orc_")
+
+
+_oracle_omp = None
+
+
+def oracle_omp_lib():
+    """the strict oracle source with its elementwise loops spread over the host cores (-fopenmp); bench.py's CPU baseline"""
+    global _oracle_omp
+    if _oracle_omp is None:
+        oracle_lib()
+        _oracle_omp = ctypes.CDLL(os.path.join(ORACLE_DIR, "liblcx_oracle_omp.so"))
+        _oracle_omp.orc_num_threads.restype = ctypes.c_int
+    return _oracle_omp
+
+
+def oracle_omp_particles(opts_init):
+    return lgrngn.particles_t(opts_init, np.float64, lib=oracle_omp_lib(), prefix="orc_")
 
 
 def hip_particles(opts_init, real_t=np.float64):

@@ -314,3 +314,23 @@ def check_puddle(puddle, tab, oi):
 @pytest.mark.parametrize("seed", [44, 1234])
 def test_puddle_known_totals(seed):
     check_puddle(*run_puddle(oracle_particles, seed))
+
+
+def test_openmp_build_of_the_oracle_is_bit_identical():
+    """liblcx_oracle_omp.so (bench.py's cpu_baseline leg) spreads only elementwise loops over the cores; reductions and
+    scans stay serial, so its results equal the serial oracle's bit for bit"""
+    from _harness import oracle_omp_particles, box_opts, box_fields
+    oi = box_opts(5, 4, 6, 32)
+    th0, rv0, rhod, C = box_fields(oi)
+    out = []
+    for make in (oracle_particles, oracle_omp_particles):
+        pr = make(oi)
+        th, rv = th0.copy(), rv0.copy()
+        pr.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        for _ in range(3):
+            pr.step_sync(opts, th, rv, rhod, **C)
+            pr.step_async(opts)
+        out.append((th.copy(), rv.copy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.state_u64("n"), pr.state_u64("sorted_id")))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
