@@ -166,12 +166,13 @@ constexpr uint32_t DEAD_CELL = 0xFFFFFFFFu;   // ijk of a super-droplet with n =
 template <class T>
 __device__ __forceinline__ uint32_t cell_of(const grid_t &g, T x, T y, T z)
 {
-  const size_t i = g.nx ? size_t(double(x) / g.dx) : 0, j = g.ny ? size_t(double(y) / g.dy) : 0, k = g.nz ? size_t(double(z) / g.dz) : 0;
+  // size_t(double(x) / dx) of the reference; indices are < 2^32 here, so the native f64 -> u32 conversion gives the same value
+  const uint32_t i = g.nx ? uint32_t(double(x) / g.dx) : 0u, j = g.ny ? uint32_t(double(y) / g.dy) : 0u, k = g.nz ? uint32_t(double(z) / g.dz) : 0u;
   switch (g.ndims) {
     case 0: return 0u;
-    case 1: return uint32_t(i);
-    case 2: return uint32_t(i * g.nz + k);
-    default: return uint32_t(i * (size_t(g.nz) * g.ny) + j * g.nz + k);
+    case 1: return i;
+    case 2: return i * uint32_t(g.nz) + k;
+    default: return i * (uint32_t(g.nz) * uint32_t(g.ny)) + j * uint32_t(g.nz) + k;
   }
 }
 // Histogram with per-SD arrival rank, wave-aggregated: lanes of a wave that fall into the same cell are
@@ -839,10 +840,24 @@ struct move_args {
 template <class T>
 __device__ __forceinline__ T adve_1d(int scheme, T x, uint32_t fl, T C_l, T C_r, T dx)
 {
-  if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - size_t(fl) * (C_r - C_l))) / (1 - (C_r - C_l));
-  return 1 * x + (C_r - C_l) * (x - dx * size_t(fl)) + dx * C_l;
+  const T f = T(fl);                 // the reference multiplies by a size_t index: same value, native u32 conversion
+  if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - f * (C_r - C_l))) / (1 - (C_r - C_l));
+  return 1 * x + (C_r - C_l) * (x - dx * f) + dx * C_l;
 }
-template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return a + fmod((x - a) + 10 * (b - a), b - a); }
+// bcnd.ipp:99-110: a + fmod((x - a) + 10 (b - a), b - a).  fmod is exact, so for a non-negative argument it equals
+// fma(-q, L, arg) with q = trunc(arg / L) -- computed here with one division and a sign check instead of the ~100
+// instruction library loop (the rounded quotient can only be one too large; the remainder is recomputed from the
+// original argument, so the result is the exactly representable fmod value in every case)
+template <class T> __device__ __forceinline__ T fmod_nonneg(T arg, T L)
+{
+  if (!(arg >= 0 && arg < L * T(1e6))) return fmod(arg, L);
+  const T q = trunc(arg / L);
+  T r = fma(-q, L, arg);
+  if (r < 0) r = fma(-(q - 1), L, arg);
+  else if (r >= L) r = fma(-(q + 1), L, arg);
+  return r;
+}
+template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return a + fmod_nonneg((x - a) + 10 * (b - a), b - a); }
 
 template <class T>
 __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
@@ -860,24 +875,24 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   }
   if (c != DEAD_CELL) {
     const grid_t &g = a.g;
-    const size_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
+    const uint32_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;          // 32-bit index arithmetic: n_cell < 2^32
     T x = g.nx ? a.x[i] : T(0), y = g.ny ? a.y[i] : T(0), z = g.nz ? a.z[i] : T(0);
+    uint32_t ci = c, cj = 0, ck = 0;
+    if (g.ndims >= 2) { const uint32_t cij = c / nz; ck = c - cij * nz; ci = cij; if (g.ndims == 3) { ci = cij / ny; cj = cij - ci * ny; } }
     if (a.do_adve && g.ndims > 0) {
-      uint32_t ci, cj = 0, ck = 0;
-      if (g.ndims == 1) ci = c; else if (g.ndims == 2) { ci = c / nz; ck = c % nz; } else { ci = c / (nz * ny); cj = (c / nz) % ny; ck = c % nz; }
-      const size_t rgt = size_t(c) + (g.ndims == 3 ? nz * ny : size_t(g.nz));           // init_grid.ipp:96-121
+      const size_t rgt = size_t(c) + (g.ndims == 3 ? size_t(nz) * ny : size_t(g.nz));   // init_grid.ipp:96-121
       x = adve_1d(a.scheme, x, ci, a.courant_x[c], a.courant_x[rgt], a.dx);
       if (g.ndims > 2) {
-        const size_t fre = size_t(c) + (c / (nz * ny)) * nz;
+        const size_t fre = size_t(c) + size_t(ci) * nz;
         y = adve_1d(a.scheme, y, cj, a.courant_y[fre], a.courant_y[fre + nz], a.dy);
       }
       if (g.ndims > 1) {
-        const size_t blw = g.ndims == 2 ? size_t(c) + c / nz : size_t(c) + ny * (c / (nz * ny)) + (c - (c / (nz * ny)) * (nz * ny)) / nz;
+        const size_t blw = g.ndims == 2 ? size_t(c) + ci : size_t(c) + size_t(ny) * ci + cj;
         z = adve_1d(a.scheme, z, ck, a.courant_z[blw], a.courant_z[blw + 1], a.dz);
       }
     }
     if (a.do_sedi) z = z - a.dt * a.vt[i];
-    if (a.do_subs) z = z - a.dt * a.w_LS[c % nz];
+    if (a.do_subs) z = z - a.dt * a.w_LS[ck];
     bool kill = false;
     if (a.do_bcnd && g.ndims > 0) {
       if (!a.distmem) {

@@ -82,7 +82,7 @@ struct orc_particles {
   /* particle attributes */
   n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
   sz *ijk, *sorted_id, *sorted_ijk;
-  double *n_filtered, *tmp_part, *col;
+  double *n_filtered, *tmp_part, *col, *mom_vals;
   /* cell fields */
   double *rhod, *th, *rv, *p, *T, *RH, *eta, *dv, *lambda_D, *lambda_K;
   double *sstp_tmp_rv, *sstp_tmp_th, *sstp_tmp_rh, *drw_mom3, *rw_mom3, *scl;
@@ -182,7 +182,7 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->n = NEW(n_t, c); s->rd3 = NEW(double, c); s->rw2 = NEW(double, c); s->kpa = NEW(double, c);
   s->x = NEW(double, c); s->y = NEW(double, c); s->z = NEW(double, c); s->vt = NEW(double, c);
   s->ijk = NEW(sz, c); s->sorted_id = NEW(sz, c); s->sorted_ijk = NEW(sz, c);
-  s->n_filtered = NEW(double, c); s->tmp_part = NEW(double, c); s->col = NEW(double, c);
+  s->n_filtered = NEW(double, c); s->tmp_part = NEW(double, c); s->col = NEW(double, c); s->mom_vals = NEW(double, c);
   s->lft_id = NEW(sz, c); s->rgt_id = NEW(sz, c);
   s->rhod = NEW(double, nc); s->th = NEW(double, nc); s->rv = NEW(double, nc); s->p = NEW(double, nc);
   s->T = NEW(double, nc); s->RH = NEW(double, nc); s->eta = NEW(double, nc); s->dv = NEW(double, nc);
@@ -204,7 +204,8 @@ void orc_destroy(orc_particles *s)
 {
   if (!s) return;
   void *ptrs[] = {s->distros, s->sizes, s->kernel_parameters, s->w_LS, s->aerosol_conc_factor, s->n, s->rd3, s->rw2,
-    s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col,
+    s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col, s->mom_vals,
+    s->pp_rv, s->pp_th, s->pp_rh, s->pp_p, s->rc2, s->dlt_rv, s->dlt_th, s->dlt_rh, s->dlt_p, s->rwX, s->drwX, s->Tp, s->pp_sstp,
     s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
     s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
     s->count_num, s->count_mom, s->outbuf, s->courant_x, s->courant_y, s->courant_z};
@@ -415,7 +416,7 @@ static double moment_counter(double n, double x, double xp)
 static void moms_calc(orc_particles *s, const double *vec, double power, int specific)
 {
   sz cn = 0;
-  double *vals = s->tmp_part;
+  double *vals = s->mom_vals;            /* not tmp_part: diag_precip_rate passes that one as vec */
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) { const sz id = s->sorted_id[p]; vals[p] = moment_counter(s->n_filtered[id], vec[id], power); }
   for (sz p = 0; p < s->n_part; ++p) {
