@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--dx", type=float, default=40.)
     ap.add_argument("--sstp-cond", type=int, default=1)
     ap.add_argument("--sstp-coal", type=int, default=1)
+    ap.add_argument("--cond-mode", choices=["percell", "pp_nomix", "pp_adaptive", "pp_mix"], default="percell",
+                    help="condensation substepping: per cell (default) or per particle (exact_sstp_cond) without mixing / "
+                         "adaptive / with mixing; only meaningful with --sstp-cond > 1")
     ap.add_argument("--real", choices=["f64", "f32"], default="f64")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--strict-fp", action="store_true",
@@ -153,6 +156,11 @@ def main():
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = local_rank
     oi.strict_fp = args.strict_fp
+    if args.cond_mode != "percell":
+        oi.exact_sstp_cond = True
+        oi.sstp_cond_mix = args.cond_mode == "pp_mix"
+        oi.adaptive_sstp_cond = args.cond_mode == "pp_adaptive"
+        oi.n_sd_max = int(oi.n_sd_max)
     if world > 1:
         prt = multi.particles_multi_t(oi, real_t, device=dev)
         nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
@@ -217,7 +225,7 @@ def main():
         cond_bytes_per_sd = 5 * R + 8 + 8
         n_local = sd_done / max(args.steps, 1)
         roof = None
-        if "cond" in stage_ms:
+        if "cond" in stage_ms and args.cond_mode == "percell":
             launches = args.steps * args.sstp_cond
             avg_ms = stage_ms["cond"] / launches
             ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
@@ -270,7 +278,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
                                    % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
-                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d" % world,
+                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d" % world, "cond_mode": args.cond_mode,
                        "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
                        "init_s": t_init},
             "roofline": roof,

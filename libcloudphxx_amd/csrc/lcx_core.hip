@@ -100,7 +100,7 @@ struct Particles : IParticles {
   std::vector<lcx_dry_size_t> sizes; int n_size_keys = 0;   // dry_sizes.size() of the reference = number of (kappa, rd_insol) keys
   std::vector<double> kernel_parameters_h, w_LS_h, conc_factor_h;
   int n_dims; size_t ncell, npart = 0, nphys = 0, cap;   // npart: living SDs (API); nphys: storage extent incl. not yet compacted dead SDs
-  bool eager_compact = false;
+  bool eager_compact = false, fused_pending = false; size_t n_before_unpack = 0;
   grid_t g;
   // ---- order-of-operation flags (particles_impl.ipp:32) ----
   bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
@@ -381,7 +381,7 @@ struct Particles : IParticles {
   {
     if (do_hist) HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
     if (nphys)
-      hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
+      hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, size_t(0), nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
                          do_hist ? cell_cnt.p : nullptr, rank.p, int(do_ijk));
   }
   void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(true, false); sorted = false; }
@@ -494,10 +494,12 @@ struct Particles : IParticles {
   // make storage order == the reference's (no dead SDs in it) before anything that exposes storage order
   void ensure_compact()
   {
+    if (lft_count || rgt_count || fused_pending)
+      throw lcx_error("libcloudph++: the neighbour exchange of this step is pending (migrate_pack / _unpack / _finish) -- particle state cannot be read or compacted now");
     if (nphys == npart) return;
-    lcx_opts_t od; lcx_opts_default(&od);
-    post_copy(od, true);
+    ensure_compact_forced();
   }
+  void ensure_compact_forced() { lcx_opts_t od; lcx_opts_default(&od); post_copy(od, true); }
 
   // ------------------------------------------------------------------------------------------
   // condensation (particles_step.ipp:188-267)
@@ -660,13 +662,13 @@ struct Particles : IParticles {
     const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     size_t *cnt[2] = {&lft_count, &rgt_count};
     for (int side = 0; side < 2; ++side) {
-      uint32_t tot = 0;
       hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p);
-      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p + side);
       hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
-      read_back(&tot, scan_total.p, 1);
-      *cnt[side] = tot;
     }
+    uint32_t tot[2];
+    read_back(tot, scan_total.p, 2);                  // one host sync for both directions
+    *cnt[0] = tot[0]; *cnt[1] = tot[1];
   }
 
   // ------------------------------------------------------------------------------------------
@@ -933,10 +935,14 @@ struct Particles : IParticles {
       hskpng_approximate_rc2_invalid();                                                  // particles_step.ipp:402-403
     }
     // single device, > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions
-    const bool fused = !distmem() && n_dims > 0 && nphys > 0 && !opts.rcyc;
+    // > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions; with a decomposed
+    // domain the histogram is completed by the immigrants in migrate_finish
+    const bool fused = n_dims > 0 && nphys > 0 && !opts.rcyc;
     move(opts.adve, opts.sedi, opts.subs, true, fused);
     adve_scheme = o.adve_scheme;
-    if (fused) post_copy_after_fused_move(opts);
+    fused_pending = fused && distmem();
+    n_before_unpack = nphys;
+    if (fused && !distmem()) post_copy_after_fused_move(opts);
     else if (!distmem()) post_copy(opts);
     sync();
     selected_before_counting = false;
@@ -1115,10 +1121,21 @@ struct Particles : IParticles {
     hipLaunchKernelGGL(k_pack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, mig_ids[side].p, aset(A), g, T(x_rmt), T(side == 0 ? o.x0 : o.x1), nb, rb);
     sync();
   }
+  // emigrants leave (n = 0) once they are packed: the protocol is pack (both sides) -> unpack -> finish
+  void flag_emigrants()
+  {
+    if (lft_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(lft_count)), dim3(BS), 0, st, lft_count, mig_ids[0].p, A.n.p);
+    if (rgt_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(rgt_count)), dim3(BS), 0, st, rgt_count, mig_ids[1].p, A.n.p);
+    lft_count = rgt_count = 0;
+  }
   void migrate_unpack(const void *buf, size_t cnt) override
   {
     if (!cnt) return;
-    if (nphys + cnt > cap) ensure_compact();
+    flag_emigrants();
+    if (nphys + cnt > cap) {                           // make room: compaction re-indexes everything, the fused histogram is void
+      ensure_compact_forced();
+      fused_pending = false;
+    }
     check_npart(nphys + cnt);
     Range r(this, "migrate_unpack");
     const n_t *nb = (const n_t *)buf; const T *rb = (const T *)((const n_t *)buf + cnt);
@@ -1128,10 +1145,15 @@ struct Particles : IParticles {
   }
   void migrate_finish(const lcx_opts_t &opts) override
   {
-    if (lft_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(lft_count)), dim3(BS), 0, st, lft_count, mig_ids[0].p, A.n.p);
-    if (rgt_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(rgt_count)), dim3(BS), 0, st, rgt_count, mig_ids[1].p, A.n.p);
-    lft_count = rgt_count = 0;
-    post_copy(opts);
+    flag_emigrants();
+    if (fused_pending) {
+      // k_move left the histogram of the SDs that stayed; add the immigrants appended since, then scan/scatter/rank
+      if (nphys > n_before_unpack)
+        hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys - n_before_unpack)), dim3(BS), 0, st, n_before_unpack, nphys, g, A.n.p, A.x.p, A.y.p, A.z.p,
+                           ijk.p, cell_cnt.p, rank.p, 1);
+      fused_pending = false;
+      post_copy_after_fused_move(opts);
+    } else post_copy(opts);
     sync();
   }
 };

@@ -209,9 +209,9 @@ __device__ __forceinline__ uint32_t wave_hist_rank(uint32_t *cnt, uint32_t c, bo
 // and take no part in the histogram, so they never enter the sorted order.
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_ijk_hist(size_t n, grid_t g, const n_t *mult, const T *x, const T *y, const T *z, uint32_t *ijk, uint32_t *cnt, uint32_t *rank, int do_ijk)
+k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const T *y, const T *z, uint32_t *ijk, uint32_t *cnt, uint32_t *rank, int do_ijk)
 {
-  const size_t i = gid();
+  const size_t i = first + gid();                    // [first, n): the whole storage, or only the immigrants appended by unpack
   bool active = i < n;
   uint32_t c = 0;
   if (active) {
@@ -893,7 +893,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     }
     if (a.do_sedi) z = z - a.dt * a.vt[i];
     if (a.do_subs) z = z - a.dt * a.w_LS[ck];
-    bool kill = false;
+    bool kill = false, emigrant = false;
     if (a.do_bcnd && g.ndims > 0) {
       if (!a.distmem) {
         if (!a.open_side_walls) x = periodic(x, a.x0, a.x1);
@@ -903,6 +903,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
         if (x < a.x0) { m = 1; if (a.bcond_lft == 3) kill = true; }
         if (x >= a.x1) { m = 2; if (a.bcond_rgt == 3) kill = true; }
         a.mig[i] = m;
+        emigrant = m != 0;
       }
       if (g.ndims == 3) {
         if (!a.open_side_walls) y = periodic(y, a.y0, a.y1);
@@ -928,7 +929,10 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     if (g.ny) a.y[i] = y;
     if (g.nz) a.z[i] = z;
     if (kill) { a.n[i] = 0; dead_now = true; }
-    else if (a.reindex) c_new = cell_of(g, x, y, z);
+    else if (a.reindex) {
+      // an emigrant leaves the cell-sorted order at once (it is packed by id and its multiplicity zeroed in migrate_finish)
+      if (emigrant) dead_now = true; else c_new = cell_of(g, x, y, z);
+    }
   }
   if (a.reindex) {                                    // every lane of the wave takes part (ballots inside)
     const bool live = c_new != DEAD_CELL;
