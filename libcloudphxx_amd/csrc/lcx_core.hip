@@ -377,14 +377,14 @@ struct Particles : IParticles {
     hipLaunchKernelGGL(k_cell_mfp<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, Tk.p, p.p, lambda_D.p, lambda_K.p);
   }
   // cell index of every SD (+ optionally the cell histogram with per-SD ranks in the same pass)
-  void ijk_and_hist(bool do_ijk, bool do_hist)
+  void ijk_and_hist(int do_ijk, bool do_hist)      // do_ijk: see k_ijk_hist
   {
     if (do_hist) HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
     if (nphys)
       hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, size_t(0), nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
-                         do_hist ? cell_cnt.p : nullptr, rank.p, int(do_ijk));
+                         do_hist ? cell_cnt.p : nullptr, rank.p, do_ijk);
   }
-  void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(true, false); sorted = false; }
+  void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(2, false); sorted = false; }
   // finish a sort given cell_cnt/rank: scan -> scatter -> per-cell order
   void sort_from_hist(bool shuffle)
   {
@@ -429,7 +429,7 @@ struct Particles : IParticles {
   {
     Range r(this, shuffle ? "hskpng_shuffle_and_sort" : "hskpng_sort");
     if (sorted && shuffle) { order_cells(true); return; }   // cells unchanged since the last sort: re-order the segments only
-    ijk_and_hist(false, true);
+    ijk_and_hist(0, true);
     sort_from_hist(shuffle);
   }
   void hskpng_sort() { if (!sorted) hskpng_sort_helper(false); }
@@ -477,7 +477,7 @@ struct Particles : IParticles {
       A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
       for (int e = 0; e < n_ext; ++e) A.ext[e].swap(B.ext[e]);
       nphys = alive;
-    } else ijk_and_hist(true, true);                 // re-index in place (dead SDs get DEAD_CELL)
+    } else ijk_and_hist(1, true);                    // re-index in place (dead SDs get DEAD_CELL)
     npart = alive;
     sort_from_hist(false);
   }
@@ -1079,6 +1079,7 @@ struct Particles : IParticles {
     };
     if (n) HIPCHK(hipMemcpy(A.n.p, mult, n * sizeof(n_t), hipMemcpyHostToDevice));
     up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
+    if (n) HIPCHK(hipMemsetAsync(ijk.p, 0, n * sizeof(uint32_t), st));     // every SD is in the order again, n == 0 included
     hskpng_ijk();
     if (use_rc2 && n) { hipLaunchKernelGGL(k_fill<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_rc2].p, n, T(-1)); hskpng_approximate_rc2_invalid(); }
     sstp_save();

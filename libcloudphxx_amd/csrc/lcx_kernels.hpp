@@ -215,8 +215,10 @@ k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const 
   bool active = i < n;
   uint32_t c = 0;
   if (active) {
+    // do_ijk: 0 keep ijk; 1 removal point (post_copy): n == 0 leaves the order; 2 plain hskpng_ijk: an SD with n == 0 stays in
+    // the order until the next removal point, exactly as in the reference (e.g. zero-multiplicity SDs right after init)
     if (do_ijk) {
-      if (mult[i] == 0) c = DEAD_CELL;
+      if (do_ijk == 1 ? mult[i] == 0 : ijk[i] == DEAD_CELL) c = DEAD_CELL;
       else c = cell_of(g, g.nx ? x[i] : T(0), g.ny ? y[i] : T(0), g.nz ? z[i] : T(0));
       ijk[i] = c;
     } else c = ijk[i];

@@ -1,0 +1,162 @@
+"""BASELINE.json's configurations as parity cases (the bench line is configs[2]; tests/test_hip_fullsize.py holds its
+full-size properties):
+  C1  0-D adiabatic parcel, 1e4 super-droplets, geometric kernel, beard76                      -> vs oracle, replayed stream
+  C2  2-D kinematic icicle set-up (GMD 2015): 76 x 76 cells x 64 SDs, sstp 10/10, implicit advection,
+      khvorostyanov_spherical, geometric x 0.5 (models/kinematic_2D/src/opts_lgrngn.hpp:262,340-343,
+      kin_cloud_2d_lgrngn.hpp:167-196) -- reduced to 24 x 24 cells for the oracle, full size in float as a property run
+  C4  1-D decomposition over 8 slabs (256 x 256 x 128 in BASELINE; 16 x 4 x 6 here) as a ring on one GPU -> vs oracle ring
+  C5  512 super-droplets per cell (per-cell segments larger than a wave / the ranking crossover)  -> vs oracle
+"""
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+from test_hip_parity import step_pair, exact
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_parcel_0d_1e4():
+    oi = h.box_opts(0, 0, 0, 10000, sedi_switch=False, kernel=lgrngn.kernel_t.geometric, terminal_velocity=lgrngn.vt_t.beard76)
+    oi.dx = oi.dy = oi.dz = 1.
+    oi.x1 = oi.y1 = oi.z1 = 1.
+    fields = (np.array([300.]), np.array([0.02]), np.array([1.1]), {})          # supersaturated variant, lgrngn_cond.py:70-73
+    orc, hip = h.make_pair(oi, fields)
+    assert hip.n_part == 10000
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.adve = False
+    for it in range(3):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        h.copy_state(orc, hip)
+
+
+def icicle_opts(nx, nz, sd_conc=64, sstp=10):
+    dx = 1500. / 75
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.ny, oi.nz = nx, 0, nz
+    oi.dx = oi.dz = dx
+    oi.dy = 1.
+    oi.x0, oi.z0 = dx / 2, dx / 2                       # kin_cloud_2d_lgrngn.hpp:167-170
+    oi.x1, oi.z1 = (nx - .5) * dx, (nz - .5) * dx
+    oi.y1 = 1.
+    oi.dt = 1.
+    oi.sd_conc = sd_conc
+    oi.n_sd_max = int(sd_conc * nx * nz * 1.2)
+    oi.dry_distros = {(.61, 0.): h.lgrngn_bimodal()}
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.kernel_parameters = [0.5]
+    oi.terminal_velocity = lgrngn.vt_t.khvorostyanov_spherical
+    oi.adve_scheme = lgrngn.as_t.implicit
+    oi.sstp_cond = oi.sstp_coal = sstp
+    return oi
+
+
+def icicle_fields(nx, nz, dtype=np.float64):
+    """th = 289 K, rv = 7.5e-3, hydrostatic-like rhod(z); stream function psi = -sin(pi z/Z) cos(2 pi x/X), w_max = 0.6 m/s
+    (models/kinematic_2D/cases/icmw8_case1.hpp:166-228), Courant numbers divided by rhod"""
+    dx = 1500. / 75
+    X, Z = nx * dx, nz * dx
+    z = (np.arange(nz) + .5) * dx
+    rhod = np.broadcast_to(1.2 * np.exp(-z / 8000.), (nx, nz)).astype(dtype).copy()
+    th = np.full((nx, nz), 289., dtype=dtype)
+    rv = np.full((nx, nz), 7.5e-3, dtype=dtype)
+    A = 0.6 / np.pi * X / (2 * np.pi) * 0 + 0.6 * X / (2 * np.pi)        # scale so that max |w| = 0.6
+    xe, ze = np.arange(nx + 1) * dx, np.arange(nz + 1) * dx
+    xc, zc = (np.arange(nx) + .5) * dx, (np.arange(nz) + .5) * dx
+    u = -A * np.pi / Z * np.cos(np.pi * zc[None, :] / Z) * np.cos(2 * np.pi * xe[:, None] / X)      # -d psi / dz
+    w = A * 2 * np.pi / X * np.sin(np.pi * ze[None, :] / Z) * np.sin(2 * np.pi * xc[:, None] / X)    #  d psi / dx
+    Cx = (u * 1. / dx / 1.2).astype(dtype)
+    Cz = (w * 1. / dx / 1.2).astype(dtype)
+    return th, rv, rhod, {"Cx": np.ascontiguousarray(Cx), "Cz": np.ascontiguousarray(Cz)}
+
+
+def test_c2_icicle_2d_reduced_vs_oracle():
+    oi = icicle_opts(24, 24, 32, sstp=10)
+    fields = icicle_fields(24, 24)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    for it in range(2):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=2e-4)
+        np.testing.assert_allclose(hip.get_attr("x"), orc.get_attr("x"), rtol=1e-13)
+        np.testing.assert_allclose(hip.get_attr("z"), orc.get_attr("z"), rtol=1e-13, atol=1e-7)   # dt * vt(rw2 to 1e-4)
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        h.copy_state(orc, hip)
+
+
+def test_c2_icicle_2d_full_size_float():
+    """76 x 76 x 64 = 369 664 super-droplets in real_t = float as icicle runs it: 20 steps; water is conserved between
+    vapour and droplets up to precipitation, the SD count only decreases, the cell-sorted order stays a stable argsort"""
+    nx = nz = 76
+    oi = icicle_opts(nx, nz)
+    th, rv, rhod, C = icicle_fields(nx, nz, np.float32)
+    pr = lgrngn.factory(lgrngn.backend_t.HIP, oi, np.float32)
+    pr.init(th, rv, rhod, **C)
+    assert pr.n_part == nx * nz * 64
+    opts = lgrngn.opts_t()
+
+    def liquid():
+        pr.diag_all()
+        pr.diag_wet_mom(3)
+        return (pr.outbuf_array().reshape(nx, nz).astype(np.float64) * 4. / 3 * np.pi * 1e3)
+    w0 = float(np.sum((rv + liquid()) * rhod))
+    n_prev = pr.n_part
+    for it in range(20):
+        pr.step_sync(opts, th, rv, rhod, **C)
+        pr.step_async(opts)
+        assert pr.n_part <= n_prev
+        n_prev = pr.n_part
+    assert np.isfinite(th).all() and np.isfinite(rv).all()
+    w1 = float(np.sum((rv + liquid()) * rhod))
+    puddle = pr.diag_puddle()
+    assert abs(w1 - w0) <= 2e-4 * w0 + 1e3 * abs(puddle["liquid_volume"])      # float accumulation over 200 cond substeps
+    sid, sijk, ijk = pr.state_u64("sorted_id"), pr.state_u64("sorted_ijk"), pr.state_u64("ijk")
+    assert np.array_equal(ijk[sid], sijk) and np.all(np.diff(sijk.astype(np.int64)) >= 0)
+
+
+def test_c4_ring_of_8_slabs_vs_oracle():
+    import test_hip_migration as mig
+    nx, ny, nz, size = 16, 4, 6, 8
+    oi = h.box_opts(nx, ny, nz, 16, dx=20., coal_switch=False)
+    oi.n_sd_max = 16 * nx * ny * nz * 2
+    fields = h.box_fields(oi)
+    orc, hip = mig.ring_pair(oi, size, fields)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    for it in range(4):
+        a = [x.copy() for x in (th, rv, rhod)]
+        b = [x.copy() for x in (th, rv, rhod)]
+        orc.step(opts, *a, **C)
+        hip.step(opts, *b, **C)
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-7)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            np.testing.assert_allclose(ph.get_attr("x"), po.get_attr("x"), rtol=1e-14, atol=1e-9)
+    assert sum(p.n_part for p in hip.prts) == sum(p.n_part for p in orc.prts)
+
+
+def test_c5_512_sd_per_cell_vs_oracle():
+    oi = h.box_opts(3, 2, 3, 512, kernel=lgrngn.kernel_t.hall_pinsky_stratocumulus)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    for it in range(2):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=2e-4)
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        h.copy_state(orc, hip)
