@@ -121,6 +121,13 @@ class particles_multi_t:
         n_lft, n_rgt = self.prt.migrate_counts()
         rec = self.prt.migrate_record_bytes()
         dev = self.device if self.on_gpu else "cpu"
+        # 0) pack on the device (x re-based to the receiver's frame): needs only this rank's own counts, so it is issued
+        #    before the count exchange
+        out_l, out_r = self._buf(n_lft * rec), self._buf(n_rgt * rec)
+        if self.lft is not None and n_lft:
+            self.prt.migrate_pack(0, self.lft_x1, out_l.data_ptr(), out_l.numel())
+        if self.rgt is not None and n_rgt:
+            self.prt.migrate_pack(1, self.rgt_x0, out_r.data_ptr(), out_r.numel())
         # 1) counts.  send order (left, right); receive order (from right, from left): with two ranks both
         #    messages travel between the same pair and are matched in posting order.
         cnt_out = [torch.tensor([n_lft], dtype=torch.int64, device=dev), torch.tensor([n_rgt], dtype=torch.int64, device=dev)]
@@ -137,12 +144,7 @@ class particles_multi_t:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         in_rgt, in_lft = int(cnt_in[0].item()), int(cnt_in[1].item())
-        # 2) pack on the device (x re-based to the receiver's frame) and exchange the payloads
-        out_l, out_r = self._buf(n_lft * rec), self._buf(n_rgt * rec)
-        if self.lft is not None and n_lft:
-            self.prt.migrate_pack(0, self.lft_x1, out_l.data_ptr(), out_l.numel())
-        if self.rgt is not None and n_rgt:
-            self.prt.migrate_pack(1, self.rgt_x0, out_r.data_ptr(), out_r.numel())
+        # 2) exchange the payloads
         buf_r, buf_l = self._buf(in_rgt * rec), self._buf(in_lft * rec)
         ops = []
         if self.lft is not None and n_lft:
