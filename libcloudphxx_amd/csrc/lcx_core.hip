@@ -402,14 +402,19 @@ struct Particles : IParticles {
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
         HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
-        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
-                                        rs, big_list.p, big_meta.p, big_meta.p + 1);
-        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p,
-                                rs, big_list.p, big_meta.p, big_meta.p + 1);
+        hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p,
+                           uint32_t(shuffle ? cellrank_max<uint64_t> : cellrank_max<uint32_t>), big_list.p, big_meta.p, big_meta.p + 1);
+        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
+        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         uint32_t meta[2];
         read_back(meta, big_meta.p, 2);
         if (meta[0]) {
+          const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
+          if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
+          else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
+        }
+        if (meta[0] && meta[1] > uint32_t(CELLSORT_WAVE_MAX)) {
           const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
           if (shuffle) hipLaunchKernelGGL(k_cellsort_lds<uint64_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
           else         hipLaunchKernelGGL(k_cellsort_lds<uint32_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);

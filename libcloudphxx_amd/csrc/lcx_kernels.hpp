@@ -244,12 +244,11 @@ __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *
 // its 256 positions touch (its own range plus the overhang of the first and last cell) in LDS; every lane then
 // ranks its key inside its cell by counting smaller keys (keys are unique) with LDS broadcast reads and writes
 // its id to `out` at cell_start + rank.  O(count) reads per lane, no data-dependent branching, no atomics.
-// cells with more SDs than cellrank_max are listed and sorted by a bitonic network instead (O(n log^2 n)); the
-// crossover is later for the 4-byte keys of the plain order (measured at 512 SDs per cell: 56 vs 74 ms)
+// cells with more SDs than cellrank_max are listed and sorted by a bitonic network instead (O(n log^2 n))
 constexpr int CELLRANK_MAX = 256;
-template <class KEY> constexpr int cellrank_max = sizeof(KEY) == 8 ? CELLRANK_MAX : 1024;
+template <class KEY> constexpr int cellrank_max = CELLRANK_MAX;
 constexpr int CELLSORT_LDS_MAX = 2048;  // ... in LDS up to this size (k_cellsort_lds), in global scratch beyond (k_cellsort_big)
-template <class KEY> constexpr int cr_cap = sizeof(KEY) == 8 ? 1024 : 4096;   // keys staged per workgroup (8 / 16 KiB)
+template <class KEY> constexpr int cr_cap = 1024;                               // keys staged per workgroup (4 / 8 KiB)
 struct rng_src { const uint32_t *un; uint64_t call, seed; };
 
 __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng_src &r)
@@ -261,8 +260,7 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // KEY = uint32_t for the plain order (key == id), uint64_t for the shuffled order ((un << 32) | id)
 template <class KEY>
 __global__ void __launch_bounds__(BS)
-k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out,
-           rng_src r, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
   __shared__ KEY lds[cr_cap<KEY>];
@@ -275,11 +273,7 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   const size_t p = p0 + threadIdx.x;
   if (p >= n) return;
   const uint32_t c = sorted_ijk[p], s = cell_start[c], e = cell_start[c + 1], cnt = e - s;
-  if (cnt > uint32_t(cellrank_max<KEY>)) {
-    if (p == s) { const uint32_t k = atomicAdd(big_count, 1u); big_list[k] = c; atomicMax(big_max, cnt); }
-    out[p] = in[p];
-    return;
-  }
+  if (cnt > uint32_t(cellrank_max<KEY>)) { out[p] = in[p]; return; }      // listed by k_list_big_cells, sorted by a bitonic network
   uint32_t rank = 0;
   KEY mine;
   if (staged) {
@@ -292,7 +286,57 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   }
   out[s + rank] = uint32_t(mine);
 }
-// listed segments of up to CELLSORT_LDS_MAX keys (e.g. 512 SDs per cell): one workgroup per segment, bitonic network
+// the cells with more than `thr` SDs: wave-aggregated append (one atomic per wave of 64 cells, not one per cell -- with
+// 512 SDs in every cell a per-cell atomicAdd on one counter cost more than the sort itself)
+__global__ void k_list_big_cells(size_t n_cell, const uint32_t *cell_start, uint32_t thr, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+{
+  const size_t c = gid();
+  uint32_t cnt = 0;
+  if (c < n_cell) cnt = cell_start[c + 1] - cell_start[c];
+  const bool big = cnt > thr;
+  const unsigned long long bal = __ballot(big);
+  if (!bal) return;
+  uint32_t mx = cnt;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) { const uint32_t o = __shfl_down(mx, d); mx = o > mx ? o : mx; }
+  uint32_t base = 0;
+  if (lane_id() == 0) { base = atomicAdd(big_count, uint32_t(__popcll(bal))); atomicMax(big_max, mx); }
+  base = __shfl(base, 0);
+  if (big) big_list[base + __popcll(bal & ((1ull << lane_id()) - 1ull))] = uint32_t(c);
+}
+// listed segments of up to CELLSORT_WAVE_MAX keys (e.g. 512 SDs per cell): ONE WAVE per segment, bitonic network on a
+// power-of-two padded copy in a wave-private LDS slice.  No workgroup barriers: a wave executes its LDS instructions in
+// order, so only the compiler has to be kept from moving them across a pass (wave-scope fence); the four waves of a
+// workgroup sort four cells independently.
+constexpr int CELLSORT_WAVE_MAX = 1024;
+template <class KEY>
+__global__ void __launch_bounds__(BS)
+k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r)
+{
+  constexpr int shuffle = sizeof(KEY) == 8;
+  __shared__ KEY lds[BS / WAVE][CELLSORT_WAVE_MAX];
+  KEY *a = lds[wave_id()];
+  const uint32_t lane = lane_id();
+  for (uint32_t b = blockIdx.x * (BS / WAVE) + wave_id(); b < n_big; b += gridDim.x * (BS / WAVE)) {
+    const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
+    if (cnt > uint32_t(CELLSORT_WAVE_MAX)) continue;         // k_cellsort_lds / k_cellsort_big take it
+    uint32_t P = 2 * WAVE; while (P < cnt) P <<= 1;
+    for (uint32_t i = lane; i < P; i += WAVE) a[i] = i < cnt ? KEY(sort_key(sorted_id[start + i], shuffle, r)) : KEY(~KEY(0));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = 2; k <= P; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = lane; t < (P >> 1); t += WAVE) {
+          const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+          const KEY u = a[lo], v = a[hi];
+          if ((u > v) == ((lo & k) == 0)) { a[lo] = v; a[hi] = u; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      }
+    for (uint32_t i = lane; i < cnt; i += WAVE) sorted_id[start + i] = uint32_t(a[i]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  }
+}
+// listed segments of up to CELLSORT_LDS_MAX keys: one workgroup per segment, bitonic network
 // on a power-of-two padded copy in LDS; each thread does one compare-exchange per pass per 2*BS keys
 template <class KEY>
 __global__ void __launch_bounds__(BS)
@@ -302,7 +346,7 @@ k_cellsort_lds(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_st
   __shared__ KEY a[CELLSORT_LDS_MAX];
   for (uint32_t b = blockIdx.x; b < n_big; b += gridDim.x) {
     const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
-    if (cnt > uint32_t(CELLSORT_LDS_MAX)) continue;          // k_cellsort_big takes it
+    if (cnt > uint32_t(CELLSORT_LDS_MAX) || cnt <= uint32_t(CELLSORT_WAVE_MAX)) continue;   // k_cellsort_big / k_cellsort_wave take it
     uint32_t P = 2; while (P < cnt) P <<= 1;
     for (uint32_t i = threadIdx.x; i < P; i += BS) a[i] = i < cnt ? KEY(sort_key(sorted_id[start + i], shuffle, r)) : KEY(~KEY(0));
     __syncthreads();
