@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--strict-fp", action="store_true",
                     help="IEEE operation order in the condensation kernel (bit-faithful to the reference's formulas); default: "
                          "the collected one-division form with FMA contraction, parity-tested at the same tolerances")
+    ap.add_argument("--reorder-every", type=int, default=0,
+                    help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
+                         "many steps (long runs; 0 = never, the reference's storage order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=40)
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
@@ -156,6 +159,7 @@ def main():
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = local_rank
     oi.strict_fp = args.strict_fp
+    oi.reorder_every = args.reorder_every
     if args.cond_mode != "percell":
         oi.exact_sstp_cond = True
         oi.sstp_cond_mix = args.cond_mode == "pp_mix"

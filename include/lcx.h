@@ -102,6 +102,10 @@ typedef struct {
   int n_x_bfr;          /* x-planes owned by ranks to the left (distmem_opts.hpp:27) */
   int bcond_lft, bcond_rgt; /* 0 sharedmem, 1 distmem, 3 open  (src/detail/bcond.hpp) */
   int strict_fp;        /* 1: IEEE order-preserving arithmetic (parity mode, default); 0: allow contraction */
+  int reorder_every;    /* > 0: every so many steps the storage is physically re-ordered into the cell-sorted order (keeps the
+                         * per-cell gathers line-coalesced in long runs).  Ids are renumbered: the relative order of SDs that were
+                         * in different cells changes, i.e. later tie-breaks and the id -> random-number association differ from
+                         * the reference's (statistically equivalent).  0 (default): never, storage order == the reference's */
 } lcx_opts_init_t;
 
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */

@@ -57,5 +57,8 @@ namespace libcloudphxx { namespace lgrngn {
     unsigned long long rlx_bins = 0;
     real_t rlx_sd_per_bin = 0, rlx_timescale = 1;
     int supstp_rlx = 1;
+    // --- extensions of this backend (no reference counterpart, see include/lcx.h) ---
+    bool strict_fp = true;     // false: contracted one-division form of the condensational growth rate
+    int reorder_every = 0;     // > 0: physical re-ordering of the storage into the cell-sorted order every so many steps
   };
 } }

@@ -100,7 +100,7 @@ struct Particles : IParticles {
   std::vector<lcx_dry_size_t> sizes; int n_size_keys = 0;   // dry_sizes.size() of the reference = number of (kappa, rd_insol) keys
   std::vector<double> kernel_parameters_h, w_LS_h, conc_factor_h;
   int n_dims; size_t ncell, npart = 0, nphys = 0, cap;   // npart: living SDs (API); nphys: storage extent incl. not yet compacted dead SDs
-  bool eager_compact = false, fused_pending = false; size_t n_before_unpack = 0;
+  bool eager_compact = false, fused_pending = false; size_t n_before_unpack = 0; int steps_since_reorder = 0;
   grid_t g;
   // ---- order-of-operation flags (particles_impl.ipp:32) ----
   bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
@@ -479,8 +479,7 @@ struct Particles : IParticles {
       if (!B.n.p) alloc_attrs(B);
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
       hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, nphys, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
-      A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
-      for (int e = 0; e < n_ext; ++e) A.ext[e].swap(B.ext[e]);
+      swap_attr_sets();
       nphys = alive;
     } else ijk_and_hist(1, true);                    // re-index in place (dead SDs get DEAD_CELL)
     npart = alive;
@@ -495,6 +494,25 @@ struct Particles : IParticles {
     Range r(this, "post_copy");
     npart = nphys - dead;
     sort_from_hist(false);
+    if (o.reorder_every > 0 && ++steps_since_reorder >= o.reorder_every) reorder_storage();
+  }
+  // opts_init.reorder_every: storage := cell-sorted order (ids renumbered, dead SDs dropped); needs the plain sorted order
+  void reorder_storage()
+  {
+    steps_since_reorder = 0;
+    if (!npart) return;
+    Range r(this, "reorder_storage");
+    if (!B.n.p) alloc_attrs(B);
+    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, aset(A), aset(B), g, rank.p);
+    swap_attr_sets();
+    ijk.swap(rank);
+    hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
+    nphys = npart;
+  }
+  void swap_attr_sets()
+  {
+    A.n.swap(B.n); A.rd3.swap(B.rd3); A.rw2.swap(B.rw2); A.kpa.swap(B.kpa); A.vt.swap(B.vt); A.x.swap(B.x); A.y.swap(B.y); A.z.swap(B.z);
+    for (int e = 0; e < n_ext; ++e) A.ext[e].swap(B.ext[e]);
   }
   // make storage order == the reference's (no dead SDs in it) before anything that exposes storage order
   void ensure_compact()

@@ -1081,6 +1081,22 @@ k_compact(size_t n_part, attr_set<T> src, attr_set<T> dst, const uint32_t *tile_
   }
 }
 
+// physical re-ordering of the storage into the cell-sorted order (opts_init.reorder_every): position pos of the sorted
+// order becomes storage slot pos; dead SDs are not in the order, so this is a compaction as well
+template <class T>
+__global__ void __launch_bounds__(BS)
+k_reorder(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, attr_set<T> src, attr_set<T> dst, grid_t g, uint32_t *ijk_out)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t i = sorted_id[pos];
+  dst.n[pos] = src.n[i]; dst.rd3[pos] = src.rd3[i]; dst.rw2[pos] = src.rw2[i]; dst.kpa[pos] = src.kpa[i]; dst.vt[pos] = src.vt[i];
+  if (g.nx) dst.x[pos] = src.x[i];
+  if (g.ny) dst.y[pos] = src.y[i];
+  if (g.nz) dst.z[pos] = src.z[i];
+  for (int e = 0; e < src.n_ext; ++e) dst.ext[e][pos] = src.ext[e][i];
+  ijk_out[pos] = sorted_ijk[pos];
+}
+
 // ============================================================================================
 // moments / diagnostics (moms.ipp:50-387, particles_diag.ipp)
 // ============================================================================================

@@ -545,3 +545,39 @@ def test_fast_math_accuracy():
         assert float(ulp.max()) <= 1.0, (which, float(ulp.max()))
     xf = np.array([800., -800., 710., -745., np.inf, -np.inf])
     np.testing.assert_array_equal(probe(1, xf), probe(3, xf))
+
+
+def test_storage_reorder_is_a_permutation_of_the_same_state():
+    """opts_init.reorder_every (extension): physically re-ordering the storage into the cell order renumbers the ids but
+    must not change any super-droplet: with coalescence off (no id-keyed random numbers) a run that re-orders after every
+    step carries the same set of droplets as one that never does; th / rv agree to summation-order rounding"""
+    runs = []
+    for every in (0, 1):
+        oi = h.box_opts(5, 4, 6, 40, reorder_every=every)
+        fields = h.box_fields(oi)
+        th, rv, rhod, C = fields
+        pr = h.hip_particles(oi)
+        pr.init(th.copy(), rv.copy(), rhod.copy(), **C)
+        opts = lgrngn.opts_t()
+        opts.coal = False
+        tht, rvt = th.copy(), rv.copy()
+        for _ in range(6):
+            pr.step_sync(opts, tht, rvt, rhod, **C)
+            pr.step_async(opts)
+        key = np.argsort(pr.get_attr("rd3"), kind="stable")
+        runs.append((tht, rvt, pr.n_part, {a: pr.get_attr(a)[key] for a in ("rd3", "rw2", "x", "y", "z", "kappa")},
+                     pr.state_u64("n")[key], pr.state_u64("sorted_id"), pr.state_u64("sorted_ijk"), pr.state_u64("ijk")))
+    a, b = runs
+    assert a[2] == b[2]
+    np.testing.assert_allclose(b[0], a[0], rtol=1e-9)
+    np.testing.assert_allclose(b[1], a[1], rtol=1e-8)
+    exact(b[4], a[4], "multiplicities")
+    exact(b[3]["rd3"], a[3]["rd3"], "rd3")
+    for k in ("x", "y", "z"):
+        np.testing.assert_allclose(b[3][k], a[3][k], rtol=1e-12, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(b[3]["rw2"], a[3]["rw2"], rtol=2e-4)       # the root finder's tolerance (rounding of th / rv decides its last iteration)
+    assert np.median(np.abs(b[3]["rw2"] / a[3]["rw2"] - 1)) < 1e-9
+    # the re-ordered run's storage IS the cell order
+    sid, sijk, ijk = b[5], b[6], b[7]
+    exact(sid, np.arange(len(sid), dtype=sid.dtype), "sorted_id is the identity right after a re-order")
+    exact(ijk, sijk, "ijk == sorted_ijk")
