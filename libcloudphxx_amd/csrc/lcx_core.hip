@@ -151,8 +151,8 @@ struct Particles : IParticles {
   explicit Particles(const lcx_opts_init_t &oi) : o(oi)
   {
     if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_adve_switch || oi.turb_cond_switch ||
-        oi.turb_coal_switch || oi.sd_const_multi || oi.sd_conc_large_tail || oi.diag_incloud_time)
-      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/const_multi/tail)");
+        oi.turb_coal_switch || oi.diag_incloud_time)
+      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
     if (oi.adve_scheme == LCX_ADVE_PRED_CORR) throw lcx_error("libcloudph++: pred_corr advection not supported by this backend");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
@@ -725,13 +725,129 @@ struct Particles : IParticles {
       }
     } else throw lcx_error("opts_init.rd_min * opts_init.rd_max < 0");
   }
+  // ---- constant-multiplicity and large-tail initialisation (host analysis as in the reference, sampling on the device) ----
+  // Brent's minimiser: the reference calls boost::math::tools::brent_find_minima (init_dist_analysis.ipp:95); Boost is not
+  // vendored by the reference and its version is not pinned, so this is the published algorithm (Brent 1973, ch. 5)
+  // restated, identical to the oracle's (parity with the reference UNPINNED for this routine).
+  template <class F> static double brent_find_minimum(F f, double min, double max, int bits, unsigned &max_iter, double &fmin)
+  {
+    if (bits > 53 / 2) bits = 53 / 2;
+    const double tolerance = std::ldexp(1.0, 1 - bits), golden = 0.3819660f;
+    double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+    x = w = v = max;
+    fw = fv = fx = f(x);
+    delta2 = delta = 0;
+    unsigned count = max_iter;
+    do {
+      mid = (min + max) / 2;
+      fract1 = tolerance * std::fabs(x) + tolerance / 4;
+      fract2 = 2 * fract1;
+      if (std::fabs(x - mid) <= (fract2 - (max - min) / 2)) break;
+      if (std::fabs(delta2) > fract1) {
+        double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+        q = 2 * (q - r);
+        if (q > 0) p = -p;
+        q = std::fabs(q);
+        const double td = delta2;
+        delta2 = delta;
+        if ((std::fabs(p) >= std::fabs(q * td / 2)) || (p <= q * (min - x)) || (p >= q * (max - x))) {
+          delta2 = (x >= mid) ? min - x : max - x;
+          delta = golden * delta2;
+        } else {
+          delta = p / q;
+          u = x + delta;
+          if (((u - min) < fract2) || ((max - u) < fract2)) delta = (mid - x) < 0 ? -std::fabs(fract1) : std::fabs(fract1);
+        }
+      } else {
+        delta2 = (x >= mid) ? min - x : max - x;
+        delta = golden * delta2;
+      }
+      u = (std::fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + std::fabs(fract1) : x - std::fabs(fract1));
+      fu = f(u);
+      if (fu <= fx) {
+        if (u >= x) min = x; else max = x;
+        v = w; w = x; x = u; fv = fw; fw = fx; fx = fu;
+      } else {
+        if (u < x) min = u; else max = u;
+        if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
+        else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
+      }
+    } while (--count);
+    max_iter -= count;
+    fmin = fx;
+    return x;
+  }
+  void init_dist_analysis_const_multi(const lcx_distro_t &d)
+  {                                                                                      // init_dist_analysis.ipp:80-120
+    if (o.rd_min >= 0 && o.rd_max >= 0) { log_rd_min = T(std::log(T(o.rd_min))); log_rd_max = T(std::log(T(o.rd_max))); }
+    else if (o.rd_min < 0 && o.rd_max < 0) {
+      unsigned n_iter = 100;
+      double fmin;
+      const T lnrd_max = T(brent_find_minimum([&](double x) { return double(T(eval_distro(d, T(x))) * T(-1)); }, double(T(std::log(T(1e-14)))),
+                                              double(T(std::log(T(1e-3)))), 200, n_iter, fmin));
+      const T bound = T(-T(fmin) / T(1e20));                                             // config.hpp:21 threshold
+      struct lvl_t { const Particles *self; const lcx_distro_t *d; T bound; T operator()(T x) const { return T(self->eval_distro(*d, x)) + (-bound); } };
+      const lvl_t lvl{this, &d, bound};
+      const T lo = T(std::log(T(1e-14))), hi = T(std::log(T(1e-3)));
+      log_rd_min = toms748_solve(lvl, lo, lnrd_max, lvl(lo), lvl(lnrd_max), eps_tol, 100u);
+      log_rd_max = toms748_solve(lvl, lnrd_max, hi, lvl(lnrd_max), lvl(hi), eps_tol, 100u);
+    } else throw lcx_error("opts_init.rd_min * opts_init.rd_max < 0");
+  }
+  DevBuf<uint32_t> init_off; DevBuf<T> init_cdf;
+  // init_count_num.ipp:14-24,41-101 + init_ijk + init_dry_const_multi.ipp:20-80 + init_n_const_multi, then finalize
+  void init_const_multi_like(const lcx_distro_t &d, n_t const_multi)
+  {
+    const T bin = T(1e-4), lo = T(log_rd_min), hi = T(log_rd_max);                       // config.hpp:20 bin_precision
+    const int nb = int((hi - lo) / bin);
+    T integral = (T(eval_distro(d, lo)) + T(eval_distro(d, hi))) / T(2.);
+    for (int i = 1; i < nb; ++i) integral += T(eval_distro(d, lo + i * bin));
+    integral = integral * bin;
+    std::vector<T> dv_h = d2h(dv.p, ncell), rhod_h = d2h(rhod.p, ncell);
+    std::vector<uint32_t> off(ncell + 1, 0);
+    size_t total = 0;
+    for (size_t c = 0; c < ncell; ++c) {                                                 // init_count_num_hlpr + conc_to_number
+      T conc = integral;
+      conc = conc * dv_h[c];
+      if (!o.aerosol_independent_of_rhod) conc = rhod_h[c] / cst<T>::rho_stp * conc;
+      if (!conc_factor_h.empty()) conc = conc * T(conc_factor_h[c % size_t(m1(o.nz))]);
+      off[c] = uint32_t(total);
+      total += size_t(n_t(conc / const_multi + T(0.5)));
+      if (total >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
+    }
+    off[ncell] = uint32_t(total);
+    const size_t n_old = npart, n_new = total;
+    check_npart(n_old + n_new);
+    npart = nphys = n_old + n_new;
+    if (n_new == 0) return;
+    const size_t ncdf = size_t((hi - lo) / bin + 1);
+    std::vector<T> cdf(ncdf);
+    for (size_t i = 0; i < ncdf; ++i) cdf[i] = T(eval_distro(d, lo + bin * i)) * 1;
+    for (size_t i = 1; i < ncdf; ++i) cdf[i] = cdf[i - 1] + cdf[i];
+    { const T back = cdf[ncdf - 1]; for (size_t i = 0; i < ncdf; ++i) cdf[i] = cdf[i] / back; }
+    init_off.alloc(ncell + 1); init_cdf.alloc(ncdf);
+    HIPCHK(hipMemcpyAsync(init_off.p, off.data(), (ncell + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(init_cdf.p, cdf.data(), ncdf * sizeof(T), hipMemcpyHostToDevice, st));
+    const u01_src<T> rs = rand_u01(n_new);
+    hipLaunchKernelGGL(k_init_const_multi<T>, dim3(nblk(n_new)), dim3(BS), 0, st, n_new, n_old, init_off.p, uint32_t(ncell), init_cdf.p, uint32_t(ncdf),
+                       lo, bin, rs, const_multi, ijk.p, A.rd3.p, A.kpa.p, T(d.kappa), A.vt.p, A.n.p);
+    hipLaunchKernelGGL(k_init_wet<T>, dim3(nblk(n_new)), dim3(BS), 0, st, n_new, n_old, A.rd3.p, A.kpa.p, ijk.p, RH.p, Tk.p, T(o.RH_max), A.rw2.p);
+    init_positions(n_new, n_old);
+    sync();                                                                              // the host tables go out of scope
+  }
   void init_SD_with_distros()
   {
     T dv0 = 0;
     if (n_dims == 0) { HIPCHK(hipMemcpyAsync(&dv0, dv.p, sizeof(T), hipMemcpyDeviceToHost, st)); sync(); }
     T tot_lnrd_rng = 0;
-    for (auto &d : distros) { init_dist_analysis_sd_conc(d, o.sd_conc, dv0); tot_lnrd_rng += T(log_rd_max - log_rd_min); }
+    if (o.sd_conc > 0)
+      for (auto &d : distros) { init_dist_analysis_sd_conc(d, o.sd_conc, dv0); tot_lnrd_rng += T(log_rd_max - log_rd_min); }
     for (auto &d : distros) {
+      if (o.sd_const_multi > 0) {                                                        // init_SD_with_distros_const_multi.ipp:14-38
+        init_dist_analysis_const_multi(d);
+        if (log_rd_min >= log_rd_max) throw lcx_error("Distribution analysis error: rd_min >= rd_max");
+        init_const_multi_like(d, o.sd_const_multi);
+        continue;
+      }
       init_dist_analysis_sd_conc(d, o.sd_conc, dv0);                                     // init_SD_with_distros_sd_conc.ipp:14-46
       if (log_rd_min >= log_rd_max) throw lcx_error("Distribution analysis error: rd_min >= rd_max");
       const T fraction = T(log_rd_max - log_rd_min) / tot_lnrd_rng;
@@ -764,6 +880,13 @@ struct Particles : IParticles {
                          T(T(o.dx) * T(o.dy) * T(o.dz)), A.n.p);
       hipLaunchKernelGGL(k_init_wet<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, A.rd3.p, A.kpa.p, ijk.p, RH.p, Tk.p, T(o.RH_max), A.rw2.p);
       init_positions(n_new, n_old);
+      if (o.sd_conc_large_tail) {                                                        // init_SD_with_distros_tail.ipp:14-40
+        const double log_rd_min_init = log_rd_max;
+        init_dist_analysis_const_multi(d);
+        log_rd_min = log_rd_min_init;
+        if (log_rd_min >= log_rd_max) throw lcx_error("Distribution analysis error: rd_min >= rd_max");
+        init_const_multi_like(d, 1);
+      }
     }
     release_replay_keep();
   }
@@ -876,7 +999,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
                          T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
     hskpng_Tpr();
-    if (!o.no_ccn_at_init && !distros.empty() && o.sd_conc > 0) init_SD_with_distros();
+    if (!o.no_ccn_at_init && !distros.empty()) init_SD_with_distros();
     if (!o.no_ccn_at_init && !sizes.empty()) init_SD_with_sizes();
     if (o.coal_switch) init_kernel();
     if (o.terminal_velocity == LCX_VT_BEARD77FAST) {

@@ -1170,6 +1170,23 @@ __global__ void k_init_dry(size_t n_new, size_t n_old, n_t per_cell, T log_rd_mi
   kpa[n_old + gI] = kappa;
   vt[n_old + gI] = T(-1);                                                    // resize fills vt with `invalid`
 }
+// constant-multiplicity / large-tail initialisation (init_ijk.ipp:36-52 with a per-cell count, init_dry_const_multi.ipp:52-80):
+// SD g belongs to the cell whose offset range holds g; its dry radius is drawn from the tabulated CDF of the spectrum
+// (index = upper_bound(cdf, u01)); multiplicity const_multi
+template <class T>
+__global__ void k_init_const_multi(size_t n_new, size_t n_old, const uint32_t *cell_off, uint32_t n_cell, const T *cdf, uint32_t n_cdf,
+                                   T log_rd_min, T bin, u01_src<T> rs, n_t const_multi, uint32_t *ijk, T *rd3, T *kpa, T kappa, T *vt, n_t *n)
+{
+  const size_t gI = gid(); if (gI >= n_new) return;
+  uint32_t a = 0, b = n_cell;                                  // last cell with cell_off[c] <= g
+  while (b - a > 1) { const uint32_t m = a + (b - a) / 2; if (cell_off[m] <= gI) a = m; else b = m; }
+  const T u = rs.arr ? rs.arr[gI] : philox::u01<T>(gI, rs.call, rs.seed);
+  uint32_t lo = 0, hi = n_cdf;                                 // first index with cdf > u
+  while (lo < hi) { const uint32_t m = lo + (hi - lo) / 2; if (!(u < cdf[m])) lo = m + 1; else hi = m; }
+  const T lnrd = log_rd_min + T(lo) * bin;
+  const size_t p = n_old + gI;
+  ijk[p] = a; rd3[p] = exp(3 * lnrd); kpa[p] = kappa; vt[p] = T(-1); n[p] = const_multi;
+}
 // init_SD_with_sizes.ipp:14-77: `per_cell` SDs of one dry radius in every cell; multiplicity from the STP
 // concentration (conc_to_number, init_count_num.ipp:41-70, and init_n.ipp:130-143)
 template <class T>

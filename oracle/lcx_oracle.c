@@ -143,9 +143,8 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
   if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
   if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->turb_adve_switch ||
-      oi->turb_cond_switch || oi->turb_coal_switch ||
-      oi->sd_const_multi || oi->sd_conc_large_tail || oi->diag_incloud_time)
-    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb/const_multi/tail)");
+      oi->turb_cond_switch || oi->turb_coal_switch || oi->diag_incloud_time)
+    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
   if (oi->adve_scheme == LCX_ADVE_PRED_CORR) FAIL("libcloudph++: pred_corr advection not supported by this backend");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
@@ -938,6 +937,154 @@ static int resize_npart(orc_particles *s)
   if (s->n_part > s->o.n_sd_max) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, s->n_part);
   return 0;
 }
+/* init_SD_with_distros_finalize: init_kappa, init_wet (init_wet.ipp:17-78), init_xyz (init_xyz.ipp:40-74) for the SDs
+ * [n_part_old, n_part) */
+static void init_finalize(orc_particles *s, double kappa)
+{
+  const lcx_opts_init_t *o = &s->o;
+  for (sz p = s->n_part_old; p < s->n_part; ++p) s->kpa[p] = kappa;
+  for (sz p = s->n_part_old; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
+  }
+  const int nn[3] = {o->nx, o->ny, o->nz};
+  const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
+  double *v[3] = {s->x, s->y, s->z};
+  const sz nz = m1(o->nz), ny = m1(o->ny);
+  for (int ix = 0; ix < 3; ++ix) {
+    if (nn[ix] == 0) continue;
+    for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+    for (sz g = 0; g < s->n_part_to_init; ++g) {
+      const sz p = s->n_part_old + g, c = s->ijk[p];
+      sz ii;
+      if (s->n_dims == 1) ii = c;
+      else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
+      else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
+      const double u = s->tmp_part[g];
+      v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
+    }
+  }
+}
+
+/* ---- constant-multiplicity and large-tail initialisation (init_SD_with_distros_const_multi.ipp, ..._tail.ipp) ---- */
+/* Brent's minimiser: the reference calls boost::math::tools::brent_find_minima (init_dist_analysis.ipp:95; Boost is NOT
+ * vendored and its version is not pinned by the reference: parity UNPINNED for this routine).  Restated from the
+ * published algorithm (R. P. Brent, Algorithms for Minimization without Derivatives, 1973, ch. 5) in the form Boost
+ * documents: golden ratio 0.3819660, tolerance 2^(1-bits) with bits = min(digits/2, requested). */
+typedef double (*orc_fn1)(double, void *);
+static double brent_find_minimum(orc_fn1 f, void *ctx, double min, double max, int bits, uintmax_t *max_iter, double *fmin)
+{
+  if (bits > 53 / 2) bits = 53 / 2;
+  const double tolerance = ldexp(1.0, 1 - bits), golden = 0.3819660f;
+  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  x = w = v = max;
+  fw = fv = fx = f(x, ctx);
+  delta2 = delta = 0;
+  uintmax_t count = *max_iter;
+  do {
+    mid = (min + max) / 2;
+    fract1 = tolerance * fabs(x) + tolerance / 4;
+    fract2 = 2 * fract1;
+    if (fabs(x - mid) <= (fract2 - (max - min) / 2)) break;
+    if (fabs(delta2) > fract1) {
+      double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+      q = 2 * (q - r);
+      if (q > 0) p = -p;
+      q = fabs(q);
+      const double td = delta2;
+      delta2 = delta;
+      if ((fabs(p) >= fabs(q * td / 2)) || (p <= q * (min - x)) || (p >= q * (max - x))) {
+        delta2 = (x >= mid) ? min - x : max - x;
+        delta = golden * delta2;
+      } else {
+        delta = p / q;
+        u = x + delta;
+        if (((u - min) < fract2) || ((max - u) < fract2)) delta = (mid - x) < 0 ? -fabs(fract1) : fabs(fract1);
+      }
+    } else {
+      delta2 = (x >= mid) ? min - x : max - x;
+      delta = golden * delta2;
+    }
+    u = (fabs(delta) >= fract1) ? x + delta : (delta > 0 ? x + fabs(fract1) : x - fabs(fract1));
+    fu = f(u, ctx);
+    if (fu <= fx) {
+      if (u >= x) min = x; else max = x;
+      v = w; w = x; x = u; fv = fw; fw = fx; fx = fu;
+    } else {
+      if (u < x) min = u; else max = u;
+      if ((fu <= fw) || (w == x)) { v = w; w = u; fv = fw; fw = fu; }
+      else if ((fu <= fv) || (v == x) || (v == w)) { v = u; fv = fu; }
+    }
+  } while (--count);
+  *max_iter -= count;
+  *fmin = fx;
+  return x;
+}
+typedef struct { const lcx_distro_t *d; double mul, add; } distro_ctx;
+static double distro_mul_add(double lnrd, void *vc) { const distro_ctx *c = (const distro_ctx *)vc; return eval_distro(c->d, lnrd) * c->mul + c->add; }
+/* init_dist_analysis.ipp:80-120 */
+static int init_dist_analysis_const_multi(orc_particles *s, const lcx_distro_t *d)
+{
+  const lcx_opts_init_t *o = &s->o;
+  if (o->rd_min >= 0 && o->rd_max >= 0) { s->log_rd_min = log(o->rd_min); s->log_rd_max = log(o->rd_max); }
+  else if (o->rd_min < 0 && o->rd_max < 0) {
+    distro_ctx neg = {d, -1., 0.};
+    uintmax_t n_iter = 100;
+    double fmin;
+    const double lnrd_max = brent_find_minimum(distro_mul_add, &neg, log(1e-14), log(1e-3), 200, &n_iter, &fmin);
+    const double bound = -fmin / 1e20;                         /* config.hpp:21 threshold */
+    distro_ctx lvl = {d, 1., -bound};
+    n_iter = 100;
+    s->log_rd_min = orc_toms748(distro_mul_add, &lvl, log(1e-14), lnrd_max, distro_mul_add(log(1e-14), &lvl), distro_mul_add(lnrd_max, &lvl),
+                                s->eps_tol, &n_iter);
+    n_iter = 100;
+    s->log_rd_max = orc_toms748(distro_mul_add, &lvl, lnrd_max, log(1e-3), distro_mul_add(lnrd_max, &lvl), distro_mul_add(log(1e-3), &lvl),
+                                s->eps_tol, &n_iter);
+  } else FAIL("opts_init.rd_min * opts_init.rd_max < 0");
+  return 0;
+}
+/* init_count_num.ipp:14-24,41-101 + init_ijk + init_dry_const_multi.ipp:20-80 + init_n_const_multi: SDs of multiplicity
+ * const_multi whose dry radii are drawn from the CDF of the spectrum on [log_rd_min, log_rd_max] */
+static int init_const_multi_like(orc_particles *s, const lcx_distro_t *d, n_t const_multi)
+{
+  const lcx_opts_init_t *o = &s->o;
+  const double bin = 1e-4, lo = s->log_rd_min, hi = s->log_rd_max;         /* config.hpp:20 bin_precision */
+  const int nb = (int)((hi - lo) / bin);
+  double integral = (eval_distro(d, lo) + eval_distro(d, hi)) / 2.;
+  for (int i = 1; i < nb; ++i) integral += eval_distro(d, lo + i * bin);
+  integral = integral * bin;
+  sz total = 0;
+  for (sz c = 0; c < s->n_cell; ++c) {                                     /* init_count_num_hlpr + conc_to_number */
+    double conc = integral;
+    conc = conc * s->dv[c];
+    if (!o->aerosol_independent_of_rhod) conc = s->rhod[c] / rho_stp * conc;
+    if (o->n_aerosol_conc_factor > 0) conc = conc * s->aerosol_conc_factor[c % o->nz];
+    s->count_num[c] = (n_t)(conc / const_multi + 0.5);
+    total += (sz)s->count_num[c];
+  }
+  s->n_part_old = s->n_part;
+  s->n_part_to_init = total;
+  s->n_part += total;
+  if (resize_npart(s)) return 1;
+  for (sz p = s->n_part_old; p < s->n_part; ++p) { s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
+  { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < s->count_num[c]; ++q) s->ijk[w++] = c; }
+  const sz ncdf = (sz)((hi - lo) / bin + 1);
+  double *cdf = NEW(double, ncdf);
+  for (sz i = 0; i < ncdf; ++i) cdf[i] = eval_distro(d, lo + bin * i) * 1;
+  for (sz i = 1; i < ncdf; ++i) cdf[i] = cdf[i - 1] + cdf[i];
+  { const double back = cdf[ncdf - 1]; for (sz i = 0; i < ncdf; ++i) cdf[i] = cdf[i] / back; }
+  for (sz g = 0; g < total; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+  for (sz g = 0; g < total; ++g) {
+    const double u = s->tmp_part[g];
+    sz a = 0, b = ncdf;                                                    /* thrust::upper_bound: first index with cdf > u */
+    while (a < b) { const sz m = a + (b - a) / 2; if (!(u < cdf[m])) a = m + 1; else b = m; }
+    const double lnrd = lo + (double)a * bin;
+    s->rd3[s->n_part_old + g] = exp(3 * lnrd);
+  }
+  free(cdf);
+  for (sz p = s->n_part_old; p < s->n_part; ++p) s->n[p] = const_multi;
+  return 0;
+}
 static int init_SD_with_distros(orc_particles *s)
 {
   const lcx_opts_init_t *o = &s->o;
@@ -949,6 +1096,7 @@ static int init_SD_with_distros(orc_particles *s)
     }
   for (int d = 0; d < o->n_dry_distros; ++d) {
     const lcx_distro_t *dd = &s->distros[d];
+    if (o->sd_conc > 0) {
     /* init_SD_with_distros_sd_conc.ipp:14-46 */
     if (init_dist_analysis_sd_conc(s, dd, o->sd_conc, 1.)) return 1;
     if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
@@ -981,29 +1129,21 @@ static int init_SD_with_distros(orc_particles *s)
       if (s->n_dims > 0) v = v * s->dv[c] / (o->dx * o->dy * o->dz);
       s->n[p] = (n_t)(v + 0.5);
     }
-    /* init_SD_with_distros_finalize: init_kappa, init_wet (init_wet.ipp:17-78) */
-    for (sz p = s->n_part_old; p < s->n_part; ++p) s->kpa[p] = dd->kappa;
-    for (sz p = s->n_part_old; p < s->n_part; ++p) {
-      const sz c = s->ijk[p];
-      s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
+    init_finalize(s, dd->kappa);
+    if (o->sd_conc_large_tail) {                                            /* init_SD_with_distros_tail.ipp:14-40 */
+      const double log_rd_min_init = s->log_rd_max;
+      if (init_dist_analysis_const_multi(s, dd)) return 1;
+      s->log_rd_min = log_rd_min_init;
+      if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
+      if (init_const_multi_like(s, dd, 1)) return 1;
+      init_finalize(s, dd->kappa);
     }
-    /* init_xyz.ipp:40-74 */
-    const int nn[3] = {o->nx, o->ny, o->nz};
-    const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
-    double *v[3] = {s->x, s->y, s->z};
-    const sz nz = m1(o->nz), ny = m1(o->ny);
-    for (int ix = 0; ix < 3; ++ix) {
-      if (nn[ix] == 0) continue;
-      for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
-      for (sz g = 0; g < s->n_part_to_init; ++g) {
-        const sz p = s->n_part_old + g, c = s->ijk[p];
-        sz ii;
-        if (s->n_dims == 1) ii = c;
-        else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
-        else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
-        const double u = s->tmp_part[g];
-        v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
-      }
+    }
+    if (o->sd_const_multi > 0) {                                            /* init_SD_with_distros_const_multi.ipp:14-38 */
+      if (init_dist_analysis_const_multi(s, dd)) return 1;
+      if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
+      if (init_const_multi_like(s, dd, o->sd_const_multi)) return 1;
+      init_finalize(s, dd->kappa);
     }
   }
   return 0;

@@ -130,3 +130,88 @@ def test_nd_sd_conc_is_conserved_by_advection(make, dims):
     pr.diag_all()
     pr.diag_sd_conc()
     assert frombuffer(pr.outbuf()).sum() == 64 * int(np.prod(shp))
+
+
+def two_distros_opts():
+    """api_lgrngn.py:20-52: two lognormal modes, each n_tot = 60e6 per STP m^3"""
+    oi = base_opts()
+    oi.dry_distros = {(kappa1, rd_insol): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6), (kappa2, rd_insol): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6)}
+    return oi
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_0d_large_tail(make):
+    """api_lgrngn.py:188-206: sd_conc_large_tail adds multiplicity-1 SDs beyond the sampled range"""
+    oi = two_distros_opts()
+    oi.sd_conc_large_tail = True
+    pr = make(oi)
+    th, rv = th0.copy(), rv0.copy()
+    pr.init(th, rv, rhod0.copy())
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.adve = False
+    pr.step_sync(opts, th, rv)
+    pr.step_async(opts)
+    pr.diag_all()
+    pr.diag_sd_conc()
+    out = frombuffer(pr.outbuf())
+    assert len(out) == 1 and (out > 0).all() and out.sum() >= oi.sd_conc
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_0d_const_multi(make):
+    """api_lgrngn.py:209-238: every SD carries sd_const_multi particles, before and after two steps (coalescence on)"""
+    oi = two_distros_opts()
+    oi.sd_conc = 0
+    prtcls_per_cell = 2 * 60e6 / rho_stp            # rhod = 1; two distributions
+    oi.sd_const_multi = int(prtcls_per_cell / 64)
+    pr = make(oi)
+    th, rv = th0.copy(), rv0.copy()
+    pr.init(th, rv, rhod0.copy())
+    pr.diag_all()
+    pr.diag_sd_conc()
+    sd0 = frombuffer(pr.outbuf()).sum()
+    assert abs(sd0 - 64) <= 1                       # 2 x int(integral / const_multi + .5)
+    opts = lgrngn.opts_t()
+    opts.sedi = opts.adve = False
+    pr.step_sync(opts, th, rv)
+    pr.step_async(opts)
+    pr.step_sync(opts, th, rv, rhod0)
+    pr.step_async(opts)
+    pr.diag_all()
+    pr.diag_sd_conc()
+    out = frombuffer(pr.outbuf())
+    assert len(out) == 1 and (out > 0).all()
+    sd_tot = out.sum()
+    pr.diag_all()
+    pr.diag_wet_mom(0)
+    prtcls_tot = frombuffer(pr.outbuf()).sum()
+    assert prtcls_tot / sd_tot == oi.sd_const_multi
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["const_multi", "tail"])
+def test_const_multi_init_matches_oracle(mode):
+    """constant-multiplicity / large-tail initialisation on a 3-D box against the oracle with its random stream replayed:
+    same per-cell counts, cells, dry radii (CDF look-up), multiplicities and positions"""
+    kw = dict(sd_const_multi=int(1.5e11)) if mode == "const_multi" else dict(sd_conc_large_tail=True)
+    sdc = 256                    # fine bins: the sampled range ends early and the multiplicity-1 tail is not empty
+    oi = h.box_opts(3, 2, 4, 0 if mode == "const_multi" else sdc, **kw)
+    oi.n_sd_max = 200000
+    th, rv, rhod, C = h.box_fields(oi)
+    probe = h.oracle_particles(oi)
+    probe.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    n_tot = probe.n_part
+    n1 = sdc * 24 if mode == "tail" else 0
+    calls = ([(0, n1)] * 4 if n1 else []) + [(0, n_tot - n1)] * 4
+    orc, hip = h.oracle_particles(oi), h.hip_particles(oi)
+    for arr in h.oracle_rng_preview(orc, calls):
+        hip.rng_replay_push(0, arr)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    assert hip.n_part == orc.n_part == n_tot and n_tot > n1 + 24
+    for nm in ("n", "ijk", "sorted_id"):
+        assert np.array_equal(hip.state_u64(nm), orc.state_u64(nm)), nm
+    np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-12)
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)
+    for a in ("x", "y", "z"):
+        np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14)
