@@ -1,5 +1,5 @@
 """Statistical checks of the device random-number path (Philox instead of the CPU stream): the reference's
-analytic Golovin test, tests/python/physics/coalescence_golovin.py:31-153 (sd_conc variant, RMSD < 1.2e-5)."""
+analytic Golovin test, tests/python/physics/coalescence_golovin.py:31-153 (sd_conc variant, RMSD < 1.2e-5; const_multi variant, RMSD < 3e-5)."""
 import numpy as np
 import pytest
 from scipy import special
@@ -30,8 +30,9 @@ def mass_dens(pr, rad, sig0=0.62):
     return est * 4. / 3. * 1e3 * np.sqrt(np.pi / 2.)       # dv = 1/rhod = 1
 
 
+@pytest.mark.parametrize("init", ["sd_conc", "const_multi"])
 @pytest.mark.parametrize("opts_dt", [-1, 400.])
-def test_golovin_analytic(opts_dt):
+def test_golovin_analytic(opts_dt, init):
     simulation_time = 800
     r_zero, n_zero, b = 30.084e-6, 2 ** 23, 1500.
     v_zero = 4. / 3. * r_zero ** 3 * np.pi
@@ -47,8 +48,13 @@ def test_golovin_analytic(opts_dt):
     oi.kernel = lgrngn.kernel_t.golovin
     oi.terminal_velocity = lgrngn.vt_t.beard77
     oi.kernel_parameters = np.array([b])
-    oi.sd_conc = 2 ** 14
-    oi.n_sd_max = 2 ** 14
+    if init == "sd_conc":                              # coalescence_golovin.py:112-120
+        oi.sd_conc = 2 ** 14
+        oi.n_sd_max = 2 ** 14
+    else:
+        oi.sd_conc = 0
+        oi.sd_const_multi = 1000
+        oi.n_sd_max = int(float(n_zero) / oi.sd_const_multi + 10)
     opts = lgrngn.opts_t()
     opts.adve = opts.sedi = opts.cond = False
     opts.dt = opts_dt
@@ -74,4 +80,4 @@ def test_golovin_analytic(opts_dt):
         ana[i] = golovin(vol, simulation_time, n_init, v_zero, b) * vol * vol * 3000.
     sel = (res > 0) | (ana > 0)
     rmsd = np.sqrt(np.sum((res[sel] - ana[sel]) ** 2) / np.sum(sel))
-    assert rmsd < 1.2e-5, rmsd
+    assert rmsd < (1.2e-5 if init == "sd_conc" else 3e-5), rmsd          # coalescence_golovin.py:147-153
