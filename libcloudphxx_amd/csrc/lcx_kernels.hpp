@@ -452,8 +452,10 @@ struct cond_args {
   T *m3_before, *m3_after;
   T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
 };
+// Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms, 4 waves with 24 B of scratch per
+// lane: 10.1 ms, 5 waves: 13.0 ms).
 template <class T, bool FAST>
-__global__ void __launch_bounds__(BS) k_cond(size_t n_part, cond_args<T> a)
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond(size_t n_part, cond_args<T> a)
 {
   const size_t pos = gid(); if (pos >= n_part) return;
   const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];

@@ -173,30 +173,48 @@ template <class T> LCX_HD bool prof(const st<T> &s, T fe)
 }
 } // namespace t748
 
+// toms748.hpp:289-431 in two halves that a kernel may run on different lanes (same operations on the same values, hence
+// the same result): toms748_head = the entry checks plus the secant and the first quadratic step; toms748_tail = the
+// main loop and the final midpoint.  `carry` is everything the loop needs.
+template <class T> struct toms_carry { t748::st<T> s; T e, fe; unsigned count; };
 template <class T, class F>
-LCX_HD T toms748_solve(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter)
-{                                                                  // toms748.hpp:289-431
+LCX_HD bool toms748_head(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter, toms_carry<T> &k, T &root)
+{                                                                  // returns true when `root` is final
   using namespace t748;
-  unsigned count = max_iter;
-  st<T> s{ax, bx, fax, fbx, T(0), T(0)};
-  T c, u, fu, a0, b0, e, fe;
-  const T mu = 0.5f;
+  k.count = max_iter;
+  k.s = st<T>{ax, bx, fax, fbx, T(0), T(0)};
+  st<T> &s = k.s;
+  T c;
   if (tol_reached(eps, s.a, s.b) || s.fa == 0 || s.fb == 0) {
     if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
-    return (s.a + s.b) / 2;
+    root = (s.a + s.b) / 2;
+    return true;
   }
-  fe = e = s.fd = 1e5f;
+  k.fe = k.e = s.fd = 1e5f;
   if (s.fa != 0) {
     c = secant(s.a, s.b, s.fa, s.fb);
     bracket(f, s, c);
-    --count;
-    if (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
+    --k.count;
+    if (k.count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
       c = quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
-      e = s.d; fe = s.fd;
+      k.e = s.d; k.fe = s.fd;
       bracket(f, s, c);
-      --count;
+      --k.count;
     }
   }
+  if (k.count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) return false;       // the loop has work to do
+  if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
+  root = (s.a + s.b) / 2;
+  return true;
+}
+template <class T, class F>
+LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
+{
+  using namespace t748;
+  st<T> &s = k.s;
+  T c, u, fu, a0, b0, &e = k.e, &fe = k.fe;
+  unsigned &count = k.count;
+  const T mu = 0.5f;
   while (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
     a0 = s.a; b0 = s.b;
     c = prof(s, fe) ? quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2) : cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
@@ -219,6 +237,14 @@ LCX_HD T toms748_solve(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max
   }
   if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
   return (s.a + s.b) / 2;
+}
+template <class T, class F>
+LCX_HD T toms748_solve(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter)
+{                                                                  // toms748.hpp:289-431
+  toms_carry<T> k;
+  T root;
+  if (toms748_head(f, ax, bx, fax, fbx, eps, max_iter, k, root)) return root;
+  return toms748_tail(f, k, eps);
 }
 
 // ---- equilibrium wet radius at init: kappa_koehler.hpp:58-146, init_wet.ipp:17-38
@@ -386,32 +412,54 @@ template <class T> struct cond_fun_fast {
 //   persistent lanes refilled from an LDS-staged chunk (mean instead of max iterations/wave)  22.0 ms
 // The kernel is bound by fp64 VALU issue (~500 instructions per evaluation, ~15 IEEE divisions), not by
 // divergence or instruction fetch, so the plain form with the lowest register count wins.
+// Later, with the lean growth rate (10.7 ms): the root finder split at its loop entry (toms748_head / toms748_tail below)
+// with the ~40 % of droplets that enter the loop compacted onto fewer lanes -- in one kernel through LDS 12.0 ms, as
+// two kernels through HBM 5.5 + 7..8.8 ms.  Dense waves of "hard" droplets pay the maximum over 64 of them, which costs
+// more than the idle lanes it removes.
+// cond_common.ipp:197-337 up to and including the first two root-finder steps.  Returns true when `result` is final.
 template <class T, class F>
-LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
-{                                                                  // cond_common.ipp:197-337
+LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, toms_carry<T> &k, T &result)
+{
   const T drw2 = dt * f.drw2_dt(rw2_old);
-  if (drw2 == 0) return rw2_old;
+  if (drw2 == 0) { result = rw2_old; return true; }
   const T rd = cbrt(rd3);
   const T rd2 = rd * rd;
   const T a = mx(rd2, rw2_old + mn(T(0), cond_mlt * drw2)),
           b = rw2_old + mx(T(0), cond_mlt * drw2);
-  if (a == b) return rw2_old;
+  if (a == b) { result = rw2_old; return true; }
   T fa, fb;
   // the reference takes f(rw2_old) == drw2 at the near end of the bracket (cond_common.ipp:296-305)
   if (drw2 > 0) { fa = drw2; fb = f(b); }
   else          { fa = f(a); fb = drw2; }
   T rw2_new;
   if (fa * fb > 0) rw2_new = rw2_old + drw2;
-  else rw2_new = toms748_solve(f, a, b, fa, fb, eps, n_iter);
+  else if (!toms748_head(f, a, b, fa, fb, eps, n_iter, k, rw2_new)) return false;
+  if (rw2_new < rd2) rw2_new = rd2;
+  result = rw2_new;
+  return true;
+}
+template <class T, class F>
+LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k)
+{
+  T rw2_new = toms748_tail(f, k, eps);
+  const T rd = cbrt(rd3);
+  const T rd2 = rd * rd;
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
 }
-template <class T, bool FAST = false>
-LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt,
-                     T lambda_D, T lambda_K, T RH, T RH_max, T eps, T cond_mlt, unsigned n_iter)
-{                                                                  // cond_common.ipp:187-337
+template <class T, class F>
+LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+{                                                                  // cond_common.ipp:197-337
+  toms_carry<T> k;
+  T r;
+  if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) return r;
+  return advance_rw2_tail_with(f, rd3, eps, k);
+}
+// builds the growth-rate functor (strict or collected form) and hands it to `body`
+template <class T, bool FAST, class Body>
+LCX_HD auto with_cond_fun(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt, T lambda_D, T lambda_K, T RH, T RH_max, const Body &body)
+{
   using c = cst<T>;
-  if (rw2_old <= 0) return rw2_old;
   cond_fun<T> f;
   f.rw2_old = rw2_old; f.dt = dt; f.rd3 = rd3; f.kpa = kpa; f.vt = vt; f.rhod = rhod; f.eta = eta;
   f.Sc = eta / rhod / c::D_0;
@@ -421,8 +469,16 @@ LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T
   f.lv = l_v(Tk);
   f.A = kelvin_A(Tk);
   f.lv_term = f.lv / c::R_v / Tk - T(1);
-  if (FAST) { cond_fun_fast<T> ff; ff.setup(f); return advance_rw2_with(ff, rw2_old, rd3, dt, eps, cond_mlt, n_iter); }
-  return advance_rw2_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter);
+  if constexpr (FAST) { cond_fun_fast<T> ff; ff.setup(f); return body(ff); }
+  else return body(f);
+}
+template <class T, bool FAST = false>
+LCX_HD T advance_rw2(T rw2_old, T dt, T rhod, T rv, T Tk, T eta, T rd3, T kpa, T vt,
+                     T lambda_D, T lambda_K, T RH, T RH_max, T eps, T cond_mlt, unsigned n_iter)
+{                                                                  // cond_common.ipp:187-337
+  if (rw2_old <= 0) return rw2_old;
+  return with_cond_fun<T, FAST>(rw2_old, dt, rhod, rv, Tk, eta, rd3, kpa, vt, lambda_D, lambda_K, RH, RH_max,
+                                [&](const auto &fn) { return advance_rw2_with(fn, rw2_old, rd3, dt, eps, cond_mlt, n_iter); });
 }
 
 // ---- terminal velocities: common/vterm.hpp:33-220 (khvorostyanov and beard77_v0 in double whatever real_t)
