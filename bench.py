@@ -129,8 +129,8 @@ def main():
                     help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
                          "many steps (long runs; 0 = never, the reference's storage order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=40)
-    ap.add_argument("--cpu-sample-steps", type=int, default=6)
+    ap.add_argument("--cpu-sample-n", type=int, default=48)
+    ap.add_argument("--cpu-sample-steps", type=int, default=12)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
     args = ap.parse_args()
 
