@@ -106,7 +106,7 @@ struct Particles : IParticles {
   bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
   bool var_rho = false, sorted = false, sorted_shuffled = false;
   int sstp_cond, sstp_coal; bool allow_sstp_cond, pure_const_multi; double dt;
-  int adve_scheme;
+  int adve_scheme, halo = 0;      // halo: x-planes of Courant halo on each side (pred_corr)
   hipStream_t st = nullptr;
   // ---- particle attributes (two buffer sets: stable compaction writes from one into the other) ----
   struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
@@ -153,7 +153,6 @@ struct Particles : IParticles {
     if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_adve_switch || oi.turb_cond_switch ||
         oi.turb_coal_switch || oi.diag_incloud_time)
       throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
-    if (oi.adve_scheme == LCX_ADVE_PRED_CORR) throw lcx_error("libcloudph++: pred_corr advection not supported by this backend");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
     sizes.assign(oi.dry_sizes, oi.dry_sizes + oi.n_dry_sizes);
@@ -177,6 +176,8 @@ struct Particles : IParticles {
     if (use_rc2) ix_rc2 = n_ext++;
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
     adve_scheme = oi.adve_scheme;
+    halo = oi.adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;                               // particles_impl.ipp:361
+    if (halo && distmem()) throw lcx_error("libcloudph++: pred_corr advection on a decomposed domain needs the Courant halo exchange, which this backend does not have yet");
     if (o.n_x_tot == 0) o.n_x_tot = oi.nx;
     dt = oi.dt;
     eps_tol = eps_tolerance<T>(sizeof(T) * 8 / 4);                                   // src/detail/config.hpp:39
@@ -278,23 +279,28 @@ struct Particles : IParticles {
       default: s0 = a->strides[0]; s1 = a->strides[1]; s2 = a->strides[2];
     }
   }
-  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez)
+  // halo_planes > 0 (Courant numbers with pred_corr): the device array starts that many x-planes left of the user's array;
+  // planes outside it wrap around the n_x_tot + ex planes cyclically (init_e2l.ipp:44-46,109-113)
+  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0)
   {
     if (is_null(a)) return;
     int n1, n2; long s0, s1, s2;
     arr_geom(a, ex, ey, ez, n1, n2, s0, s1, s2);
+    const long wrap = halo_planes ? long(o.n_x_tot) + ex : 0;
     if (a->on_device) {
-      hipLaunchKernelGGL(k_gather_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, to.p, (const T *)a->data, n, n_dims, n1, n2, s0, s1, s2, long(o.n_x_bfr));
+      hipLaunchKernelGGL(k_gather_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, to.p, (const T *)a->data, n, n_dims, n1, n2, s0, s1, s2,
+                         long(o.n_x_bfr) - halo_planes, wrap);
       return;
     }
     stage_host.resize(n);
     const T *d = (const T *)a->data;
-    const long ioff = o.n_x_bfr;
+    const long ioff = long(o.n_x_bfr) - halo_planes;
+    auto pl = [&](long i) { i += ioff; if (wrap) { if (i >= wrap) i -= wrap; else if (i < 0) i += wrap; } return i; };
     switch (n_dims) {
       case 0: stage_host[0] = d[0]; break;
-      case 1: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c) + ioff) * s0]; break;
-      case 2: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c / n2) + ioff) * s0 + long(c % n2) * s1]; break;
-      default: for (size_t c = 0; c < n; ++c) stage_host[c] = d[(long(c / (size_t(n2) * n1)) + ioff) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2];
+      case 1: for (size_t c = 0; c < n; ++c) stage_host[c] = d[pl(long(c)) * s0]; break;
+      case 2: for (size_t c = 0; c < n; ++c) stage_host[c] = d[pl(long(c / n2)) * s0 + long(c % n2) * s1]; break;
+      default: for (size_t c = 0; c < n; ++c) stage_host[c] = d[pl(long(c / (size_t(n2) * n1))) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2];
     }
     HIPCHK(hipMemcpyAsync(to.p, stage_host.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
     sync();     // stage_host is reused by the next field
@@ -657,7 +663,7 @@ struct Particles : IParticles {
     a.dt = T(dt);
     a.x = A.x.p; a.y = A.y.p; a.z = A.z.p; a.vt = A.vt.p; a.rw2 = A.rw2.p; a.rd3 = A.rd3.p; a.n = A.n.p; a.ijk = ijk.p;
     a.courant_x = courant_x.p; a.courant_y = courant_y.p; a.courant_z = courant_z.p; a.w_LS = w_LS.p;
-    a.do_adve = do_adve; a.scheme = adve_scheme; a.do_sedi = do_sedi; a.do_subs = do_subs; a.do_bcnd = do_bcnd;
+    a.do_adve = do_adve; a.scheme = adve_scheme; a.halo = halo; a.do_sedi = do_sedi; a.do_subs = do_subs; a.do_bcnd = do_bcnd;
     a.distmem = distmem(); a.bcond_lft = o.bcond_lft; a.bcond_rgt = o.bcond_rgt;
     a.open_side_walls = o.open_side_walls; a.periodic_topbot = o.periodic_topbot_walls;
     const bool want_puddle = do_bcnd && n_dims > 1 && !o.periodic_topbot_walls;
@@ -983,10 +989,11 @@ struct Particles : IParticles {
             const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) override
   {
     sanity_init(th_, rv_, rhod_, p_, cx, cy, cz);
-    switch (n_dims) {                                                                    // init_sync.ipp:28-44 (halo 0)
-      case 3: n_cx = size_t(o.nx + 1) * o.ny * o.nz; n_cy = size_t(o.nx) * (o.ny + 1) * o.nz; n_cz = size_t(o.nx) * o.ny * (o.nz + 1); break;
-      case 2: n_cx = size_t(o.nx + 1) * o.nz; n_cz = size_t(o.nx) * (o.nz + 1); break;
-      case 1: n_cx = size_t(o.nx) + 1; break;
+    const int nxh = o.nx + 2 * halo;
+    switch (n_dims) {                                                                    // init_sync.ipp:28-44, particles_impl.ipp:413-431
+      case 3: n_cx = size_t(nxh + 1) * o.ny * o.nz; n_cy = size_t(nxh) * (o.ny + 1) * o.nz; n_cz = size_t(nxh) * o.ny * (o.nz + 1); break;
+      case 2: n_cx = size_t(nxh + 1) * o.nz; n_cz = size_t(nxh) * (o.nz + 1); break;
+      case 1: n_cx = size_t(nxh) + 1; break;
       default: break;
     }
     courant_x.alloc_zero(n_cx, st); courant_y.alloc_zero(n_cy, st); courant_z.alloc_zero(n_cz, st);
@@ -994,7 +1001,7 @@ struct Particles : IParticles {
     if (!conc_factor_h.empty()) { std::vector<T> h(conc_factor_h.begin(), conc_factor_h.end()); conc_factor.alloc(h.size()); HIPCHK(hipMemcpy(conc_factor.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     sync_in_arr(p_, p, ncell, 0, 0, 0);
-    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1);
+    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
     if (n_dims > 0)
       hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
                          T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
@@ -1028,7 +1035,14 @@ struct Particles : IParticles {
     Range r(this, "sync_in");
     var_rho = !is_null(rhod_);
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
-    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1);
+    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
+    if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
+      HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_flag_outside<T>, dim3(nblk(n_cx)), dim3(BS), 0, st, courant_x.p, n_cx, T(-2.), T(2.), d_flag.p);
+      int flag = 0;
+      read_back(&flag, d_flag.p, 1);
+      if (flag) { adve_scheme = LCX_ADVE_EULER; HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st)); }
+    }
     should_now_run_cond = true;
   }
   void step_cond(const lcx_opts_t &opts, const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_) override

@@ -28,18 +28,27 @@ template <class T> __global__ void k_fill(T *a, size_t n, T v) { size_t i = gid(
 __global__ void k_iota(uint32_t *a, size_t n) { size_t i = gid(); if (i < n) a[i] = uint32_t(i); }
 template <class D, class S> __global__ void k_convert(D *d, const S *s, size_t n) { size_t i = gid(); if (i < n) d[i] = D(s[i]); }
 
+// particles_step.ipp:127-142: is any Courant number outside [-2, 2] (beyond the pred_corr halo)?
+template <class T> __global__ void k_flag_outside(const T *v, size_t n, T lo, T hi, int *flag)
+{ const size_t i = gid(); if (i < n && (v[i] < lo || v[i] > hi)) *flag = 1; }
 // strided host-layout array -> contiguous library layout (particles_impl_sync.ipp:15-68, init_e2l.ipp:34-114)
 // ext: extents (n0,n1,n2) of the device-layout field (z fastest), st: element strides of the source,
 // i_off: index offset in the first dimension (x-planes owned by ranks to the left)
 template <class T>
-__global__ void k_gather_strided(T *dst, const T *src, size_t n, int ndims, int n1, int n2, long s0, long s1, long s2, long i_off)
+__global__ void k_gather_strided(T *dst, const T *src, size_t n, int ndims, int n1, int n2, long s0, long s1, long s2, long i_off,
+                                 long wrap_planes = 0)
 {
+  // wrap_planes > 0 (Courant numbers with an x-halo): plane indices outside [0, wrap_planes) wrap around the user's array
+  // cyclically (init_e2l.ipp:109-113)
   size_t c = gid(); if (c >= n) return;
+  long i = ndims == 0 ? 0 : ndims == 1 ? long(c) : ndims == 2 ? long(c / n2) : long(c / (size_t(n2) * n1));
+  i += i_off;
+  if (wrap_planes > 0) { if (i >= wrap_planes) i -= wrap_planes; else if (i < 0) i += wrap_planes; }
   long off;
   if (ndims == 0) off = 0;
-  else if (ndims == 1) off = (long(c) + i_off) * s0;
-  else if (ndims == 2) off = (long(c / n2) + i_off) * s0 + long(c % n2) * s1;
-  else off = (long(c / (size_t(n2) * n1)) + i_off) * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2;
+  else if (ndims == 1) off = i * s0;
+  else if (ndims == 2) off = i * s0 + long(c % n2) * s1;
+  else off = i * s0 + long((c / n2) % n1) * s1 + long(c % n2) * s2;
   dst[c] = src[off];
 }
 template <class T>
@@ -878,7 +887,7 @@ struct move_args {
   T dx, dy, dz, x0, y0, z0, x1, y1, z1, dt;
   T *x, *y, *z; const T *vt, *rw2, *rd3; n_t *n; const uint32_t *ijk;
   const T *courant_x, *courant_y, *courant_z, *w_LS;
-  int do_adve, scheme, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
+  int do_adve, scheme, halo, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
   double *puddle_partial;      // [gridDim][4]: liq_vol, dry_vol, liq_num, prtcl_num
   uint8_t *mig;                // distmem: 1 = left the domain through the left face, 2 = right
   // fused re-indexing (single-device runs): the new cell index, the cell histogram with per-SD rank and the number of
@@ -927,20 +936,70 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     T x = g.nx ? a.x[i] : T(0), y = g.ny ? a.y[i] : T(0), z = g.nz ? a.z[i] : T(0);
     uint32_t ci = c, cj = 0, ck = 0;
     if (g.ndims >= 2) { const uint32_t cij = c / nz; ck = c - cij * nz; ci = cij; if (g.ndims == 3) { ci = cij / ny; cj = cij - ci * ny; } }
-    if (a.do_adve && g.ndims > 0) {
-      const size_t rgt = size_t(c) + (g.ndims == 3 ? size_t(nz) * ny : size_t(g.nz));   // init_grid.ipp:96-121
-      x = adve_1d(a.scheme, x, ci, a.courant_x[c], a.courant_x[rgt], a.dx);
+    uint32_t k_subs = ck;                               // subs reads w_LS at the k of `ijk`, which pred_corr leaves at the predictor cell
+    if (a.do_adve && g.ndims > 0 && a.scheme != LCX_ADVE_PRED_CORR) {
+      // euler / implicit; with a Courant halo (opts_init.adve_scheme == pred_corr, fallen back to first order for this
+      // step) the arrays start `halo` planes to the left: adve_calc(true, halo_x), adve.ipp:169-183
+      const uint32_t cih = ci + a.halo;
+      const size_t ce = size_t(c) + size_t(a.halo) * (g.ndims == 1 ? 1u : g.ndims == 2 ? nz : nz * ny);
+      const size_t rgt = ce + (g.ndims == 3 ? size_t(nz) * ny : size_t(g.nz));            // init_grid.ipp:96-121
+      x = adve_1d(a.scheme, x, ci, a.courant_x[ce], a.courant_x[rgt], a.dx);
       if (g.ndims > 2) {
-        const size_t fre = size_t(c) + size_t(ci) * nz;
+        const size_t fre = ce + size_t(cih) * nz;
         y = adve_1d(a.scheme, y, cj, a.courant_y[fre], a.courant_y[fre + nz], a.dy);
       }
       if (g.ndims > 1) {
-        const size_t blw = g.ndims == 2 ? size_t(c) + ci : size_t(c) + size_t(ny) * ci + cj;
+        const size_t blw = g.ndims == 2 ? ce + cih : ce + size_t(ny) * cih + cj;
         z = adve_1d(a.scheme, z, ck, a.courant_z[blw], a.courant_z[blw + 1], a.dz);
       }
+    } else if (a.do_adve && g.ndims > 0) {
+      // predictor-corrector with nearest-neighbour interpolation (adve.ipp:184-304), all in registers: coordinates that
+      // start at the halo's left edge; predictor = explicit Euler from the old cell; corrector = the explicit increment at the
+      // predicted position averaged with it
+      const T shift = T(a.halo) * a.dx;
+      x = x + shift;
+      auto cell3 = [&](T xx, T yy, T zz, uint32_t &i_, uint32_t &j_, uint32_t &k_) {
+        i_ = g.nx ? uint32_t(double(xx) / g.dx) : 0u; j_ = g.ny ? uint32_t(double(yy) / g.dy) : 0u; k_ = g.nz ? uint32_t(double(zz) / g.dz) : 0u;
+      };
+      auto face_C = [&](uint32_t i_, uint32_t j_, uint32_t k_, T &xl, T &xr, T &yl, T &yr, T &zl, T &zr) {
+        const size_t ce = g.ndims == 1 ? size_t(i_) : g.ndims == 2 ? size_t(i_) * nz + k_ : (size_t(i_) * ny + j_) * nz + k_;
+        xl = a.courant_x[ce]; xr = a.courant_x[ce + (g.ndims == 3 ? size_t(nz) * ny : size_t(g.nz))];
+        if (g.ndims > 2) { const size_t fre = ce + size_t(i_) * nz; yl = a.courant_y[fre]; yr = a.courant_y[fre + nz]; }
+        if (g.ndims > 1) { const size_t blw = g.ndims == 2 ? ce + i_ : ce + size_t(ny) * i_ + j_; zl = a.courant_z[blw]; zr = a.courant_z[blw + 1]; }
+      };
+      uint32_t i1, j1, k1;
+      T xl, xr, yl = 0, yr = 0, zl = 0, zr = 0;
+      cell3(x, y, z, i1, j1, k1);
+      T x_old = x, y_old = y, z_old = z;
+      face_C(i1, j1, k1, xl, xr, yl, yr, zl, zr);
+      x = 1 * x + (xr - xl) * (x - a.dx * T(i1)) + a.dx * xl;
+      if (g.ndims > 2) y = 1 * y + (yr - yl) * (y - a.dy * T(j1)) + a.dy * yl;
+      if (g.ndims > 1) z = 1 * z + (zr - zl) * (z - a.dz * T(k1)) + a.dz * zl;
+      if (g.ndims > 1) {
+        if (z >= a.z1) z = a.z1 - T(1e-8) * a.dz;
+        if (z <= a.z0) z = a.z0 + T(1e-8) * a.dz;
+      }
+      if (g.ndims == 3) {
+        if (y >= a.y1) y_old = y_old + (a.y1 - a.y0);
+        if (y < a.y0) y_old = y_old - (a.y1 - a.y0);
+        y = periodic(y, a.y0, a.y1);
+      }
+      cell3(x, y, z, i1, j1, k1);
+      k_subs = k1;
+      x_old = x + x_old;
+      if (g.ndims > 2) y_old = y + y_old;
+      if (g.ndims > 1) z_old = z + z_old;
+      face_C(i1, j1, k1, xl, xr, yl, yr, zl, zr);
+      x = 0 * x + (xr - xl) * (x - a.dx * T(i1)) + a.dx * xl;
+      if (g.ndims > 2) y = 0 * y + (yr - yl) * (y - a.dy * T(j1)) + a.dy * yl;
+      if (g.ndims > 1) z = 0 * z + (zr - zl) * (z - a.dz * T(k1)) + a.dz * zl;
+      x = (x + x_old) / T(2.);
+      if (g.ndims > 2) y = (y + y_old) / T(2.);
+      if (g.ndims > 1) z = (z + z_old) / T(2.);
+      x = x - shift;
     }
     if (a.do_sedi) z = z - a.dt * a.vt[i];
-    if (a.do_subs) z = z - a.dt * a.w_LS[ck];
+    if (a.do_subs) z = z - a.dt * a.w_LS[k_subs];
     bool kill = false, emigrant = false;
     if (a.do_bcnd && g.ndims > 0) {
       if (!a.distmem) {

@@ -77,7 +77,7 @@ struct orc_particles {
   int n_dims; sz n_cell, n_part, n_part_old, n_part_to_init, cap;
   int init_called, should_now_run_async, should_now_run_cond, selected_before_counting, var_rho, sorted;
   int sstp_cond, sstp_coal, allow_sstp_cond, pure_const_multi, increase_sstp_coal;
-  double dt; int adve_scheme;
+  double dt; int adve_scheme; int halo;      /* halo: x-planes of Courant halo on each side (2 with pred_corr, particles_impl.ipp:361) */
   mt19937_t rng;
   /* particle attributes */
   n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
@@ -145,7 +145,6 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->turb_adve_switch ||
       oi->turb_cond_switch || oi->turb_coal_switch || oi->diag_incloud_time)
     FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
-  if (oi->adve_scheme == LCX_ADVE_PRED_CORR) FAIL("libcloudph++: pred_corr advection not supported by this backend");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
   s->distros = NEW(lcx_distro_t, oi->n_dry_distros);
@@ -172,6 +171,8 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->use_rc2 = oi->sstp_cond_act > 1 && s->allow_sstp_cond;
   s->pure_const_multi = (oi->sd_conc == 0) && (oi->sd_const_multi > 0 || oi->n_dry_sizes > 0);
   s->adve_scheme = oi->adve_scheme;
+  s->halo = oi->adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;
+  if (s->halo && distmem(s)) FAIL("libcloudph++: pred_corr advection on a decomposed domain needs the Courant halo exchange, which this backend does not have yet");
   if (s->o.n_x_tot == 0) s->o.n_x_tot = oi->nx;
   mt_seed(&s->rng, (uint32_t)oi->rng_seed);
   s->eps_tol = orc_eps_tolerance(sizeof(double) * 8 / 4);   /* src/detail/config.hpp:39 */
@@ -214,24 +215,41 @@ void orc_destroy(orc_particles *s)
 
 /* ---------------- Eulerian <-> Lagrangian sync (particles_impl_sync.ipp:15-68, init_e2l.ipp:34-114) ----- */
 /* device index c (z fastest) of a field with extents (nx+ex, ny+ey, nz+ez) -> element offset in the user's array */
-static ptrdiff_t l2e(const orc_particles *s, const lcx_arrinfo_t *a, sz c, int ex, int ey, int ez)
+/* halo > 0: the device array starts `halo` x-planes left of the user's (Courant numbers with pred_corr); planes outside the
+ * user's array wrap around it cyclically (init_e2l.ipp:44-46,109-113: periodic_cellno over the whole array of
+ * n_x_tot + ext_x planes), across MPI / device boundaries they are overwritten by the halo exchange afterwards */
+static ptrdiff_t l2e_halo(const orc_particles *s, const lcx_arrinfo_t *a, sz c, int ex, int ey, int ez, int halo)
 {
   const int ny = s->o.ny + ey, nz = s->o.nz + ez;
-  (void)ex;
+  const ptrdiff_t n_planes = (ptrdiff_t)s->o.n_x_tot + ex;
+  ptrdiff_t i;
   switch (s->n_dims) {
     case 0: return 0;
-    case 1: return (ptrdiff_t)c + s->o.n_x_bfr;
-    case 2: return a->strides[0] * (ptrdiff_t)(c / nz + s->o.n_x_bfr) + a->strides[1] * (ptrdiff_t)(c % nz);
-    default: return a->strides[0] * (ptrdiff_t)(c / ((sz)nz * ny) + s->o.n_x_bfr) +
-                    a->strides[1] * (ptrdiff_t)((c / nz) % ny) + a->strides[2] * (ptrdiff_t)(c % nz);
+    case 1: i = (ptrdiff_t)c; break;
+    case 2: i = (ptrdiff_t)(c / nz); break;
+    default: i = (ptrdiff_t)(c / ((sz)nz * ny));
+  }
+  i += s->o.n_x_bfr - halo;
+  if (halo) { if (i >= n_planes) i -= n_planes; else if (i < 0) i += n_planes; }
+  switch (s->n_dims) {
+    case 1: return i;
+    case 2: return a->strides[0] * i + a->strides[1] * (ptrdiff_t)(c % nz);
+    default: return a->strides[0] * i + a->strides[1] * (ptrdiff_t)((c / nz) % ny) + a->strides[2] * (ptrdiff_t)(c % nz);
   }
 }
+static ptrdiff_t l2e(const orc_particles *s, const lcx_arrinfo_t *a, sz c, int ex, int ey, int ez) { return l2e_halo(s, a, c, ex, ey, ez, 0); }
 static int arr_null(const lcx_arrinfo_t *a) { return !a || !a->data || !a->strides; }
 static void sync_in_arr(const orc_particles *s, const lcx_arrinfo_t *a, double *to, sz n, int ex, int ey, int ez)
 {
   if (arr_null(a)) return;
   const double *d = (const double *)a->data;
   for (sz c = 0; c < n; ++c) to[c] = d[l2e(s, a, c, ex, ey, ez)];
+}
+static void sync_in_courant(const orc_particles *s, const lcx_arrinfo_t *a, double *to, sz n, int ex, int ey, int ez)
+{
+  if (arr_null(a)) return;
+  const double *d = (const double *)a->data;
+  for (sz c = 0; c < n; ++c) to[c] = d[l2e_halo(s, a, c, ex, ey, ez, s->halo)];
 }
 static void sync_out_arr(const orc_particles *s, const double *from, const lcx_arrinfo_t *a, sz n)
 {
@@ -822,16 +840,89 @@ static double adve_1d(int scheme, double x, sz fl, double C_l, double C_r, doubl
   if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - fl * (C_r - C_l))) / (1 - (C_r - C_l));
   return 1 * x + (C_r - C_l) * (x - dx * fl) + dx * C_l;
 }
+/* Courant numbers at the faces of extended-grid cell ce (grid with nx + 2 halo planes), init_grid.ipp:57-158 */
+static void faces(const orc_particles *s, sz ce, double *Cxl, double *Cxr, double *Cyl, double *Cyr, double *Czl, double *Czr)
+{
+  const lcx_opts_init_t *o = &s->o;
+  const sz nz = m1(o->nz), ny = m1(o->ny);
+  const sz rgt = ce + (s->n_dims == 3 ? nz * ny : (sz)o->nz);
+  *Cxl = s->courant_x[ce]; *Cxr = s->courant_x[rgt];
+  if (s->n_dims > 2) { const sz fre = ce + (ce / (nz * ny)) * nz; *Cyl = s->courant_y[fre]; *Cyr = s->courant_y[fre + nz]; }
+  if (s->n_dims > 1) {
+    const sz blw = s->n_dims == 2 ? ce + ce / nz : ce + ny * (ce / (nz * ny)) + (ce - (ce / (nz * ny)) * (nz * ny)) / nz;
+    *Czl = s->courant_z[blw]; *Czr = s->courant_z[blw + 1];
+  }
+}
+static sz cell_ext(const orc_particles *s, double x, double y, double z)
+{                                                   /* hskpng_ijk in the coordinates that start at the halo's left edge */
+  const lcx_opts_init_t *o = &s->o;
+  const sz i = o->nx ? (sz)(x / o->dx) : 0, j = o->ny ? (sz)(y / o->dy) : 0, k = o->nz ? (sz)(z / o->dz) : 0;
+  switch (s->n_dims) { case 1: return i; case 2: return i * o->nz + k; default: return i * ((sz)o->nz * o->ny) + j * o->nz + k; }
+}
+static double periodic(double x, double a, double b);
+/* adve.ipp:184-304: predictor-corrector with nearest-neighbour interpolation */
+static void adve_pred_corr(orc_particles *s)
+{
+  const lcx_opts_init_t *o = &s->o;
+  const sz nz = m1(o->nz), ny = m1(o->ny);
+  const double shift = (double)s->halo * o->dx;
+  for (sz p = 0; p < s->n_part; ++p) {
+    double x = s->x[p] + shift, y = s->y[p], z = s->z[p];
+    double Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0;
+    sz ce = cell_ext(s, x, y, z);
+    double x_old = x, y_old = y, z_old = z;
+    faces(s, ce, &Cxl, &Cxr, &Cyl, &Cyr, &Czl, &Czr);             /* predictor: explicit Euler */
+    {
+      sz i, j = 0, k = 0;
+      if (s->n_dims == 1) i = ce; else if (s->n_dims == 2) { i = ce / nz; k = ce % nz; } else { i = ce / (nz * ny); j = (ce / nz) % ny; k = ce % nz; }
+      x = 1 * x + (Cxr - Cxl) * (x - o->dx * i) + o->dx * Cxl;
+      if (s->n_dims > 2) y = 1 * y + (Cyr - Cyl) * (y - o->dy * j) + o->dy * Cyl;
+      if (s->n_dims > 1) z = 1 * z + (Czr - Czl) * (z - o->dz * k) + o->dz * Czl;
+    }
+    if (s->n_dims > 1) {
+      if (z >= o->z1) z = o->z1 - 1e-8 * o->dz;
+      if (z <= o->z0) z = o->z0 + 1e-8 * o->dz;
+    }
+    if (s->n_dims == 3) {
+      if (y >= o->y1) y_old = y_old + (o->y1 - o->y0);
+      if (y < o->y0) y_old = y_old - (o->y1 - o->y0);
+      y = periodic(y, o->y0, o->y1);
+    }
+    ce = cell_ext(s, x, y, z);                                      /* cell after the predictor step */
+    s->ijk[p] = ce;
+    x_old = x + x_old;
+    if (s->n_dims > 2) y_old = y + y_old;
+    if (s->n_dims > 1) z_old = z + z_old;
+    faces(s, ce, &Cxl, &Cxr, &Cyl, &Cyr, &Czl, &Czr);             /* corrector: rhs at the midpoint position */
+    {
+      sz i, j = 0, k = 0;
+      if (s->n_dims == 1) i = ce; else if (s->n_dims == 2) { i = ce / nz; k = ce % nz; } else { i = ce / (nz * ny); j = (ce / nz) % ny; k = ce % nz; }
+      x = 0 * x + (Cxr - Cxl) * (x - o->dx * i) + o->dx * Cxl;
+      if (s->n_dims > 2) y = 0 * y + (Cyr - Cyl) * (y - o->dy * j) + o->dy * Cyl;
+      if (s->n_dims > 1) z = 0 * z + (Czr - Czl) * (z - o->dz * k) + o->dz * Czl;
+    }
+    x = (x + x_old) / 2.;
+    if (s->n_dims > 2) y = (y + y_old) / 2.;
+    if (s->n_dims > 1) z = (z + z_old) / 2.;
+    s->x[p] = x - shift;
+    if (s->n_dims > 2) s->y[p] = y;
+    if (s->n_dims > 1) s->z[p] = z;
+  }
+}
 static void adve(orc_particles *s)
 {
   if (s->n_dims == 0) return;
+  if (s->adve_scheme == LCX_ADVE_PRED_CORR) { adve_pred_corr(s); return; }
   const lcx_opts_init_t *o = &s->o;
   const sz nz = m1(o->nz), ny = m1(o->ny);
+  const sz halo_cells = (sz)s->halo * (s->n_dims == 1 ? 1 : s->n_dims == 2 ? nz : nz * ny);    /* adve_calc(true, halo_x) */
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
-    const sz c = s->ijk[p];
+    const sz c0 = s->ijk[p];
     sz i, j = 0, k = 0;
-    if (s->n_dims == 1) i = c; else if (s->n_dims == 2) { i = c / nz; k = c % nz; } else { i = c / (nz * ny); j = (c / nz) % ny; k = c % nz; }
+    { const sz c = c0;
+    if (s->n_dims == 1) i = c; else if (s->n_dims == 2) { i = c / nz; k = c % nz; } else { i = c / (nz * ny); j = (c / nz) % ny; k = c % nz; } }
+    const sz c = c0 + halo_cells;                                   /* index into the halo-extended Courant arrays */
     /* init_grid.ipp:57-158 face maps */
     const sz lft = c, rgt = c + (s->n_dims == 3 ? nz * ny : (sz)o->nz); /* 1-D: rgt == lft as in init_grid.ipp:96-107 */
     s->x[p] = adve_1d(s->adve_scheme, s->x[p], i, s->courant_x[lft], s->courant_x[rgt], o->dx);
@@ -1283,12 +1374,13 @@ static int init_sanity_check(orc_particles *s, const lcx_arrinfo_t *th, const lc
   return 0;
 }
 static void alloc_courants(orc_particles *s)
-{                                                   /* init_sync.ipp:28-44 (halo_size 0) */
+{                                                   /* init_sync.ipp:28-44, particles_impl.ipp:413-431 */
   const lcx_opts_init_t *o = &s->o;
+  const int nxh = o->nx + 2 * s->halo;
   switch (s->n_dims) {
-    case 3: s->n_cx = (sz)(o->nx + 1) * o->ny * o->nz; s->n_cy = (sz)o->nx * (o->ny + 1) * o->nz; s->n_cz = (sz)o->nx * o->ny * (o->nz + 1); break;
-    case 2: s->n_cx = (sz)(o->nx + 1) * o->nz; s->n_cz = (sz)o->nx * (o->nz + 1); break;
-    case 1: s->n_cx = (sz)o->nx + 1; break;
+    case 3: s->n_cx = (sz)(nxh + 1) * o->ny * o->nz; s->n_cy = (sz)nxh * (o->ny + 1) * o->nz; s->n_cz = (sz)nxh * o->ny * (o->nz + 1); break;
+    case 2: s->n_cx = (sz)(nxh + 1) * o->nz; s->n_cz = (sz)nxh * (o->nz + 1); break;
+    case 1: s->n_cx = (sz)nxh + 1; break;
     default: break;
   }
   s->courant_x = NEW(double, s->n_cx); s->courant_y = NEW(double, s->n_cy); s->courant_z = NEW(double, s->n_cz);
@@ -1303,9 +1395,9 @@ int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
   sync_in_arr(s, rv, s->rv, s->n_cell, 0, 0, 0);
   sync_in_arr(s, rhod, s->rhod, s->n_cell, 0, 0, 0);
   sync_in_arr(s, p, s->p, s->n_cell, 0, 0, 0);
-  sync_in_arr(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
-  sync_in_arr(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
-  sync_in_arr(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
+  sync_in_courant(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
+  sync_in_courant(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
+  sync_in_courant(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
   init_grid(s);
   hskpng_Tpr(s);
   if (!s->o.no_ccn_at_init) {
@@ -1340,9 +1432,12 @@ int orc_sync_in(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *
   sync_in_arr(s, th, s->th, s->n_cell, 0, 0, 0);
   sync_in_arr(s, rv, s->rv, s->n_cell, 0, 0, 0);
   sync_in_arr(s, rhod, s->rhod, s->n_cell, 0, 0, 0);
-  sync_in_arr(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
-  sync_in_arr(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
-  sync_in_arr(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
+  sync_in_courant(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
+  sync_in_courant(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
+  sync_in_courant(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
+  /* particles_step.ipp:127-142: Courant numbers beyond the 2-cell halo break the predictor-corrector: first order this step */
+  if (s->o.adve_scheme == LCX_ADVE_PRED_CORR && !arr_null(cx))
+    for (sz c = 0; c < s->n_cx; ++c) if (s->courant_x[c] < -2. || s->courant_x[c] > 2.) { s->adve_scheme = LCX_ADVE_EULER; break; }
   s->should_now_run_cond = 1;
   return 0;
 }

@@ -299,7 +299,30 @@ def test_coal_two_kappas_replay():
 
 
 # ------------------------------------------------------------------ advection / sedimentation / boundary (a13-a16)
-@pytest.mark.parametrize("scheme", [lgrngn.as_t.euler, lgrngn.as_t.implicit])
+@pytest.mark.parametrize("dims", [(7, 0, 0), (6, 0, 5), (5, 4, 6)])
+def test_pred_corr_falls_back_to_euler_beyond_the_halo(dims):
+    """particles_step.ipp:127-142: a Courant number outside [-2, 2] makes the step first order (Courant arrays keep their
+    2-plane halo, read with the halo offset); the next step with tame Courant numbers is predictor-corrector again"""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, adve_scheme=lgrngn.as_t.pred_corr, dx=30., sedi_switch=nz > 0)
+    th, rv, rhod, C = h.box_fields(oi)
+    wild = {k: v.copy() for k, v in C.items()}
+    wild["Cx"].flat[3] = 2.5
+    orc, hip = h.make_pair(oi, (th, rv, rhod, C))
+    opts = lgrngn.opts_t()
+    opts.cond = opts.coal = opts.sedi = False
+    for fields in ((th, rv, rhod, wild), (th, rv, rhod, C), (th, rv, rhod, C)):
+        step_pair(orc, hip, opts, fields)
+        assert hip.n_part == orc.n_part
+        for a in ("x", "y", "z"):
+            if getattr(oi, "n" + a):
+                np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14, atol=1e-9, err_msg=a)
+        for nm in ("ijk", "sorted_id"):
+            exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+
+
+# ------------------------------------------------------------------ advection / sedimentation / boundary (a13-a16)
+@pytest.mark.parametrize("scheme", [lgrngn.as_t.euler, lgrngn.as_t.implicit, lgrngn.as_t.pred_corr])
 @pytest.mark.parametrize("dims", [(6, 0, 5), (5, 4, 6)])
 def test_move_and_post_copy(scheme, dims):
     nx, ny, nz = dims
