@@ -217,6 +217,13 @@ int lcx_migrate_pack(lcx_particles *, int side, double x_rmt, void *dev_buf, siz
 int lcx_migrate_unpack(lcx_particles *, const void *dev_buf, size_t count);
 /* flag emigrants n=0 and run post_copy (post_copy.ipp:18-35) */
 int lcx_migrate_finish(lcx_particles *, const lcx_opts_t *);
+/* Courant halo of pred_corr advection on a decomposed domain (xchng_courants.ipp:15-160).  which: 0 Cx, 1 Cy, 2 Cz;
+ * side: 0 left, 1 right.  _count: reals per side (0: nothing to exchange); _pack: the interior planes next to `side`
+ * (what that neighbour needs) -> device buffer; _unpack: device buffer received from the neighbour at `side` -> the halo
+ * planes on that side.  Call after sync_in, before step_async. */
+size_t lcx_courant_halo_count(lcx_particles *, int which);
+int lcx_courant_halo_pack(lcx_particles *, int which, int side, void *dev_buf);
+int lcx_courant_halo_unpack(lcx_particles *, int which, int side, const void *dev_buf);
 /* device pointer helpers so that a host language without device allocation can stage buffers */
 int lcx_dev_alloc(void **ptr, size_t bytes);
 int lcx_dev_free(void *ptr);

@@ -89,6 +89,8 @@ struct IParticles {
   virtual void migrate_pack(int side, double x_rmt, void *buf, size_t cap) = 0;
   virtual void migrate_unpack(const void *buf, size_t count) = 0;
   virtual void migrate_finish(const lcx_opts_t &) = 0;
+  virtual size_t courant_halo_count(int which) = 0;
+  virtual void courant_halo_copy(int which, int side, void *buf, bool pack) = 0;
 };
 
 template <class real_t>
@@ -177,7 +179,6 @@ struct Particles : IParticles {
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
     adve_scheme = oi.adve_scheme;
     halo = oi.adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;                               // particles_impl.ipp:361
-    if (halo && distmem()) throw lcx_error("libcloudph++: pred_corr advection on a decomposed domain needs the Courant halo exchange, which this backend does not have yet");
     if (o.n_x_tot == 0) o.n_x_tot = oi.nx;
     dt = oi.dt;
     eps_tol = eps_tolerance<T>(sizeof(T) * 8 / 4);                                   // src/detail/config.hpp:39
@@ -1304,6 +1305,32 @@ struct Particles : IParticles {
     nphys += cnt;
     sync();
   }
+  // Courant halo of pred_corr on a decomposed domain (xchng_courants.ipp:15-160): element ranges inside the halo-extended
+  // arrays [send to left, send to right, recv from left, recv from right]
+  size_t courant_halo_geom(int which, T **arr, size_t off[4])
+  {
+    if (!halo || n_dims == 0) return 0;
+    const size_t ny = m1(o.ny), nz = m1(o.nz), h = size_t(halo);
+    size_t plane, n;
+    if (which == 0) { plane = n_dims == 1 ? 1 : n_dims == 2 ? nz : nz * ny; *arr = courant_x.p; n = n_cx; }
+    else if (which == 1) { if (n_dims < 3) return 0; plane = (ny + 1) * nz; *arr = courant_y.p; n = n_cy; }
+    else { if (n_dims < 2) return 0; plane = n_dims == 2 ? nz + 1 : (nz + 1) * ny; *arr = courant_z.p; n = n_cz; }
+    const size_t cnt = h * plane;
+    if (which == 0) { off[0] = (h + 1) * plane; off[1] = size_t(o.nx) * plane; }
+    else            { off[0] = cnt;             off[1] = size_t(o.nx) * plane; }
+    off[2] = 0; off[3] = n - cnt;
+    return cnt;
+  }
+  size_t courant_halo_count(int which) override { T *a; size_t off[4]; return courant_halo_geom(which, &a, off); }
+  void courant_halo_copy(int which, int side, void *buf, bool pack) override
+  {
+    T *a; size_t off[4];
+    const size_t cnt = courant_halo_geom(which, &a, off);
+    if (!cnt) return;
+    if (pack) HIPCHK(hipMemcpyAsync(buf, a + off[side], cnt * sizeof(T), hipMemcpyDeviceToDevice, st));
+    else      HIPCHK(hipMemcpyAsync(a + off[2 + side], buf, cnt * sizeof(T), hipMemcpyDeviceToDevice, st));
+    sync();
+  }
   void migrate_finish(const lcx_opts_t &opts) override
   {
     flag_emigrants();
@@ -1412,6 +1439,9 @@ size_t lcx_migrate_record_bytes(lcx_particles *h) { return H->migrate_record_byt
 int lcx_migrate_pack(lcx_particles *h, int side, double x_rmt, void *buf, size_t cap) { LCX_TRY(H->migrate_pack(side, x_rmt, buf, cap)) }
 int lcx_migrate_unpack(lcx_particles *h, const void *buf, size_t count) { LCX_TRY(H->migrate_unpack(buf, count)) }
 int lcx_migrate_finish(lcx_particles *h, const lcx_opts_t *o) { LCX_TRY(H->migrate_finish(*o)) }
+size_t lcx_courant_halo_count(lcx_particles *h, int which) { return H->courant_halo_count(which); }
+int lcx_courant_halo_pack(lcx_particles *h, int which, int side, void *buf) { LCX_TRY(H->courant_halo_copy(which, side, buf, true)) }
+int lcx_courant_halo_unpack(lcx_particles *h, int which, int side, const void *buf) { LCX_TRY(H->courant_halo_copy(which, side, const_cast<void *>(buf), false)) }
 int lcx_dev_alloc(void **ptr, size_t bytes) { LCX_TRY({ if (hipMalloc(ptr, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed"); }) }
 int lcx_dev_free(void *ptr) { LCX_TRY({ if (hipFree(ptr) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipFree failed"); }) }
 int lcx_dev_copy(void *dst, const void *src, size_t bytes, int kind)

@@ -497,6 +497,17 @@ class particles_t:
         self._chk(self._f("migrate_counts")(self._h, C.byref(l), C.byref(r)))
         return l.value, r.value
 
+    def courant_halo_count(self, which):
+        f = self._f("courant_halo_count")
+        f.restype = C.c_size_t
+        return int(f(self._h, C.c_int(which)))
+
+    def courant_halo_pack(self, which, side, ptr):
+        self._chk(self._f("courant_halo_pack")(self._h, C.c_int(which), C.c_int(side), C.c_void_p(ptr)))
+
+    def courant_halo_unpack(self, which, side, ptr):
+        self._chk(self._f("courant_halo_unpack")(self._h, C.c_int(which), C.c_int(side), C.c_void_p(ptr)))
+
     def migrate_record_bytes(self):
         f = self._f("migrate_record_bytes")
         f.restype = C.c_size_t

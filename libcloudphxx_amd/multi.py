@@ -79,6 +79,7 @@ class particles_multi_t:
         oi, self.n_x_bfr = distmem_opts(opts_init, self.rank, self.size)
         if not global_arrays:
             oi.n_x_bfr = 0
+            oi.n_x_tot = oi.nx        # slab-local arrays: a Courant halo wraps inside the slab, the exchange below overwrites it
         self.opts_init = oi
         self.device = device
         if make_particles is None:
@@ -104,8 +105,45 @@ class particles_multi_t:
     def init(self, *a, **kw):
         self.prt.init(*a, **kw)
 
+    def sync_in(self, *a, **kw):
+        self.prt.sync_in(*a, **kw)
+        self._exchange_courant_halo()
+
     def step_sync(self, *a, **kw):
         self.prt.step_sync(*a, **kw)
+        self._exchange_courant_halo()
+
+    def _exchange_courant_halo(self):
+        """pred_corr advection reads Courant numbers up to two x-planes outside the slab: every rank sends the planes next
+        to its edges to the neighbours (particles_impl_xchng_courants.ipp:15-160), three small messages per side"""
+        if self.size == 1:
+            return
+        torch, dist = self.torch, self.dist
+        isz = self.real_t.itemsize
+        for which in (0, 1, 2):
+            cnt = self.prt.courant_halo_count(which)
+            if not cnt:
+                continue
+            out_l, out_r, in_l, in_r = (self._buf(cnt * isz) for _ in range(4))
+            ops = []
+            if self.lft is not None:
+                self.prt.courant_halo_pack(which, 0, out_l.data_ptr())
+                ops.append(dist.P2POp(dist.isend, out_l, self.lft))
+            if self.rgt is not None:
+                self.prt.courant_halo_pack(which, 1, out_r.data_ptr())
+                ops.append(dist.P2POp(dist.isend, out_r, self.rgt))
+            if self.rgt is not None:
+                ops.append(dist.P2POp(dist.irecv, in_r, self.rgt))
+            if self.lft is not None:
+                ops.append(dist.P2POp(dist.irecv, in_l, self.lft))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if self.on_gpu:
+                torch.cuda.current_stream().synchronize()
+            if self.lft is not None:
+                self.prt.courant_halo_unpack(which, 0, in_l.data_ptr())
+            if self.rgt is not None:
+                self.prt.courant_halo_unpack(which, 1, in_r.data_ptr())
 
     def _buf(self, nbytes):
         t = self.torch.empty(max(int(nbytes), 8), dtype=self.torch.uint8, device=self.device if self.on_gpu else "cpu")

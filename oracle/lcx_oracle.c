@@ -172,7 +172,6 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->pure_const_multi = (oi->sd_conc == 0) && (oi->sd_const_multi > 0 || oi->n_dry_sizes > 0);
   s->adve_scheme = oi->adve_scheme;
   s->halo = oi->adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;
-  if (s->halo && distmem(s)) FAIL("libcloudph++: pred_corr advection on a decomposed domain needs the Courant halo exchange, which this backend does not have yet");
   if (s->o.n_x_tot == 0) s->o.n_x_tot = oi->nx;
   mt_seed(&s->rng, (uint32_t)oi->rng_seed);
   s->eps_tol = orc_eps_tolerance(sizeof(double) * 8 / 4);   /* src/detail/config.hpp:39 */
@@ -1714,4 +1713,35 @@ int orc_migrate_finish(orc_particles *s, const lcx_opts_t *opts)
   for (sz i = 0; i < s->rgt_count; ++i) s->n[s->rgt_id[i]] = 0;
   s->lft_count = s->rgt_count = 0;
   return post_copy(s, opts);
+}
+
+/* ---------------- Courant halo exchange of pred_corr (xchng_courants.ipp:15-160) ---------------- */
+/* element ranges inside the halo-extended arrays: [send to left, send to right, recv from left, recv from right] */
+static sz courant_halo_geom(orc_particles *s, int which, double **arr, sz off[4])
+{
+  const lcx_opts_init_t *o = &s->o;
+  if (!s->halo || s->n_dims == 0) return 0;
+  const sz ny = m1(o->ny), nz = m1(o->nz), h = (sz)s->halo;
+  sz plane, n;                                       /* reals per x-plane of this array, total */
+  if (which == 0) { plane = s->n_dims == 1 ? 1 : s->n_dims == 2 ? nz : nz * ny; *arr = s->courant_x; n = s->n_cx; }
+  else if (which == 1) { if (s->n_dims < 3) return 0; plane = (ny + 1) * nz; *arr = s->courant_y; n = s->n_cy; }
+  else { if (s->n_dims < 2) return 0; plane = s->n_dims == 2 ? nz + 1 : (nz + 1) * ny; *arr = s->courant_z; n = s->n_cz; }
+  const sz cnt = h * plane;
+  if (which == 0) { off[0] = (h + 1) * plane; off[1] = (sz)o->nx * plane; }      /* cx_lft_internal_idx, cx_rgt_internal_idx = n_cell */
+  else            { off[0] = cnt;             off[1] = (sz)o->nx * plane; }      /* c[yz]_lft_internal_idx = halo, _rgt = nx planes in */
+  off[2] = 0; off[3] = n - cnt;
+  return cnt;
+}
+size_t orc_courant_halo_count(orc_particles *s, int which) { double *a; sz off[4]; return courant_halo_geom(s, which, &a, off); }
+int orc_courant_halo_pack(orc_particles *s, int which, int side, void *buf)
+{
+  double *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
+  if (cnt) memcpy(buf, a + off[side], cnt * sizeof(double));
+  return 0;
+}
+int orc_courant_halo_unpack(orc_particles *s, int which, int side, const void *buf)
+{
+  double *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
+  if (cnt) memcpy(a + off[2 + side], buf, cnt * sizeof(double));
+  return 0;
 }

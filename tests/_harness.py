@@ -219,6 +219,7 @@ class LocalRing:
         for r in range(size):
             o, b = multi.distmem_opts(oi_global, r, size)
             o.n_x_bfr = 0
+            o.n_x_tot = o.nx
             o.rng_seed = oi_global.rng_seed + r
             self.prts.append(make(o))
             self.bfr.append(b)
@@ -242,8 +243,25 @@ class LocalRing:
             p.step_sync(opts, *a)
             th[self.bfr[r]:self.bfr[r] + self.nxl[r]] = a[0]
             rv[self.bfr[r]:self.bfr[r] + self.nxl[r]] = a[1]
-            p.step_async(opts)
         n = self.size
+        # Courant halo of pred_corr (multi.py _exchange_courant_halo): pack on every slab, then unpack
+        isz = 8
+        for which in (0, 1, 2):
+            cnt = self.prts[0].courant_halo_count(which)
+            if not cnt:
+                continue
+            bufs = []
+            for p in self.prts:
+                kl, pl = self.alloc(cnt * isz)
+                kr, pr_ = self.alloc(cnt * isz)
+                p.courant_halo_pack(which, 0, pl)
+                p.courant_halo_pack(which, 1, pr_)
+                bufs.append((pl, kl, pr_, kr))
+            for r, p in enumerate(self.prts):
+                p.courant_halo_unpack(which, 0, bufs[(r - 1) % n][2])     # left halo <- left neighbour's right-edge planes
+                p.courant_halo_unpack(which, 1, bufs[(r + 1) % n][0])     # right halo <- right neighbour's left-edge planes
+        for p in self.prts:
+            p.step_async(opts)
         packs = []
         for r, p in enumerate(self.prts):
             nl, nr = p.migrate_counts()

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
-def run(rank, world, port, nx, nz, Cx_val, result_path):
+def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler"):
     import torch.distributed as dist
     import _harness as h
     from libcloudphxx_amd import lgrngn, multi
@@ -26,7 +26,7 @@ def run(rank, world, port, nx, nz, Cx_val, result_path):
         oi.x1, oi.z1 = nx * oi.dx, nz * oi.dz
         oi.sd_conc = 8
         oi.n_sd_max = 8 * nx * nz * 2
-        oi.adve_scheme = lgrngn.as_t.euler
+        oi.adve_scheme = lgrngn.as_t[scheme]         # pred_corr: the Courant halo is exchanged between the ranks as well
         oi.rng_seed = 44 + rank                      # mpi_adve_test.cpp:95 seeds every rank differently
         prt = multi.particles_multi_t(oi, np.float64, make_particles=h.oracle_particles)
         nxl = prt.opts_init.nx
@@ -59,4 +59,4 @@ def run(rank, world, port, nx, nz, Cx_val, result_path):
 
 if __name__ == "__main__":
     a = sys.argv
-    run(int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), a[7])
+    run(int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), a[7], a[8] if len(a) > 8 else "euler")

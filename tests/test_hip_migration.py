@@ -54,6 +54,33 @@ def test_migration_matches_oracle(dims, size):
     assert sum(p.n_part for p in hip.prts) <= tot0
 
 
+@pytest.mark.parametrize("dims,size", [((8, 0, 5), 2), ((9, 3, 4), 3)])
+def test_pred_corr_on_a_ring_matches_oracle(dims, size):
+    """pred_corr advection on a decomposed domain: Courant halos (2 x-planes per side) exchanged between the slabs
+    (xchng_courants.ipp:15-160) -- device ring against the oracle ring, every slab, positions bit for bit"""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False, adve_scheme=lgrngn.as_t.pred_corr)
+    oi.n_sd_max = 24 * max(nx, 1) * max(ny, 1) * nz * 3
+    fields = h.box_fields(oi)
+    orc, hip = ring_pair(oi, size, fields)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    for it in range(4):
+        a = [x.copy() for x in (th, rv, rhod)]
+        b = [x.copy() for x in (th, rv, rhod)]
+        orc.step(opts, *a, **C)
+        hip.step(opts, *b, **C)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            for a_ in ("x", "y", "z"):
+                if getattr(oi, "n" + a_):
+                    np.testing.assert_allclose(ph.get_attr(a_), po.get_attr(a_), rtol=1e-14, atol=1e-9, err_msg="%s slab %d" % (a_, r))
+            np.testing.assert_array_equal(ph.state_real("courant_x"), po.state_real("courant_x"))
+
+
 def test_migration_carries_perparticle_state():
     """exact_sstp_cond + sstp_cond_act: the private (rv, th, rhod) of a droplet and rc2 are attributes that are packed,
     unpacked and compacted with it (particles_impl.ipp:452-491); condensation on, so the carried values matter"""
