@@ -470,9 +470,88 @@ struct Particles : IParticles {
   // the storage, or until something observes storage order (get_attr / state getters, a replayed random stream,
   // set_particles, capacity pressure).  Relative order of the living SDs, hence every tie-break of the stable sort, is
   // the same as after the reference's eager remove_if.  LCX_EAGER_COMPACT=1 forces a compaction every step.
+  // ordered list of the ids whose flag byte is 1 (the scan-compaction of the migrant lists), returns the count
+  size_t ordered_ids(const uint8_t *flag, DevBuf<uint32_t> &out)
+  {
+    const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
+    out.alloc(cap);
+    hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, flag, nphys, uint8_t(1), tile_sums.p);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+    hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, flag, nphys, uint8_t(1), tile_sums.p, out.p);
+    uint32_t tot = 0;
+    read_back(&tot, scan_total.p, 1);
+    return tot;
+  }
+  // housekeeping/particles_impl_rcyc.ipp:44-140.  The reference sorts all multiplicities (stable) and pairs the t-th SD of
+  // the sorted sequence (the zeros, ids ascending) with the t-th from its end (largest n first, higher id first among equal
+  // n).  Here: counts -> radix select of the k-th largest multiplicity -> ordered id lists of the zeros, of n > n* and of
+  // n == n* -> the same pairs.  Storage must hold no stale dead SDs (post_copy compacts eagerly while rcyc is on).
+  void rcyc()
+  {
+    if (!nphys) return;
+    const size_t N = nphys;
+    rc_stat.alloc_zero(4, st); rc_max.alloc_zero(1, st);
+    hipLaunchKernelGGL(k_rcyc_stat, dim3(nblk(N)), dim3(BS), 0, st, A.n.p, N, rc_stat.p, rc_max.p);
+    unsigned int stat[4]; unsigned long long nmax = 0;
+    read_back(stat, rc_stat.p, 4); read_back(&nmax, rc_max.p, 1);
+    size_t n_flagged = stat[0];
+    if (n_flagged == 0 || pure_const_multi) return;                      // (pure_const_multi: removal only)
+    const size_t n_splittable = stat[1] > 0 ? size_t(stat[2]) : N;      // entries behind the last n == 1 of the sorted sequence
+    if (n_splittable == 0) return;
+    const size_t k = std::min(n_flagged, n_splittable);
+    // radix select: n* = k-th largest multiplicity, rem = how many donors carry exactly n*
+    int bytes = 1; while (bytes < 8 && (nmax >> (8 * bytes))) ++bytes;
+    n_t prefix = 0; size_t rem = k;
+    rc_hist.alloc(256);
+    for (int b = bytes - 1; b >= 0; --b) {
+      HIPCHK(hipMemsetAsync(rc_hist.p, 0, 256 * sizeof(unsigned int), st));
+      hipLaunchKernelGGL(k_rcyc_hist, dim3(nblk(N)), dim3(BS), 0, st, A.n.p, N, prefix, 8 * b, rc_hist.p);
+      std::vector<unsigned int> hst = d2h(rc_hist.p, 256);
+      size_t above = 0; int bin = 255;
+      for (; bin > 0; --bin) { if (above + hst[bin] >= rem) break; above += hst[bin]; }
+      rem -= above;
+      prefix |= n_t(bin) << (8 * b);
+    }
+    const n_t thr = prefix;
+    const size_t m = k - rem;                                            // donors with n > n*
+    if (!mig.p) mig.alloc(cap);
+    std::vector<uint32_t> recv(k), donor(k);
+    hipLaunchKernelGGL(k_rcyc_flag, dim3(nblk(N)), dim3(BS), 0, st, A.n.p, N, 0, n_t(0), mig.p);
+    ordered_ids(mig.p, mig_ids[0]);
+    HIPCHK(hipMemcpyAsync(recv.data(), mig_ids[0].p, k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sync();
+    if (m) {
+      hipLaunchKernelGGL(k_rcyc_flag, dim3(nblk(N)), dim3(BS), 0, st, A.n.p, N, 2, thr, mig.p);
+      const size_t got = ordered_ids(mig.p, mig_ids[0]);
+      if (got != m) throw lcx_error("libcloudph++ (HIP): rcyc selection inconsistent");
+      rc_vals.alloc(m);
+      hipLaunchKernelGGL(k_gather_n, dim3(nblk(m)), dim3(BS), 0, st, mig_ids[0].p, m, A.n.p, rc_vals.p);
+      std::vector<uint32_t> ids = d2h(mig_ids[0].p, m);
+      std::vector<n_t> vals = d2h(rc_vals.p, m);
+      std::vector<size_t> ord(m);
+      for (size_t i = 0; i < m; ++i) ord[i] = i;
+      std::sort(ord.begin(), ord.end(), [&](size_t a_, size_t b_) { return vals[a_] != vals[b_] ? vals[a_] > vals[b_] : ids[a_] > ids[b_]; });
+      for (size_t i = 0; i < m; ++i) donor[i] = ids[ord[i]];
+    }
+    if (rem) {
+      hipLaunchKernelGGL(k_rcyc_flag, dim3(nblk(N)), dim3(BS), 0, st, A.n.p, N, 1, thr, mig.p);
+      const size_t e = ordered_ids(mig.p, mig_ids[1]);
+      if (e < rem) throw lcx_error("libcloudph++ (HIP): rcyc selection inconsistent");
+      std::vector<uint32_t> tail(rem);
+      HIPCHK(hipMemcpyAsync(tail.data(), mig_ids[1].p + (e - rem), rem * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      sync();
+      for (size_t i = 0; i < rem; ++i) donor[m + i] = tail[rem - 1 - i];       // highest id first
+    }
+    rc_pairs.alloc(2 * k);
+    HIPCHK(hipMemcpyAsync(rc_pairs.p, recv.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(rc_pairs.p + k, donor.data(), k * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rcyc_apply<T>, dim3(nblk(k)), dim3(BS), 0, st, k, rc_pairs.p, rc_pairs.p + k, aset(A), g);
+    sync();
+  }
+  DevBuf<unsigned int> rc_stat, rc_hist; DevBuf<unsigned long long> rc_max; DevBuf<n_t> rc_vals; DevBuf<uint32_t> rc_pairs;
   void post_copy(const lcx_opts_t &opts, bool force_compact = false)
   {
-    if (opts.rcyc) throw lcx_error("libcloudph++: rcyc not supported by this backend");
+    if (opts.rcyc) { Range r(this, "rcyc"); rcyc(); force_compact = true; }      // what could not be recycled is removed at once
     Range r(this, "post_copy");
     const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     uint32_t alive = 0;

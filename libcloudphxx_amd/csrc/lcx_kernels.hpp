@@ -1377,6 +1377,67 @@ __global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, co
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 
+// ============================================================================================
+// recycling (housekeeping/particles_impl_rcyc.ipp:44-140): SDs with n == 0 become halves of the SDs with the highest
+// multiplicities.  The reference sorts ALL multiplicities; here the k largest are found by a radix select (one 256-bin
+// histogram pass per significant byte) and two ordered compactions.
+// ============================================================================================
+// stat[0..2] = number of SDs with n == 0, n == 1, n >= 2; stat64 = max n
+__global__ void __launch_bounds__(BS) k_rcyc_stat(const n_t *n, size_t N, unsigned int *stat, unsigned long long *nmax)
+{
+  const size_t i = gid();
+  const n_t v = i < N ? n[i] : n_t(2);
+  const bool in = i < N;
+  const unsigned long long b0 = __ballot(in && v == 0), b1 = __ballot(in && v == 1), b2 = __ballot(in && v >= 2);
+  n_t m = in ? v : 0;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) { const n_t o = __shfl_down(m, d); m = o > m ? o : m; }
+  if (lane_id() == 0) {
+    if (b0) atomicAdd(stat + 0, (unsigned int)__popcll(b0));
+    if (b1) atomicAdd(stat + 1, (unsigned int)__popcll(b1));
+    if (b2) atomicAdd(stat + 2, (unsigned int)__popcll(b2));
+    atomicMax(nmax, m);
+  }
+}
+// histogram of byte (n >> shift) & 255 over the SDs whose higher bytes equal `prefix`
+__global__ void __launch_bounds__(BS) k_rcyc_hist(const n_t *n, size_t N, n_t prefix, int shift, unsigned int *hist)
+{
+  __shared__ unsigned int lds[256];
+  lds[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t i = gid();
+  if (i < N) {
+    const n_t v = n[i];
+    const bool match = shift + 8 >= 64 ? true : (v >> (shift + 8)) == (prefix >> (shift + 8));
+    if (match) atomicAdd(&lds[(v >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (lds[threadIdx.x]) atomicAdd(hist + threadIdx.x, lds[threadIdx.x]);
+}
+// flag[i] = 1 where  mode 0: n == 0;  1: n == thr;  2: n > thr   (input of the ordered compaction k_mig_tiles / k_mig_ids)
+__global__ void k_rcyc_flag(const n_t *n, size_t N, int mode, n_t thr, uint8_t *flag)
+{
+  const size_t i = gid(); if (i >= N) return;
+  const n_t v = n[i];
+  flag[i] = uint8_t(mode == 0 ? v == 0 : mode == 1 ? v == thr : v > thr);
+}
+__global__ void k_gather_n(const uint32_t *ids, size_t m, const n_t *n, n_t *out) { const size_t i = gid(); if (i < m) out[i] = n[ids[i]]; }
+// receiver t takes every attribute of donor t and the bigger half of its multiplicity (rcyc.ipp:95-133)
+template <class T>
+__global__ void k_rcyc_apply(size_t k, const uint32_t *recv, const uint32_t *donor, attr_set<T> s, grid_t g)
+{
+  const size_t t = gid(); if (t >= k) return;
+  const uint32_t r = recv[t], d = donor[t];
+  s.rd3[r] = s.rd3[d]; s.rw2[r] = s.rw2[d]; s.kpa[r] = s.kpa[d]; s.vt[r] = s.vt[d];
+  if (g.nx) s.x[r] = s.x[d];
+  if (g.ny) s.y[r] = s.y[d];
+  if (g.nz) s.z[r] = s.z[d];
+  for (int e = 0; e < s.n_ext; ++e) s.ext[e][r] = s.ext[e][d];
+  const n_t big = s.n[d];
+  s.n[r] = big - big / 2;
+  s.n[d] = big / 2;
+}
+
 // parity hook (lcx_math_probe): the device elementary functions on an array
 __global__ void k_math_probe(int which, double *v, size_t n)
 {

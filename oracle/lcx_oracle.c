@@ -833,6 +833,7 @@ static void coal(orc_particles *s, double dt)
     }
 }
 
+static int mig_attrs(orc_particles *s, double **a);
 /* ---------------- advection, sedimentation, boundary (adve.ipp:28-304, sedi.ipp:13-25, subs.ipp:13-25, bcnd.ipp:99-368) -------- */
 static double adve_1d(int scheme, double x, sz fl, double C_l, double C_r, double dx)
 {
@@ -980,10 +981,47 @@ static void bcnd(orc_particles *s)
   }
 }
 /* post_copy.ipp:18-35 */
+/* housekeeping/particles_impl_rcyc.ipp:44-140: SDs with n == 0 are re-used as halves of the SDs with the highest
+ * multiplicities.  thrust::sort_by_key of the multiplicities is taken as the stable (radix) sort the CPU backends use. */
+static void rcyc(orc_particles *s)
+{
+  const sz N = s->n_part;
+  sz n_flagged = 0;
+  for (sz p = 0; p < N; ++p) n_flagged += s->n[p] == 0;
+  if (n_flagged == 0) return;
+  const sz n_to_rcyc = n_flagged;
+  if (s->pure_const_multi) { hskpng_remove_n0(s); return; }
+  s->sorted = 0;
+  sz *key = s->sorted_ijk, *sid = s->sorted_id;
+  for (sz p = 0; p < N; ++p) { sid[p] = p; key[p] = (sz)s->n[p]; }
+  {                                                   /* stable LSD radix sort of the 64-bit keys, 16 bits per pass */
+    sz *k2 = NEW(sz, N), *v2 = NEW(sz, N);
+    for (int pass = 0; pass < 4; ++pass) {
+      sz *cnt = NEW(sz, 65537);
+      const int sh = 16 * pass;
+      for (sz i = 0; i < N; ++i) cnt[((key[i] >> sh) & 0xffff) + 1]++;
+      for (sz c = 0; c < 65536; ++c) cnt[c + 1] += cnt[c];
+      for (sz i = 0; i < N; ++i) { const sz d = cnt[(key[i] >> sh) & 0xffff]++; k2[d] = key[i]; v2[d] = sid[i]; }
+      memcpy(key, k2, N * sizeof(sz)); memcpy(sid, v2, N * sizeof(sz));
+      free(cnt);
+    }
+    free(k2); free(v2);
+  }
+  sz n_splittable = 0;                               /* entries behind the last multiplicity-1 SD of the sorted sequence */
+  while (n_splittable < N && key[N - 1 - n_splittable] != 1) ++n_splittable;
+  if (n_splittable == 0) { hskpng_remove_n0(s); return; }
+  if (n_splittable < n_flagged) n_flagged = n_splittable;
+  double *attrs[16]; const int na = mig_attrs(s, attrs);             /* distmem_real_vctrs: everything but n */
+  for (int a = 0; a < na; ++a)
+    for (sz t = 0; t < n_flagged; ++t) attrs[a][sid[t]] = attrs[a][sid[N - 1 - t]];
+  for (sz t = 0; t < n_flagged; ++t) { const n_t big = s->n[sid[N - 1 - t]]; s->n[sid[t]] = big - big / 2; }
+  for (sz t = 0; t < n_flagged; ++t) { const n_t big = s->n[sid[N - 1 - t]]; s->n[sid[N - 1 - t]] = big / 2; }
+  if (n_flagged < n_to_rcyc) hskpng_remove_n0(s);
+}
 static int post_copy(orc_particles *s, const lcx_opts_t *opts)
 {
-  if (opts->rcyc) FAIL("libcloudph++: rcyc not supported by this backend");
-  hskpng_remove_n0(s);
+  if (opts->rcyc) rcyc(s);
+  else hskpng_remove_n0(s);
   hskpng_ijk(s);
   hskpng_count(s);
   return 0;

@@ -215,3 +215,38 @@ def test_const_multi_init_matches_oracle(mode):
     np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)
     for a in ("x", "y", "z"):
         np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14)
+
+
+@pytest.mark.parametrize("make", MAKERS)
+@pytest.mark.parametrize("vt", [lgrngn.vt_t.beard76, lgrngn.vt_t.beard77fast, lgrngn.vt_t.khvorostyanov_spherical])
+def test_sd_removal_with_recycling(make, vt):
+    """tests/python/unit/SD_removal.py (without its chemistry): 900 steps of pure coalescence with opts.rcyc -- recycling
+    splits the biggest SDs into the freed slots, so in the end every surviving SD has multiplicity 1"""
+    def expvolumelnr(lnr):
+        r_zero, n_zero = 30.531e-6, 2 ** 8
+        r = np.exp(lnr)
+        return n_zero * 3. * np.power(r, 3) / np.power(r_zero, 3) * np.exp(-np.power((r / r_zero), 3))
+    oi = lgrngn.opts_init_t()
+    oi.dt = 2 ** 15
+    oi.sstp_coal = 1
+    oi.dry_distros = {(.01, 0.): expvolumelnr}
+    oi.sd_conc = oi.n_sd_max = 64
+    oi.sedi_switch = False
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.terminal_velocity = vt
+    pr = make(oi)
+    th, rv, rhod = 300. * np.ones(1), .01 * np.ones(1), np.ones(1)
+    pr.init(th, rv, rhod)
+    opts = lgrngn.opts_t()
+    opts.adve = opts.sedi = opts.cond = False
+    opts.rcyc = True
+    for _ in range(900):
+        pr.step_sync(opts, th, rv, rhod)
+        pr.step_async(opts)
+    pr.diag_all()
+    pr.diag_sd_conc()
+    sd_conc = frombuffer(pr.outbuf())[0]
+    assert 0 < sd_conc <= 10
+    pr.diag_all()
+    pr.diag_wet_mom(0)
+    assert frombuffer(pr.outbuf())[0] == sd_conc

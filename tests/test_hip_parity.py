@@ -570,6 +570,45 @@ def test_fast_math_accuracy():
     np.testing.assert_array_equal(probe(1, xf), probe(3, xf))
 
 
+@pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
+def test_rcyc_matches_oracle(dims):
+    """opts.rcyc: the SDs freed by coalescence / precipitation are re-used as halves of the SDs with the highest
+    multiplicities (rcyc.ipp:44-140) -- same receivers, same donors (largest n first, higher id first among equals), same
+    split as the oracle's full stable sort of the multiplicities"""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 256 if nx == 0 else 40, sedi_switch=nz > 0)
+    if nx == 0:
+        oi.dx = oi.dy = oi.dz = oi.x1 = oi.y1 = oi.z1 = 1.
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    # rain-sized droplets: plenty of collisions and fall-out, so that several SDs per step reach n == 0
+    rw2 = orc.get_attr("rw2")
+    rw2[::2] = np.linspace(40e-6, 1.2e-3, len(rw2[::2])) ** 2
+    nn = orc.state_u64("n")
+    nn[1::3] = 1 + nn[1::3] % 3                                  # low multiplicities: collisions exhaust them
+    g = lambda nm: orc.state_real(nm)
+    args = (nn, g("rd3"), rw2, g("kappa"), g("vt"), g("x") if nx else None, g("y") if ny else None, g("z") if nz else None)
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.cond = False
+    opts.rcyc = True
+    if nz == 0:
+        opts.sedi = opts.adve = False
+    recycled = 0
+    for it in range(5):
+        n_before = orc.n_part
+        step_pair(orc, hip, opts, fields)
+        assert hip.n_part == orc.n_part
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-13)
+        np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-13)
+        recycled += int(orc.n_part == n_before)
+        h.copy_state(orc, hip)
+    assert recycled > 0, "test needs steps in which every freed SD was recycled"
+
+
 def test_storage_reorder_is_a_permutation_of_the_same_state():
     """opts_init.reorder_every (extension): physically re-ordering the storage into the cell order renumbers the ids but
     must not change any super-droplet: with coalescence off (no id-keyed random numbers) a run that re-orders after every
