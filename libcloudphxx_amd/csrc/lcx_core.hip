@@ -449,8 +449,14 @@ struct Particles : IParticles {
   void hskpng_vterm(bool only_invalid)
   {
     Range r(this, only_invalid ? "hskpng_vterm_invalid" : "hskpng_vterm_all");
-    if (nphys)
-      hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
+    if (!nphys) return;
+    if (vtc.formula == LCX_VT_BEARD77 || vtc.formula == LCX_VT_BEARD77FAST) {
+      vt_pre.alloc(ncell);
+      hipLaunchKernelGGL(k_vterm_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, p.p, rhod.p, eta.p, vt_pre.p);
+      hipLaunchKernelGGL(k_vterm_b77<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
+      return;
+    }
+    hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);
   }
   // cells per workgroup of the LDS-staged per-cell walks: as many as fit the staging buffer at the mean occupancy (+25 %)
   int cf_cells() const
@@ -755,7 +761,8 @@ struct Particles : IParticles {
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
       HIPCHK(hipMemsetAsync(d_dead.p, 0, sizeof(unsigned int), st));
     }
-    hipLaunchKernelGGL(k_move<T>, dim3(blocks), dim3(BS), 0, st, a);
+    if (adve_scheme == LCX_ADVE_PRED_CORR) hipLaunchKernelGGL((k_move<T, true>), dim3(blocks), dim3(BS), 0, st, a);
+    else hipLaunchKernelGGL((k_move<T, false>), dim3(blocks), dim3(BS), 0, st, a);
     if (want_puddle) {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
       hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
@@ -879,7 +886,7 @@ struct Particles : IParticles {
       log_rd_max = toms748_solve(lvl, lnrd_max, hi, lvl(lnrd_max), lvl(hi), eps_tol, 100u);
     } else throw lcx_error("opts_init.rd_min * opts_init.rd_max < 0");
   }
-  DevBuf<uint32_t> init_off; DevBuf<T> init_cdf;
+  DevBuf<uint32_t> init_off; DevBuf<T> init_cdf; DevBuf<beard77_cell<T>> vt_pre;
   // init_count_num.ipp:14-24,41-101 + init_ijk + init_dry_const_multi.ipp:20-80 + init_n_const_multi, then finalize
   void init_const_multi_like(const lcx_distro_t &d, n_t const_multi)
   {

@@ -433,6 +433,28 @@ __device__ __forceinline__ T vt_eval(const vt_cfg &v, T rw2, T Tk, T p, T rhod, 
     default: return T(0);
   }
 }
+// beard77 / beard77fast: the cell-only part of the correction factor (two square roots and four divisions of every
+// evaluation) is computed once per cell; k_vterm_b77 then needs one load per SD of it instead of p, rhod, eta
+template <class T>
+__global__ void k_vterm_cellpre(size_t n_cell, const T *p, const T *rhod, const T *eta, beard77_cell<T> *out)
+{ const size_t c = gid(); if (c < n_cell) out[c] = vt_beard77_cellpart(p[c], rhod[c], eta[c]); }
+template <class T>
+__global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const beard77_cell<T> *pre, const T *vt_0, T *vt)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const T r2 = rw2[i];
+  if (!(r2 > T(0))) return;
+  if (only_invalid && !(vt[i] == T(-1))) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
+  const T r = sqrt(r2);
+  const T f = vt_beard77_fact_pre(r, pre[c]);
+  if (v.formula == LCX_VT_BEARD77) { vt[i] = f * T(vt_beard77_v0(double(r))); return; }
+  const T lnmin = T(v.ln_r_min), lnmax = T(v.ln_r_max), dlnr = (lnmax - lnmin) / v.n_bin;
+  const T lnr = .5 * log(r2);
+  const int bin = lnr <= lnmin ? 0 : lnr >= lnmax ? v.n_bin - 1 : int((lnr - lnmin) / dlnr);
+  vt[i] = f * vt_0[bin];
+}
 template <class T>
 __global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const T *Tk, const T *p,
                         const T *rhod, const T *eta, const T *vt_0, T *vt)
@@ -916,7 +938,8 @@ template <class T> __device__ __forceinline__ T fmod_nonneg(T arg, T L)
 }
 template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return a + fmod_nonneg((x - a) + 10 * (b - a), b - a); }
 
-template <class T>
+// PC: the predictor-corrector scheme is a separate instantiation (its extra live state costs the first-order schemes 12 %)
+template <class T, bool PC>
 __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
 {
   __shared__ double red[4][BS / WAVE];
@@ -937,7 +960,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     uint32_t ci = c, cj = 0, ck = 0;
     if (g.ndims >= 2) { const uint32_t cij = c / nz; ck = c - cij * nz; ci = cij; if (g.ndims == 3) { ci = cij / ny; cj = cij - ci * ny; } }
     uint32_t k_subs = ck;                               // subs reads w_LS at the k of `ijk`, which pred_corr leaves at the predictor cell
-    if (a.do_adve && g.ndims > 0 && a.scheme != LCX_ADVE_PRED_CORR) {
+    if (!PC && a.do_adve && g.ndims > 0) {
       // euler / implicit; with a Courant halo (opts_init.adve_scheme == pred_corr, fallen back to first order for this
       // step) the arrays start `halo` planes to the left: adve_calc(true, halo_x), adve.ipp:169-183
       const uint32_t cih = ci + a.halo;
@@ -952,7 +975,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
         const size_t blw = g.ndims == 2 ? ce + cih : ce + size_t(ny) * cih + cj;
         z = adve_1d(a.scheme, z, ck, a.courant_z[blw], a.courant_z[blw + 1], a.dz);
       }
-    } else if (a.do_adve && g.ndims > 0) {
+    } else if (PC && a.do_adve && g.ndims > 0) {
       // predictor-corrector with nearest-neighbour interpolation (adve.ipp:184-304), all in registers: coordinates that
       // start at the halo's left edge; predictor = explicit Euler from the old cell; corrector = the explicit increment at the
       // predicted position averaged with it

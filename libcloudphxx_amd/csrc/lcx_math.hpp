@@ -512,6 +512,29 @@ LCX_HD double vt_beard77_v0(double r)
   else            for (int i = 0; i < 8; ++i) y += m_l[i] * pow(x, double(i));
   return exp(y) / 100.;
 }
+// The part of vt_beard77_fact that depends on the cell only (evaluated once per cell by k_vterm_cellpre, the very same
+// expressions): l of the small-droplet branch, eta_0 / eta, eps_c of the large-droplet branch
+template <class T> struct beard77_cell { T l, e0e, eps_c; };
+template <class T> LCX_HD beard77_cell<T> vt_beard77_cellpart(T p, T rhoa, T eta)
+{
+  using c = cst<T>;
+  const T eta_0 = T(1.818e-5), l_0 = T(6.62e-8);
+  beard77_cell<T> b;
+  b.l = l_0 * (eta / eta_0) * sqrt(c::p_stp / p * c::rho_stp / rhoa);
+  b.e0e = eta_0 / eta;
+  b.eps_c = sqrt(c::rho_stp / rhoa) - 1;
+  return b;
+}
+template <class T> LCX_HD T vt_beard77_fact_pre(T r, const beard77_cell<T> &b)
+{
+  if (r <= T(20e-6)) {
+    const T l_0 = T(6.62e-8);
+    return b.e0e * (1 + T(1.255) * (b.l / r)) / (1 + T(1.255) * (l_0 / r));
+  } else {
+    const T eps_s = b.e0e - 1;
+    return T(1.104) * eps_s + ((T(1.058) * b.eps_c - T(1.104) * eps_s) * (T(5.52) + log(2 * 100 * r)) / T(5.01)) + 1;
+  }
+}
 template <class T> LCX_HD T vt_beard77_fact(T r, T p, T rhoa, T eta)
 {
   using c = cst<T>;
