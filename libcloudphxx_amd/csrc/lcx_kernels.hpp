@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // stages in LDS with coalesced loads; then one lane per cell walks its segment in LDS.  (A lane-per-cell walk
 // straight from global memory touches 64 different cache lines per load instruction and ran 10x slower.)
 constexpr int CF_CELLS = 64;            // cells per workgroup at most; the host lowers it (cf_cells) when cells hold many SDs
-constexpr int CF_CAP = 6144;            // reals staged per workgroup (48 KiB of fp64)
+constexpr int CF_CAP = 2048;            // reals staged per workgroup (16 KiB of fp64 = 10 workgroups per CU; measured 6144: 1.05 ms, 2048: 0.64, 1024: 0.80)
 template <class T>
 __device__ __forceinline__ T seg_sum(const T *lds, const T *glob, bool staged, uint32_t base, uint32_t s, uint32_t e)
 {
