@@ -166,6 +166,11 @@ int lcx_diag_kappa_rng_cons(lcx_particles *, double k_mi, double k_mx);
 int lcx_diag_dry_mom(lcx_particles *, int k);
 int lcx_diag_wet_mom(lcx_particles *, int k);
 int lcx_diag_kappa_mom(lcx_particles *, int k);
+/* selections by activation state (particles_diag.ipp:350-407): RH >= critical supersaturation / r_w >= critical radius */
+int lcx_diag_RH_ge_Sc(lcx_particles *);
+int lcx_diag_rw_ge_rc(lcx_particles *);
+/* kernel-density estimate of the wet mass density function at radius rad (particles_diag.ipp:494-497, mass_dens.ipp:7-120) */
+int lcx_diag_wet_mass_dens(lcx_particles *, double rad, double sig0);
 int lcx_diag_precip_rate(lcx_particles *);
 int lcx_diag_max_rw(lcx_particles *);
 /* outbuf(): pointer into library-owned HOST memory, n_cell reals, valid until the next

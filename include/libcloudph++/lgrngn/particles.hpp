@@ -50,6 +50,9 @@ namespace libcloudphxx { namespace lgrngn {
     virtual void diag_kappa_mom(const int &) { assert(false); }
     virtual void diag_max_rw() { assert(false); }
     virtual void diag_precip_rate() { assert(false); }
+    virtual void diag_RH_ge_Sc() { assert(false); }
+    virtual void diag_rw_ge_rc() { assert(false); }
+    virtual void diag_wet_mass_dens(const real_t &, const real_t &) { assert(false); }
     virtual std::map<common::output_t, real_t> diag_puddle() { assert(false); return std::map<common::output_t, real_t>(); }
     virtual std::vector<real_t> get_attr(const std::string &) { assert(false); return std::vector<real_t>(); }
     virtual real_t *outbuf() { assert(false); return nullptr; }
@@ -187,6 +190,9 @@ namespace libcloudphxx { namespace lgrngn {
     void diag_kappa_mom(const int &k) override { detail::lcx_check(lcx_diag_kappa_mom(pimpl->h, k)); }
     void diag_max_rw() override { detail::lcx_check(lcx_diag_max_rw(pimpl->h)); }
     void diag_precip_rate() override { detail::lcx_check(lcx_diag_precip_rate(pimpl->h)); }
+    void diag_RH_ge_Sc() override { detail::lcx_check(lcx_diag_RH_ge_Sc(pimpl->h)); }
+    void diag_rw_ge_rc() override { detail::lcx_check(lcx_diag_rw_ge_rc(pimpl->h)); }
+    void diag_wet_mass_dens(const real_t &rad, const real_t &sig0) override { detail::lcx_check(lcx_diag_wet_mass_dens(pimpl->h, rad, sig0)); }
     std::map<common::output_t, real_t> diag_puddle() override
     {
       double v[LCX_OUT_COUNT];

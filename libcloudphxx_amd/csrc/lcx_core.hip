@@ -69,6 +69,8 @@ struct IParticles {
   virtual void diag_select(int mode, int cons, int attr, double a, double b) = 0;   // attr: 0 rd3, 1 rw2, 2 kpa
   virtual void diag_mom(int attr, double power) = 0;
   virtual void diag_precip_rate() = 0;
+  virtual void diag_act(int which) = 0;             // 0 RH >= Sc, 1 rw >= rc
+  virtual void diag_wet_mass_dens(double rad, double sig0) = 0;
   virtual void diag_max_rw() = 0;
   virtual void outbuf(const void **data, size_t *n) = 0;
   virtual void get_attr(const char *name, void *out, size_t cap, size_t *n) = 0;
@@ -213,6 +215,15 @@ struct Particles : IParticles {
     memcpy(dst, pinned, n * sizeof(S));
   }
 
+  // host -> device on OUR stream.  (A plain hipMemcpy runs on the null stream, which a non-blocking stream does not wait
+  // for: it may return with the DMA from its staging buffer still in flight and the next kernel on `st` could read stale
+  // device memory.)
+  void h2d(void *dst, const void *src, size_t bytes)
+  {
+    if (!bytes) return;
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    sync();
+  }
   void alloc_attrs(Attrs &a)
   {
     a.n.alloc(cap); a.rd3.alloc(cap); a.rw2.alloc(cap); a.kpa.alloc(cap); a.vt.alloc(cap);
@@ -360,11 +371,11 @@ struct Particles : IParticles {
     if (kind == 0) {
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(data[i]);
       r.u01.reset(new DevBuf<T>()); r.u01->alloc(n);
-      HIPCHK(hipMemcpy(r.u01->p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+      h2d(r.u01->p, h.data(), n * sizeof(T));
     } else if (kind == 1) {
       std::vector<uint32_t> h(n); for (size_t i = 0; i < n; ++i) h[i] = uint32_t(T(data[i]));   // fnctr_un goes through real_t
       r.un.reset(new DevBuf<uint32_t>()); r.un->alloc(n);
-      HIPCHK(hipMemcpy(r.un->p, h.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+      h2d(r.un->p, h.data(), n * sizeof(uint32_t));
     } else throw lcx_error("libcloudph++: unknown rng replay kind");
     replay.push_back(std::move(r));
   }
@@ -1024,7 +1035,7 @@ struct Particles : IParticles {
     }
     std::vector<T> h(params.begin(), params.end());
     kparams.alloc(h.size());
-    if (!h.empty()) HIPCHK(hipMemcpy(kparams.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    h2d(kparams.p, h.data(), h.size() * sizeof(T));
   }
   void sanity_init(const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *p_,
                    const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz)
@@ -1084,8 +1095,8 @@ struct Particles : IParticles {
       default: break;
     }
     courant_x.alloc_zero(n_cx, st); courant_y.alloc_zero(n_cy, st); courant_z.alloc_zero(n_cz, st);
-    if (!w_LS_h.empty()) { std::vector<T> h(w_LS_h.begin(), w_LS_h.end()); w_LS.alloc(h.size()); HIPCHK(hipMemcpy(w_LS.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
-    if (!conc_factor_h.empty()) { std::vector<T> h(conc_factor_h.begin(), conc_factor_h.end()); conc_factor.alloc(h.size()); HIPCHK(hipMemcpy(conc_factor.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+    if (!w_LS_h.empty()) { std::vector<T> h(w_LS_h.begin(), w_LS_h.end()); w_LS.alloc(h.size()); h2d(w_LS.p, h.data(), h.size() * sizeof(T)); }
+    if (!conc_factor_h.empty()) { std::vector<T> h(conc_factor_h.begin(), conc_factor_h.end()); conc_factor.alloc(h.size()); h2d(conc_factor.p, h.data(), h.size() * sizeof(T)); }
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     sync_in_arr(p_, p, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
@@ -1227,6 +1238,27 @@ struct Particles : IParticles {
                        int(specific && n_dims > 0), count_mom.p);
     sync();
   }
+  void diag_act(int which) override
+  {                                                                                      // particles_diag.ipp:350-407
+    hskpng_sort();
+    need_nfiltered();
+    if (nphys)
+      hipLaunchKernelGGL(k_nfilt_act<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, which, A.n.p, A.rd3.p, A.kpa.p, A.rw2.p, ijk.p, Tk.p, RH.p, n_filtered.p);
+    selected_before_counting = true;
+    sync();
+  }
+  void diag_wet_mass_dens(double rad, double sig0) override
+  {                                                                                      // mass_dens.ipp:36-118
+    if (!selected_before_counting) throw lcx_error("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
+    hskpng_sort();
+    if (npart)
+      hipLaunchKernelGGL(k_massdens_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, n_filtered.p, A.rw2.p,
+                         T(rad), T(sig0), m3_after.p);
+    hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p, 0, count_mom.p);
+    hipLaunchKernelGGL(k_massdens_scale<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, dv.p,
+                       T(T(4. / 3.) * cst<T>::rho_w * T(std::sqrt(M_PI / 2.))), count_mom.p);
+    sync();
+  }
   void diag_sd_conc() override { moms_sum(A.rw2.p, T(0), 1, false); }
   void diag_mom(int attr, double power) override { moms_sum(attr_ptr(attr), T(power), 0, true); }
   void diag_precip_rate() override
@@ -1322,9 +1354,9 @@ struct Particles : IParticles {
     auto up = [&](DevBuf<T> &b, const double *src) {
       if (!src || !b.p || !n) return;
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(src[i]);
-      HIPCHK(hipMemcpy(b.p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+      h2d(b.p, h.data(), n * sizeof(T));
     };
-    if (n) HIPCHK(hipMemcpy(A.n.p, mult, n * sizeof(n_t), hipMemcpyHostToDevice));
+    h2d(A.n.p, mult, n * sizeof(n_t));
     up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
     if (n) HIPCHK(hipMemsetAsync(ijk.p, 0, n * sizeof(uint32_t), st));     // every SD is in the order again, n == 0 included
     hskpng_ijk();
@@ -1503,6 +1535,9 @@ int lcx_diag_kappa_rng_cons(lcx_particles *h, double a, double b) { LCX_TRY(H->d
 int lcx_diag_dry_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(0, k / 3.)) }
 int lcx_diag_wet_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(1, k / 2.)) }
 int lcx_diag_kappa_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(2, k)) }
+int lcx_diag_RH_ge_Sc(lcx_particles *h) { LCX_TRY(H->diag_act(0)) }
+int lcx_diag_rw_ge_rc(lcx_particles *h) { LCX_TRY(H->diag_act(1)) }
+int lcx_diag_wet_mass_dens(lcx_particles *h, double rad, double sig0) { LCX_TRY(H->diag_wet_mass_dens(rad, sig0)) }
 int lcx_diag_precip_rate(lcx_particles *h) { LCX_TRY(H->diag_precip_rate()) }
 int lcx_diag_max_rw(lcx_particles *h) { LCX_TRY(H->diag_max_rw()) }
 int lcx_outbuf(lcx_particles *h, const void **data, size_t *n) { LCX_TRY(H->outbuf(data, n)) }

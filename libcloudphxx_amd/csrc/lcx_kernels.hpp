@@ -67,7 +67,8 @@ __global__ void k_scatter_strided(T *dst, const T *src, size_t n, int ndims, int
 constexpr int SCAN_TILE = 2048;         // 256 threads x 8 items, items interleaved for coalescing
 
 // block-wide exclusive prefix of one value per thread (wave shuffles + LDS across the 4 waves)
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &total, uint32_t *lds /*>=5*/)
+constexpr int SCAN_MAX_WAVES = 16;      // block_exclusive_scan serves workgroups of up to 1024 threads (k_scan_sums)
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &total, uint32_t *lds /* SCAN_MAX_WAVES entries */)
 {
   uint32_t inc = v;
 #pragma unroll
@@ -82,7 +83,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &t
 }
 __global__ void k_scan_tiles(const uint32_t *in, uint32_t *out, uint32_t *tile_sums, size_t n)
 {
-  __shared__ uint32_t lds[8];
+  __shared__ uint32_t lds[SCAN_MAX_WAVES];
   const size_t base = size_t(blockIdx.x) * SCAN_TILE;
   uint32_t run = 0;
   for (int it = 0; it < SCAN_TILE / BS; ++it) {
@@ -98,7 +99,7 @@ __global__ void k_scan_tiles(const uint32_t *in, uint32_t *out, uint32_t *tile_s
 // single workgroup: in-place exclusive scan of the tile sums; writes the grand total to *total
 __global__ void k_scan_sums(uint32_t *sums, size_t m, uint32_t *total)
 {
-  __shared__ uint32_t lds[8];
+  __shared__ uint32_t lds[SCAN_MAX_WAVES];
   uint32_t run = 0;
   for (size_t base = 0; base < m; base += blockDim.x) {
     const size_t i = base + threadIdx.x;
@@ -1194,6 +1195,30 @@ __global__ void k_nfilt(size_t n_part, int mode, int cons, const n_t *n, const T
   else if (mode == 1) { const T v = vec[i]; nf[i] = (v >= vmin && v < vmax) ? y : T(0); }
   else nf[i] = y * (vec[i] > 0);
 }
+// selections by activation state (particles_diag.ipp:350-407): which 0: RH[cell] - S_cr >= 0, 1: rw2 >= rc2
+template <class T>
+__global__ void k_nfilt_act(size_t n_part, int which, const n_t *n, const T *rd3, const T *kpa, const T *rw2, const uint32_t *ijk,
+                            const T *Tk, const T *RH, T *nf)
+{
+  const size_t i = gid(); if (i >= n_part) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) { nf[i] = 0; return; }
+  const T y = T(n[i]);
+  if (which == 0) { const T v = RH[c] - S_cr(rd3[i], kpa[i], Tk[c]); nf[i] = y * (v >= 0); }
+  else nf[i] = rw2[i] >= rc2_of(rd3[i], kpa[i], Tk[c]) ? y : T(0);
+}
+// mass_dens_estimator (mass_dens.ipp:14-34) per sorted position; the kernel width uses the SD count of the cell
+template <class T>
+__global__ void k_massdens_vals(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
+                                const T *nf, const T *rw2, T rad, T sig0, T *out)
+{
+  const size_t p = gid(); if (p >= n_part) return;
+  const uint32_t id = sorted_id[p], c = sorted_ijk[p];
+  const T x = rw2[id], sig = sig0 / pow(T(cell_start[c + 1] - cell_start[c]), T(0.2));
+  out[p] = nf[id] / sig * pow(x, 3 * T(.5)) * exp(-pow((log(pow(x, T(.5))) - log(rad)) / sig, T(2)) / T(2.));
+}
+template <class T> __global__ void k_massdens_scale(size_t n_cell, const uint32_t *cell_start, const T *dv, T prefactor, T *v)
+{ const size_t c = gid(); if (c < n_cell && cell_start[c + 1] > cell_start[c]) v[c] = prefactor * v[c] / dv[c]; }
 // per sorted position: value to be summed.  kind 0: n_f * vec^power (moment_counter, moms.ipp:243-275), 1: n_f > 0,
 // 2: n_f * (rw2^(3/2) * vt)  (precip_rate, particles_diag.ipp:56-68 with power 1)
 template <class T>

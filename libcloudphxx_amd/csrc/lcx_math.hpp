@@ -274,6 +274,19 @@ template <class T> LCX_HD T rc2_of(T rd3, T kappa, T Tk)
   return pow(rw3, T(2. / 3));
 }
 
+template <class T> LCX_HD T rw3_cr_of(T rd3, T kappa, T Tk)
+{
+  const rw3_cr_minfun f{double(rd3), double(kappa), kelvin_A(double(Tk))};
+  const double a = 1e0 * double(rd3), b = 1e8 * double(rd3);
+  return T(toms748_solve(f, a, b, f(a), f(b), eps_tolerance<double>(sizeof(double) * 8 / 4), 100u));
+}
+// critical supersaturation, kappa_koehler.hpp:168-189
+template <class T> LCX_HD T S_cr(T rd3, T kappa, T Tk)
+{
+  const T rw3 = rw3_cr_of(rd3, kappa, Tk);
+  return a_w(rw3, rd3, kappa) * exp(kelvin_A(Tk) / T(cbrt(rw3)));
+}
+
 // ---- condensational growth: condensation/common/particles_impl_cond_common.ipp:80-338,
 //      maxwell-mason.hpp:15-47, ventil.hpp:16-80
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet

@@ -399,6 +399,11 @@ class particles_t:
     diag_all = _diag0("diag_all")
     diag_water = _diag0("diag_water")
     diag_precip_rate = _diag0("diag_precip_rate")
+    diag_RH_ge_Sc = _diag0("diag_RH_ge_Sc")
+    diag_rw_ge_rc = _diag0("diag_rw_ge_rc")
+
+    def diag_wet_mass_dens(self, rad, sig0):
+        self._chk(self._f("diag_wet_mass_dens")(self._h, C.c_double(rad), C.c_double(sig0)))
     diag_max_rw = _diag0("diag_max_rw")
     diag_dry_rng = _diag2("diag_dry_rng")
     diag_wet_rng = _diag2("diag_wet_rng")

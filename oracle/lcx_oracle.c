@@ -1587,6 +1587,49 @@ int orc_diag_precip_rate(orc_particles *s)
   moms_calc(s, s->tmp_part, 1., 0);
   return 0;
 }
+/* particles_diag.ipp:350-407 + moms.ipp:112-155 */
+int orc_diag_RH_ge_Sc(orc_particles *s)
+{
+  hskpng_sort(s);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const sz c = s->ijk[p];
+    const double v = s->RH[c] - S_cr(s->rd3[p], s->kpa[p], s->T[c]);
+    s->n_filtered[p] = (double)s->n[p] * (v >= 0);
+  }
+  s->selected_before_counting = 1;
+  return 0;
+}
+int orc_diag_rw_ge_rc(orc_particles *s)
+{
+  hskpng_sort(s);
+  for (sz p = 0; p < s->n_part; ++p) {
+    const double rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
+    s->n_filtered[p] = s->rw2[p] >= rc2 ? (double)s->n[p] : 0;
+  }
+  s->selected_before_counting = 1;
+  return 0;
+}
+/* particles_diag.ipp:494-497, mass_dens.ipp:7-120 (the kernel width uses the number of SDs of the SD's cell) */
+int orc_diag_wet_mass_dens(orc_particles *s, double rad, double sig0)
+{
+  NEED_SELECTION;
+  hskpng_sort(s);
+  hskpng_count(s);
+  for (sz c = 0; c < s->n_cell; ++c) s->scl[c] = 0.;
+  for (sz i = 0; i < s->count_n; ++i) s->scl[s->count_ijk[i]] = (double)s->count_num[i];
+  sz cn = 0;
+  for (sz q = 0; q < s->n_part; ++q) {
+    const sz id = s->sorted_id[q], c = s->sorted_ijk[q];
+    const double x = s->rw2[id], sig = sig0 / pow(s->scl[c], 0.2);
+    const double v = s->n_filtered[id] / sig * pow(x, 3 * .5) * exp(-pow((log(pow(x, .5)) - log(rad)) / sig, 2) / 2.);
+    if (q == 0 || c != s->sorted_ijk[q - 1]) { s->count_ijk[cn] = c; s->count_mom[cn] = v; ++cn; }
+    else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
+  }
+  s->count_n = cn;
+  const double prefactor = 4. / 3. * rho_w * sqrt(ORC_PI / 2.);
+  for (sz i = 0; i < cn; ++i) s->count_mom[i] = prefactor * s->count_mom[i] / s->dv[s->count_ijk[i]];
+  return 0;
+}
 /* particles_diag.ipp:607-640: max wet radius per cell */
 int orc_diag_max_rw(orc_particles *s)
 {

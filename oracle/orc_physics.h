@@ -267,6 +267,13 @@ static inline double rw3_cr(double rd3, double kappa, double T)
                      orc_eps_tolerance(sizeof(double) * 8 / 4), &it);
 }
 
+/* critical supersaturation, kappa_koehler.hpp:168-189 */
+static inline double S_cr(double rd3, double kappa, double T)
+{
+  const double rw3 = rw3_cr(rd3, kappa, T);
+  return a_w(rw3, rd3, kappa) * klvntrm(cbrt(rw3), T);
+}
+
 /* ---- condensation: src/impl/condensation/common/particles_impl_cond_common.ipp:80-338 ---- */
 typedef struct {
   double rw2_old, dt, rhod, rv, T, p, RH, eta, rd3, kpa, vt, RH_max, lambda_D, lambda_K;

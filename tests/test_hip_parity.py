@@ -472,12 +472,18 @@ def test_diagnostics_match_oracle():
         lambda p: (p.diag_water(), p.diag_wet_mom(2)),
         lambda p: (p.diag_all(), p.diag_precip_rate()),
         lambda p: p.diag_max_rw(), lambda p: p.diag_RH(), lambda p: p.diag_temperature(), lambda p: p.diag_pressure(),
+        lambda p: (p.diag_RH_ge_Sc(), p.diag_wet_mom(0)), lambda p: (p.diag_rw_ge_rc(), p.diag_wet_mom(0)),
+        lambda p: (p.diag_rw_ge_rc(), p.diag_sd_conc()),
+        lambda p: (p.diag_all(), p.diag_wet_mass_dens(8e-6, .62)), lambda p: (p.diag_wet_rng(1e-6, 1.), p.diag_wet_mass_dens(2e-6, .4)),
     ]
     for i, fn in enumerate(checks):
         o, g_ = both(fn)
         # #10 (precip rate) recomputes vt on both sides, #12-14 (RH, T, p) are functions of th/rv AFTER the condensation
         # feedback of the step above: exp/log/pow/cbrt differ by an ulp between glibc and the device
-        np.testing.assert_allclose(g_, o, rtol=1e-8 if i in (10, 12, 13, 14) else 1e-11, atol=0, err_msg="diag #%d" % i)
+        # #15-17 select by the critical radius / supersaturation (exact counts unless an SD sits on the threshold), #18-19 kernel estimate
+        np.testing.assert_allclose(g_, o, rtol=1e-8 if i in (10, 12, 13, 14, 18, 19) else 1e-11, atol=0, err_msg="diag #%d" % i)
+        if i in (15, 16, 17):
+            assert o.sum() > 0 and o.sum() < orc.n_part * 1e12, "selection must be neither empty nor everything"
     with pytest.raises(RuntimeError):
         fresh = h.hip_particles(oi)
         fresh.init(fields[0].copy(), fields[1].copy(), fields[2].copy(), **fields[3])

@@ -76,6 +76,9 @@ def test_golovin_analytic(opts_dt, init):
     for i in range(res.size):
         rad = (bins[i] + bins[i + 1]) / 2.
         res[i] = mass_dens(pr, rad)
+        pr.diag_all()
+        pr.diag_wet_mass_dens(rad, .62)                    # the device estimator against the host restatement above
+        assert abs(np.frombuffer(pr.outbuf())[0] - res[i]) <= 1e-9 * abs(res[i]) + 1e-300
         vol = 4. / 3. * rad ** 3 * np.pi
         ana[i] = golovin(vol, simulation_time, n_init, v_zero, b) * vol * vol * 3000.
     sel = (res > 0) | (ana > 0)
