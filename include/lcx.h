@@ -89,6 +89,7 @@ typedef struct {
   int rng_seed, rng_seed_init, rng_seed_init_switch;
   int dev_count, dev_id;
   const double *w_LS; int n_w_LS;
+  const double *SGS_mix_len; int n_SGS_mix_len;             /* opts_init.hpp: SGS mixing length profile [m], size nz */
   const double *aerosol_conc_factor; int n_aerosol_conc_factor;
   double rd_min, rd_max;
   int no_ccn_at_init, open_side_walls, periodic_topbot_walls;

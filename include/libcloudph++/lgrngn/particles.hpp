@@ -94,8 +94,7 @@ namespace libcloudphxx { namespace lgrngn {
 
     explicit particles_t(opts_init_t<real_t> oi, int n_x_tot = 0) : pimpl(new impl)
     {
-      if (!oi.rlx_dry_distros.empty() || !oi.SGS_mix_len.empty() && (oi.turb_adve_switch || oi.turb_cond_switch))
-        throw std::runtime_error("libcloudph++: option outside the accelerated hot path (rlx / SGS turbulence)");
+      if (!oi.rlx_dry_distros.empty()) throw std::runtime_error("libcloudph++: option outside the accelerated hot path (rlx)");
       pimpl->opts_init = oi;
       this->opts_init = &pimpl->opts_init;
       lcx_opts_init_t c;
@@ -108,7 +107,8 @@ namespace libcloudphxx { namespace lgrngn {
       c.variable_dt_switch = o.variable_dt_switch; c.sd_const_multi = o.sd_const_multi; c.n_sd_max = o.n_sd_max;
       c.kernel = int(o.kernel); c.terminal_velocity = int(o.terminal_velocity); c.adve_scheme = int(o.adve_scheme); c.RH_formula = int(o.RH_formula);
       std::vector<double> kp(o.kernel_parameters.begin(), o.kernel_parameters.end()), wls(o.w_LS.begin(), o.w_LS.end()),
-                          acf(o.aerosol_conc_factor.begin(), o.aerosol_conc_factor.end());
+                          acf(o.aerosol_conc_factor.begin(), o.aerosol_conc_factor.end()), sgs(o.SGS_mix_len.begin(), o.SGS_mix_len.end());
+      c.SGS_mix_len = sgs.data(); c.n_SGS_mix_len = int(sgs.size());
       c.kernel_parameters = kp.data(); c.n_kernel_parameters = int(kp.size());
       c.w_LS = wls.data(); c.n_w_LS = int(wls.size());
       c.aerosol_conc_factor = acf.data(); c.n_aerosol_conc_factor = int(acf.size());

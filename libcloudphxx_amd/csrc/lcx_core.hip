@@ -118,6 +118,9 @@ struct Particles : IParticles {
   // further attributes (ext[]) that are compacted and migrate with it
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
+  int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
+  std::vector<double> SGS_mix_len_h; DevBuf<T> SGS_mix_len, diss_rate, tau_cell, tau_rlx;
+  bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
   DevBuf<uint8_t> mig;
   DevBuf<uint64_t> sort_scratch;
@@ -154,9 +157,8 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   explicit Particles(const lcx_opts_init_t &oi) : o(oi)
   {
-    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_adve_switch || oi.turb_cond_switch ||
-        oi.turb_coal_switch || oi.diag_incloud_time)
-      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
+    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_coal_switch || oi.diag_incloud_time)
+      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb_coal)");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
     sizes.assign(oi.dry_sizes, oi.dry_sizes + oi.n_dry_sizes);
@@ -178,6 +180,12 @@ struct Particles : IParticles {
     use_rc2 = oi.sstp_cond_act > 1 && allow_sstp_cond;                               // :488-491
     if (exact) { ix_rv = n_ext++; ix_th = n_ext++; ix_rh = n_ext++; if (oi.const_p) ix_p = n_ext++; }
     if (use_rc2) ix_rc2 = n_ext++;
+    // SGS turbulence: velocity perturbations (turb_adve: one per dimension; turb_cond: the vertical one) and the supersaturation
+    // perturbation with its tendency travel with the SD as well (particles_impl.ipp:461-473)
+    if (oi.turb_adve_switch) { if (oi.nx) ix_up = n_ext++; if (oi.ny) ix_vp = n_ext++; if (oi.nz) ix_wp = n_ext++; }
+    if (oi.turb_cond_switch) { if (ix_wp < 0) ix_wp = n_ext++; ix_ssp = n_ext++; ix_dot_ssp = n_ext++; }
+    SGS_mix_len_h.assign(oi.SGS_mix_len, oi.SGS_mix_len + oi.n_SGS_mix_len);
+    o.SGS_mix_len = nullptr;
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
     adve_scheme = oi.adve_scheme;
     halo = oi.adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;                               // particles_impl.ipp:361
@@ -192,6 +200,13 @@ struct Particles : IParticles {
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
     alloc_attrs(A);
+    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp}) if (ix >= 0) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, cap * sizeof(T), st));
+    if (turb()) {
+      diss_rate.alloc_zero(ncell, st); tau_cell.alloc_zero(ncell, st); tau_rlx.alloc_zero(ncell, st);
+      std::vector<T> hm(SGS_mix_len_h.begin(), SGS_mix_len_h.end());
+      SGS_mix_len.alloc(hm.size());
+      h2d(SGS_mix_len.p, hm.data(), hm.size() * sizeof(T));
+    }
     if (use_rc2) hipLaunchKernelGGL(k_fill<T>, dim3(nblk(cap)), dim3(BS), 0, st, A.ext[ix_rc2].p, cap, T(-1));   // detail::invalid, particles_impl.ipp:490
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
@@ -368,7 +383,7 @@ struct Particles : IParticles {
   void rng_replay_push(int kind, const double *data, size_t n) override
   {
     Replay r; r.kind = kind; r.n = n;
-    if (kind == 0) {
+    if (kind == 0 || kind == 2) {                        // 0: uniform [0,1), 2: standard normal
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(data[i]);
       r.u01.reset(new DevBuf<T>()); r.u01->alloc(n);
       h2d(r.u01->p, h.data(), n * sizeof(T));
@@ -650,13 +665,14 @@ struct Particles : IParticles {
     for (int ix = 0; ix < (var_rho ? 3 : 2); ++ix)
       hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
   }
-  void cond_substep(double RH_max, int step)
+  void cond_substep(double RH_max, int step, bool turb_cond = false)
   {
     hskpng_sort();
     if (npart) {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
-                     lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell};
+                     lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
+                     turb_cond ? A.ext[ix_ssp].p : nullptr};
       if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
       else hipLaunchKernelGGL((k_cond<T, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
     }
@@ -720,6 +736,41 @@ struct Particles : IParticles {
     hipLaunchKernelGGL(k_pp_mix_finish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, A.ext[ix_rv].p, A.ext[ix_th].p,
                        pp_dst_rv.p, pp_dst_th.p, rv.p, th.p);
   }
+  bool turb_adve_now = false;
+  normal_src<T> rand_normal(size_t n)
+  {
+    if (!replay.empty()) {
+      Replay r = std::move(replay.front()); replay.pop_front();
+      if (r.kind != 2 || r.n < n) throw lcx_error("libcloudph++: rng replay queue does not match the requested rand_normal call");
+      const T *ptr = r.u01->p;
+      replay_keep_T.push_back(std::move(r.u01));
+      return normal_src<T>{ptr, 0, 0};
+    }
+    return normal_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+  }
+  // hskpng_tke + hskpng_turb_vel (+ hskpng_turb_dot_ss): particles_step.ipp:406-427
+  void sgs_turbulence(const lcx_opts_t &opts)
+  {
+    Range r(this, "sgs_turbulence");
+    if (!replay.empty()) ensure_compact();
+    hipLaunchKernelGGL(k_tke_tau<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, m1(o.nz), SGS_mix_len.p, diss_rate.p, tau_cell.p);
+    const int comp[3] = {ix_up, ix_wp, ix_vp};                                           // the reference's order: up, wp, vp
+    const int lo = opts.turb_adve ? 0 : 1, hi = opts.turb_adve ? n_dims : 2;
+    for (int i = lo; i < hi; ++i) {
+      const normal_src<T> rs = rand_normal(npart);
+      hipLaunchKernelGGL(k_turb_vel<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, tau_cell.p, diss_rate.p, T(dt), rs, A.ext[comp[i]].p);
+    }
+    if (opts.turb_cond) {
+      need_nfiltered();
+      hskpng_sort();
+      hipLaunchKernelGGL(k_nfilt<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, 0, 0, A.n.p, A.rw2.p, T(0), T(0), n_filtered.p);     // moms_all
+      selected_before_counting = true;
+      moms_sum(A.rw2.p, T(1. / 2), 0, false);                                            // sum n r_w per cell, not specific
+      hipLaunchKernelGGL(k_tau_rlx<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, count_mom.p, dv.p, tau_rlx.p);
+      hipLaunchKernelGGL(k_turb_dot_ss<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, tau_rlx.p, A.ext[ix_ssp].p, A.ext[ix_wp].p, A.ext[ix_dot_ssp].p);
+      selected_before_counting = false;
+    }
+  }
   void adjust_timesteps(double dt_)
   {                                                                                      // particles_impl_adjust_timesteps.ipp:13-24
     if (dt_ > 0 && !o.variable_dt_switch) throw lcx_error("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
@@ -760,6 +811,11 @@ struct Particles : IParticles {
     a.dt = T(dt);
     a.x = A.x.p; a.y = A.y.p; a.z = A.z.p; a.vt = A.vt.p; a.rw2 = A.rw2.p; a.rd3 = A.rd3.p; a.n = A.n.p; a.ijk = ijk.p;
     a.courant_x = courant_x.p; a.courant_y = courant_y.p; a.courant_z = courant_z.p; a.w_LS = w_LS.p;
+    a.up = a.vp = a.wp = nullptr;
+    if (turb_adve_now && do_bcnd) {                 // (the full step: turb_adve follows adve, turb_adve.ipp)
+      a.up = ix_up >= 0 ? A.ext[ix_up].p : A.ext[ix_wp].p;      // a.up != nullptr switches the block on; unused components are not read
+      a.vp = ix_vp >= 0 ? A.ext[ix_vp].p : nullptr; a.wp = ix_wp >= 0 ? A.ext[ix_wp].p : nullptr;
+    }
     a.do_adve = do_adve; a.scheme = adve_scheme; a.halo = halo; a.do_sedi = do_sedi; a.do_subs = do_subs; a.do_bcnd = do_bcnd;
     a.distmem = distmem(); a.bcond_lft = o.bcond_lft; a.bcond_rgt = o.bcond_rgt;
     a.open_side_walls = o.open_side_walls; a.periodic_topbot = o.periodic_topbot_walls;
@@ -772,8 +828,11 @@ struct Particles : IParticles {
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
       HIPCHK(hipMemsetAsync(d_dead.p, 0, sizeof(unsigned int), st));
     }
-    if (adve_scheme == LCX_ADVE_PRED_CORR) hipLaunchKernelGGL((k_move<T, true>), dim3(blocks), dim3(BS), 0, st, a);
-    else hipLaunchKernelGGL((k_move<T, false>), dim3(blocks), dim3(BS), 0, st, a);
+    const bool pc = adve_scheme == LCX_ADVE_PRED_CORR, tb = a.up != nullptr;
+    if (pc && tb) hipLaunchKernelGGL((k_move<T, true, true>), dim3(blocks), dim3(BS), 0, st, a);
+    else if (pc) hipLaunchKernelGGL((k_move<T, true, false>), dim3(blocks), dim3(BS), 0, st, a);
+    else if (tb) hipLaunchKernelGGL((k_move<T, false, true>), dim3(blocks), dim3(BS), 0, st, a);
+    else hipLaunchKernelGGL((k_move<T, false, false>), dim3(blocks), dim3(BS), 0, st, a);
     if (want_puddle) {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
       hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
@@ -1069,6 +1128,10 @@ struct Particles : IParticles {
     if (o.const_p && is_null(p_)) throw lcx_error("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
     if (!o.const_p && !is_null(p_)) throw lcx_error("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
     if (o.sstp_cond < 1) throw lcx_error("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+    if (o.turb_adve_switch && o.nz == 0) throw lcx_error("libcloudph++: opts_init.turb_adve_switch can be True only if n_dims > 1");
+    if (o.turb_cond_switch && o.nz == 0) throw lcx_error("libcloudph++: opts_init.turb_cond_switch can be True only if n_dims > 1");
+    if (turb() && size_t(o.nz) != SGS_mix_len_h.size()) throw lcx_error("libcloudph++: at least one of opts_init.turb_adve_switch, opts_init.turb_cond_switch is true, but SGS mixing length profile size != nz");
+    for (double v : SGS_mix_len_h) if (v <= 0) throw lcx_error("libcloudph++: SGS_mix_len <= 0");
     if (o.adaptive_sstp_cond && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Adaptive condensation substepping (opts_init.adaptive_sstp_cond) works oly for per-particle substepping (opts_init.exact_sstp_cond)");
     if (!o.sstp_cond_mix && !o.exact_sstp_cond) throw lcx_error("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
     if (o.sstp_cond_mix && o.adaptive_sstp_cond && o.exact_sstp_cond) throw lcx_error("libcloudph++: Adaptive cond substepping (opts_init.adaptive_sstp_cond) with per-particle substepping (opts_init.exact_sstp_cond) requires mixing of th and rv between subteps (opts_init.sstp_cond_mix) to be disabled");
@@ -1129,10 +1192,12 @@ struct Particles : IParticles {
     if (should_now_run_async) throw lcx_error("libcloudph++: please call step_async() before calling step_sync() again");
     if (is_null(th_) || is_null(rv_)) throw lcx_error("libcloudph++: passing th and rv is mandatory");
     courant_checks(cx, cy, cz);
-    if (!is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
+    if (turb() && is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are not switched off and diss_rate is empty");
+    if (!turb() && !is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
     Range r(this, "sync_in");
     var_rho = !is_null(rhod_);
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
+    if (turb()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
     if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
       HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
@@ -1146,7 +1211,8 @@ struct Particles : IParticles {
   void step_cond(const lcx_opts_t &opts, const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_) override
   {
     if (!should_now_run_cond) throw lcx_error("libcloudph++: please call sync_in() before calling step_cond()");
-    if (opts.turb_cond) throw lcx_error("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+    if (opts.turb_cond && !o.turb_cond_switch) throw lcx_error("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+    if (opts.turb_cond && o.exact_sstp_cond) throw lcx_error("libcloudph++: turb_cond with per-particle substepping is not supported by this backend");
     should_now_run_cond = false;
     adjust_timesteps(opts.dt);
     if (opts.cond) {
@@ -1155,8 +1221,10 @@ struct Particles : IParticles {
       if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) cond_perparticle(opts.RH_max);
       else for (int step = 0; step < sstp_cond; ++step) {
         sstp_percell_step(step);
+        if (opts.turb_cond && nphys)                                                     // apply_perparticle_sgs_supersat.ipp
+          hipLaunchKernelGGL(k_sgs_supersat<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, T(T(dt) / sstp_cond), A.ext[ix_dot_ssp].p, A.ext[ix_ssp].p);
         hskpng_Tpr();
-        cond_substep(opts.RH_max, step);
+        cond_substep(opts.RH_max, step, opts.turb_cond);
       }
       sstp_save();
       { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); }
@@ -1173,7 +1241,8 @@ struct Particles : IParticles {
     if (opts.coal && !o.coal_switch) throw lcx_error("libcloudph++: coalescence was switched off in opts_init");
     if (opts.sedi && !o.sedi_switch) throw lcx_error("libcloudph++: sedimentation was switched off in opts_init");
     if (opts.subs && !o.subs_switch) throw lcx_error("libcloudph++: subsidence was switched off in opts_init");
-    if (opts.turb_adve) throw lcx_error("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+    if (opts.turb_adve && !o.turb_adve_switch) throw lcx_error("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+    if (opts.turb_adve && n_dims == 0) throw lcx_error("libcloudph++: turbulent advection does not work in 0D");
     if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
     adjust_timesteps(opts.dt);
@@ -1193,6 +1262,8 @@ struct Particles : IParticles {
       hskpng_approximate_rc2_invalid();                                                  // particles_step.ipp:402-403
     }
     // single device, > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions
+    if ((opts.turb_adve || opts.turb_cond) && nphys) sgs_turbulence(opts);              // particles_step.ipp:406-427
+    turb_adve_now = opts.turb_adve;
     // > 0 dimensions: advection + sedimentation + boundary + re-indexing in ONE pass over the positions; with a decomposed
     // domain the histogram is completed by the immigrants in migrate_finish
     const bool fused = n_dims > 0 && nphys > 0 && !opts.rcyc;
@@ -1334,7 +1405,11 @@ struct Particles : IParticles {
       {"sstp_tmp_th", exact ? A.ext[ix_th].p : sstp_tmp_th.p, exact ? npart : ncell},
       {"sstp_tmp_rh", exact ? A.ext[ix_rh].p : sstp_tmp_rh.p, exact ? npart : ncell},
       {"sstp_tmp_p", exact && o.const_p ? A.ext[ix_p].p : nullptr, exact && o.const_p ? npart : 0},
-      {"rc2", use_rc2 ? A.ext[ix_rc2].p : nullptr, use_rc2 ? npart : 0}};
+      {"rc2", use_rc2 ? A.ext[ix_rc2].p : nullptr, use_rc2 ? npart : 0},
+      {"up", ix_up >= 0 ? A.ext[ix_up].p : nullptr, ix_up >= 0 ? npart : 0}, {"vp", ix_vp >= 0 ? A.ext[ix_vp].p : nullptr, ix_vp >= 0 ? npart : 0},
+      {"wp", ix_wp >= 0 ? A.ext[ix_wp].p : nullptr, ix_wp >= 0 ? npart : 0}, {"ssp", ix_ssp >= 0 ? A.ext[ix_ssp].p : nullptr, ix_ssp >= 0 ? npart : 0},
+      {"dot_ssp", ix_dot_ssp >= 0 ? A.ext[ix_dot_ssp].p : nullptr, ix_dot_ssp >= 0 ? npart : 0},
+      {"diss_rate", diss_rate.p, turb() ? ncell : 0}};
     for (const E &e : tab)
       if (s == e.nm) {
         *n = e.len;
@@ -1360,6 +1435,7 @@ struct Particles : IParticles {
     up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
     if (n) HIPCHK(hipMemsetAsync(ijk.p, 0, n * sizeof(uint32_t), st));     // every SD is in the order again, n == 0 included
     hskpng_ijk();
+    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp}) if (ix >= 0 && n) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, n * sizeof(T), st));
     if (use_rc2 && n) { hipLaunchKernelGGL(k_fill<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_rc2].p, n, T(-1)); hskpng_approximate_rc2_invalid(); }
     sstp_save();
     hskpng_count();

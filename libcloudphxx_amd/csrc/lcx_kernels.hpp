@@ -483,6 +483,7 @@ struct cond_args {
   const T *rhod, *rv, *Tk, *eta, *RH, *lambda_D, *lambda_K;
   T *m3_before, *m3_after;
   T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
+  const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
 };
 // Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms, 4 waves with 24 B of scratch per
 // lane: 10.1 ms, 5 waves: 13.0 ms).
@@ -495,7 +496,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
   if (a.first) a.m3_before[pos] = rw2_old >= 0 ? nn * (rw2_old * T(sqrt(rw2_old))) : nn * rw2_old;
   const T r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
-                          a.lambda_D[c], a.lambda_K[c], a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
+                          a.lambda_D[c], a.lambda_K[c], a.ssp ? T(a.RH[c] + a.ssp[id]) : a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
   a.rw2[id] = r;
   a.m3_after[pos] = r >= 0 ? nn * (r * T(sqrt(r))) : nn * r;
 }
@@ -760,6 +761,52 @@ __global__ void k_pp_mix_finish(size_t n_cell, const uint32_t *cell_start, const
 }
 
 // ============================================================================================
+// SGS turbulence (hskpng_tke.ipp, hskpng_turb_vel.ipp, hskpng_turb_ss.ipp, apply_perparticle_sgs_supersat.ipp;
+// formulas common/GA17_turbulence.hpp:52-113)
+// ============================================================================================
+template <class T> struct normal_src { const T *arr; uint64_t call, seed; };
+// diss_rate := TKE = ((L eps) / C_E)^(2/3);  tau = L / (2 pi)^(1/3) sqrt(C_tau / TKE);  L = SGS_mix_len[k]
+template <class T>
+__global__ void k_tke_tau(size_t n_cell, int nz, const T *mix_len, T *diss_rate, T *tau)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const T L = mix_len[c % size_t(nz)];
+  const T ret = cbrt((L * diss_rate[c]) / T(0.845));
+  const T tke = ret * ret;
+  diss_rate[c] = tke;
+  tau[c] = L / T(pow(T(2) * cst<T>::pi, T(1. / 3.))) * sqrt(T(1.5) / tke);
+}
+// update_turb_vel: Ornstein-Uhlenbeck step of one velocity component
+template <class T>
+__global__ void k_turb_vel(size_t n, const uint32_t *ijk, const T *tau, const T *tke, T dt, normal_src<T> rs, T *vel)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
+  const T r = rs.arr ? rs.arr[i] : philox::normal<T>(i, rs.call, rs.seed);
+  const T e = exp(-dt / tau[c]);
+  vel[i] = vel[i] * e + sqrt((T(1) - e * e) * T(2. / 3.) * tke[c]) * r;
+}
+// tau_relax from the first wet moment per volume (count_mom holds sum n r_w of the cell), then dot_turb_ss per SD
+template <class T>
+__global__ void k_tau_rlx(size_t n_cell, const uint32_t *cell_start, const T *mom1, const T *dv, T *tau_rlx)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  if (cell_start[c + 1] > cell_start[c]) tau_rlx[c] = T(1) / (T(2.8e-4) * (mom1[c] / dv[c]));
+}
+template <class T>
+__global__ void k_turb_dot_ss(size_t n, const uint32_t *ijk, const T *tau_rlx, const T *ssp, const T *wp, T *dot_ssp)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
+  dot_ssp[i] = T(3e-4) * wp[i] - ssp[i] / tau_rlx[c];
+}
+template <class T>
+__global__ void k_sgs_supersat(size_t n, T dt_sub, const T *dot_ssp, T *ssp)
+{ const size_t i = gid(); if (i < n) ssp[i] = ssp[i] + dt_sub * dot_ssp[i]; }
+
+// ============================================================================================
 // coalescence (particles_impl_coal.ipp:99-546, src/detail/kernels.hpp:38-202, kernel_interpolation.hpp:9-65)
 // ============================================================================================
 template <class T> struct coal_kernel_cfg { int kernel; int n_user_params; T r_max; const T *params; };
@@ -910,6 +957,7 @@ struct move_args {
   T dx, dy, dz, x0, y0, z0, x1, y1, z1, dt;
   T *x, *y, *z; const T *vt, *rw2, *rd3; n_t *n; const uint32_t *ijk;
   const T *courant_x, *courant_y, *courant_z, *w_LS;
+  const T *up, *vp, *wp;  // turb_adve (turb_adve.ipp:13-33): x += up dt, y += vp dt, z += wp dt after the advection; else nullptr
   int do_adve, scheme, halo, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
   double *puddle_partial;      // [gridDim][4]: liq_vol, dry_vol, liq_num, prtcl_num
   uint8_t *mig;                // distmem: 1 = left the domain through the left face, 2 = right
@@ -939,8 +987,9 @@ template <class T> __device__ __forceinline__ T fmod_nonneg(T arg, T L)
 }
 template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return a + fmod_nonneg((x - a) + 10 * (b - a), b - a); }
 
-// PC: the predictor-corrector scheme is a separate instantiation (its extra live state costs the first-order schemes 12 %)
-template <class T, bool PC>
+// PC / TURB: the predictor-corrector scheme and the SGS velocity perturbations are separate instantiations (their extra
+// live state costs the plain first-order pass 8..12 %)
+template <class T, bool PC, bool TURB>
 __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
 {
   __shared__ double red[4][BS / WAVE];
@@ -1021,6 +1070,11 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
       if (g.ndims > 2) y = (y + y_old) / T(2.);
       if (g.ndims > 1) z = (z + z_old) / T(2.);
       x = x - shift;
+    }
+    if (TURB) {
+      if (g.nx) x = x + a.up[i] * a.dt;
+      if (g.ny) y = y + a.vp[i] * a.dt;
+      if (g.nz) z = z + a.wp[i] * a.dt;
     }
     if (a.do_sedi) z = z - a.dt * a.vt[i];
     if (a.do_subs) z = z - a.dt * a.w_LS[k_subs];
@@ -1125,7 +1179,7 @@ __global__ void __launch_bounds__(BS) k_alive_tiles(const n_t *n, size_t n_part,
   if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[w]; tile_sums[blockIdx.x] = s; }
 }
 // ext[]: further real-valued attributes that travel with a super-droplet (per-particle substepping state, rc2)
-constexpr int MAX_EXT = 5;
+constexpr int MAX_EXT = 10;
 template <class T> struct attr_set { n_t *n; T *rd3, *rw2, *kpa, *vt, *x, *y, *z; T *ext[MAX_EXT]; int n_ext; };
 
 template <class T>

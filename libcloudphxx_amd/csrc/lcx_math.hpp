@@ -615,6 +615,14 @@ struct philox {
     if (sizeof(T) == 8) return T(double((uint64_t(r[0]) << 21) ^ (uint64_t(r[1]) >> 11)) * (1.0 / 9007199254740992.0));
     return T(float(r[0] >> 8) * (1.0f / 16777216.0f));
   }
+  // standard normal: Box-Muller from two uniforms of one Philox block
+  template <class T> static LCX_HD T normal(uint64_t idx, uint64_t call, uint64_t seed)
+  {
+    uint32_t r[4]; gen(idx, call, seed, r);
+    const double u1 = (double((uint64_t(r[0]) << 21) ^ (uint64_t(r[1]) >> 11)) + 1.0) * (1.0 / 9007199254740992.0);     // (0, 1]
+    const double u2 = double((uint64_t(r[2]) << 21) ^ (uint64_t(r[3]) >> 11)) * (1.0 / 9007199254740992.0);
+    return T(sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925286766559 * u2));
+  }
   static LCX_HD uint32_t un(uint64_t idx, uint64_t call, uint64_t seed)
   {
     uint32_t r[4]; gen(idx, call, seed, r);

@@ -112,6 +112,7 @@ class _opts_init_c(C.Structure):
         ("rng_seed", C.c_int), ("rng_seed_init", C.c_int), ("rng_seed_init_switch", C.c_int),
         ("dev_count", C.c_int), ("dev_id", C.c_int),
         ("w_LS", C.POINTER(C.c_double)), ("n_w_LS", C.c_int),
+        ("SGS_mix_len", C.POINTER(C.c_double)), ("n_SGS_mix_len", C.c_int),
         ("aerosol_conc_factor", C.POINTER(C.c_double)), ("n_aerosol_conc_factor", C.c_int),
         ("rd_min", C.c_double), ("rd_max", C.c_double),
         ("no_ccn_at_init", C.c_int), ("open_side_walls", C.c_int), ("periodic_topbot_walls", C.c_int),
@@ -193,6 +194,7 @@ class opts_init_t:
         self.dev_count = 0
         self.dev_id = -1
         self.w_LS = np.zeros(0)
+        self.SGS_mix_len = np.zeros(0)
         self.aerosol_conc_factor = np.zeros(0)
         self.rd_min = self.rd_max = -1.
         self.no_ccn_at_init = False
@@ -211,14 +213,14 @@ class opts_init_t:
 
     def _to_c(self, keep):
         c = _opts_init_c()
-        special = {"kernel_parameters", "n_kernel_parameters", "w_LS", "n_w_LS", "aerosol_conc_factor",
+        special = {"kernel_parameters", "n_kernel_parameters", "w_LS", "n_w_LS", "SGS_mix_len", "n_SGS_mix_len", "aerosol_conc_factor",
                    "n_aerosol_conc_factor", "dry_distros", "n_dry_distros", "dry_sizes", "n_dry_sizes"}
         for name, ctype in _opts_init_c._fields_:
             if name in special:
                 continue
             v = getattr(self, name)
             setattr(c, name, float(v) if ctype is C.c_double else int(v))
-        for name in ("kernel_parameters", "w_LS", "aerosol_conc_factor"):
+        for name in ("kernel_parameters", "w_LS", "SGS_mix_len", "aerosol_conc_factor"):
             arr = np.ascontiguousarray(np.asarray(getattr(self, name), dtype=np.float64).ravel())
             keep.append(arr)
             setattr(c, name, arr.ctypes.data_as(C.POINTER(C.c_double)))

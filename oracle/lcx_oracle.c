@@ -66,6 +66,25 @@ static double rng_u01(mt19937_t *g)
 /* uniform_int_distribution<unsigned>(0,UINT_MAX): one draw; fnctr_un returns it through real_t */
 static double rng_un(mt19937_t *g) { return (double)mt_next(g); }
 
+/* std::normal_distribution<double>(0,1) of libstdc++ (bits/random.tcc): Marsaglia polar method; every second call returns
+ * the value saved by the previous one.  The distribution object is a member of the reference's rng (urand.hpp:30,43), so
+ * the saved value survives from one generate_normal_n call to the next. */
+typedef struct { int saved_available; double saved; } normal_state;
+static double rng_normal(mt19937_t *g, normal_state *ns)
+{
+  if (ns->saved_available) { ns->saved_available = 0; return ns->saved; }
+  double x, y, r2;
+  do {
+    x = 2.0 * rng_u01(g) - 1.0;
+    y = 2.0 * rng_u01(g) - 1.0;
+    r2 = x * x + y * y;
+  } while (r2 > 1.0 || r2 == 0.0);
+  const double mult = sqrt(-2 * log(r2) / r2);
+  ns->saved = x * mult;
+  ns->saved_available = 1;
+  return y * mult;
+}
+
 /* ---------------- state (src/impl/particles_impl.ipp:26-325) ---------------- */
 typedef struct { double *q; sz len, pos; } fifo_arr;
 
@@ -78,7 +97,11 @@ struct orc_particles {
   int init_called, should_now_run_async, should_now_run_cond, selected_before_counting, var_rho, sorted;
   int sstp_cond, sstp_coal, allow_sstp_cond, pure_const_multi, increase_sstp_coal;
   double dt; int adve_scheme; int halo;      /* halo: x-planes of Courant halo on each side (2 with pred_corr, particles_impl.ipp:361) */
-  mt19937_t rng;
+  mt19937_t rng; normal_state rng_ns;
+  /* SGS turbulence (turb_adve / turb_cond): cell field diss_rate (holds TKE after hskpng_tke), SGS mixing length profile,
+   * per-particle velocity perturbations and supersaturation perturbation (particles_impl.ipp:141-144,461-473) */
+  double *diss_rate, *SGS_mix_len, *tau_cell;
+  double *up, *vp, *wp, *ssp, *dot_ssp;
   /* particle attributes */
   n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
   sz *ijk, *sorted_id, *sorted_ijk;
@@ -142,9 +165,9 @@ static int distmem(const orc_particles *s) { return s->o.bcond_lft == 1 || s->o.
 int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
   if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
-  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->turb_adve_switch ||
-      oi->turb_cond_switch || oi->turb_coal_switch || oi->diag_incloud_time)
-    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb)");
+  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type ||
+      oi->turb_coal_switch || oi->diag_incloud_time)
+    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb_coal)");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
   s->distros = NEW(lcx_distro_t, oi->n_dry_distros);
@@ -194,6 +217,13 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
     s->rwX = NEW(double, c); s->drwX = NEW(double, c); s->Tp = NEW(double, c); s->pp_sstp = NEW(unsigned, c);
   }
   if (s->use_rc2) s->rc2 = NEW(double, c);
+  if (oi->turb_adve_switch || oi->turb_cond_switch) {
+    s->diss_rate = NEW(double, nc); s->tau_cell = NEW(double, nc);
+    s->SGS_mix_len = NEW(double, oi->n_SGS_mix_len);
+    if (oi->n_SGS_mix_len) memcpy(s->SGS_mix_len, oi->SGS_mix_len, sizeof(double) * oi->n_SGS_mix_len);
+    s->up = NEW(double, c); s->vp = NEW(double, c); s->wp = NEW(double, c);       /* resized with the initial value 0 */
+    if (oi->turb_cond_switch) { s->ssp = NEW(double, c); s->dot_ssp = NEW(double, c); }
+  }
   s->count_ijk = NEW(sz, nc); s->off = NEW(sz, nc + 1); s->count_num = NEW(n_t, nc); s->count_mom = NEW(double, nc);
   s->outbuf = NEW(double, nc);
   *out = s;
@@ -204,6 +234,7 @@ void orc_destroy(orc_particles *s)
   if (!s) return;
   void *ptrs[] = {s->distros, s->sizes, s->kernel_parameters, s->w_LS, s->aerosol_conc_factor, s->n, s->rd3, s->rw2,
     s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col, s->mom_vals,
+    s->diss_rate, s->SGS_mix_len, s->tau_cell, s->up, s->vp, s->wp, s->ssp, s->dot_ssp,
     s->pp_rv, s->pp_th, s->pp_rh, s->pp_p, s->rc2, s->dlt_rv, s->dlt_th, s->dlt_rh, s->dlt_p, s->rwX, s->drwX, s->Tp, s->pp_sstp,
     s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
     s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
@@ -393,6 +424,8 @@ static int hskpng_remove_n0(orc_particles *s)
       s->vt[w] = s->vt[p]; s->x[w] = s->x[p]; s->y[w] = s->y[p]; s->z[w] = s->z[p];
       if (s->exact) { s->pp_rv[w] = s->pp_rv[p]; s->pp_th[w] = s->pp_th[p]; s->pp_rh[w] = s->pp_rh[p]; s->pp_p[w] = s->pp_p[p]; }
       if (s->use_rc2) s->rc2[w] = s->rc2[p];
+      if (s->up) { s->up[w] = s->up[p]; s->vp[w] = s->vp[p]; s->wp[w] = s->wp[p]; }
+      if (s->ssp) { s->ssp[w] = s->ssp[p]; s->dot_ssp[w] = s->dot_ssp[p]; }
     }
     ++w;
   }
@@ -489,7 +522,7 @@ static void save_liq_before(orc_particles *s)
   for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = -s->count_mom[i];
 }
 /* percell/particles_impl_cond.ipp:13-139 */
-static void cond(orc_particles *s, double dt, double RH_max, int step)
+static void cond(orc_particles *s, double dt, double RH_max, int step, int turb_cond)
 {
   hskpng_sort(s);
   if (step == 0) { if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->rw_mom3[c] = 0.; }
@@ -497,8 +530,8 @@ static void cond(orc_particles *s, double dt, double RH_max, int step)
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
-    cond_ctx cc = {s->rw2[p], dt / s->sstp_cond, s->rhod[c], s->rv[c], s->T[c], s->p[c], s->RH[c], s->eta[c],
-                   s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};
+    cond_ctx cc = {s->rw2[p], dt / s->sstp_cond, s->rhod[c], s->rv[c], s->T[c], s->p[c], s->RH[c] + (turb_cond ? s->ssp[p] : 0.), s->eta[c],
+                   s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};   /* RH_sgs, percell/particles_impl_cond.ipp:50-72 */
     s->rw2[p] = advance_rw2(&cc, s->eps_tol, 2., 100);     /* config.hpp:13,26: n_iter 100, cond_mlt 2 */
   }
   moms_all(s);
@@ -700,6 +733,39 @@ static void cond_perparticle(orc_particles *s, double RH_max)
     calc_liq_content_change(s);
     update_th_rv(s);
   }
+}
+
+/* ---------------- SGS turbulence (hskpng_tke.ipp, hskpng_turb_vel.ipp, hskpng_turb_ss.ipp; common/GA17_turbulence.hpp) ---------------- */
+static void hskpng_tke(orc_particles *s)
+{                                                   /* diss_rate := TKE = ((L eps) / C_E)^(2/3), L = SGS_mix_len[k] */
+  const sz nz = m1(s->o.nz);
+  for (sz c = 0; c < s->n_cell; ++c) {
+    const double ret = cbrt((s->SGS_mix_len[c % nz] * s->diss_rate[c]) / 0.845);
+    s->diss_rate[c] = ret * ret;
+  }
+}
+static void hskpng_turb_vel(orc_particles *s, double dt, int only_vertical)
+{
+  const sz nz = m1(s->o.nz);
+  const double cube_root_of_two_pi = pow(2. * ORC_PI, 1. / 3.);
+  for (sz c = 0; c < s->n_cell; ++c) s->tau_cell[c] = s->SGS_mix_len[c % nz] / cube_root_of_two_pi * sqrt(1.5 / s->diss_rate[c]);
+  double *vel[3] = {s->up, s->wp, s->vp};
+  for (int i = only_vertical ? 1 : 0; i < (only_vertical ? 2 : s->n_dims); ++i) {
+    for (sz p = 0; p < s->n_part; ++p) s->tmp_part[p] = rng_normal(&s->rng, &s->rng_ns);
+    for (sz p = 0; p < s->n_part; ++p) {
+      const sz c = s->ijk[p];
+      const double e = exp(-dt / s->tau_cell[c]);                              /* update_turb_vel */
+      vel[i][p] = vel[i][p] * e + sqrt((1. - e * e) * (2. / 3.) * s->diss_rate[c]) * s->tmp_part[p];
+    }
+  }
+}
+static void hskpng_turb_dot_ss(orc_particles *s)
+{
+  double *tau_rlx = s->scl;
+  moms_all(s);
+  moms_calc(s, s->rw2, 1. / 2, 0);
+  for (sz i = 0; i < s->count_n; ++i) tau_rlx[s->count_ijk[i]] = 1. / (2.8e-4 * (s->count_mom[i] / s->dv[s->count_ijk[i]]));   /* tau_relax */
+  for (sz p = 0; p < s->n_part; ++p) s->dot_ssp[p] = 3e-4 * s->wp[p] - s->ssp[p] / tau_rlx[s->ijk[p]];                          /* dot_turb_ss */
 }
 
 /* particles_impl_adjust_timesteps.ipp:13-24 */
@@ -1011,7 +1077,7 @@ static void rcyc(orc_particles *s)
   while (n_splittable < N && key[N - 1 - n_splittable] != 1) ++n_splittable;
   if (n_splittable == 0) { hskpng_remove_n0(s); return; }
   if (n_splittable < n_flagged) n_flagged = n_splittable;
-  double *attrs[16]; const int na = mig_attrs(s, attrs);             /* distmem_real_vctrs: everything but n */
+  double *attrs[24]; const int na = mig_attrs(s, attrs);             /* distmem_real_vctrs: everything but n */
   for (int a = 0; a < na; ++a)
     for (sz t = 0; t < n_flagged; ++t) attrs[a][sid[t]] = attrs[a][sid[N - 1 - t]];
   for (sz t = 0; t < n_flagged; ++t) { const n_t big = s->n[sid[N - 1 - t]]; s->n[sid[t]] = big - big / 2; }
@@ -1404,6 +1470,10 @@ static int init_sanity_check(orc_particles *s, const lcx_arrinfo_t *th, const lc
   if (o->const_p && arr_null(p)) FAIL("libcloudph++: In const_p option, pressure profile must be passed (p in init())");
   if (!o->const_p && !arr_null(p)) FAIL("libcloudph++: pressure profile was passed in init(), but the constant pressure option was not used");
   if (o->sstp_cond < 1) FAIL("libcloudph++: opts_init.sstp_cond needs to be greater than 0");
+  if (o->turb_adve_switch && o->nz == 0) FAIL("libcloudph++: opts_init.turb_adve_switch can be True only if n_dims > 1");
+  if (o->turb_cond_switch && o->nz == 0) FAIL("libcloudph++: opts_init.turb_cond_switch can be True only if n_dims > 1");
+  if ((o->turb_adve_switch || o->turb_cond_switch) && o->nz != o->n_SGS_mix_len) FAIL("libcloudph++: at least one of opts_init.turb_adve_switch, opts_init.turb_cond_switch is true, but SGS mixing length profile size != nz");
+  for (int k = 0; k < o->n_SGS_mix_len; ++k) if (s->SGS_mix_len && s->SGS_mix_len[k] <= 0) FAIL("libcloudph++: SGS_mix_len <= 0");
   if (o->adaptive_sstp_cond && !o->exact_sstp_cond) FAIL("libcloudph++: Adaptive condensation substepping (opts_init.adaptive_sstp_cond) works oly for per-particle substepping (opts_init.exact_sstp_cond)");
   if (!o->sstp_cond_mix && !o->exact_sstp_cond) FAIL("libcloudph++: Mixing of rv and th (opts_init.sstp_cond_mix) can only be disable for per-particle substepping (opts_init.exact_sstp_cond)");
   if (o->sstp_cond_mix && o->adaptive_sstp_cond && o->exact_sstp_cond) FAIL("libcloudph++: Adaptive cond substepping (opts_init.adaptive_sstp_cond) with per-particle substepping (opts_init.exact_sstp_cond) requires mixing of th and rv between subteps (opts_init.sstp_cond_mix) to be disabled");
@@ -1464,11 +1534,14 @@ int orc_sync_in(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *
     if (s->n_dims == 2 && (arr_null(cx) || !arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: Only X and Z Courant numbers allowed in 2D setup");
     if (s->n_dims == 3 && (arr_null(cx) || arr_null(cy) || arr_null(cz))) FAIL("libcloudph++: All XYZ Courant number components required in 3D setup");
   }
-  if (!arr_null(diss)) FAIL("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
+  { const int turb = s->o.turb_adve_switch || s->o.turb_cond_switch || s->o.turb_coal_switch;              /* particles_step.ipp:74-78 */
+    if (turb && arr_null(diss)) FAIL("libcloudph++: turbulent advection, coalescence and condesation are not switched off and diss_rate is empty");
+    if (!turb && !arr_null(diss)) FAIL("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty"); }
   s->var_rho = !arr_null(rhod);
   sync_in_arr(s, th, s->th, s->n_cell, 0, 0, 0);
   sync_in_arr(s, rv, s->rv, s->n_cell, 0, 0, 0);
   sync_in_arr(s, rhod, s->rhod, s->n_cell, 0, 0, 0);
+  if (s->diss_rate) sync_in_arr(s, diss, s->diss_rate, s->n_cell, 0, 0, 0);
   sync_in_courant(s, cx, s->courant_x, s->n_cx, 1, 0, 0);
   sync_in_courant(s, cy, s->courant_y, s->n_cy, 0, 1, 0);
   sync_in_courant(s, cz, s->courant_z, s->n_cz, 0, 0, 1);
@@ -1481,7 +1554,8 @@ int orc_sync_in(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *
 int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv)
 {
   if (!s->should_now_run_cond) FAIL("libcloudph++: please call sync_in() before calling step_cond()");
-  if (opts->turb_cond) FAIL("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+  if (opts->turb_cond && !s->o.turb_cond_switch) FAIL("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
+  if (opts->turb_cond && s->o.exact_sstp_cond) FAIL("libcloudph++: turb_cond with per-particle substepping is not supported by this backend");
   s->should_now_run_cond = 0;
   if (adjust_timesteps(s, opts->dt)) return 1;
   if (opts->cond) {
@@ -1490,9 +1564,10 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
     if (s->o.exact_sstp_cond && (s->sstp_cond > 1 || s->sstp_cond_act > 1)) cond_perparticle(s, opts->RH_max);
     else for (int step = 0; step < s->sstp_cond; ++step) {
       sstp_percell_step(s, step);
+      if (opts->turb_cond) for (sz p = 0; p < s->n_part; ++p) s->ssp[p] = s->ssp[p] + s->dt / s->sstp_cond * s->dot_ssp[p];   /* apply_perparticle_sgs_supersat.ipp */
       hskpng_Tpr(s);
       if (step == 0) save_liq_before(s);
-      cond(s, s->dt, opts->RH_max, step);
+      cond(s, s->dt, opts->RH_max, step, opts->turb_cond);
       update_th_rv(s);
     }
     sstp_save(s);
@@ -1518,7 +1593,8 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
   if (opts->coal && !s->o.coal_switch) FAIL("libcloudph++: coalescence was switched off in opts_init");
   if (opts->sedi && !s->o.sedi_switch) FAIL("libcloudph++: sedimentation was switched off in opts_init");
   if (opts->subs && !s->o.subs_switch) FAIL("libcloudph++: subsidence was switched off in opts_init");
-  if (opts->turb_adve) FAIL("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+  if (opts->turb_adve && !s->o.turb_adve_switch) FAIL("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+  if (opts->turb_adve && s->n_dims == 0) FAIL("libcloudph++: turbulent advection does not work in 0D");
   if (opts->src) FAIL("libcloudph++: aerosol source was switched off in opts_init");
   if (opts->rlx) FAIL("libcloudph++: aerosol relaxation was switched off in opts_init");
   if (adjust_timesteps(s, opts->dt)) return 1;
@@ -1532,8 +1608,16 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
     if (s->increase_sstp_coal) { ++s->sstp_coal; s->increase_sstp_coal = 0; }
     hskpng_approximate_rc2_invalid(s);       /* particles_step.ipp:402-403 */
   }
+  if (opts->turb_adve || opts->turb_cond) hskpng_tke(s);                     /* particles_step.ipp:406-427 */
+  if (opts->turb_adve) hskpng_turb_vel(s, s->dt, 0);
+  else if (opts->turb_cond) hskpng_turb_vel(s, s->dt, 1);
+  if (opts->turb_cond) hskpng_turb_dot_ss(s);
   if (opts->adve) adve(s);
   s->adve_scheme = s->o.adve_scheme;
+  if (opts->turb_adve) {                                                      /* turb_adve.ipp:13-33: x, z, y get up, wp, vp */
+    double *pos[3] = {s->x, s->z, s->y}, *vel[3] = {s->up, s->wp, s->vp};
+    for (int i = 0; i < s->n_dims; ++i) for (sz p = 0; p < s->n_part; ++p) pos[i][p] = pos[i][p] + vel[i][p] * s->dt;
+  }
   if (opts->sedi) sedi(s, s->dt);
   if (opts->subs) subs(s, s->dt);
   bcnd(s);
@@ -1692,7 +1776,10 @@ int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t c
     {"sstp_tmp_rv", s->exact ? s->pp_rv : s->sstp_tmp_rv, s->exact ? s->n_part : s->n_cell},
     {"sstp_tmp_th", s->exact ? s->pp_th : s->sstp_tmp_th, s->exact ? s->n_part : s->n_cell},
     {"sstp_tmp_rh", s->exact ? s->pp_rh : s->sstp_tmp_rh, s->exact ? s->n_part : s->n_cell},
-    {"sstp_tmp_p", s->pp_p, s->exact && s->o.const_p ? s->n_part : 0}, {"rc2", s->rc2, s->use_rc2 ? s->n_part : 0}};
+    {"sstp_tmp_p", s->pp_p, s->exact && s->o.const_p ? s->n_part : 0}, {"rc2", s->rc2, s->use_rc2 ? s->n_part : 0},
+    {"up", s->up, s->up ? s->n_part : 0}, {"vp", s->vp, s->vp ? s->n_part : 0}, {"wp", s->wp, s->wp ? s->n_part : 0},
+    {"ssp", s->ssp, s->ssp ? s->n_part : 0}, {"dot_ssp", s->dot_ssp, s->dot_ssp ? s->n_part : 0},
+    {"diss_rate", s->diss_rate, s->diss_rate ? s->n_cell : 0}};
   for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
     if (!strcmp(name, tab[i].nm)) {
       *n = tab[i].len;
@@ -1713,6 +1800,8 @@ int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult
   if (z) memcpy(s->z, z, n * 8);
   hskpng_ijk(s);
   if (s->use_rc2) { for (sz p = 0; p < n; ++p) s->rc2[p] = -1.; hskpng_approximate_rc2_invalid(s); }
+  if (s->up) { memset(s->up, 0, n * 8); memset(s->vp, 0, n * 8); memset(s->wp, 0, n * 8); }
+  if (s->ssp) { memset(s->ssp, 0, n * 8); memset(s->dot_ssp, 0, n * 8); }
   sstp_save(s);
   hskpng_count(s);
   return 0;
@@ -1722,8 +1811,9 @@ int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult
 int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int ncalls, double *out)
 {
   mt19937_t g = s->rng;
+  normal_state ns = s->rng_ns;
   for (int c = 0; c < ncalls; ++c)
-    for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : rng_un(&g);
+    for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : kinds[c] == 1 ? rng_un(&g) : rng_normal(&g, &ns);
   return 0;
 }
 int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
@@ -1756,10 +1846,12 @@ static int mig_attrs(orc_particles *s, double **a)
   if (s->o.ny != 0) a[k++] = s->y;
   if (s->o.nz != 0) a[k++] = s->z;
   if (s->exact) { a[k++] = s->pp_rv; a[k++] = s->pp_th; a[k++] = s->pp_rh; if (s->o.const_p) a[k++] = s->pp_p; }
+  if (s->o.turb_adve_switch) { if (s->o.nx != 0) a[k++] = s->up; if (s->o.ny != 0) a[k++] = s->vp; if (s->o.nz != 0) a[k++] = s->wp; }
+  if (s->o.turb_cond_switch) { if (!(s->o.turb_adve_switch && s->o.nz != 0)) a[k++] = s->wp; a[k++] = s->ssp; a[k++] = s->dot_ssp; }
   if (s->use_rc2) a[k++] = s->rc2;
   return k;
 }
-size_t orc_migrate_record_bytes(orc_particles *s) { double *a[16]; return 8 + 8 * (size_t)mig_attrs(s, a); }
+size_t orc_migrate_record_bytes(orc_particles *s) { double *a[24]; return 8 + 8 * (size_t)mig_attrs(s, a); }
 int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t cap_bytes)
 {
   const sz cnt = side == 0 ? s->lft_count : s->rgt_count;
@@ -1768,7 +1860,7 @@ int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t
   const double x_lcl = side == 0 ? s->o.x0 : s->o.x1;
   for (sz i = 0; i < cnt; ++i) s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;   /* detail::remote, pack.ipp:14-26 */
   n_t *nb = (n_t *)buf; double *rb = (double *)buf + cnt;
-  double *attrs[16]; const int na = mig_attrs(s, attrs);
+  double *attrs[24]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) nb[i] = s->n[id[i]];
   for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) rb[(sz)a * cnt + i] = attrs[a][id[i]];
   return 0;
@@ -1779,7 +1871,7 @@ int orc_migrate_unpack(orc_particles *s, const void *buf, size_t cnt)
   const sz old = s->n_part;
   if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
   const n_t *nb = (const n_t *)buf; const double *rb = (const double *)buf + cnt;
-  double *attrs[16]; const int na = mig_attrs(s, attrs);
+  double *attrs[24]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) s->n[old + i] = nb[i];
   for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) attrs[a][old + i] = rb[(sz)a * cnt + i];
   const double tol = 5e-4;                          /* config.hpp:31, tolerance_away_from_bcond */

@@ -250,3 +250,36 @@ def test_sd_removal_with_recycling(make, vt):
     pr.diag_all()
     pr.diag_wet_mom(0)
     assert frombuffer(pr.outbuf())[0] == sd_conc
+
+
+@pytest.mark.parametrize("make", MAKERS)
+def test_turb_adve_moves_super_droplets(make):
+    """tests/python/unit/lgrngn_turb_adve.py: no resolved flow, only the SGS velocity perturbations -- after 100 steps the
+    SD counts per cell have changed; the perturbation velocities have the stationary variance 2/3 TKE"""
+    oi = lgrngn.opts_init_t()
+    oi.dt = 1
+    oi.dry_distros = {(.61, 0.): h.lognormal_fn(.04e-6 / 2, 1.4, 60e6)}
+    oi.coal_switch = oi.sedi_switch = False
+    oi.turb_adve_switch = True
+    oi.nx, oi.nz, oi.dx, oi.dz = 10, 10, 1, 1
+    oi.x1 = oi.z1 = 10
+    oi.SGS_mix_len = np.ones(10)
+    oi.sd_conc = 100
+    oi.n_sd_max = 100 * 100
+    pr = make(oi)
+    th, rv, rhod = 300. * np.ones((10, 10)), .01 * np.ones((10, 10)), np.ones((10, 10))
+    diss = 1e-4 * np.ones((10, 10))
+    pr.init(th, rv, rhod)
+    opts = lgrngn.opts_t()
+    opts.adve = opts.sedi = opts.cond = opts.coal = False
+    opts.turb_adve = True
+    pr.diag_all(); pr.diag_sd_conc()
+    tab_in = pr.outbuf_array().copy()
+    for _ in range(100):
+        pr.step_sync(opts, th, rv, rhod, diss_rate=diss)
+        pr.step_async(opts)
+    pr.diag_all(); pr.diag_sd_conc()
+    assert not np.array_equal(tab_in, pr.outbuf_array())
+    sigma = np.sqrt(2. / 3 * (1e-4 / 0.845) ** (2. / 3))
+    for comp in ("up", "wp"):
+        assert abs(np.sqrt(np.mean(pr.state_real(comp) ** 2)) / sigma - 1) < 0.05

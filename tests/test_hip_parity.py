@@ -649,3 +649,48 @@ def test_storage_reorder_is_a_permutation_of_the_same_state():
     sid, sijk, ijk = b[5], b[6], b[7]
     exact(sid, np.arange(len(sid), dtype=sid.dtype), "sorted_id is the identity right after a re-order")
     exact(ijk, sijk, "ijk == sorted_ijk")
+
+
+# ------------------------------------------------------------------ SGS turbulence
+@pytest.mark.parametrize("mode,dims", [("adve", (6, 0, 5)), ("adve", (4, 3, 5)), ("cond", (5, 0, 6)), ("both", (4, 3, 4))])
+def test_sgs_turbulence_matches_oracle(mode, dims):
+    """turb_adve (Ornstein-Uhlenbeck velocity perturbations added to the advection) and turb_cond (SGS supersaturation
+    perturbation in the condensation) against the oracle, its normal deviates (std::normal_distribution over mt19937)
+    replayed: hskpng_tke / _turb_vel / _turb_dot_ss, turb_adve, apply_perparticle_sgs_supersat, RH_sgs"""
+    nx, ny, nz = dims
+    kw = dict(coal_switch=False, turb_adve_switch=mode in ("adve", "both"), turb_cond_switch=mode in ("cond", "both"),
+              SGS_mix_len=np.linspace(20., 40., nz), sstp_cond=2 if mode == "cond" else 1)
+    oi = h.box_opts(nx, ny, nz, 32, dx=30., **kw)
+    th, rv, rhod, C = h.box_fields(oi)
+    diss = 1e-3 * (1 + np.random.default_rng(3).random(th.shape))
+    orc, hip = h.make_pair(oi, (th, rv, rhod, C))
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    opts.turb_adve = mode in ("adve", "both")
+    opts.turb_cond = mode in ("cond", "both")
+    ndim = sum(1 for n_ in dims if n_ > 0)
+    for it in range(3):
+        tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()
+        orc.step_sync(opts, tho, rvo, rhod, diss_rate=diss, **C)
+        hip.step_sync(opts, thh, rvh, rhod, diss_rate=diss, **C)
+        n_calls = ndim if opts.turb_adve else 1
+        for arr in h.oracle_rng_preview(orc, [(2, orc.n_part)] * n_calls):
+            hip.rng_replay_push(2, arr)
+        orc.step_async(opts)
+        hip.step_async(opts)
+        assert hip.n_part == orc.n_part
+        exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
+        for nm in (("up", "wp") + (("vp",) if ny else ())) if opts.turb_adve else ("wp",):
+            np.testing.assert_allclose(hip.state_real(nm), orc.state_real(nm), rtol=1e-10, atol=1e-14, err_msg=nm)   # vel e + sqrt(..) r cancels
+        if opts.turb_cond:
+            # tau_relax comes from the first wet moment, i.e. from radii that carry the root finder's tolerance
+            np.testing.assert_allclose(hip.state_real("ssp"), orc.state_real("ssp"), rtol=1e-5, atol=1e-11)
+            np.testing.assert_allclose(hip.state_real("dot_ssp"), orc.state_real("dot_ssp"), rtol=1e-5, atol=1e-11)
+            np.testing.assert_allclose(thh, tho, rtol=1e-7)
+            np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=2e-4)
+        for a in ("x", "y", "z"):
+            if getattr(oi, "n" + a):
+                # with condensation on, z carries dt * vt(rw2) and rw2 the root finder's 2e-4 tolerance
+                np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-13, atol=1e-3 if opts.turb_cond and a == "z" else 1e-9, err_msg=a)
+    with pytest.raises(RuntimeError):                       # diss_rate is mandatory once a turbulence switch is on
+        hip.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
