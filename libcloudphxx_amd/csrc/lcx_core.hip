@@ -121,6 +121,7 @@ struct Particles : IParticles {
   int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
   std::vector<double> SGS_mix_len_h; DevBuf<T> SGS_mix_len, diss_rate, tau_cell, tau_rlx;
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
+  bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
   DevBuf<uint8_t> mig;
   DevBuf<uint64_t> sort_scratch;
@@ -157,8 +158,8 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   explicit Particles(const lcx_opts_init_t &oi) : o(oi)
   {
-    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.turb_coal_switch || oi.diag_incloud_time)
-      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb_coal)");
+    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.diag_incloud_time)
+      throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx)");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
     sizes.assign(oi.dry_sizes, oi.dry_sizes + oi.n_dry_sizes);
@@ -201,8 +202,9 @@ struct Particles : IParticles {
     HIPCHK(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
     alloc_attrs(A);
     for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp}) if (ix >= 0) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, cap * sizeof(T), st));
+    if (turb_any()) diss_rate.alloc_zero(ncell, st);
     if (turb()) {
-      diss_rate.alloc_zero(ncell, st); tau_cell.alloc_zero(ncell, st); tau_rlx.alloc_zero(ncell, st);
+      tau_cell.alloc_zero(ncell, st); tau_rlx.alloc_zero(ncell, st);
       std::vector<T> hm(SGS_mix_len_h.begin(), SGS_mix_len_h.end());
       SGS_mix_len.alloc(hm.size());
       h2d(SGS_mix_len.p, hm.data(), hm.size() * sizeof(T));
@@ -783,16 +785,21 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   // coalescence (coal.ipp:273-546)
   // ------------------------------------------------------------------------------------------
-  void coal(double dt_sub)
+  void coal(double dt_sub, bool turb_coal = false)
   {
     if (!replay.empty()) ensure_compact();     // un[id] of a replayed CPU stream is indexed by the reference's (compact) ids
     hskpng_sort_helper(true);
     if (npart < 2) { if (npart) (void)rand_u01(npart); return; }
     Range r(this, "coal");
     const u01_src<T> rs = rand_u01(npart);
-    coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p};
-    hipLaunchKernelGGL(k_coal<T>, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
-                       A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr);
+    const bool onishi = o.kernel == LCX_KERNEL_ONISHI_HALL || o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS;
+    // diss == nullptr stands for the reference's constant-zero dissipation rate when opts.turb_coal is off (coal.ipp:392-403,439-451)
+    coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p, eta.p, rhod.p, turb_coal ? diss_rate.p : nullptr};
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
+                         A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr);
+    };
+    if (onishi) launch(k_coal<T, true>); else launch(k_coal<T, false>);
     if (o.n_dry_distros + n_size_keys > 1)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
   }
@@ -1087,10 +1094,19 @@ struct Particles : IParticles {
       case LCX_KERNEL_GEOMETRIC: if (n_user_params > 1) throw lcx_error("Not more than 1 parameter is required by the geometric kernel"); break;
       case LCX_KERNEL_GOLOVIN: if (n_user_params != 1) throw lcx_error("Golovin kernel accepts exactly one parameter"); break;
       case LCX_KERNEL_LONG: if (n_user_params != 0) throw lcx_error("Long kernel doesn't accept parameters"); break;
-      default:
-        if (n_user_params != 0) throw lcx_error("this kernel doesn't accept parameters");
-        if (!load_efficiency_table(o.kernel, params, kernel_r_max))
+      default: {
+        const bool onishi = o.kernel == LCX_KERNEL_ONISHI_HALL || o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS;
+        if (onishi) {                                                                    // init_kernel.ipp:183-231
+          if (n_user_params != 1) throw lcx_error("libcloudph++: Please supply one kernel parameter: Taylor microscale Reynolds number.");
+          if (!o.turb_coal_switch) throw lcx_error("libcloudph++: To use the turbulent Onishis kernel, set turb_coal_switch=True");
+        } else if (n_user_params != 0) throw lcx_error("this kernel doesn't accept parameters");
+        const int eff = o.kernel == LCX_KERNEL_ONISHI_HALL ? LCX_KERNEL_HALL :
+                        o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS ? LCX_KERNEL_HALL_DAVIS_NO_WAALS : o.kernel;
+        std::vector<double> tab;
+        if (!load_efficiency_table(eff, tab, kernel_r_max))
           throw lcx_error("libcloudph++: kernel " + std::to_string(o.kernel) + " not available in this backend");
+        params.insert(params.end(), tab.begin(), tab.end());                             // user parameters first, then the efficiencies
+      }
     }
     std::vector<T> h(params.begin(), params.end());
     kparams.alloc(h.size());
@@ -1192,12 +1208,12 @@ struct Particles : IParticles {
     if (should_now_run_async) throw lcx_error("libcloudph++: please call step_async() before calling step_sync() again");
     if (is_null(th_) || is_null(rv_)) throw lcx_error("libcloudph++: passing th and rv is mandatory");
     courant_checks(cx, cy, cz);
-    if (turb() && is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are not switched off and diss_rate is empty");
-    if (!turb() && !is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
+    if (turb_any() && is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are not switched off and diss_rate is empty");
+    if (!turb_any() && !is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
     Range r(this, "sync_in");
     var_rho = !is_null(rhod_);
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
-    if (turb()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
+    if (turb_any()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
     if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
       HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
@@ -1242,6 +1258,7 @@ struct Particles : IParticles {
     if (opts.sedi && !o.sedi_switch) throw lcx_error("libcloudph++: sedimentation was switched off in opts_init");
     if (opts.subs && !o.subs_switch) throw lcx_error("libcloudph++: subsidence was switched off in opts_init");
     if (opts.turb_adve && !o.turb_adve_switch) throw lcx_error("libcloudph++: turb_adve_switch=False, but turb_adve==True");
+    if (opts.turb_coal && !o.turb_coal_switch) throw lcx_error("libcloudph++: turb_coal_switch=False, but turb_coal==True");   // the reference reads an empty diss_rate here
     if (opts.turb_adve && n_dims == 0) throw lcx_error("libcloudph++: turbulent advection does not work in 0D");
     if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
@@ -1250,7 +1267,7 @@ struct Particles : IParticles {
     if (opts.sedi || opts.coal || opts.cond) hskpng_vterm(false);
     if (opts.coal) {
       for (int step = 0; step < sstp_coal; ++step) {
-        coal(dt / sstp_coal);
+        coal(dt / sstp_coal, opts.turb_coal);
         if (step + 1 != sstp_coal) hskpng_vterm(true);
       }
       if (pure_const_multi) {
@@ -1409,7 +1426,7 @@ struct Particles : IParticles {
       {"up", ix_up >= 0 ? A.ext[ix_up].p : nullptr, ix_up >= 0 ? npart : 0}, {"vp", ix_vp >= 0 ? A.ext[ix_vp].p : nullptr, ix_vp >= 0 ? npart : 0},
       {"wp", ix_wp >= 0 ? A.ext[ix_wp].p : nullptr, ix_wp >= 0 ? npart : 0}, {"ssp", ix_ssp >= 0 ? A.ext[ix_ssp].p : nullptr, ix_ssp >= 0 ? npart : 0},
       {"dot_ssp", ix_dot_ssp >= 0 ? A.ext[ix_dot_ssp].p : nullptr, ix_dot_ssp >= 0 ? npart : 0},
-      {"diss_rate", diss_rate.p, turb() ? ncell : 0}};
+      {"diss_rate", diss_rate.p, turb_any() ? ncell : 0}};
     for (const E &e : tab)
       if (s == e.nm) {
         *n = e.len;
@@ -1452,7 +1469,7 @@ struct Particles : IParticles {
     else if (s == "hskpng_count") hskpng_count();
     else if (s == "hskpng_vterm_all") hskpng_vterm(false);
     else if (s == "hskpng_vterm_invalid") hskpng_vterm(true);
-    else if (s == "coal") { adjust_timesteps(opts ? opts->dt : -1); coal(dt / sstp_coal); }
+    else if (s == "coal") { adjust_timesteps(opts ? opts->dt : -1); coal(dt / sstp_coal, opts && opts->turb_coal); }
     else if (s == "adve") move(true, false, false, false);
     else if (s == "sedi") { adjust_timesteps(opts ? opts->dt : -1); move(false, true, false, false); }
     else if (s == "bcnd") move(false, false, false, true);

@@ -809,7 +809,10 @@ __global__ void k_sgs_supersat(size_t n, T dt_sub, const T *dot_ssp, T *ssp)
 // ============================================================================================
 // coalescence (particles_impl_coal.ipp:99-546, src/detail/kernels.hpp:38-202, kernel_interpolation.hpp:9-65)
 // ============================================================================================
-template <class T> struct coal_kernel_cfg { int kernel; int n_user_params; T r_max; const T *params; };
+template <class T> struct coal_kernel_cfg {
+  int kernel; int n_user_params; T r_max; const T *params;
+  const T *eta, *rhod, *diss;     // per-cell fields of the turbulent (Onishi) kernel; diss == nullptr: dissipation rate 0 (opts.turb_coal off)
+};
 
 __device__ __forceinline__ int kernel_index(n_t R) { return R <= 100. ? int(R) : int(100 + (R - 100.) / 10.); }
 __device__ __forceinline__ size_t kernel_vector_index(int i, int j, n_t nup)
@@ -840,9 +843,100 @@ __device__ __forceinline__ T k_geometric(n_t na, n_t nb, T rw2a, T rw2b, T vta, 
   const n_t nmax = na < nb ? nb : na;
   return cst<T>::pi * nmax * fabs(vta - vtb) * (rw2a + rw2b + 2. * sqrt(rw2a * rw2b));
 }
+// Onishi turbulent kernel without gravitational settling, 2 pi R^2 <|Wr|> g(R) (src/detail/kernel_onishi_nograv.hpp:29-153).
+// The reference evaluates the Kolmogorov length as pow(nu^3/eps, real_t(1/4)) with an integer 1/4 == 0, i.e. leta == 1:
+// kept, so that the kernel values are the reference's.
 template <class T>
-__device__ __forceinline__ T kernel_calc(const coal_kernel_cfg<T> &k, n_t na, n_t nb, T rw2a, T rw2b, T vta, T vtb)
+__device__ T kernel_onishi_nograv(T r1, T r2, T Re_l, T eps, T dnu, T ratio_den)
 {
+  if (eps < 1e-10) return T(0);
+  const T urms = sqrt(Re_l / sqrt(15. / dnu / eps));
+  const T CR = r1 + r2;
+  const T taup1 = ratio_den * 4. * r1 * r1 / 18. / dnu, taup2 = ratio_den * 4. * r2 * r2 / 18. / dnu;
+  const T leta = T(1);
+  const T tauk = leta * leta / dnu;
+  const T Te = Re_l * tauk / sqrt(15.);
+  const T theta1 = 2.5 * taup1 / Te, theta2 = 2.5 * taup2 / Te;
+  const T phi = mx(T(theta2 / theta1), T(theta1 / theta2));
+  const T cw = 1. + 0.6 * exp(-pow(phi - 1., 1.5));
+  T gamma = 0.183 * urms * urms / (dnu * dnu / leta / leta);
+  gamma = phi * gamma;
+  const T WrS2 = (dnu * dnu * CR * CR) / (leta * leta * leta * leta) / 15.;
+  T WrA2 = urms * urms * gamma / (gamma - 1.)
+    * ((theta1 + theta2) - 4. * theta1 * theta2 / (theta1 + theta2) * sqrt((1. + theta1 + theta2) / (1. + theta1) / (1. + theta2)))
+    * (1. / (1. + theta1) / (1. + theta2) - 1. / (1. + gamma * theta1) / (1. + gamma * theta2));
+  WrA2 = cw * WrA2;
+  WrA2 = WrA2 / 3.;
+  const T Wr = sqrt(2. / cst<T>::pi * (WrA2 + WrS2));
+  const T A1 = 110.0, A2 = 0.38, A3 = 0.16;
+  T alpha = log10(0.26 * sqrt(Re_l)) / log10(T(2.0));
+  alpha = mx(alpha, T(1.e-20));
+  const T CA = 0.06 * pow(Re_l, T(0.30)), CB = 0.4;
+  const T StA = pow(A2 / A1 * Re_l, T(0.25));
+  const T hlpr = cbrt(A2 / A3);
+  const T StB = hlpr * hlpr * cbrt(Re_l);
+  const T St1 = taup1 / tauk, St2 = taup2 / tauk;
+  T y11, y21, y12, y22;
+  if (St2 <= StA) { y11 = A1 * St1 * St1; y21 = 0.; } else { y11 = 0.; y21 = A2 * Re_l / (St1 * St1); }
+  const T y31 = A3 * sqrt(Re_l / St1);
+  if (St1 <= StA) { y12 = A1 * St2 * St2; y22 = 0.; } else { y12 = 0.; y22 = A2 * Re_l / (St2 * St2); }
+  const T y32 = A3 * sqrt(Re_l / St2);
+  const T za1 = 0.5 * (1. - tanh((log10(St1) - log10(StA)) / CA));
+  const T zb1 = 0.5 * (1. + tanh((log10(St1) - log10(StB)) / CB));
+  const T za2 = 0.5 * (1. - tanh((log10(St2) - log10(StA)) / CA));
+  const T zb2 = 0.5 * (1. + tanh((log10(St2) - log10(StB)) / CB));
+  const T gR1 = y11 * pow(za1, alpha) + y21 * pow(T(1.) - za1, alpha) + y31 * zb1 + 1.;
+  const T gR2 = y12 * pow(za2, alpha) + y22 * pow(T(1.) - za2, alpha) + y32 * zb2 + 1.;
+  const T xai = mx(T(taup2 / taup1), T(taup1 / taup2));
+  const T RG12 = 2.6 * exp(-xai) + 0.205 * exp(-0.0206 * xai) * 0.5 * (1.0 + tanh(xai - 3.0));
+  const T gR = 1. + RG12 * sqrt(gR1 - 1.) * sqrt(gR2 - 1.);
+  return 2. * cst<T>::pi * CR * CR * Wr * gR;
+}
+// Wang et al. (2009) turbulent enhancement of the collision efficiency, [ratio][eps class][collector radius]
+// (src/detail/wang_collision_enhancement.hpp:13-92)
+__device__ const double wang_eta_e[11][2][7] = {
+  {{1.74, 1.74, 1.773, 1.49, 1.207, 1.207, 1.0}, {4.976, 4.976, 3.593, 2.519, 1.445, 1.445, 1.0}},
+  {{1.46, 1.46, 1.421, 1.245, 1.069, 1.069, 1.0}, {2.984, 2.984, 2.181, 1.691, 1.201, 1.201, 1.0}},
+  {{1.32, 1.32, 1.245, 1.123, 1.000, 1.000, 1.0}, {1.988, 1.988, 1.475, 1.313, 1.150, 1.150, 1.0}},
+  {{1.250, 1.250, 1.148, 1.087, 1.025, 1.025, 1.0}, {1.490, 1.490, 1.187, 1.156, 1.126, 1.126, 1.0}},
+  {{1.186, 1.186, 1.066, 1.060, 1.056, 1.056, 1.0}, {1.249, 1.249, 1.088, 1.090, 1.092, 1.092, 1.0}},
+  {{1.045, 1.045, 1.000, 1.014, 1.028, 1.028, 1.0}, {1.139, 1.139, 1.130, 1.091, 1.051, 1.051, 1.0}},
+  {{1.070, 1.070, 1.030, 1.038, 1.046, 1.046, 1.0}, {1.220, 1.220, 1.190, 1.138, 1.086, 1.086, 1.0}},
+  {{1.000, 1.000, 1.054, 1.042, 1.029, 1.029, 1.0}, {1.325, 1.325, 1.267, 1.165, 1.063, 1.063, 1.0}},
+  {{1.223, 1.223, 1.117, 1.069, 1.021, 1.021, 1.0}, {1.716, 1.716, 1.345, 1.223, 1.100, 1.100, 1.0}},
+  {{1.570, 1.570, 1.244, 1.166, 1.088, 1.088, 1.0}, {3.788, 3.788, 1.501, 1.311, 1.120, 1.120, 1.0}},
+  {{20.3, 20.3, 14.6, 8.61, 2.60, 2.60, 1.0}, {36.52, 36.52, 19.16, 22.80, 26.0, 26.0, 1.0}}};
+template <class T>
+__device__ T wang_collision_enhancement(T r1, T r2, T eps)
+{
+  const T R0[7] = {10e-6, 20e-6, 30e-6, 40e-6, 50e-6, 60e-6, 100e-6};
+  const T rat[11] = {0., .1, .2, .3, .4, .5, .6, .7, .8, .9, 1.};
+  const T R = r1 > r2 ? r1 : r2, r = r1 > r2 ? r2 : r1;
+  if (R > 100e-6) return T(1);
+  const int n_eps = eps <= 2.5e-2 ? 0 : 1;
+  int n_R0, n_rat;
+  for (n_R0 = 0; n_R0 < 7; ++n_R0) if (R0[n_R0] > R) break;
+  const T ratio = r / R;
+  for (n_rat = 1; n_rat < 11; ++n_rat) if (rat[n_rat] > ratio) break;
+  if (n_R0 == 0) return T(wang_eta_e[n_rat][n_eps][n_R0]);
+  const T w0 = R - R0[n_R0 - 1], w1 = R0[n_R0] - R, w2 = ratio - rat[n_rat - 1], w3 = rat[n_rat] - ratio;
+  return (T(wang_eta_e[n_rat - 1][n_eps][n_R0 - 1]) * w1 * w3 + T(wang_eta_e[n_rat - 1][n_eps][n_R0]) * w0 * w3 +
+          T(wang_eta_e[n_rat][n_eps][n_R0 - 1]) * w1 * w2 + T(wang_eta_e[n_rat][n_eps][n_R0]) * w0 * w2)
+         / (R0[n_R0] - R0[n_R0 - 1]) / (rat[n_rat] - rat[n_rat - 1]);
+}
+// ONISHI is a template parameter so that the other kernels' instantiation carries none of the code above
+template <class T, bool ONISHI>
+__device__ __forceinline__ T kernel_calc(const coal_kernel_cfg<T> &k, n_t na, n_t nb, T rw2a, T rw2b, T vta, T vtb, uint32_t cell)
+{
+  if constexpr (ONISHI) {                                                         // kernel_onishi::calc, kernels.hpp:209-250
+    const T rwa = sqrt(rw2a), rwb = sqrt(rw2b);
+    const T Re_l = k.params[0];
+    const T rhod = k.rhod[cell];
+    const T nograv = kernel_onishi_nograv<T>(rwa, rwb, Re_l, k.diss ? k.diss[cell] : T(0), k.eta[cell] / rhod, T(1e3) / rhod);
+    const T geometric = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+    // the reference passes k_params[0] (Re_lambda) as the enhancement's dissipation-rate argument: kept
+    return interpolated_efficiency(k, rwa, rwb) * wang_collision_enhancement<T>(rwa, rwb, Re_l) * sqrt(geometric * geometric + nograv * nograv);
+  }
   switch (k.kernel) {
     case LCX_KERNEL_GOLOVIN: {
       const n_t nmax = na < nb ? nb : na;
@@ -872,7 +966,7 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // owned by exactly one lane and all 64 lanes of a wave carry work.  Pairs are disjoint, so the read-modify-write
 // of the two SDs needs no atomics.  The collision count / who-was-bigger flags go to col[] exactly as in the
 // reference (coal.ipp:209,233-267) because the kappa update (and tests) read them.
-template <class T>
+template <class T, bool ONISHI>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
@@ -901,7 +995,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
   const uint32_t a = sorted_id[p], b = sorted_id[p + 1];
   n_t na = n[a], nb = n[b];
   const T rw2a = rw2[a], rw2b = rw2[b];
-  const T prob = dt / dv[ca] * scl * kernel_calc(kc, na, nb, rw2a, rw2b, vt[a], vt[b]);
+  const T prob = dt / dv[ca] * scl * kernel_calc<T, ONISHI>(kc, na, nb, rw2a, rw2b, vt[a], vt[b], ca);
   n_t col_no = n_t(prob);
   if (pure_const_multi && col_no >= 1) *increase_sstp_coal = 1;
   const T u = rs.arr ? rs.arr[p] : philox::u01<T>(p, rs.call, rs.seed);

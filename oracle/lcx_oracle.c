@@ -165,9 +165,8 @@ static int distmem(const orc_particles *s) { return s->o.bcond_lft == 1 || s->o.
 int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
   if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
-  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type ||
-      oi->turb_coal_switch || oi->diag_incloud_time)
-    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx/turb_coal)");
+  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->diag_incloud_time)
+    FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx)");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
   s->distros = NEW(lcx_distro_t, oi->n_dry_distros);
@@ -217,6 +216,7 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
     s->rwX = NEW(double, c); s->drwX = NEW(double, c); s->Tp = NEW(double, c); s->pp_sstp = NEW(unsigned, c);
   }
   if (s->use_rc2) s->rc2 = NEW(double, c);
+  if (oi->turb_coal_switch && !(oi->turb_adve_switch || oi->turb_cond_switch)) s->diss_rate = NEW(double, nc);
   if (oi->turb_adve_switch || oi->turb_cond_switch) {
     s->diss_rate = NEW(double, nc); s->tau_cell = NEW(double, nc);
     s->SGS_mix_len = NEW(double, oi->n_SGS_mix_len);
@@ -809,9 +809,99 @@ static double k_geometric(n_t na, n_t nb, double rw2a, double rw2b, double vta, 
   const n_t nmax = na < nb ? nb : na;
   return ORC_PI * nmax * fabs(vta - vtb) * (rw2a + rw2b + 2. * sqrt(rw2a * rw2b));
 }
-static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb)
+/* Onishi turbulent kernel without gravitational settling, 2 pi R^2 <|Wr|> g(R) (src/detail/kernel_onishi_nograv.hpp:29-153).
+   The reference computes the Kolmogorov length as pow(nu^3/eps, real_t(1/4)) with an INTEGER 1/4 == 0, i.e. leta == 1:
+   reproduced, the results are what the reference produces. */
+static double kernel_onishi_nograv(double r1, double r2, double Re_l, double eps, double dnu, double ratio_den)
+{
+  if (eps < 1e-10) return 0.;
+  const double urms = sqrt(Re_l / sqrt(15. / dnu / eps));
+  const double CR = r1 + r2;
+  const double taup1 = ratio_den * 4. * r1 * r1 / 18. / dnu, taup2 = ratio_den * 4. * r2 * r2 / 18. / dnu;
+  const double leta = pow(dnu * dnu * dnu / eps, 0.);
+  const double tauk = leta * leta / dnu;
+  const double Te = Re_l * tauk / sqrt(15.);
+  const double theta1 = 2.5 * taup1 / Te, theta2 = 2.5 * taup2 / Te;
+  const double phi = dmax(theta2 / theta1, theta1 / theta2);
+  const double cw = 1. + 0.6 * exp(-pow(phi - 1., 1.5));
+  double gamma = 0.183 * urms * urms / (dnu * dnu / leta / leta);
+  gamma = phi * gamma;
+  const double WrS2 = (dnu * dnu * CR * CR) / (leta * leta * leta * leta) / 15.;
+  double WrA2 = urms * urms * gamma / (gamma - 1.)
+    * ((theta1 + theta2) - 4. * theta1 * theta2 / (theta1 + theta2) * sqrt((1. + theta1 + theta2) / (1. + theta1) / (1. + theta2)))
+    * (1. / (1. + theta1) / (1. + theta2) - 1. / (1. + gamma * theta1) / (1. + gamma * theta2));
+  WrA2 = cw * WrA2;
+  WrA2 = WrA2 / 3.;
+  const double Wr = sqrt(2. / ORC_PI * (WrA2 + WrS2));
+  const double A1 = 110.0, A2 = 0.38, A3 = 0.16;
+  double alpha = log10(0.26 * sqrt(Re_l)) / log10(2.0);
+  alpha = dmax(alpha, 1.e-20);
+  const double CA = 0.06 * pow(Re_l, 0.30), CB = 0.4;
+  const double StA = pow(A2 / A1 * Re_l, 0.25);
+  const double hlpr = cbrt(A2 / A3);
+  const double StB = hlpr * hlpr * cbrt(Re_l);
+  const double St1 = taup1 / tauk, St2 = taup2 / tauk;
+  double y11, y21, y12, y22;
+  if (St2 <= StA) { y11 = A1 * St1 * St1; y21 = 0.; } else { y11 = 0.; y21 = A2 * Re_l / (St1 * St1); }
+  const double y31 = A3 * sqrt(Re_l / St1);
+  if (St1 <= StA) { y12 = A1 * St2 * St2; y22 = 0.; } else { y12 = 0.; y22 = A2 * Re_l / (St2 * St2); }
+  const double y32 = A3 * sqrt(Re_l / St2);
+  const double za1 = 0.5 * (1. - tanh((log10(St1) - log10(StA)) / CA));
+  const double zb1 = 0.5 * (1. + tanh((log10(St1) - log10(StB)) / CB));
+  const double za2 = 0.5 * (1. - tanh((log10(St2) - log10(StA)) / CA));
+  const double zb2 = 0.5 * (1. + tanh((log10(St2) - log10(StB)) / CB));
+  const double gR1 = y11 * pow(za1, alpha) + y21 * pow(1. - za1, alpha) + y31 * zb1 + 1.;
+  const double gR2 = y12 * pow(za2, alpha) + y22 * pow(1. - za2, alpha) + y32 * zb2 + 1.;
+  const double xai = dmax(taup2 / taup1, taup1 / taup2);
+  const double RG12 = 2.6 * exp(-xai) + 0.205 * exp(-0.0206 * xai) * 0.5 * (1.0 + tanh(xai - 3.0));
+  const double gR = 1. + RG12 * sqrt(gR1 - 1.) * sqrt(gR2 - 1.);
+  return 2. * ORC_PI * CR * CR * Wr * gR;
+}
+/* Wang et al. (2009) turbulent enhancement of the collision efficiency (src/detail/wang_collision_enhancement.hpp:13-92);
+   table values: the published Table 1 as the reference tabulates it, [ratio][eps class][collector radius] */
+static double wang_collision_enhancement(double r1, double r2, double eps)
+{
+  static const double R0[7] = {10e-6, 20e-6, 30e-6, 40e-6, 50e-6, 60e-6, 100e-6};
+  static const double rat[11] = {0., .1, .2, .3, .4, .5, .6, .7, .8, .9, 1.};
+  static const double eta_e[11][2][7] = {
+    {{1.74, 1.74, 1.773, 1.49, 1.207, 1.207, 1.0}, {4.976, 4.976, 3.593, 2.519, 1.445, 1.445, 1.0}},
+    {{1.46, 1.46, 1.421, 1.245, 1.069, 1.069, 1.0}, {2.984, 2.984, 2.181, 1.691, 1.201, 1.201, 1.0}},
+    {{1.32, 1.32, 1.245, 1.123, 1.000, 1.000, 1.0}, {1.988, 1.988, 1.475, 1.313, 1.150, 1.150, 1.0}},
+    {{1.250, 1.250, 1.148, 1.087, 1.025, 1.025, 1.0}, {1.490, 1.490, 1.187, 1.156, 1.126, 1.126, 1.0}},
+    {{1.186, 1.186, 1.066, 1.060, 1.056, 1.056, 1.0}, {1.249, 1.249, 1.088, 1.090, 1.092, 1.092, 1.0}},
+    {{1.045, 1.045, 1.000, 1.014, 1.028, 1.028, 1.0}, {1.139, 1.139, 1.130, 1.091, 1.051, 1.051, 1.0}},
+    {{1.070, 1.070, 1.030, 1.038, 1.046, 1.046, 1.0}, {1.220, 1.220, 1.190, 1.138, 1.086, 1.086, 1.0}},
+    {{1.000, 1.000, 1.054, 1.042, 1.029, 1.029, 1.0}, {1.325, 1.325, 1.267, 1.165, 1.063, 1.063, 1.0}},
+    {{1.223, 1.223, 1.117, 1.069, 1.021, 1.021, 1.0}, {1.716, 1.716, 1.345, 1.223, 1.100, 1.100, 1.0}},
+    {{1.570, 1.570, 1.244, 1.166, 1.088, 1.088, 1.0}, {3.788, 3.788, 1.501, 1.311, 1.120, 1.120, 1.0}},
+    {{20.3, 20.3, 14.6, 8.61, 2.60, 2.60, 1.0}, {36.52, 36.52, 19.16, 22.80, 26.0, 26.0, 1.0}}};
+  const double R = r1 > r2 ? r1 : r2, r = r1 > r2 ? r2 : r1;
+  if (R > 100e-6) return 1.;
+  const int n_eps = eps <= 2.5e-2 ? 0 : 1;
+  int n_R0, n_rat;
+  for (n_R0 = 0; n_R0 < 7; ++n_R0) if (R0[n_R0] > R) break;
+  const double ratio = r / R;
+  for (n_rat = 1; n_rat < 11; ++n_rat) if (rat[n_rat] > ratio) break;
+  if (n_R0 == 0) return eta_e[n_rat][n_eps][n_R0];
+  const double w0 = R - R0[n_R0 - 1], w1 = R0[n_R0] - R, w2 = ratio - rat[n_rat - 1], w3 = rat[n_rat] - ratio;
+  return (eta_e[n_rat - 1][n_eps][n_R0 - 1] * w1 * w3 + eta_e[n_rat - 1][n_eps][n_R0] * w0 * w3 +
+          eta_e[n_rat][n_eps][n_R0 - 1] * w1 * w2 + eta_e[n_rat][n_eps][n_R0] * w0 * w2)
+         / (R0[n_R0] - R0[n_R0 - 1]) / (rat[n_rat] - rat[n_rat - 1]);
+}
+/* c = cell of the pair, diss = its TKE dissipation rate when opts.turb_coal, else 0 (coal.ipp:392-416,439-451) */
+static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb, sz c, double diss)
 {
   switch (s->o.kernel) {
+    case LCX_KERNEL_ONISHI_HALL:
+    case LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS: {                                   /* kernel_onishi::calc, kernels.hpp:209-250 */
+      const double rwa = sqrt(rw2a), rwb = sqrt(rw2b);
+      const double Re_l = s->kernel_parameters[0];
+      const double nograv = kernel_onishi_nograv(rwa, rwb, Re_l, diss, s->eta[c] / s->rhod[c], 1e3 / s->rhod[c]);
+      const double geometric = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+      /* the reference hands k_params[0] (Re_lambda) to the enhancement's dissipation-rate argument: reproduced */
+      return interpolated_efficiency(s, rwa, rwb) * wang_collision_enhancement(rwa, rwb, Re_l) *
+             sqrt(geometric * geometric + nograv * nograv);
+    }
     case LCX_KERNEL_GOLOVIN: {
       const n_t nmax = na < nb ? nb : na;
       return ORC_PI * 4. / 3. * s->kernel_parameters[0] * nmax * (rw2a * sqrt(rw2a) + rw2b * sqrt(rw2b));
@@ -842,7 +932,7 @@ static void collide(orc_particles *s, sz a, sz b, n_t col_no)
   s->vt[b] = -1.;
   if (s->use_rc2) s->rc2[b] = -1.;        /* invalidator, coal.ipp:33-44,527-545 */
 }
-static void coal(orc_particles *s, double dt)
+static void coal(orc_particles *s, double dt, int turb_coal)
 {
   hskpng_sort_helper(s, 1);
   s->sorted = 1;
@@ -870,7 +960,8 @@ static void coal(orc_particles *s, double dt)
     const sz cix_b = (p + 1) - s->off[cb];
     if (cix_a != cix_b - 1) { s->col[p] = 0.; continue; }
     const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
-    const double prob = dt / s->dv[ca] * s->scl[ca] * kernel_calc(s, s->n[a], s->n[b], s->rw2[a], s->rw2[b], s->vt[a], s->vt[b]);
+    const double prob = dt / s->dv[ca] * s->scl[ca] *
+      kernel_calc(s, s->n[a], s->n[b], s->rw2[a], s->rw2[b], s->vt[a], s->vt[b], ca, turb_coal ? s->diss_rate[ca] : 0.);
     n_t col_no = (n_t)prob;
     if (s->pure_const_multi && col_no >= 1) s->increase_sstp_coal = 1;
     if (u01[p] < prob - col_no) ++col_no;
@@ -1419,14 +1510,22 @@ static int init_kernel(orc_particles *s)
       if (s->n_user_params != 0) FAIL("Long kernel doesn't accept parameters, %d given", s->n_user_params);
       return 0;
     default: {
-      if (s->n_user_params != 0) FAIL("this kernel doesn't accept parameters");
+      const int onishi = o->kernel == LCX_KERNEL_ONISHI_HALL || o->kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS;
+      if (onishi) {                                                                          /* init_kernel.ipp:183-231 */
+        if (s->n_user_params != 1) FAIL("libcloudph++: Please supply one kernel parameter: Taylor microscale Reynolds number.");
+        if (!o->turb_coal_switch) FAIL("libcloudph++: To use the turbulent Onishis kernel, set turb_coal_switch=True");
+      } else if (s->n_user_params != 0) FAIL("this kernel doesn't accept parameters");
       sz n = 0; double r_max = 0;
-      const double *tab = orc_efficiency_table(o->kernel, &n, &r_max);
+      const int eff = o->kernel == LCX_KERNEL_ONISHI_HALL ? LCX_KERNEL_HALL :
+                      o->kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS ? LCX_KERNEL_HALL_DAVIS_NO_WAALS : o->kernel;
+      const double *tab = orc_efficiency_table(eff, &n, &r_max);
       if (!tab) FAIL("libcloudph++: kernel %d not available in this backend", o->kernel);
+      double *kp = NEW(double, n + s->n_user_params);                    /* user parameters first, then the efficiencies */
+      for (int i = 0; i < s->n_user_params; ++i) kp[i] = s->kernel_parameters[i];
+      memcpy(kp + s->n_user_params, tab, n * sizeof(double));
       free(s->kernel_parameters);
-      s->kernel_parameters = NEW(double, n);
-      memcpy(s->kernel_parameters, tab, n * sizeof(double));
-      s->n_kernel_parameters = n; s->kernel_r_max = r_max;
+      s->kernel_parameters = kp;
+      s->n_kernel_parameters = n + s->n_user_params; s->kernel_r_max = r_max;
       return 0;
     }
   }
@@ -1595,6 +1694,7 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
   if (opts->subs && !s->o.subs_switch) FAIL("libcloudph++: subsidence was switched off in opts_init");
   if (opts->turb_adve && !s->o.turb_adve_switch) FAIL("libcloudph++: turb_adve_switch=False, but turb_adve==True");
   if (opts->turb_adve && s->n_dims == 0) FAIL("libcloudph++: turbulent advection does not work in 0D");
+  if (opts->turb_coal && !s->o.turb_coal_switch) FAIL("libcloudph++: turb_coal_switch=False, but turb_coal==True");  /* the reference reads an empty diss_rate here */
   if (opts->src) FAIL("libcloudph++: aerosol source was switched off in opts_init");
   if (opts->rlx) FAIL("libcloudph++: aerosol relaxation was switched off in opts_init");
   if (adjust_timesteps(s, opts->dt)) return 1;
@@ -1602,7 +1702,7 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
   if (opts->sedi || opts->coal || opts->cond) hskpng_vterm(s, 0);
   if (opts->coal) {
     for (int step = 0; step < s->sstp_coal; ++step) {
-      coal(s, s->dt / s->sstp_coal);
+      coal(s, s->dt / s->sstp_coal, opts->turb_coal);
       if (step + 1 != s->sstp_coal) hskpng_vterm(s, 1);
     }
     if (s->increase_sstp_coal) { ++s->sstp_coal; s->increase_sstp_coal = 0; }
@@ -1826,7 +1926,7 @@ int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
   else if (!strcmp(st, "hskpng_count")) hskpng_count(s);
   else if (!strcmp(st, "hskpng_vterm_all")) hskpng_vterm(s, 0);
   else if (!strcmp(st, "hskpng_vterm_invalid")) hskpng_vterm(s, 1);
-  else if (!strcmp(st, "coal")) { if (adjust_timesteps(s, opts ? opts->dt : -1)) return 1; coal(s, s->dt / s->sstp_coal); }
+  else if (!strcmp(st, "coal")) { if (adjust_timesteps(s, opts ? opts->dt : -1)) return 1; coal(s, s->dt / s->sstp_coal, opts ? opts->turb_coal : 0); }
   else if (!strcmp(st, "adve")) adve(s);
   else if (!strcmp(st, "sedi")) { if (adjust_timesteps(s, opts ? opts->dt : -1)) return 1; sedi(s, s->dt); }
   else if (!strcmp(st, "bcnd")) bcnd(s);

@@ -238,7 +238,9 @@ def test_cond_moment_feedback_conservation():
 
 # ------------------------------------------------------------------ coalescence (a11, a12)
 @pytest.mark.parametrize("kernel,params", [(lgrngn.kernel_t.geometric, []), (lgrngn.kernel_t.geometric, [0.5]),
-                                           (lgrngn.kernel_t.golovin, [1500.]), (lgrngn.kernel_t.Long, [])])
+                                           (lgrngn.kernel_t.golovin, [1500.]), (lgrngn.kernel_t.Long, []),
+                                           (lgrngn.kernel_t.hall, []), (lgrngn.kernel_t.hall_davis_no_waals, []),
+                                           (lgrngn.kernel_t.vohl_davis_no_waals, []), (lgrngn.kernel_t.hall_pinsky_cumulonimbus, [])])
 def test_coal_replay(kernel, params):
     oi = h.box_opts(3, 3, 3, 96, kernel=kernel, kernel_parameters=np.array(params), dx=1.)
     oi.dt = 30.      # long step + small cells -> many collisions
@@ -268,6 +270,41 @@ def test_coal_replay(kernel, params):
     np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-14)
     exact(hip.state_real("vt") == -1, orc.state_real("vt") == -1, "invalidated vt flags")
     np.testing.assert_allclose(hip.state_real("col")[:-1], orc.state_real("col")[:-1], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("turb_coal", [False, True])
+@pytest.mark.parametrize("kernel", [lgrngn.kernel_t.onishi_hall, lgrngn.kernel_t.onishi_hall_davis_no_waals])
+def test_onishi_turbulent_kernel_replay(kernel, turb_coal):
+    """f4: Onishi turbulent kernel (kernels.hpp:209-250, kernel_onishi_nograv.hpp, wang_collision_enhancement.hpp) through
+    full steps with the cell field diss_rate; opts.turb_coal off = dissipation rate 0 (coal.ipp:392-451)"""
+    oi = h.box_opts(3, 3, 3, 96, kernel=kernel, kernel_parameters=np.array([66.]), dx=1., turb_coal_switch=True)
+    oi.dt = 30.
+    th, rv, rhod, C = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, (th, rv, rhod, C))
+    n = orc.n_part
+    rng = np.random.default_rng(2)
+    rw2 = (10 ** rng.uniform(-5.3, -3.7, n)) ** 2
+    g = lambda nm: orc.state_real(nm)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    diss = rng.uniform(1e-3, 0.1, th.shape)
+    opts = lgrngn.opts_t()
+    opts.adve = opts.sedi = opts.cond = False
+    opts.coal = True
+    opts.turb_coal = turb_coal
+    for pr in (orc, hip):
+        pr.step_sync(opts, th.copy(), rv.copy(), rhod.copy(), diss_rate=diss, **C)
+    h.push_coal_replay(orc, hip)
+    orc.step_async(opts)
+    hip.step_async(opts)
+    col = orc.state_real("col")[:-1]
+    assert np.all(np.isfinite(col))
+    n_o, n_h = orc.state_u64("n"), hip.state_u64("n")
+    assert np.sum(n_o != args[0]) > 10, "test needs collisions to happen"
+    exact(n_h, n_o, "multiplicities after coalescence")
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-14)
+    np.testing.assert_allclose(hip.state_real("col")[:-1], col, rtol=0, atol=0)
 
 
 def test_coal_two_kappas_replay():
