@@ -238,6 +238,12 @@ int lcx_dev_sync(void);
 /* parity hook: evaluate one of the device elementary functions on a host array of doubles
  * (which: 0 seeded cbrt, 1 reduced exp [the fast-mode growth rate uses these], 2 library cbrt, 3 library exp) */
 int lcx_math_probe(int which, const double *x_host, double *y_host, size_t n);
+/* host-side scalar evaluation of the formula library, = the functions the reference's Python module exposes as
+ * libcloudphxx.common (ref: bindings/python/common.hpp:19-172, lib.cpp:129-144): name is one of
+ *   th_dry2std(th_dry,r) th_std2dry(th_std,r) exner(p) p_v(p,r) p_vs(T) r_vs(T,p) p_vs_tet(T) l_v(T) T(th,rhod)
+ *   p(rhod,r,T) visc(T) rw3_cr(rd3,kappa,T) S_cr(rd3,kappa,T) p_hydro(z,th_0,r_0,z_0,p_0) rhod(p,th_std,rv)
+ * or a constant (no arguments): R_d R_v c_pd c_pv c_pw g p_1000 eps rho_stp rho_w.  Needs no GPU. */
+int lcx_common_eval(const char *name, const double *args, int n_args, double *out);
 
 #ifdef __cplusplus
 }

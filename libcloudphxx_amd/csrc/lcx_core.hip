@@ -691,7 +691,7 @@ struct Particles : IParticles {
     hipLaunchKernelGGL(k_rc2<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, A.rd3.p, A.kpa.p, T(T(o.rc2_T) + T(273.15)), A.ext[ix_rc2].p);
   }
   // particles_step.ipp:199-236: per-particle substepping; sorted (plain order) on entry
-  void cond_perparticle(double RH_max)
+  void cond_perparticle(double RH_max, bool turb_cond)
   {
     if (!npart) return;
     pp_args<T> a{};
@@ -700,6 +700,7 @@ struct Particles : IParticles {
     a.pp_rv = A.ext[ix_rv].p; a.pp_th = A.ext[ix_th].p; a.pp_rh = A.ext[ix_rh].p; a.pp_p = o.const_p ? A.ext[ix_p].p : nullptr;
     a.rv = rv.p; a.th = th.p; a.rhod = rhod.p; a.p = p.p;
     a.dv = dv.p; a.lambda_D = lambda_D.p; a.lambda_K = lambda_K.p; a.rc2 = use_rc2 ? A.ext[ix_rc2].p : nullptr;
+    a.ssp = turb_cond ? A.ext[ix_ssp].p : nullptr; a.dot_ssp = turb_cond ? A.ext[ix_dot_ssp].p : nullptr;
     a.m3_before = m3_before.p; a.m3_after = m3_after.p;
     a.dt = T(dt); a.RH_max = T(RH_max); a.eps = eps_tol; a.cond_mlt = T(2.); a.n_iter = 100u;
     a.adapt_eps = T(o.sstp_cond_adapt_drw2_eps); a.adapt_max = T(o.sstp_cond_adapt_drw2_max);
@@ -1228,13 +1229,12 @@ struct Particles : IParticles {
   {
     if (!should_now_run_cond) throw lcx_error("libcloudph++: please call sync_in() before calling step_cond()");
     if (opts.turb_cond && !o.turb_cond_switch) throw lcx_error("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
-    if (opts.turb_cond && o.exact_sstp_cond) throw lcx_error("libcloudph++: turb_cond with per-particle substepping is not supported by this backend");
     should_now_run_cond = false;
     adjust_timesteps(opts.dt);
     if (opts.cond) {
       hskpng_sort();
       hskpng_mfp();
-      if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) cond_perparticle(opts.RH_max);
+      if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) cond_perparticle(opts.RH_max, opts.turb_cond);
       else for (int step = 0; step < sstp_cond; ++step) {
         sstp_percell_step(step);
         if (opts.turb_cond && nphys)                                                     // apply_perparticle_sgs_supersat.ipp
@@ -1677,6 +1677,41 @@ int lcx_math_probe(int which, const double *x, double *y, size_t n)
     const hipError_t e = hipMemcpy(y, d, n * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) throw std::runtime_error(std::string("libcloudph++ (HIP): math probe failed: ") + hipGetErrorString(e));
+  })
+}
+
+int lcx_common_eval(const char *name, const double *a, int n, double *out)
+{
+  LCX_TRY({
+    const std::string s(name);
+    auto need = [&](int k) { if (n != k) throw std::runtime_error("libcloudph++: common." + s + " takes " + std::to_string(k) + " argument(s)"); };
+    using c = lcx::cst<double>;
+    const double kap = c::R_d / c::c_pd;
+    if (s == "th_dry2std") { need(2); *out = a[0] / pow(1 + a[1] * c::R_v / c::R_d, kap); }                    // theta_dry.hpp:101-113
+    else if (s == "th_std2dry") { need(2); *out = a[0] * pow(1 + a[1] * c::R_v / c::R_d, kap); }               // theta_dry.hpp:86-99
+    else if (s == "exner") { need(1); *out = lcx::exner(a[0]); }
+    else if (s == "p_v") { need(2); *out = lcx::p_v(a[0], a[1]); }
+    else if (s == "p_vs") { need(1); *out = lcx::p_vs(a[0]); }
+    else if (s == "r_vs") { need(2); *out = c::eps / (a[1] / lcx::p_vs(a[0]) - 1); }                            // const_cp.hpp r_vs
+    else if (s == "p_vs_tet") { need(1); *out = lcx::tet_p_vs(a[0]); }
+    else if (s == "l_v") { need(1); *out = lcx::l_v(a[0]); }
+    else if (s == "T") { need(2); *out = lcx::theta_dry_T(a[0], a[1]); }
+    else if (s == "p") { need(3); *out = lcx::theta_dry_p(a[0], a[1], a[2]); }
+    else if (s == "visc") { need(1); *out = lcx::visc(a[0]); }
+    else if (s == "rw3_cr") { need(3); *out = lcx::rw3_cr_of(a[0], a[1], a[2]); }
+    else if (s == "S_cr") { need(3); *out = lcx::S_cr(a[0], a[1], a[2]); }
+    else if (s == "p_hydro") {                                                                                  // hydrostatic.hpp:24-38
+      need(5);
+      const double R_moist = (c::R_d + a[2] * c::R_v) / (1 + a[2]);                                             // moist_air.hpp:54-70
+      *out = c::p_1000 * pow(pow(a[4] / c::p_1000, kap) - kap * c::g / a[1] / R_moist * (a[0] - a[3]), c::c_pd / c::R_d);
+    }
+    else if (s == "rhod") { need(3); *out = (a[0] - lcx::p_v(a[0], a[2])) / (pow(a[0] / c::p_1000, kap) * c::R_d * a[1]); }   // theta_std.hpp:23-32
+    else if (s == "R_d") { need(0); *out = c::R_d; } else if (s == "R_v") { need(0); *out = c::R_v; }
+    else if (s == "c_pd") { need(0); *out = c::c_pd; } else if (s == "c_pv") { need(0); *out = c::c_pv; }
+    else if (s == "c_pw") { need(0); *out = c::c_pw; } else if (s == "g") { need(0); *out = c::g; }
+    else if (s == "p_1000") { need(0); *out = c::p_1000; } else if (s == "eps") { need(0); *out = c::eps; }
+    else if (s == "rho_stp") { need(0); *out = c::rho_stp; } else if (s == "rho_w") { need(0); *out = c::rho_w; }
+    else throw std::runtime_error("libcloudph++: common." + s + " is not provided by this backend");
   })
 }
 

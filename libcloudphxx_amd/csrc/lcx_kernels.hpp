@@ -576,6 +576,7 @@ struct pp_args {
   T *pp_rv, *pp_th, *pp_rh, *pp_p;            // per-particle "old" state (sstp_tmp_* of the reference)
   const T *rv, *th, *rhod, *p;                // cell state after sync_in
   const T *dv, *lambda_D, *lambda_K, *rc2;
+  T *ssp; const T *dot_ssp;                   // opts.turb_cond: SGS supersaturation perturbation and its tendency, else nullptr
   T *m3_before, *m3_after;                    // position-ordered: n rw^3 before / after (no mixing)
   T *dlt_rv, *dlt_th, *dlt_rh, *dlt_p, *rw3s; // mixing only: per-particle deltas and stored rw^3
   T *drv, *dth;                               // mixing only, position-ordered: this substep's change of rv, th
@@ -590,11 +591,13 @@ template <class T> __device__ __forceinline__ T rw3diff2drv(T d, T rhod, n_t n, 
   return n_dims > 0 ? mlt * d * T(n) / rhod / dv : mlt * d * T(n);
 }
 // temperature, pressure and RH of one super-droplet's private air (cond_perparticle_advance_rw2.ipp:30-125)
-template <class T> __device__ __forceinline__ void pp_state(const pp_args<T> &a, T t_th, T t_rv, T t_rh, T &t_p, T &Tp, T &RH)
+// ssp: SGS supersaturation perturbation, RH_sgs = RH + ssp (cond_perparticle_advance_rw2.ipp:8-22); 0 without turb_cond
+template <class T> __device__ __forceinline__ void pp_state(const pp_args<T> &a, T t_th, T t_rv, T t_rh, T &t_p, T &Tp, T &RH, T ssp)
 {
   Tp = a.th_dry ? theta_dry_T(t_th, t_rh) : T(t_th * exner(t_p));
   if (!a.const_p) t_p = theta_dry_p(t_rh, t_rv, Tp);
   RH = RH_of(a.RH_formula, t_p, t_rv, Tp);
+  if (a.ssp) RH = RH + ssp;
 }
 template <class T, bool FAST> __device__ __forceinline__ T pp_advance(const pp_args<T> &a, T rw2, T dt, T t_rh, T t_rv, T Tp, T RH,
                                                                       T rd3, T kpa, T vt, T lD, T lK)
@@ -629,12 +632,15 @@ __global__ void __launch_bounds__(BS) k_pp_cond_nomix(size_t n_part, pp_args<T> 
   T t_rv = a.pp_rv[id], t_th = a.pp_th[id], t_rh = a.pp_rh[id], t_p = a.const_p ? a.pp_p[id] : T(0);
   const T d_rv = a.rv[c] - t_rv, d_th = a.th[c] - t_th, d_rh = a.rhod[c] - t_rh, d_p = a.const_p ? a.p[c] - t_p : T(0);
   T rw2 = a.rw2[id], rw3 = 0, Tp, RH;
+  T ssp = a.ssp ? a.ssp[id] : T(0);
+  const T dot_ssp = a.ssp ? a.dot_ssp[id] : T(0);
   a.m3_before[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
   for (int step = 0; step < a.sstp_cond; ++step) {
     t_rv = t_rv + d_rv / a.sstp_cond; t_th = t_th + d_th / a.sstp_cond; t_rh = t_rh + d_rh / a.sstp_cond;      // apply_noncond_...ipp
     if (a.const_p) t_p = t_p + d_p / a.sstp_cond;
+    if (a.ssp) ssp = ssp + a.dt / a.sstp_cond * dot_ssp;                                                      // apply_perparticle_sgs_supersat.ipp
     T drw3 = step > 0 ? -rw3 : -rw2torw3(rw2);
-    pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+    pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH, ssp);
     rw2 = pp_advance<T, FAST>(a, rw2, a.dt / a.sstp_cond, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK);
     rw3 = rw2torw3(rw2);
     drw3 = rw3 + drw3;
@@ -644,6 +650,7 @@ __global__ void __launch_bounds__(BS) k_pp_cond_nomix(size_t n_part, pp_args<T> 
     t_th = drw3 + t_th;
   }
   a.rw2[id] = rw2;
+  if (a.ssp) a.ssp[id] = ssp;
   a.m3_after[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
 }
 
@@ -658,8 +665,11 @@ __global__ void __launch_bounds__(BS) k_pp_cond_adaptive(size_t n_part, pp_args<
   T t_rv = a.pp_rv[id], t_th = a.pp_th[id], t_rh = a.pp_rh[id], t_p = a.const_p ? a.pp_p[id] : T(0);
   const T d_rv = a.rv[c] - t_rv, d_th = a.th[c] - t_th, d_rh = a.rhod[c] - t_rh, d_p = a.const_p ? a.p[c] - t_p : T(0);
   T rw2 = a.rw2[id], drw2 = 0, Tp = 0, RH = 0, frac = 0;
+  T ssp = a.ssp ? a.ssp[id] : T(0);
+  const T dot_ssp = a.ssp ? a.dot_ssp[id] : T(0);
   a.m3_before[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
-  auto apply_delta = [&](T m) { t_rv += d_rv * m; t_th += d_th * m; t_rh += d_rh * m; if (a.const_p) t_p += d_p * m; };
+  auto apply_delta = [&](T m) { t_rv += d_rv * m; t_th += d_th * m; t_rh += d_rh * m; if (a.const_p) t_p += d_p * m;
+                                if (a.ssp) ssp += dot_ssp * a.dt * m; };
   const int sstp_max = a.sstp_cond;
   unsigned sstp = unsigned(sstp_max);
   bool first_done = sstp_max == 1;
@@ -668,7 +678,7 @@ __global__ void __launch_bounds__(BS) k_pp_cond_adaptive(size_t n_part, pp_args<
     for (int tr = 1; tr <= sstp_max; tr *= 2) {
       frac = tr == 1 ? T(1) : -T(1) / tr;
       apply_delta(frac);
-      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH, ssp);
       T d = rw2;                                                    // advance_rw2<real_t, false>: the increment (rw2 <= 0: rw2 itself)
       if (rw2 > 0) d = pp_advance<T, FAST>(a, rw2, a.dt / tr, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK) - rw2;
       if (tr == 1) drw2 = d; else drw2_new = d;
@@ -698,7 +708,7 @@ __global__ void __launch_bounds__(BS) k_pp_cond_adaptive(size_t n_part, pp_args<
     if (first_done && step == 0) rw2 += rw3;
     else {
       apply_delta(frac);
-      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+      pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH, ssp);
       rw2 = pp_advance<T, FAST>(a, rw2, a.dt / sstp, t_rh, t_rv, Tp, RH, rd3, kpa, vt, lD, lK);
     }
     if (step < sstp - 1) { rw3 = rw2torw3(rw2); drw3 += rw3; }
@@ -709,6 +719,7 @@ __global__ void __launch_bounds__(BS) k_pp_cond_adaptive(size_t n_part, pp_args<
     t_th += drw3;
   }
   a.rw2[id] = rw2;
+  if (a.ssp) a.ssp[id] = ssp;
   a.m3_after[pos] = rw2 >= 0 ? T(n) * rw2torw3(rw2) : T(n) * rw2;
 }
 
@@ -734,8 +745,10 @@ __global__ void __launch_bounds__(BS) k_pp_cond_mix(size_t n_part, pp_args<T> a)
   t_rv = t_rv + d_rv / a.sstp_cond; t_th = t_th + d_th / a.sstp_cond; t_rh = t_rh + d_rh / a.sstp_cond;
   if (a.const_p) t_p = t_p + d_p / a.sstp_cond;
   T rw2 = a.rw2[id], Tp, RH;
+  T ssp = T(0);
+  if (a.ssp) { ssp = a.ssp[id] + a.dt / a.sstp_cond * a.dot_ssp[id]; a.ssp[id] = ssp; }                     // apply_perparticle_sgs_supersat.ipp
   T drw3 = a.step > 0 ? -a.rw3s[id] : -rw2torw3(rw2);
-  pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH);
+  pp_state(a, t_th, t_rv, t_rh, t_p, Tp, RH, ssp);
   rw2 = pp_advance<T, FAST>(a, rw2, a.dt / a.sstp_cond, t_rh, t_rv, Tp, RH, a.rd3[id], a.kpa[id], a.vt[id], a.lambda_D[c], a.lambda_K[c]);
   const T rw3 = rw2torw3(rw2);
   if (a.step < a.sstp_cond - 1) a.rw3s[id] = rw3;

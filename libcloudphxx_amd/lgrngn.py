@@ -36,6 +36,7 @@ class kernel_t(enum.IntEnum):           # lgrngn/kernel.hpp:8
     golovin = 2
     hall = 3
     hall_davis_no_waals = 4
+    long = 5                            # the Python module's spelling (ref: bindings/python/lib.cpp, kernel_t::Long in C++)
     Long = 5
     onishi_hall = 6
     onishi_hall_davis_no_waals = 7

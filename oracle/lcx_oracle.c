@@ -590,13 +590,13 @@ static double rw3diff2drv(const orc_particles *s, double rw3diff, double rhod, n
 static double pp_T(const orc_particles *s, double th, double rhod, double p)
 { return s->o.th_dry ? theta_dry_T(th, rhod) : th * theta_std_exner(p); }     /* hskpng_Tpr.ipp:26-46 */
 /* cond_perparticle_advance_rw2.ipp:30-125 + perparticle_advance_rw2.ipp:8-43 */
-static void cond_perparticle_advance_rw2(orc_particles *s, double RH_max)
+static void cond_perparticle_advance_rw2(orc_particles *s, double RH_max, int turb_cond)
 {
   for (sz p = 0; p < s->n_part; ++p) s->Tp[p] = pp_T(s, s->pp_th[p], s->pp_rh[p], s->pp_p[p]);
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
     const double pr = s->o.const_p ? s->pp_p[p] : theta_dry_p(s->pp_rh[p], s->pp_rv[p], s->Tp[p]);
-    const double RH = RH_of(s->o.RH_formula, pr, s->pp_rv[p], s->Tp[p]);
+    const double RH = RH_of(s->o.RH_formula, pr, s->pp_rv[p], s->Tp[p]) + (turb_cond ? s->ssp[p] : 0.);   /* RH_sgs, :8-22 */
     cond_ctx cc = {s->rw2[p], s->dt / s->sstp_cond, s->pp_rh[p], s->pp_rv[p], s->Tp[p], pr, RH, visc(s->Tp[p]),
                    s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};
     s->rw2[p] = advance_rw2(&cc, s->eps_tol, 2., 100);
@@ -636,7 +636,7 @@ static void calc_liq_content_change(orc_particles *s)
   for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = s->count_mom[i] + s->drw_mom3[s->count_ijk[i]];
 }
 /* perparticle_nomixing_adaptive_sstp_cond.ipp:56-265, one super-droplet */
-static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max)
+static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max, int turb_cond)
 {
   const lcx_opts_init_t *o = &s->o;
   const sz c = s->ijk[p];
@@ -647,10 +647,12 @@ static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max)
   unsigned sstp_cond;
   double t_rv = s->pp_rv[p], t_th = s->pp_th[p], t_rh = s->pp_rh[p], t_p = o->const_p ? s->pp_p[p] : 0., rw2 = s->rw2[p];
   double drw2 = 0, Tp = 0, RH = 0, delta_fraction_applied = 0;
+  const double dot_ssp = turb_cond ? s->dot_ssp[p] : 0.;                       /* :66,74 */
+  double ssp = turb_cond ? s->ssp[p] : 0.;
 #define APPLY_DELTA(mult) do { const double m_ = (mult); t_rv += dlt_rv * m_; t_th += dlt_th * m_; t_rh += dlt_rhod * m_; \
-                               if (o->const_p) t_p += dlt_p * m_; } while (0)
+                               if (o->const_p) { t_p += dlt_p * m_; } if (turb_cond) { ssp += dot_ssp * s->dt * m_; } } while (0)
 #define CALC_STATE() do { Tp = pp_T(s, t_th, t_rh, t_p); if (!o->const_p) t_p = theta_dry_p(t_rh, t_rv, Tp); \
-                          RH = RH_of(o->RH_formula, t_p, t_rv, Tp); } while (0)
+                          RH = RH_of(o->RH_formula, t_p, t_rv, Tp) + (turb_cond ? ssp : 0.); } while (0)
   int first_cond_step_done_in_adaptation = sstp_cond_max == 1 ? 1 : 0;
   {
     double drw2_new = 0;
@@ -705,21 +707,23 @@ static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max)
   s->pp_sstp[p] = sstp_cond;
   s->pp_rv[p] = t_rv; s->pp_th[p] = t_th; s->pp_rh[p] = t_rh;
   if (o->const_p) s->pp_p[p] = t_p;
+  if (turb_cond) s->ssp[p] = ssp;
   s->rw2[p] = rw2;
 }
 /* particles_step.ipp:199-236 */
-static void cond_perparticle(orc_particles *s, double RH_max)
+static void cond_perparticle(orc_particles *s, double RH_max, int turb_cond)
 {
   if (!s->o.sstp_cond_mix) save_liq_before(s);
   calculate_noncond_perparticle_sstp_delta(s);
   if (s->o.adaptive_sstp_cond) {
-    for (sz p = 0; p < s->n_part; ++p) adaptive_sstp_cond_one(s, p, RH_max);
+    for (sz p = 0; p < s->n_part; ++p) adaptive_sstp_cond_one(s, p, RH_max, turb_cond);
   } else {
     for (int step = 0; step < s->sstp_cond; ++step) {
       apply_noncond_perparticle_sstp_delta(s);
+      if (turb_cond) for (sz p = 0; p < s->n_part; ++p) s->ssp[p] = s->ssp[p] + s->dt / s->sstp_cond * s->dot_ssp[p];   /* apply_perparticle_sgs_supersat.ipp */
       if (step == 0) for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = -rw2torw3(s->rw2[p]);   /* set_perparticle_drwX_to_minus_rwX */
       else           for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = -s->rwX[p];
-      cond_perparticle_advance_rw2(s, RH_max);
+      cond_perparticle_advance_rw2(s, RH_max, turb_cond);
       if (step < s->sstp_cond - 1) for (sz p = 0; p < s->n_part; ++p) { s->rwX[p] = rw2torw3(s->rw2[p]); s->drwX[p] = s->rwX[p] + s->drwX[p]; }
       else                         for (sz p = 0; p < s->n_part; ++p) s->drwX[p] = rw2torw3(s->rw2[p]) + s->drwX[p];
       apply_perparticle_drw3_to_perparticle_rv_and_th(s);
@@ -1654,13 +1658,12 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
 {
   if (!s->should_now_run_cond) FAIL("libcloudph++: please call sync_in() before calling step_cond()");
   if (opts->turb_cond && !s->o.turb_cond_switch) FAIL("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
-  if (opts->turb_cond && s->o.exact_sstp_cond) FAIL("libcloudph++: turb_cond with per-particle substepping is not supported by this backend");
   s->should_now_run_cond = 0;
   if (adjust_timesteps(s, opts->dt)) return 1;
   if (opts->cond) {
     hskpng_sort(s);
     hskpng_mfp(s);
-    if (s->o.exact_sstp_cond && (s->sstp_cond > 1 || s->sstp_cond_act > 1)) cond_perparticle(s, opts->RH_max);
+    if (s->o.exact_sstp_cond && (s->sstp_cond > 1 || s->sstp_cond_act > 1)) cond_perparticle(s, opts->RH_max, opts->turb_cond);
     else for (int step = 0; step < s->sstp_cond; ++step) {
       sstp_percell_step(s, step);
       if (opts->turb_cond) for (sz p = 0; p < s->n_part; ++p) s->ssp[p] = s->ssp[p] + s->dt / s->sstp_cond * s->dot_ssp[p];   /* apply_perparticle_sgs_supersat.ipp */
@@ -2017,4 +2020,37 @@ int orc_courant_halo_unpack(orc_particles *s, int which, int side, const void *b
   double *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
   if (cnt) memcpy(a + off[2 + side], buf, cnt * sizeof(double));
   return 0;
+}
+
+/* libcloudphxx.common of the reference's Python module (bindings/python/common.hpp:19-172, lib.cpp:55-66,129-144), scalar */
+int orc_common_eval(const char *name, const double *a, int n, double *out)
+{
+#define IS(nm) (!strcmp(name, nm))
+  const double kap = R_d / c_pd;
+  if (IS("th_dry2std") && n == 2) *out = a[0] / pow(1 + a[1] * R_v / R_d, kap);                   /* theta_dry.hpp:101-113 */
+  else if (IS("th_std2dry") && n == 2) *out = a[0] * pow(1 + a[1] * R_v / R_d, kap);              /* theta_dry.hpp:86-99 */
+  else if (IS("exner") && n == 1) *out = theta_std_exner(a[0]);
+  else if (IS("p_v") && n == 2) *out = p_v(a[0], a[1]);
+  else if (IS("p_vs") && n == 1) *out = p_vs(a[0]);
+  else if (IS("r_vs") && n == 2) *out = r_vs(a[0], a[1]);
+  else if (IS("p_vs_tet") && n == 1) *out = tet_p_vs(a[0]);
+  else if (IS("l_v") && n == 1) *out = l_v(a[0]);
+  else if (IS("T") && n == 2) *out = theta_dry_T(a[0], a[1]);
+  else if (IS("p") && n == 3) *out = theta_dry_p(a[0], a[1], a[2]);
+  else if (IS("visc") && n == 1) *out = visc(a[0]);
+  else if (IS("rw3_cr") && n == 3) *out = rw3_cr(a[0], a[1], a[2]);
+  else if (IS("S_cr") && n == 3) *out = S_cr(a[0], a[1], a[2]);
+  else if (IS("p_hydro") && n == 5) {                                                             /* hydrostatic.hpp:24-38 */
+    const double R_moist = (R_d + a[2] * R_v) / (1 + a[2]);                                       /* moist_air.hpp:54-70 */
+    *out = p_1000 * pow(pow(a[4] / p_1000, kap) - kap * g_earth / a[1] / R_moist * (a[0] - a[3]), c_pd / R_d);
+  }
+  else if (IS("rhod") && n == 3) *out = (a[0] - p_v(a[0], a[2])) / (pow(a[0] / p_1000, kap) * R_d * a[1]);   /* theta_std.hpp:23-32 */
+  else if (IS("R_d") && n == 0) *out = R_d; else if (IS("R_v") && n == 0) *out = R_v;
+  else if (IS("c_pd") && n == 0) *out = c_pd; else if (IS("c_pv") && n == 0) *out = c_pv;
+  else if (IS("c_pw") && n == 0) *out = c_pw; else if (IS("g") && n == 0) *out = g_earth;
+  else if (IS("p_1000") && n == 0) *out = p_1000; else if (IS("eps") && n == 0) *out = eps_v;
+  else if (IS("rho_stp") && n == 0) *out = rho_stp; else if (IS("rho_w") && n == 0) *out = rho_w;
+  else FAIL("libcloudph++: common.%s with %d argument(s) is not provided by this backend", name, n);
+  return 0;
+#undef IS
 }

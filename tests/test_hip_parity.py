@@ -689,14 +689,18 @@ def test_storage_reorder_is_a_permutation_of_the_same_state():
 
 
 # ------------------------------------------------------------------ SGS turbulence
-@pytest.mark.parametrize("mode,dims", [("adve", (6, 0, 5)), ("adve", (4, 3, 5)), ("cond", (5, 0, 6)), ("both", (4, 3, 4))])
+@pytest.mark.parametrize("mode,dims", [("adve", (6, 0, 5)), ("adve", (4, 3, 5)), ("cond", (5, 0, 6)), ("both", (4, 3, 4)),
+                                       ("cond_pp_mix", (5, 0, 6)), ("cond_pp_nomix", (5, 0, 6)), ("cond_pp_adaptive", (4, 3, 4))])
 def test_sgs_turbulence_matches_oracle(mode, dims):
     """turb_adve (Ornstein-Uhlenbeck velocity perturbations added to the advection) and turb_cond (SGS supersaturation
     perturbation in the condensation) against the oracle, its normal deviates (std::normal_distribution over mt19937)
     replayed: hskpng_tke / _turb_vel / _turb_dot_ss, turb_adve, apply_perparticle_sgs_supersat, RH_sgs"""
     nx, ny, nz = dims
-    kw = dict(coal_switch=False, turb_adve_switch=mode in ("adve", "both"), turb_cond_switch=mode in ("cond", "both"),
-              SGS_mix_len=np.linspace(20., 40., nz), sstp_cond=2 if mode == "cond" else 1)
+    pp = mode.startswith("cond_pp")            # turb_cond with per-particle substepping (unit/sstp_cond.py runs this combination)
+    kw = dict(coal_switch=False, turb_adve_switch=mode in ("adve", "both"), turb_cond_switch=mode in ("cond", "both") or pp,
+              SGS_mix_len=np.linspace(20., 40., nz), sstp_cond=2 if mode == "cond" else 4 if pp else 1)
+    if pp:
+        kw.update(exact_sstp_cond=True, sstp_cond_mix=mode == "cond_pp_mix", adaptive_sstp_cond=mode == "cond_pp_adaptive")
     oi = h.box_opts(nx, ny, nz, 32, dx=30., **kw)
     th, rv, rhod, C = h.box_fields(oi)
     diss = 1e-3 * (1 + np.random.default_rng(3).random(th.shape))
@@ -704,7 +708,7 @@ def test_sgs_turbulence_matches_oracle(mode, dims):
     opts = lgrngn.opts_t()
     opts.coal = False
     opts.turb_adve = mode in ("adve", "both")
-    opts.turb_cond = mode in ("cond", "both")
+    opts.turb_cond = mode in ("cond", "both") or pp
     ndim = sum(1 for n_ in dims if n_ > 0)
     for it in range(3):
         tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()

@@ -1,0 +1,31 @@
+"""The reference's OWN Python test scripts, unmodified, run from /root/reference against the CPU oracle through this
+repo's drop-in `libcloudphxx` package (tests/_ref_script_runner.py redirects lgrngn.factory to the oracle library).  This is
+the strongest pin of the oracle there is: the reference's assertions decide.  Build container only -- /root/reference does
+not travel, the tests skip where it is absent (the GPU box); CPU only."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference/tests/python"
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present on this machine")
+
+# (script, run with pytest?) -- what tests/python/{unit,physics}/CMakeLists.txt runs and this path covers.
+# Not run: api_lgrngn.py (needs ice + chemistry species), SD_removal.py / chem_coal.py (chemistry), source.py, relax.py,
+# ice_SD.py, diag_incloud_time.py (out of scope), lgrngn_cond_substepping.py + _test.py (280 configurations in one serial
+# script, minutes; its refdata is checked row by row in test_oracle_pins.py instead).
+SCRIPTS = [("unit/col_kernels.py", False), ("unit/terminal_velocities.py", False), ("unit/uniform_init.py", False),
+           ("unit/sstp_cond.py", False), ("unit/multiple_kappas.py", False), ("unit/adve_scheme.py", False),
+           ("unit/lgrngn_subsidence.py", False), ("unit/segfault_20150216.py", False), ("unit/lgrngn_adve.py", True),
+           ("physics/test_coal.py", False), ("physics/coalescence_golovin.py", False),
+           ("physics/coalescence_hall_davis_no_waals.py", False), ("physics/lgrngn_cond.py", False), ("physics/puddle.py", False)]
+
+
+@pytest.mark.parametrize("script,as_pytest", SCRIPTS, ids=[s for s, _ in SCRIPTS])
+def test_reference_script_passes_on_the_oracle(script, as_pytest, tmp_path):
+    env = dict(os.environ, LCX_REF_RUN_DIR=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    cmd = [sys.executable, os.path.join(HERE, "_ref_script_runner.py"), os.path.join(REF, script)] + (["--pytest"] if as_pytest else [])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
