@@ -48,6 +48,7 @@ namespace libcloudphxx { namespace lgrngn {
     virtual void diag_dry_mom(const int &) { assert(false); }
     virtual void diag_wet_mom(const int &) { assert(false); }
     virtual void diag_kappa_mom(const int &) { assert(false); }
+    virtual void diag_incloud_time_mom(const int &) { assert(false); }
     virtual void diag_max_rw() { assert(false); }
     virtual void diag_precip_rate() { assert(false); }
     virtual void diag_RH_ge_Sc() { assert(false); }
@@ -188,6 +189,7 @@ namespace libcloudphxx { namespace lgrngn {
     void diag_dry_mom(const int &k) override { detail::lcx_check(lcx_diag_dry_mom(pimpl->h, k)); }
     void diag_wet_mom(const int &k) override { detail::lcx_check(lcx_diag_wet_mom(pimpl->h, k)); }
     void diag_kappa_mom(const int &k) override { detail::lcx_check(lcx_diag_kappa_mom(pimpl->h, k)); }
+    void diag_incloud_time_mom(const int &k) override { detail::lcx_check(lcx_diag_incloud_time_mom(pimpl->h, k)); }
     void diag_max_rw() override { detail::lcx_check(lcx_diag_max_rw(pimpl->h)); }
     void diag_precip_rate() override { detail::lcx_check(lcx_diag_precip_rate(pimpl->h)); }
     void diag_RH_ge_Sc() override { detail::lcx_check(lcx_diag_RH_ge_Sc(pimpl->h)); }

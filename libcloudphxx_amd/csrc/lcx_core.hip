@@ -119,6 +119,7 @@ struct Particles : IParticles {
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
   int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
+  int ix_ict = -1;                    // opts_init.diag_incloud_time: time spent activated, travels with the SD (particles_impl.ipp:475-476)
   std::vector<double> SGS_mix_len_h; DevBuf<T> SGS_mix_len, diss_rate, tau_cell, tau_rlx;
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
@@ -158,7 +159,7 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   explicit Particles(const lcx_opts_init_t &oi) : o(oi)
   {
-    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type || oi.diag_incloud_time)
+    if (oi.chem_switch || oi.ice_switch || oi.rlx_switch || oi.src_type)
       throw lcx_error("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx)");
     if (oi.n_sd_max >= (1ull << 32)) throw lcx_error("libcloudph++: n_sd_max must be < 2^32 per device (32-bit super-droplet ids)");
     distros.assign(oi.dry_distros, oi.dry_distros + oi.n_dry_distros);
@@ -185,6 +186,7 @@ struct Particles : IParticles {
     // perturbation with its tendency travel with the SD as well (particles_impl.ipp:461-473)
     if (oi.turb_adve_switch) { if (oi.nx) ix_up = n_ext++; if (oi.ny) ix_vp = n_ext++; if (oi.nz) ix_wp = n_ext++; }
     if (oi.turb_cond_switch) { if (ix_wp < 0) ix_wp = n_ext++; ix_ssp = n_ext++; ix_dot_ssp = n_ext++; }
+    if (oi.diag_incloud_time) ix_ict = n_ext++;
     SGS_mix_len_h.assign(oi.SGS_mix_len, oi.SGS_mix_len + oi.n_SGS_mix_len);
     o.SGS_mix_len = nullptr;
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
@@ -201,7 +203,7 @@ struct Particles : IParticles {
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     HIPCHK(hipHostMalloc(&pinned, 256, hipHostMallocDefault));
     alloc_attrs(A);
-    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp}) if (ix >= 0) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, cap * sizeof(T), st));
+    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp, ix_ict}) if (ix >= 0) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, cap * sizeof(T), st));
     if (turb_any()) diss_rate.alloc_zero(ncell, st);
     if (turb()) {
       tau_cell.alloc_zero(ncell, st); tau_rlx.alloc_zero(ncell, st);
@@ -798,7 +800,8 @@ struct Particles : IParticles {
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p, eta.p, rhod.p, turb_coal ? diss_rate.p : nullptr};
     auto launch = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
-                         A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr);
+                         A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
+                         ix_ict >= 0 ? A.ext[ix_ict].p : nullptr);
     };
     if (onishi) launch(k_coal<T, true>); else launch(k_coal<T, false>);
     if (o.n_dry_distros + n_size_keys > 1)
@@ -1231,6 +1234,8 @@ struct Particles : IParticles {
     if (opts.turb_cond && !o.turb_cond_switch) throw lcx_error("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
     should_now_run_cond = false;
     adjust_timesteps(opts.dt);
+    if (ix_ict >= 0 && nphys)                                                            // update_incloud_time, particles_step.ipp:180-181
+      hipLaunchKernelGGL(k_incloud_time<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, A.rd3.p, A.kpa.p, A.rw2.p, Tk.p, T(dt), A.ext[ix_ict].p);
     if (opts.cond) {
       hskpng_sort();
       hskpng_mfp();
@@ -1305,7 +1310,14 @@ struct Particles : IParticles {
     sync();
   }
   void need_nfiltered() { if (!n_filtered.p) n_filtered.alloc(cap); }
-  T *attr_ptr(int attr) { return attr == 0 ? A.rd3.p : attr == 1 ? A.rw2.p : attr == 2 ? A.kpa.p : A.vt.p; }
+  T *attr_ptr(int attr)
+  {
+    if (attr == 4) {
+      if (ix_ict < 0) throw lcx_error("libcloudph++: diag_incloud_time_mom called, but opts_init.diag_incloud_time==false");
+      return A.ext[ix_ict].p;
+    }
+    return attr == 0 ? A.rd3.p : attr == 1 ? A.rw2.p : attr == 2 ? A.kpa.p : A.vt.p;
+  }
   void diag_select(int mode, int cons, int attr, double a, double b) override
   {
     hskpng_sort();
@@ -1425,6 +1437,7 @@ struct Particles : IParticles {
       {"rc2", use_rc2 ? A.ext[ix_rc2].p : nullptr, use_rc2 ? npart : 0},
       {"up", ix_up >= 0 ? A.ext[ix_up].p : nullptr, ix_up >= 0 ? npart : 0}, {"vp", ix_vp >= 0 ? A.ext[ix_vp].p : nullptr, ix_vp >= 0 ? npart : 0},
       {"wp", ix_wp >= 0 ? A.ext[ix_wp].p : nullptr, ix_wp >= 0 ? npart : 0}, {"ssp", ix_ssp >= 0 ? A.ext[ix_ssp].p : nullptr, ix_ssp >= 0 ? npart : 0},
+      {"incloud_time", ix_ict >= 0 ? A.ext[ix_ict].p : nullptr, ix_ict >= 0 ? npart : 0},
       {"dot_ssp", ix_dot_ssp >= 0 ? A.ext[ix_dot_ssp].p : nullptr, ix_dot_ssp >= 0 ? npart : 0},
       {"diss_rate", diss_rate.p, turb_any() ? ncell : 0}};
     for (const E &e : tab)
@@ -1452,7 +1465,7 @@ struct Particles : IParticles {
     up(A.rd3, rd3_); up(A.rw2, rw2_); up(A.kpa, kpa_); up(A.vt, vt_); up(A.x, x_); up(A.y, y_); up(A.z, z_);
     if (n) HIPCHK(hipMemsetAsync(ijk.p, 0, n * sizeof(uint32_t), st));     // every SD is in the order again, n == 0 included
     hskpng_ijk();
-    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp}) if (ix >= 0 && n) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, n * sizeof(T), st));
+    for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp, ix_ict}) if (ix >= 0 && n) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, n * sizeof(T), st));
     if (use_rc2 && n) { hipLaunchKernelGGL(k_fill<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_rc2].p, n, T(-1)); hskpng_approximate_rc2_invalid(); }
     sstp_save();
     hskpng_count();
@@ -1628,6 +1641,7 @@ int lcx_diag_kappa_rng_cons(lcx_particles *h, double a, double b) { LCX_TRY(H->d
 int lcx_diag_dry_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(0, k / 3.)) }
 int lcx_diag_wet_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(1, k / 2.)) }
 int lcx_diag_kappa_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(2, k)) }
+int lcx_diag_incloud_time_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(4, k)) }
 int lcx_diag_RH_ge_Sc(lcx_particles *h) { LCX_TRY(H->diag_act(0)) }
 int lcx_diag_rw_ge_rc(lcx_particles *h) { LCX_TRY(H->diag_act(1)) }
 int lcx_diag_wet_mass_dens(lcx_particles *h, double rad, double sig0) { LCX_TRY(H->diag_wet_mass_dens(rad, sig0)) }

@@ -614,6 +614,16 @@ __global__ void k_pp_save(size_t n, const uint32_t *ijk, const T *rv, const T *t
   pp_rv[i] = rv[c]; pp_th[i] = th[c]; pp_rh[i] = rhod[c];
   if (pp_p) pp_p[i] = p[c];
 }
+// update_incloud_time.ipp:36-66: the time a super-droplet has been activated grows by dt while rw2 > rc2(T of its cell), else 0
+template <class T>
+__global__ void k_incloud_time(size_t n, const uint32_t *ijk, const T *rd3, const T *kpa, const T *rw2, const T *Tk, T dt, T *ict)
+{
+  const size_t i = gid(); if (i >= n) return;
+  const uint32_t c = ijk[i];
+  if (c == DEAD_CELL) return;
+  const T rc2 = rc2_of(rd3[i], kpa[i], Tk[c]);
+  ict[i] = rw2[i] > rc2 ? ict[i] + dt : T(0);
+}
 // hskpng_rc2.ipp:14-32
 template <class T>
 __global__ void k_rc2(size_t n, const T *rd3, const T *kpa, T Tk, T *rc2)
@@ -983,7 +993,7 @@ template <class T, bool ONISHI>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
-       int pure_const_multi, int *increase_sstp_coal, T *rc2)
+       int pure_const_multi, int *increase_sstp_coal, T *rc2, T *ict)
 {
   const size_t p0 = 2 * gid();
   if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
@@ -1022,6 +1032,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     rd3[b] = col_no * rd3[a] + rd3[b];
     vt[b] = T(-1);
     if (rc2) rc2[b] = T(-1);                                                 // invalidator, coal.ipp:33-44,527-545
+    if (ict) ict[b] = mx(ict[a], ict[b]);                                    // selector, coal.ipp:17-31,505-525
     col[p + 1] = T(-2);
   } else {
     if (na > 0) { const n_t q = nb / na; if (q < col_no) col_no = q; }
@@ -1031,6 +1042,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     rd3[a] = col_no * rd3[b] + rd3[a];
     vt[a] = T(-1);
     if (rc2) rc2[a] = T(-1);
+    if (ict) ict[a] = mx(ict[a], ict[b]);
     col[p + 1] = T(-1);
   }
   col[p] = T(col_no);
@@ -1286,7 +1298,7 @@ __global__ void __launch_bounds__(BS) k_alive_tiles(const n_t *n, size_t n_part,
   if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[w]; tile_sums[blockIdx.x] = s; }
 }
 // ext[]: further real-valued attributes that travel with a super-droplet (per-particle substepping state, rc2)
-constexpr int MAX_EXT = 10;
+constexpr int MAX_EXT = 12;
 template <class T> struct attr_set { n_t *n; T *rd3, *rw2, *kpa, *vt, *x, *y, *z; T *ext[MAX_EXT]; int n_ext; };
 
 template <class T>

@@ -20,7 +20,14 @@ import numpy as np
 from . import _lib
 
 # ----------------------------------------------------------------------------- enums
-class backend_t(enum.IntEnum):          # lgrngn/backend.hpp:8 + the two new slots
+class _bp_enum(enum.IntEnum):
+    """str() of a Boost.Python enum value is its bare name (the reference's scripts write e.g. str(RH_formula) into CSV keys)"""
+    def __str__(self):
+        return self.name
+    __format__ = enum.Enum.__format__
+
+
+class backend_t(_bp_enum):          # lgrngn/backend.hpp:8 + the two new slots
     undefined = 0
     serial = 1
     OpenMP = 2
@@ -30,7 +37,7 @@ class backend_t(enum.IntEnum):          # lgrngn/backend.hpp:8 + the two new slo
     multi_HIP = 6
 
 
-class kernel_t(enum.IntEnum):           # lgrngn/kernel.hpp:8
+class kernel_t(_bp_enum):           # lgrngn/kernel.hpp:8
     undefined = 0
     geometric = 1
     golovin = 2
@@ -46,7 +53,7 @@ class kernel_t(enum.IntEnum):           # lgrngn/kernel.hpp:8
     vohl_davis_no_waals = 11
 
 
-class vt_t(enum.IntEnum):               # lgrngn/terminal_velocity.hpp:8
+class vt_t(_bp_enum):               # lgrngn/terminal_velocity.hpp:8
     undefined = 0
     beard76 = 1
     beard77 = 2
@@ -55,21 +62,21 @@ class vt_t(enum.IntEnum):               # lgrngn/terminal_velocity.hpp:8
     khvorostyanov_nonspherical = 5
 
 
-class as_t(enum.IntEnum):               # lgrngn/advection_scheme.hpp:8
+class as_t(_bp_enum):               # lgrngn/advection_scheme.hpp:8
     undefined = 0
     implicit = 1
     euler = 2
     pred_corr = 3
 
 
-class RH_formula_t(enum.IntEnum):       # lgrngn/RH_formula.hpp:8
+class RH_formula_t(_bp_enum):       # lgrngn/RH_formula.hpp:8
     pv_cc = 0
     rv_cc = 1
     pv_tet = 2
     rv_tet = 3
 
 
-class src_t(enum.IntEnum):              # lgrngn/ccn_source.hpp:8
+class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8
     off = 0
     simple = 1
     matching = 2
@@ -417,6 +424,7 @@ class particles_t:
     diag_dry_mom = _diagk("diag_dry_mom")
     diag_wet_mom = _diagk("diag_wet_mom")
     diag_kappa_mom = _diagk("diag_kappa_mom")
+    diag_incloud_time_mom = _diagk("diag_incloud_time_mom")
 
     def outbuf(self):
         """bytes-like view of n_cell reals (use numpy.frombuffer(..., dtype=real_t), default float64)."""

@@ -101,6 +101,7 @@ struct orc_particles {
   /* SGS turbulence (turb_adve / turb_cond): cell field diss_rate (holds TKE after hskpng_tke), SGS mixing length profile,
    * per-particle velocity perturbations and supersaturation perturbation (particles_impl.ipp:141-144,461-473) */
   double *diss_rate, *SGS_mix_len, *tau_cell;
+  double *ict;     /* opts_init.diag_incloud_time: time each SD has been activated (particles_impl.ipp:93,475-476) */
   double *up, *vp, *wp, *ssp, *dot_ssp;
   /* particle attributes */
   n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
@@ -165,7 +166,7 @@ static int distmem(const orc_particles *s) { return s->o.bcond_lft == 1 || s->o.
 int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
   if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
-  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type || oi->diag_incloud_time)
+  if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type)
     FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx)");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
@@ -216,6 +217,7 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
     s->rwX = NEW(double, c); s->drwX = NEW(double, c); s->Tp = NEW(double, c); s->pp_sstp = NEW(unsigned, c);
   }
   if (s->use_rc2) s->rc2 = NEW(double, c);
+  if (oi->diag_incloud_time) s->ict = NEW(double, c);                    /* init_incloud_time.ipp:14-17: zero */
   if (oi->turb_coal_switch && !(oi->turb_adve_switch || oi->turb_cond_switch)) s->diss_rate = NEW(double, nc);
   if (oi->turb_adve_switch || oi->turb_cond_switch) {
     s->diss_rate = NEW(double, nc); s->tau_cell = NEW(double, nc);
@@ -234,7 +236,7 @@ void orc_destroy(orc_particles *s)
   if (!s) return;
   void *ptrs[] = {s->distros, s->sizes, s->kernel_parameters, s->w_LS, s->aerosol_conc_factor, s->n, s->rd3, s->rw2,
     s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col, s->mom_vals,
-    s->diss_rate, s->SGS_mix_len, s->tau_cell, s->up, s->vp, s->wp, s->ssp, s->dot_ssp,
+    s->diss_rate, s->SGS_mix_len, s->tau_cell, s->up, s->vp, s->wp, s->ssp, s->dot_ssp, s->ict,
     s->pp_rv, s->pp_th, s->pp_rh, s->pp_p, s->rc2, s->dlt_rv, s->dlt_th, s->dlt_rh, s->dlt_p, s->rwX, s->drwX, s->Tp, s->pp_sstp,
     s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
     s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
@@ -992,6 +994,13 @@ static void coal(orc_particles *s, double dt, int turb_coal)
         else          { s->kpa[a] = (s->kpa[b] * s->rd3[b] + s->kpa[a] * rd3_old) / (s->rd3[b] + rd3_old); rd3_old += s->rd3[b]; }
       }
     }
+  if (s->o.diag_incloud_time)                              /* selector, coal.ipp:17-31,505-525: the changed SD keeps the larger value */
+    for (sz p = 0; p + 1 < s->n_part; ++p) {
+      if (s->col[p] <= 0) continue;
+      const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
+      const double m = dmax(s->ict[a], s->ict[b]);
+      if (s->col[p + 1] == -2.) s->ict[b] = m; else s->ict[a] = m;
+    }
 }
 
 static int mig_attrs(orc_particles *s, double **a);
@@ -1660,6 +1669,11 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
   if (opts->turb_cond && !s->o.turb_cond_switch) FAIL("libcloudph++: turb_cond_swtich=False, but turb_cond==True");
   s->should_now_run_cond = 0;
   if (adjust_timesteps(s, opts->dt)) return 1;
+  if (s->o.diag_incloud_time)                                  /* update_incloud_time.ipp:36-66: += dt while rw2 > rc2, else 0 */
+    for (sz p = 0; p < s->n_part; ++p) {
+      const double rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
+      if (s->rw2[p] > rc2) s->ict[p] += s->dt; else s->ict[p] = 0;
+    }
   if (opts->cond) {
     hskpng_sort(s);
     hskpng_mfp(s);
@@ -1765,6 +1779,11 @@ int orc_diag_kappa_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, 
 int orc_diag_dry_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rd3, k / 3., 1); return 0; }
 int orc_diag_wet_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rw2, k / 2., 1); return 0; }
 int orc_diag_kappa_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->kpa, k, 1); return 0; }
+int orc_diag_incloud_time_mom(orc_particles *s, int k)                        /* particles_diag.ipp:482-490 */
+{
+  if (!s->o.diag_incloud_time) FAIL("libcloudph++: diag_incloud_time_mom called, but opts_init.diag_incloud_time==false");
+  NEED_SELECTION; moms_calc(s, s->ict, k, 1); return 0;
+}
 /* particles_diag.ipp:555-584: sum of n_filtered * rw^3 * vt per cell (not specific); refreshes vt as a side effect */
 int orc_diag_precip_rate(orc_particles *s)
 {
@@ -1881,7 +1900,7 @@ int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t c
     {"sstp_tmp_rh", s->exact ? s->pp_rh : s->sstp_tmp_rh, s->exact ? s->n_part : s->n_cell},
     {"sstp_tmp_p", s->pp_p, s->exact && s->o.const_p ? s->n_part : 0}, {"rc2", s->rc2, s->use_rc2 ? s->n_part : 0},
     {"up", s->up, s->up ? s->n_part : 0}, {"vp", s->vp, s->vp ? s->n_part : 0}, {"wp", s->wp, s->wp ? s->n_part : 0},
-    {"ssp", s->ssp, s->ssp ? s->n_part : 0}, {"dot_ssp", s->dot_ssp, s->dot_ssp ? s->n_part : 0},
+    {"incloud_time", s->ict, s->ict ? s->n_part : 0}, {"ssp", s->ssp, s->ssp ? s->n_part : 0}, {"dot_ssp", s->dot_ssp, s->dot_ssp ? s->n_part : 0},
     {"diss_rate", s->diss_rate, s->diss_rate ? s->n_cell : 0}};
   for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
     if (!strcmp(name, tab[i].nm)) {
@@ -1905,6 +1924,7 @@ int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult
   if (s->use_rc2) { for (sz p = 0; p < n; ++p) s->rc2[p] = -1.; hskpng_approximate_rc2_invalid(s); }
   if (s->up) { memset(s->up, 0, n * 8); memset(s->vp, 0, n * 8); memset(s->wp, 0, n * 8); }
   if (s->ssp) { memset(s->ssp, 0, n * 8); memset(s->dot_ssp, 0, n * 8); }
+  if (s->ict) memset(s->ict, 0, n * 8);
   sstp_save(s);
   hskpng_count(s);
   return 0;
@@ -1951,6 +1971,7 @@ static int mig_attrs(orc_particles *s, double **a)
   if (s->exact) { a[k++] = s->pp_rv; a[k++] = s->pp_th; a[k++] = s->pp_rh; if (s->o.const_p) a[k++] = s->pp_p; }
   if (s->o.turb_adve_switch) { if (s->o.nx != 0) a[k++] = s->up; if (s->o.ny != 0) a[k++] = s->vp; if (s->o.nz != 0) a[k++] = s->wp; }
   if (s->o.turb_cond_switch) { if (!(s->o.turb_adve_switch && s->o.nz != 0)) a[k++] = s->wp; a[k++] = s->ssp; a[k++] = s->dot_ssp; }
+  if (s->o.diag_incloud_time) a[k++] = s->ict;
   if (s->use_rc2) a[k++] = s->rc2;
   return k;
 }

@@ -482,6 +482,31 @@ def test_full_steps_replay(dims, sstp, strict_fp):
         h.copy_state(orc, hip)
 
 
+def test_incloud_time_matches_oracle():
+    """opts_init.diag_incloud_time (update_incloud_time.ipp:36-66, the selector after collisions coal.ipp:17-31,505-525,
+    diag_incloud_time_mom particles_diag.ipp:482-490): the attribute after replayed full steps and its moments"""
+    oi = h.box_opts(4, 3, 4, 64, diag_incloud_time=True, dx=2.)
+    oi.dt = 2.
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    for it in range(4):
+        step_pair(orc, hip, opts, fields)
+    to, th_ = orc.state_real("incloud_time"), hip.state_real("incloud_time")
+    assert len(np.unique(to)) > 2 and to.max() == 3 * oi.dt          # nothing is activated at the first update (RH < 0.95 at init)
+    # rw2 > rc2 compares two numbers that carry root-finder tolerances, and a collision test may flip for the same reason
+    assert hip.n_part == orc.n_part
+    assert np.mean(to != th_) < 1e-2
+    for pr in (orc, hip):
+        pr.diag_all(); pr.diag_incloud_time_mom(1)
+    np.testing.assert_allclose(hip.outbuf_array(), orc.outbuf_array(), rtol=2e-2)
+    plain = h.hip_particles(h.box_opts(4, 3, 4, 8))
+    plain.init(*[f.copy() for f in fields[:3]], **fields[3])
+    plain.diag_all()
+    with pytest.raises(RuntimeError, match="diag_incloud_time==false"):
+        plain.diag_incloud_time_mom(1)
+
+
 # ------------------------------------------------------------------ diagnostics (a21)
 def test_diagnostics_match_oracle():
     oi = h.box_opts(4, 3, 5, 40)

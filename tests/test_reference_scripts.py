@@ -14,11 +14,12 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree n
 
 # (script, run with pytest?) -- what tests/python/{unit,physics}/CMakeLists.txt runs and this path covers.
 # Not run: api_lgrngn.py (needs ice + chemistry species), SD_removal.py / chem_coal.py (chemistry), source.py, relax.py,
-# ice_SD.py, diag_incloud_time.py (out of scope), lgrngn_cond_substepping.py + _test.py (280 configurations in one serial
-# script, minutes; its refdata is checked row by row in test_oracle_pins.py instead).
+# ice_SD.py (out of scope).  lgrngn_cond_substepping.py + _test.py (280 configurations in one serial script, 3.5 minutes) run
+# only with LCX_SLOW_REF=1 (they pass); their refdata is checked row by row, in parallel, in test_oracle_pins.py.
 SCRIPTS = [("unit/col_kernels.py", False), ("unit/terminal_velocities.py", False), ("unit/uniform_init.py", False),
            ("unit/sstp_cond.py", False), ("unit/multiple_kappas.py", False), ("unit/adve_scheme.py", False),
            ("unit/lgrngn_subsidence.py", False), ("unit/segfault_20150216.py", False), ("unit/lgrngn_adve.py", True),
+           ("unit/diag_incloud_time.py", False),
            ("physics/test_coal.py", False), ("physics/coalescence_golovin.py", False),
            ("physics/coalescence_hall_davis_no_waals.py", False), ("physics/lgrngn_cond.py", False), ("physics/puddle.py", False)]
 
@@ -29,3 +30,15 @@ def test_reference_script_passes_on_the_oracle(script, as_pytest, tmp_path):
     cmd = [sys.executable, os.path.join(HERE, "_ref_script_runner.py"), os.path.join(REF, script)] + (["--pytest"] if as_pytest else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.skipif(os.environ.get("LCX_SLOW_REF") != "1", reason="3.5 minutes; set LCX_SLOW_REF=1")
+def test_reference_cond_substepping_scripts_pass_on_the_oracle(tmp_path):
+    """physics/lgrngn_cond_substepping.py writes test_results/*.csv, physics/lgrngn_cond_substepping_test.py compares it with
+    the reference's refdata under the reference's own tolerances"""
+    env = dict(os.environ, LCX_REF_RUN_DIR=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    os.makedirs(tmp_path / "test_results")
+    for script in ("physics/lgrngn_cond_substepping.py", "physics/lgrngn_cond_substepping_test.py"):
+        r = subprocess.run([sys.executable, os.path.join(HERE, "_ref_script_runner.py"), os.path.join(REF, script)], env=env,
+                           capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (script, r.stdout[-2000:], r.stderr[-2000:])
