@@ -416,18 +416,16 @@ static void init_vterm(orc_particles *s)
   for (int it = 0; it < n_bin; ++it) s->vt_0[it] = vt_beard77_v0(exp(s->vt0_ln_r_min + (it + 0.5) * dlnr));
 }
 /* hskpng_remove.ipp:20-76 (stable), hskpng_resize.ipp:7-32 */
+static int mig_attrs(orc_particles *s, double **a);
 static int hskpng_remove_n0(orc_particles *s)
 {
+  double *attrs[24]; const int na = mig_attrs(s, attrs);       /* every registered attribute (distmem_real_vctrs) + n */
   sz w = 0;
   for (sz p = 0; p < s->n_part; ++p) {
     if (s->n[p] == 0) continue;
     if (w != p) {
-      s->n[w] = s->n[p]; s->rd3[w] = s->rd3[p]; s->rw2[w] = s->rw2[p]; s->kpa[w] = s->kpa[p];
-      s->vt[w] = s->vt[p]; s->x[w] = s->x[p]; s->y[w] = s->y[p]; s->z[w] = s->z[p];
-      if (s->exact) { s->pp_rv[w] = s->pp_rv[p]; s->pp_th[w] = s->pp_th[p]; s->pp_rh[w] = s->pp_rh[p]; s->pp_p[w] = s->pp_p[p]; }
-      if (s->use_rc2) s->rc2[w] = s->rc2[p];
-      if (s->up) { s->up[w] = s->up[p]; s->vp[w] = s->vp[p]; s->wp[w] = s->wp[p]; }
-      if (s->ssp) { s->ssp[w] = s->ssp[p]; s->dot_ssp[w] = s->dot_ssp[p]; }
+      s->n[w] = s->n[p];
+      for (int a = 0; a < na; ++a) attrs[a][w] = attrs[a][p];
     }
     ++w;
   }
