@@ -124,7 +124,7 @@ struct Particles : IParticles {
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
-  DevBuf<uint8_t> mig;
+  DevBuf<uint8_t> mig, cond_pre;
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
   // ---- cell fields ----
@@ -676,7 +676,13 @@ struct Particles : IParticles {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
-                     turb_cond ? A.ext[ix_ssp].p : nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
+      if (!o.strict_fp && !turb_cond && getenv("LCX_NO_COND_PRE") == nullptr) {
+        cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
+        a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
+        hipLaunchKernelGGL(k_cond_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, rhod.p, rv.p, Tk.p, eta.p, RH.p, lambda_D.p, lambda_K.p,
+                           T(RH_max), reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p));
+      }
       if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
       else hipLaunchKernelGGL((k_cond<T, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
     }
@@ -1199,6 +1205,7 @@ struct Particles : IParticles {
     sstp_save();
     sorted = false;
     hskpng_count();
+    if (!B.n.p) alloc_attrs(B);      // the compaction target: allocated here, not inside the first step that compacts (GBs of hipMalloc)
     sync();
   }
 

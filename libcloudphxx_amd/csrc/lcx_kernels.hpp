@@ -484,7 +484,15 @@ struct cond_args {
   T *m3_before, *m3_after;
   T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
   const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
+  const cond_cell_fast<T> *pre;   // fast arithmetic without turb_cond: the droplet-independent set-up, per cell (k_cond_cellpre)
 };
+template <class T>
+__global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
+                               const T *lambda_K, T RH_max, cond_cell_fast<T> *pre)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  pre[c] = make_cond_cell_fast(rhod[c], rv[c], Tk[c], eta[c], lambda_D[c], lambda_K[c], RH[c], RH_max);
+}
 // Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms, 4 waves with 24 B of scratch per
 // lane: 10.1 ms, 5 waves: 13.0 ms).
 template <class T, bool FAST>
@@ -495,8 +503,18 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const T rw2_old = a.rw2[id];
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
   if (a.first) a.m3_before[pos] = rw2_old >= 0 ? nn * (rw2_old * T(sqrt(rw2_old))) : nn * rw2_old;
-  const T r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
-                          a.lambda_D[c], a.lambda_K[c], a.ssp ? T(a.RH[c] + a.ssp[id]) : a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
+  T r;
+  if (FAST && a.pre) {
+    r = rw2_old;
+    if (rw2_old > 0) {
+      cond_fun_fast<T> ff;
+      const T rd3 = a.rd3[id];
+      ff.setup_cell(a.pre[c], rw2_old, a.dt_sub, rd3, a.kpa[id], a.vt[id]);
+      r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    }
+  } else
+    r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
+                             a.lambda_D[c], a.lambda_K[c], a.ssp ? T(a.RH[c] + a.ssp[id]) : a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
   a.rw2[id] = r;
   a.m3_after[pos] = r >= 0 ? nn * (r * T(sqrt(r))) : nn * r;
 }
@@ -1665,7 +1683,7 @@ __global__ void k_math_probe(int which, double *v, size_t n)
   const size_t i = gid();
   if (i >= n) return;
   const double x = v[i];
-  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : exp(x);
+  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : exp(x);
 }
 
 } // namespace lcx

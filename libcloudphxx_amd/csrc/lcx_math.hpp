@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include <cstdint>
+#include <type_traits>
 
 #define LCX_HD __host__ __device__ __forceinline__
 
@@ -112,35 +113,75 @@ template <class T> LCX_HD T eps_tolerance(unsigned bits)
 }
 template <class T> LCX_HD bool tol_reached(T eps, T a, T b) { return fabs(a - b) <= eps * mn(fabs(a), fabs(b)); }
 
+// Fast arithmetic only (functors that declare `fast_div`, i.e. the collected growth rate): the interpolation steps divide
+// ~20 times per loop iteration, a quarter of the condensation kernel's instructions as IEEE sequences (v_div_scale x2,
+// v_rcp_f64, 6 FMA, v_div_fmas, v_div_fixup).  A reciprocal refined by two Newton steps (<= 1 ulp, math probe 4) times the
+// numerator is half of that, and denominators shared between quotients are inverted once.  Quotients differ from the IEEE
+// ones by <= 2 ulp, i.e. like the growth rate itself in this mode; the strict mode keeps the IEEE divisions.
+template <class F, class = void> struct fastdiv : std::false_type {};
+template <class F> struct fastdiv<F, std::void_t<decltype(F::fast_div)>> : std::true_type {};
+LCX_HD double rcp_refined(double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r0 = __builtin_amdgcn_rcp(y);
+  const double r1 = __builtin_fma(__builtin_fma(-y, r0, 1.0), r0, r0);
+  return __builtin_fma(__builtin_fma(-y, r1, 1.0), r1, r1);
+#else
+  return 1.0 / y;
+#endif
+}
+LCX_HD float rcp_refined(float y) { return 1.f / y; }
+template <bool FD, class T> LCX_HD T dvd(T x, T y)
+{
+  if constexpr (FD) return x * rcp_refined(y);
+  else return x / y;
+}
+
 namespace t748 {
 template <class T> struct st { T a, b, fa, fb, d, fd; };
 
-template <class T> LCX_HD T safe_div(T num, T den, T r)
+template <bool FD = false, class T> LCX_HD T safe_div(T num, T den, T r)
 {                                                                  // :124-138
   if (fabs(den) < 1 && fabs(den * lim<T>::max) <= fabs(num)) return r;
-  return num / den;
+  return dvd<FD>(num, den);
 }
-template <class T> LCX_HD T secant(T a, T b, T fa, T fb)
+template <bool FD = false, class T> LCX_HD T secant(T a, T b, T fa, T fb)
 {                                                                  // :140-160
   const T tol = lim<T>::eps * 5;
-  const T c = a - (fa / (fb - fa)) * (b - a);
+  const T c = a - dvd<FD>(fa, T(fb - fa)) * (b - a);
   if (c <= a + fabs(a) * tol || c >= b - fabs(b) * tol) return (a + b) / 2;
   return c;
 }
-template <class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb, T fd, unsigned count)
+template <bool FD = false, class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb, T fd, unsigned count)
 {                                                                  // :162-222
-  T B = safe_div(T(fb - fa), T(b - a), lim<T>::max);
-  T A = safe_div(T(fd - fb), T(d - b), lim<T>::max);
-  A = safe_div(T(A - B), T(d - a), T(0));
-  if (A == 0) return secant(a, b, fa, fb);
+  T B = safe_div<FD>(T(fb - fa), T(b - a), lim<T>::max);
+  T A = safe_div<FD>(T(fd - fb), T(d - b), lim<T>::max);
+  A = safe_div<FD>(T(A - B), T(d - a), T(0));
+  if (A == 0) return secant<FD>(a, b, fa, fb);
   T c = copysign(T(1), A * fa) > 0 ? a : b;
   for (unsigned i = 1; i <= count; ++i)
-    c -= safe_div(T(fa + (B + A * (c - b)) * (c - a)), T(B + A * (2 * c - a - b)), T(1 + c - a));
-  if (c <= a || c >= b) c = secant(a, b, fa, fb);
+    c -= safe_div<FD>(T(fa + (B + A * (c - b)) * (c - a)), T(B + A * (2 * c - a - b)), T(1 + c - a));
+  if (c <= a || c >= b) c = secant<FD>(a, b, fa, fb);
   return c;
 }
-template <class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T fd, T fe)
+template <bool FD = false, class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T fd, T fe)
 {                                                                  // :224-262
+  if constexpr (FD) {                                              // six distinct denominators among the nine quotients
+    const T r_ed = rcp_refined(T(fe - fd)), r_db = rcp_refined(T(fd - fb)), r_ba = rcp_refined(T(fb - fa)),
+            r_eb = rcp_refined(T(fe - fb)), r_da = rcp_refined(T(fd - fa)), r_ea = rcp_refined(T(fe - fa));
+    const T q11 = (d - e) * fd * r_ed;
+    const T q21 = (b - d) * fb * r_db;
+    const T q31 = (a - b) * fa * r_ba;
+    const T d21 = (b - d) * fd * r_db;
+    const T d31 = (a - b) * fb * r_ba;
+    const T q22 = (d21 - q11) * fb * r_eb;
+    const T q32 = (d31 - q21) * fa * r_da;
+    const T d32 = (d31 - q21) * fd * r_da;
+    const T q33 = (d32 - q22) * fa * r_ea;
+    T c = q31 + q32 + q33 + a;
+    if (c <= a || c >= b) c = quadratic<FD>(a, b, d, fa, fb, fd, 3);
+    return c;
+  }
   const T q11 = (d - e) * fd / (fe - fd);
   const T q21 = (b - d) * fb / (fd - fb);
   const T q31 = (a - b) * fa / (fb - fa);
@@ -181,6 +222,7 @@ template <class T, class F>
 LCX_HD bool toms748_head(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter, toms_carry<T> &k, T &root)
 {                                                                  // returns true when `root` is final
   using namespace t748;
+  constexpr bool FD = fastdiv<F>::value;
   k.count = max_iter;
   k.s = st<T>{ax, bx, fax, fbx, T(0), T(0)};
   st<T> &s = k.s;
@@ -192,11 +234,11 @@ LCX_HD bool toms748_head(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned m
   }
   k.fe = k.e = s.fd = 1e5f;
   if (s.fa != 0) {
-    c = secant(s.a, s.b, s.fa, s.fb);
+    c = secant<FD>(s.a, s.b, s.fa, s.fb);
     bracket(f, s, c);
     --k.count;
     if (k.count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
-      c = quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
+      c = quadratic<FD>(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2);
       k.e = s.d; k.fe = s.fd;
       bracket(f, s, c);
       --k.count;
@@ -211,21 +253,22 @@ template <class T, class F>
 LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
 {
   using namespace t748;
+  constexpr bool FD = fastdiv<F>::value;
   st<T> &s = k.s;
   T c, u, fu, a0, b0, &e = k.e, &fe = k.fe;
   unsigned &count = k.count;
   const T mu = 0.5f;
   while (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
     a0 = s.a; b0 = s.b;
-    c = prof(s, fe) ? quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2) : cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
+    c = prof(s, fe) ? quadratic<FD>(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2) : cubic<FD>(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
     e = s.d; fe = s.fd;
     bracket(f, s, c);
     if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
-    c = prof(s, fe) ? quadratic(s.a, s.b, s.d, s.fa, s.fb, s.fd, 3) : cubic(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
+    c = prof(s, fe) ? quadratic<FD>(s.a, s.b, s.d, s.fa, s.fb, s.fd, 3) : cubic<FD>(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
     bracket(f, s, c);
     if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
     if (fabs(s.fa) < fabs(s.fb)) { u = s.a; fu = s.fa; } else { u = s.b; fu = s.fb; }
-    c = u - 2 * (fu / (s.fb - s.fa)) * (s.b - s.a);
+    c = u - 2 * dvd<FD>(fu, T(s.fb - s.fa)) * (s.b - s.a);
     if (fabs(c - u) > (s.b - s.a) / 2) c = s.a + (s.b - s.a) / 2;
     e = s.d; fe = s.fd;
     bracket(f, s, c);
@@ -380,7 +423,10 @@ LCX_HD float exp_reduced(float x) { return exp(x); }
 // tolerance; the parity tests hold it to the same bars as the strict form.
 //   r dr/dt = (da RH - na klv) nD Sh nK Nu / ( da RH rho_w (c1 dD nK Nu + c2 dK nD Sh) )
 // with beta(Kn) = n/d, a_w = na/da, c1 = 2/(D_0 rho_v), c2 = 2 l_v (l_v/(R_v T) - 1)/(K_0 RH T).
+// droplet-independent part of the collected growth rate's set-up
+template <class T> struct cond_cell_fast { T Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w, rhod, eta, pad_; };
 template <class T> struct cond_fun_fast {
+  static constexpr bool fast_div = true;      // the root finder may use refined reciprocals (t748 above)
   T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
   LCX_HD void setup(const cond_fun<T> &f)
   {
@@ -391,6 +437,15 @@ template <class T> struct cond_fun_fast {
     c1 = T(2) / (c::D_0 * f.rho_v);
     c2_rho = T(2) * f.lv * f.lv_term / (c::K_0 * f.RH_eff * f.Tk);
     RH_rho_w = f.RH_eff * c::rho_w;
+  }
+  // the same set-up split into its per-cell part (k_cond_cellpre, once per cell and substep) and the droplet's own part:
+  // identical expressions, so the values are bit-identical to setup()
+  LCX_HD void setup_cell(const cond_cell_fast<T> &cc, T rw2_old_, T dt_, T rd3_, T kpa, T vt)
+  {
+    rw2_old = rw2_old_; dt = dt_; rd3 = rd3_; rd3_1mk = rd3_ * (T(1) - kpa);
+    c_Re = vt * T(2) * cc.rhod / cc.eta;
+    Sc = cc.Sc; Pr = cc.Pr; lambda_D = cc.lambda_D; lambda_K = cc.lambda_K; A = cc.A; RH_eff = cc.RH_eff;
+    c1 = cc.c1; c2_rho = cc.c2_rho; RH_rho_w = cc.RH_rho_w;
   }
   LCX_HD T drw2_dt(T rw2) const
   {
@@ -410,7 +465,7 @@ template <class T> struct cond_fun_fast {
     const T nDSh = nD * Sh, nKNu = nK * Nu;
     const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
     const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);
-    return T(2) * (num / den);
+    return T(2) * dvd<true>(num, den);
   }
   LCX_HD T operator()(T rw2) const
   {
@@ -435,7 +490,8 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
 {
   const T drw2 = dt * f.drw2_dt(rw2_old);
   if (drw2 == 0) { result = rw2_old; return true; }
-  const T rd = cbrt(rd3);
+  T rd;
+  if constexpr (fastdiv<F>::value) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
   const T a = mx(rd2, rw2_old + mn(T(0), cond_mlt * drw2)),
           b = rw2_old + mx(T(0), cond_mlt * drw2);
@@ -455,7 +511,8 @@ template <class T, class F>
 LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k)
 {
   T rw2_new = toms748_tail(f, k, eps);
-  const T rd = cbrt(rd3);
+  T rd;
+  if constexpr (fastdiv<F>::value) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
@@ -467,6 +524,26 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
   T r;
   if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) return r;
   return advance_rw2_tail_with(f, rd3, eps, k);
+}
+// per-cell part of with_cond_fun + cond_fun_fast::setup (same expressions, same order)
+template <class T>
+LCX_HD cond_cell_fast<T> make_cond_cell_fast(T rhod, T rv, T Tk, T eta, T lambda_D, T lambda_K, T RH, T RH_max)
+{
+  using c = cst<T>;
+  cond_cell_fast<T> cc;
+  cc.Sc = eta / rhod / c::D_0;
+  cc.Pr = c::c_pd * eta / c::K_0;
+  cc.lambda_D = lambda_D; cc.lambda_K = lambda_K;
+  const T rho_v = rhod * rv;
+  cc.RH_eff = RH > RH_max ? RH_max : RH;
+  const T lv = l_v(Tk);
+  cc.A = kelvin_A(Tk);
+  const T lv_term = lv / c::R_v / Tk - T(1);
+  cc.c1 = T(2) / (c::D_0 * rho_v);
+  cc.c2_rho = T(2) * lv * lv_term / (c::K_0 * cc.RH_eff * Tk);
+  cc.RH_rho_w = cc.RH_eff * c::rho_w;
+  cc.rhod = rhod; cc.eta = eta; cc.pad_ = T(0);
+  return cc;
 }
 // builds the growth-rate functor (strict or collected form) and hands it to `body`
 template <class T, bool FAST, class Body>

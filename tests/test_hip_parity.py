@@ -636,6 +636,32 @@ def test_fast_math_accuracy():
         assert float(ulp.max()) <= 1.0, (which, float(ulp.max()))
     xf = np.array([800., -800., 710., -745., np.inf, -np.inf])
     np.testing.assert_array_equal(probe(1, xf), probe(3, xf))
+    # reciprocal of the fast-mode root finder's divisions (differences of function values and abscissae, ~1e-25 ... 1e5)
+    x = np.concatenate([10 ** rng.uniform(-40, 40, 200000), -10 ** rng.uniform(-40, 40, 100000), [1., 3., -7., 1e-300, 1e300]])
+    ref = 1 / x.astype(np.longdouble)
+    y = probe(4, x)
+    ulp = np.abs((y.astype(np.longdouble) - ref) / np.spacing(ref.astype(np.float64)))
+    assert float(ulp.max()) <= 1.0, float(ulp.max())
+
+
+def test_cond_cell_precompute_is_bit_identical(monkeypatch):
+    """the droplet-independent part of the fast growth rate's set-up, hoisted into a per-cell pass (k_cond_cellpre), gives the
+    same bits as evaluating it per droplet (LCX_NO_COND_PRE=1 switches the hoist off)"""
+    oi = h.box_opts(4, 3, 5, 64, sstp_cond=2, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("LCX_NO_COND_PRE", "1")
+        orc, hip = h.make_pair(oi, fields)
+        opts = lgrngn.opts_t()
+        opts.coal = opts.adve = opts.sedi = False
+        th, rv, rhod, C = fields
+        thh, rvh = th.copy(), rv.copy()
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        res.append((hip.get_attr("rw2"), thh, rvh))
+    for a, b in zip(*res):
+        exact(a, b, "hoisted vs per-droplet set-up")
 
 
 @pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
