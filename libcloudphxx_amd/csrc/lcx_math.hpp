@@ -483,7 +483,8 @@ template <class T> struct cond_fun_fast {
 // Later, with the lean growth rate (10.7 ms): the root finder split at its loop entry (toms748_head / toms748_tail below)
 // with the ~40 % of droplets that enter the loop compacted onto fewer lanes -- in one kernel through LDS 12.0 ms, as
 // two kernels through HBM 5.5 + 7..8.8 ms.  Dense waves of "hard" droplets pay the maximum over 64 of them, which costs
-// more than the idle lanes it removes.
+// more than the idle lanes it removes.  The growth rate as a real (noinline) function instead of ~20 inlined copies
+// (80 KB of code): 16.3 ms against 8.6 -- the call ABI's register shuffling costs far more than the instruction cache gains.
 // cond_common.ipp:197-337 up to and including the first two root-finder steps.  Returns true when `result` is final.
 template <class T, class F>
 LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, toms_carry<T> &k, T &result)

@@ -295,4 +295,7 @@ def host_alloc(nbytes):
 def dev_alloc(nbytes):
     import torch
     t = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    # the fill runs on torch's stream, the library packs into the buffer on its own (non-blocking) stream: without this
+    # synchronisation the zero fill can land AFTER the packed records and wipe them (seen as lost super-droplets, rarely)
+    torch.cuda.synchronize()
     return t, t.data_ptr()
