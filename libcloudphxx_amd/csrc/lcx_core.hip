@@ -116,6 +116,7 @@ struct Particles : IParticles {
   struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
   // per-particle condensation substepping (exact_sstp_cond): the private rv, th, rhod(, p) of a super-droplet and rc2 are
   // further attributes (ext[]) that are compacted and migrate with it
+  uint64_t cells_version = 0, nobig_version = ~0ull;   // order_cells: "no cell above CELLRANK_MAX" is remembered per cell_start
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
   int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
@@ -132,7 +133,7 @@ struct Particles : IParticles {
   DevBuf<T> courant_x, courant_y, courant_z, w_LS, conc_factor, vt_0, kparams;
   size_t n_cx = 0, n_cy = 0, n_cz = 0;
   DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
-  DevBuf<double> puddle_partial, puddle_sum;
+  DevBuf<double> puddle_partial, puddle_sum, puddle_acc;
   DevBuf<int> d_flag; DevBuf<unsigned int> d_dead;
   void *pinned = nullptr;      // 256 B of page-locked host memory for the small per-step read-backs (counts, sums)
   double puddle[LCX_OUT_COUNT];
@@ -221,7 +222,7 @@ struct Particles : IParticles {
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
       b->alloc_zero(ncell, st);
     d_flag.alloc_zero(1, st); d_dead.alloc_zero(1, st);
-    puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4);
+    puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4); puddle_acc.alloc_zero(4, st);
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
   }
@@ -383,7 +384,7 @@ struct Particles : IParticles {
     }
     return rng_src{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
   }
-  void release_replay_keep() { sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
+  void release_replay_keep() { if (replay_keep_T.empty() && replay_keep_u.empty()) return; sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
   void rng_replay_push(int kind, const double *data, size_t n) override
   {
     Replay r; r.kind = kind; r.n = n;
@@ -426,6 +427,7 @@ struct Particles : IParticles {
   void sort_from_hist(bool shuffle)
   {
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell);
+    ++cells_version;
     if (nphys)
       hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
     order_cells(shuffle);
@@ -438,14 +440,22 @@ struct Particles : IParticles {
       if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
-        HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p,
-                           uint32_t(shuffle ? cellrank_max<uint64_t> : cellrank_max<uint32_t>), big_list.p, big_meta.p, big_meta.p + 1);
+        // the list of cells too big for k_cellrank costs a host round trip; the in-cell shuffle of coalescence re-orders the
+        // SAME segments as the sort before it, so "none" is remembered until cell_start changes
+        const bool known_nobig = nobig_version == cells_version;
+        if (!known_nobig) {
+          HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
+          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p,
+                             uint32_t(shuffle ? cellrank_max<uint64_t> : cellrank_max<uint32_t>), big_list.p, big_meta.p, big_meta.p + 1);
+        }
         if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
-        uint32_t meta[2];
-        read_back(meta, big_meta.p, 2);
+        uint32_t meta[2] = {0, 0};
+        if (!known_nobig) {
+          read_back(meta, big_meta.p, 2);
+          if (!meta[0]) nobig_version = cells_version;
+        }
         if (meta[0]) {
           const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
           if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
@@ -854,9 +864,8 @@ struct Particles : IParticles {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
       hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_sum.p + 4, slices, slices, puddle_sum.p);
-      double s4[4];
-      read_back(s4, puddle_sum.p, 4);
-      puddle[LCX_OUT_LIQ_VOL] += s4[0]; puddle[LCX_OUT_DRY_VOL] += s4[1]; puddle[LCX_OUT_LIQ_NUM] += s4[2]; puddle[LCX_OUT_PRTCL_NUM] += s4[3];
+      // running totals stay on the device (same additions in the same order as on the host); diag_puddle reads them
+      hipLaunchKernelGGL(k_accumulate4, dim3(1), dim3(64), 0, st, puddle_sum.p, puddle_acc.p);
     }
     if (do_bcnd && distmem()) build_migrant_lists();
   }
@@ -1398,7 +1407,13 @@ struct Particles : IParticles {
     if (v && npart) { HIPCHK(hipMemcpyAsync(out, v, npart * sizeof(T), hipMemcpyDeviceToHost, st)); sync(); }
     else if (npart) memset(out, 0, npart * sizeof(T));
   }
-  void diag_puddle(double *out) override { for (int i = 0; i < LCX_OUT_COUNT; ++i) out[i] = puddle[i]; }
+  void diag_puddle(double *out) override
+  {
+    double s4[4];
+    read_back(s4, puddle_acc.p, 4);
+    puddle[LCX_OUT_LIQ_VOL] = s4[0]; puddle[LCX_OUT_DRY_VOL] = s4[1]; puddle[LCX_OUT_LIQ_NUM] = s4[2]; puddle[LCX_OUT_PRTCL_NUM] = s4[3];
+    for (int i = 0; i < LCX_OUT_COUNT; ++i) out[i] = puddle[i];
+  }
   size_t n_part() override { return npart; }
   size_t n_cell() override { return ncell; }
 

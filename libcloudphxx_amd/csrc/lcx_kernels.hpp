@@ -1280,6 +1280,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
 // fixed-order reduction of the per-workgroup precipitation partials (deterministic for a given launch geometry):
 // workgroup g of the first launch reduces the contiguous slice [g*per, (g+1)*per) of the partials into out[g][4];
 // the second launch (one workgroup, nblocks = number of slices, per = 1) reduces those.
+__global__ void k_accumulate4(const double *s4, double *acc) { if (threadIdx.x < 4) acc[threadIdx.x] = acc[threadIdx.x] + s4[threadIdx.x]; }
 __global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, size_t per, double *out)
 {
   __shared__ double red[4][BS];
