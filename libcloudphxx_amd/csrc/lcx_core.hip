@@ -116,6 +116,7 @@ struct Particles : IParticles {
   struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
   // per-particle condensation substepping (exact_sstp_cond): the private rv, th, rhod(, p) of a super-droplet and rc2 are
   // further attributes (ext[]) that are compacted and migrate with it
+  bool no_cond_pre = getenv("LCX_NO_COND_PRE") != nullptr;   // test switch: evaluate the per-cell set-up per droplet instead
   uint64_t cells_version = 0, nobig_version = ~0ull;   // order_cells: "no cell above CELLRANK_MAX" is remembered per cell_start
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
@@ -687,7 +688,7 @@ struct Particles : IParticles {
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
-      if (!o.strict_fp && !turb_cond && getenv("LCX_NO_COND_PRE") == nullptr) {
+      if (!o.strict_fp && !turb_cond && !no_cond_pre) {
         cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         hipLaunchKernelGGL(k_cond_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, rhod.p, rv.p, Tk.p, eta.p, RH.p, lambda_D.p, lambda_K.p,
