@@ -238,7 +238,7 @@ int lcx_dev_copy(void *dst, const void *src, size_t bytes, int kind /*1 H2D, 2 D
 int lcx_dev_sync(void);
 /* parity hook: evaluate one of the device elementary functions on a host array of doubles
  * (which: 0 seeded cbrt, 1 reduced exp [the fast-mode growth rate uses these], 2 library cbrt, 3 library exp,
- *  4 refined reciprocal [the fast-mode root finder divides with it]) */
+ *  4 refined reciprocal [the fast-mode root finder divides with it], 5 lean logarithm [fast-mode terminal velocities]) */
 int lcx_math_probe(int which, const double *x_host, double *y_host, size_t n);
 /* host-side scalar evaluation of the formula library, = the functions the reference's Python module exposes as
  * libcloudphxx.common (ref: bindings/python/common.hpp:19-172, lib.cpp:129-144): name is one of

@@ -494,7 +494,8 @@ struct Particles : IParticles {
     if (vtc.formula == LCX_VT_BEARD77 || vtc.formula == LCX_VT_BEARD77FAST) {
       vt_pre.alloc(ncell);
       hipLaunchKernelGGL(k_vterm_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, p.p, rhod.p, eta.p, vt_pre.p);
-      hipLaunchKernelGGL(k_vterm_b77<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
+      if (o.strict_fp) hipLaunchKernelGGL((k_vterm_b77<T, false>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
+      else             hipLaunchKernelGGL((k_vterm_b77<T, true>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
       return;
     }
     hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);

@@ -439,7 +439,8 @@ __device__ __forceinline__ T vt_eval(const vt_cfg &v, T rw2, T Tk, T p, T rhod, 
 template <class T>
 __global__ void k_vterm_cellpre(size_t n_cell, const T *p, const T *rhod, const T *eta, beard77_cell<T> *out)
 { const size_t c = gid(); if (c < n_cell) out[c] = vt_beard77_cellpart(p[c], rhod[c], eta[c]); }
-template <class T>
+// FAST (opts_init.strict_fp == 0): reciprocal square root, refined-reciprocal division and the lean logarithm (<= 2 ulp each)
+template <class T, bool FAST>
 __global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const beard77_cell<T> *pre, const T *vt_0, T *vt)
 {
   const size_t i = gid(); if (i >= n) return;
@@ -448,11 +449,18 @@ __global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, 
   if (only_invalid && !(vt[i] == T(-1))) return;
   const uint32_t c = ijk[i];
   if (c == DEAD_CELL) return;
-  const T r = sqrt(r2);
-  const T f = vt_beard77_fact_pre(r, pre[c]);
+  T r, f;
+  if (FAST) {
+    const T irw = rsqrt(r2);
+    r = r2 * irw;
+    f = r <= T(20e-6) ? vt_beard77_fact_pre_small_fast(irw, pre[c]) : vt_beard77_fact_pre(r, pre[c]);
+  } else {
+    r = sqrt(r2);
+    f = vt_beard77_fact_pre(r, pre[c]);
+  }
   if (v.formula == LCX_VT_BEARD77) { vt[i] = f * T(vt_beard77_v0(double(r))); return; }
   const T lnmin = T(v.ln_r_min), lnmax = T(v.ln_r_max), dlnr = (lnmax - lnmin) / v.n_bin;
-  const T lnr = .5 * log(r2);
+  const T lnr = .5 * (FAST ? log_lean(r2) : T(log(r2)));
   const int bin = lnr <= lnmin ? 0 : lnr >= lnmax ? v.n_bin - 1 : int((lnr - lnmin) / dlnr);
   vt[i] = f * vt_0[bin];
 }
@@ -1684,7 +1692,7 @@ __global__ void k_math_probe(int which, double *v, size_t n)
   const size_t i = gid();
   if (i >= n) return;
   const double x = v[i];
-  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : exp(x);
+  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : which == 5 ? log_lean(x) : exp(x);
 }
 
 } // namespace lcx

@@ -416,6 +416,39 @@ LCX_HD double exp_reduced(double x)
 }
 LCX_HD float exp_reduced(float x) { return exp(x); }
 
+// natural logarithm of a positive normal double for the fast-arithmetic terminal-velocity pass (only the index of a
+// ln(r)-uniform table is taken from it): mantissa in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) as an odd series.
+// <= 2 ulp (math probe 5); the library call costs about twice as many instructions.
+LCX_HD double log_lean(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x >= 2.3e-308 && x < 1.7e308)) return log(x);
+  int e = __builtin_amdgcn_frexp_exp(x);
+  double m = __builtin_amdgcn_frexp_mant(x);                     // [0.5, 1)
+  if (m < 0.70710678118654752) { m = m + m; e -= 1; }
+  const double s = (m - 1.0) * rcp_refined(m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 23.0;
+  p = __builtin_fma(p, z, 1.0 / 21.0);
+  p = __builtin_fma(p, z, 1.0 / 19.0);
+  p = __builtin_fma(p, z, 1.0 / 17.0);
+  p = __builtin_fma(p, z, 1.0 / 15.0);
+  p = __builtin_fma(p, z, 1.0 / 13.0);
+  p = __builtin_fma(p, z, 1.0 / 11.0);
+  p = __builtin_fma(p, z, 1.0 / 9.0);
+  p = __builtin_fma(p, z, 1.0 / 7.0);
+  p = __builtin_fma(p, z, 1.0 / 5.0);
+  p = __builtin_fma(p, z, 1.0 / 3.0);
+  const double two_s = s + s;
+  const double lm = __builtin_fma(two_s * z, p, two_s);
+  const double ed = double(e);
+  return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+#else
+  return log(x);
+#endif
+}
+LCX_HD float log_lean(float x) { return log(x); }
+
 // The same growth rate as cond_fun, algebraically collected into ONE rational expression (one IEEE division
 // instead of fifteen) with FMA contraction allowed.  Selected by opts_init.strict_fp = 0.  It is the counterpart
 // of how the reference itself is built for production (-Ofast: reassociation + contraction, CMakeLists.txt:124):
@@ -625,6 +658,12 @@ template <class T> LCX_HD T vt_beard77_fact_pre(T r, const beard77_cell<T> &b)
     const T eps_s = b.e0e - 1;
     return T(1.104) * eps_s + ((T(1.058) * b.eps_c - T(1.104) * eps_s) * (T(5.52) + log(2 * 100 * r)) / T(5.01)) + 1;
   }
+}
+// the same with the droplet radius entering as 1/r (fast arithmetic: reciprocal square root instead of sqrt and two divisions)
+template <class T> LCX_HD T vt_beard77_fact_pre_small_fast(T inv_r, const beard77_cell<T> &b)
+{
+  const T l_0 = T(6.62e-8);
+  return dvd<true>(T(b.e0e * (1 + T(1.255) * (b.l * inv_r))), T(1 + T(1.255) * (l_0 * inv_r)));
 }
 template <class T> LCX_HD T vt_beard77_fact(T r, T p, T rhoa, T eta)
 {

@@ -642,6 +642,12 @@ def test_fast_math_accuracy():
     y = probe(4, x)
     ulp = np.abs((y.astype(np.longdouble) - ref) / np.spacing(ref.astype(np.float64)))
     assert float(ulp.max()) <= 1.0, float(ulp.max())
+    # lean logarithm of the fast-mode terminal-velocity pass (argument: wet radius squared, 1e-20 ... 1e-4; test far beyond)
+    x = np.concatenate([10 ** rng.uniform(-30, 10, 300000), 1 + rng.uniform(-1e-3, 1e-3, 1000), [1., 2., .5, np.e, 1e-300, 1e300]])
+    ref = np.log(x.astype(np.longdouble))
+    y = probe(5, x)
+    err = np.abs(y.astype(np.longdouble) - ref)
+    assert float((err / np.maximum(np.spacing(np.abs(ref).astype(np.float64)), 2.3e-16)).max()) <= 2.0
 
 
 def test_cond_cell_precompute_is_bit_identical(monkeypatch):
