@@ -157,6 +157,7 @@ int lcx_diag_pressure(lcx_particles *);
 int lcx_diag_temperature(lcx_particles *);
 int lcx_diag_RH(lcx_particles *);
 int lcx_diag_all(lcx_particles *);
+int lcx_diag_vel_div(lcx_particles *);     /* particles_diag.ipp:499-555: divergence of the Courant field, per cell */
 int lcx_diag_water(lcx_particles *);
 int lcx_diag_dry_rng(lcx_particles *, double r_mi, double r_mx);
 int lcx_diag_wet_rng(lcx_particles *, double r_mi, double r_mx);

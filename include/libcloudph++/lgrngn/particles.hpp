@@ -47,6 +47,7 @@ namespace libcloudphxx { namespace lgrngn {
     virtual void diag_kappa_rng_cons(const real_t &, const real_t &) { assert(false); }
     virtual void diag_dry_mom(const int &) { assert(false); }
     virtual void diag_wet_mom(const int &) { assert(false); }
+    virtual void diag_vel_div() { assert(false); }
     virtual void diag_kappa_mom(const int &) { assert(false); }
     virtual void diag_incloud_time_mom(const int &) { assert(false); }
     virtual void diag_max_rw() { assert(false); }
@@ -188,6 +189,7 @@ namespace libcloudphxx { namespace lgrngn {
     void diag_kappa_rng_cons(const real_t &a, const real_t &b) override { detail::lcx_check(lcx_diag_kappa_rng_cons(pimpl->h, a, b)); }
     void diag_dry_mom(const int &k) override { detail::lcx_check(lcx_diag_dry_mom(pimpl->h, k)); }
     void diag_wet_mom(const int &k) override { detail::lcx_check(lcx_diag_wet_mom(pimpl->h, k)); }
+    void diag_vel_div() override { detail::lcx_check(lcx_diag_vel_div(pimpl->h)); }
     void diag_kappa_mom(const int &k) override { detail::lcx_check(lcx_diag_kappa_mom(pimpl->h, k)); }
     void diag_incloud_time_mom(const int &k) override { detail::lcx_check(lcx_diag_incloud_time_mom(pimpl->h, k)); }
     void diag_max_rw() override { detail::lcx_check(lcx_diag_max_rw(pimpl->h)); }

@@ -65,6 +65,7 @@ struct IParticles {
   virtual void step_cond(const lcx_opts_t &, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv) = 0;
   virtual void step_async(const lcx_opts_t &) = 0;
   virtual void diag_cell(int which) = 0;               // 0 p, 1 T, 2 RH
+  virtual void diag_vel_div() = 0;
   virtual void diag_sd_conc() = 0;
   virtual void diag_select(int mode, int cons, int attr, double a, double b) = 0;   // attr: 0 rd3, 1 rw2, 2 kpa
   virtual void diag_mom(int attr, double power) = 0;
@@ -1327,6 +1328,12 @@ struct Particles : IParticles {
     HIPCHK(hipMemcpyAsync(count_mom.p, src, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
     sync();
   }
+  void diag_vel_div() override
+  {
+    if (n_dims == 0) return;
+    hipLaunchKernelGGL(k_vel_div<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, g, halo, T(o.dt), courant_x.p, courant_y.p, courant_z.p, count_mom.p);
+    sync();
+  }
   void need_nfiltered() { if (!n_filtered.p) n_filtered.alloc(cap); }
   T *attr_ptr(int attr)
   {
@@ -1654,6 +1661,7 @@ int lcx_diag_sd_conc(lcx_particles *h) { LCX_TRY(H->diag_sd_conc()) }
 int lcx_diag_pressure(lcx_particles *h) { LCX_TRY(H->diag_cell(0)) }
 int lcx_diag_temperature(lcx_particles *h) { LCX_TRY(H->diag_cell(1)) }
 int lcx_diag_RH(lcx_particles *h) { LCX_TRY(H->diag_cell(2)) }
+int lcx_diag_vel_div(lcx_particles *h) { LCX_TRY(H->diag_vel_div()) }
 int lcx_diag_all(lcx_particles *h) { LCX_TRY(H->diag_select(0, 0, 1, 0, 0)) }
 int lcx_diag_water(lcx_particles *h) { LCX_TRY(H->diag_select(2, 0, 1, 0, 0)) }
 int lcx_diag_dry_rng(lcx_particles *h, double a, double b) { LCX_TRY(H->diag_select(1, 0, 0, std::pow(a, 3), std::pow(b, 3))) }

@@ -1687,6 +1687,25 @@ __global__ void k_rcyc_apply(size_t k, const uint32_t *recv, const uint32_t *don
 }
 
 // parity hook (lcx_math_probe): the device elementary functions on an array
+// diag_vel_div (particles_diag.ipp:499-555): y, then z, then x face differences of the Courant numbers, each divided by dt;
+// the face indices are those of k_move (init_grid.ipp:96-121), shifted by the Courant halo
+template <class T>
+__global__ void k_vel_div(size_t n_cell, grid_t g, int halo, T dt, const T *cx, const T *cy, const T *cz, T *out)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const size_t nz = g.nz ? g.nz : 1, ny = g.ny ? g.ny : 1;
+  const size_t plane = g.ndims == 1 ? 1 : g.ndims == 2 ? nz : nz * ny;
+  const size_t ce = c + size_t(halo) * plane;
+  T d = 0;
+  if (g.ndims == 3) { const size_t fre = ce + (ce / (nz * ny)) * nz; d = d + (cy[fre + nz] - cy[fre]) / dt; }
+  if (g.ndims >= 2) {
+    const size_t blw = g.ndims == 2 ? ce + ce / nz : ce + ny * (ce / (nz * ny)) + (ce - (ce / (nz * ny)) * (nz * ny)) / nz;
+    d = d + (cz[blw + 1] - cz[blw]) / dt;
+  }
+  const size_t rgt = ce + (g.ndims == 3 ? nz * ny : size_t(g.nz));
+  d = d + (cx[rgt] - cx[ce]) / dt;
+  out[c] = d;
+}
 __global__ void k_math_probe(int which, double *v, size_t n)
 {
   const size_t i = gid();

@@ -407,6 +407,7 @@ class particles_t:
     diag_temperature = _diag0("diag_temperature")
     diag_RH = _diag0("diag_RH")
     diag_all = _diag0("diag_all")
+    diag_vel_div = _diag0("diag_vel_div")
     diag_water = _diag0("diag_water")
     diag_precip_rate = _diag0("diag_precip_rate")
     diag_RH_ge_Sc = _diag0("diag_RH_ge_Sc")

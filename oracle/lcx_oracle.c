@@ -1749,6 +1749,23 @@ static void diag_cellfield(orc_particles *s, const double *f)
   s->count_n = s->n_cell;
   for (sz c = 0; c < s->n_cell; ++c) s->count_ijk[c] = c;
 }
+/* particles_diag.ipp:499-555: divergence of the Courant field per cell, y then z then x differences, each / opts_init.dt */
+int orc_diag_vel_div(orc_particles *s)
+{
+  if (s->n_dims == 0) return 0;
+  const sz nz = m1(s->o.nz), ny = m1(s->o.ny);
+  const sz plane = s->n_dims == 1 ? 1 : s->n_dims == 2 ? nz : nz * ny;
+  for (sz c = 0; c < s->n_cell; ++c) {
+    double Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0, d = 0.;
+    faces(s, c + (sz)s->halo * plane, &Cxl, &Cxr, &Cyl, &Cyr, &Czl, &Czr);
+    if (s->n_dims == 3) d = d + (Cyr - Cyl) / s->o.dt;
+    if (s->n_dims >= 2) d = d + (Czr - Czl) / s->o.dt;
+    d = d + (Cxr - Cxl) / s->o.dt;
+    s->count_mom[c] = d; s->count_ijk[c] = c;
+  }
+  s->count_n = s->n_cell;
+  return 0;
+}
 int orc_diag_pressure(orc_particles *s) { diag_cellfield(s, s->p); return 0; }
 int orc_diag_temperature(orc_particles *s) { diag_cellfield(s, s->T); return 0; }
 int orc_diag_RH(orc_particles *s) { diag_cellfield(s, s->RH); return 0; }

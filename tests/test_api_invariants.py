@@ -399,3 +399,23 @@ def test_onishi_speeds_up_rain_formation(make):
     slack = 0. if make is h.oracle_particles else 2 * se
     print("t10 Hall / Onishi-Hall = %.3f +- %.3f" % (ratio, se))
     assert 1.22 - slack < ratio < 1.62 + slack, ratio
+
+
+@pytest.mark.parametrize("make", MAKERS)
+@pytest.mark.parametrize("dims", [(5, 0, 0), (4, 0, 6), (4, 3, 5)])
+def test_diag_vel_div_is_the_courant_divergence(make, dims):
+    """particles_diag.ipp:499-555: per cell, (C_y differences, then C_z, then C_x) / opts_init.dt -- the same additions in numpy;
+    pred_corr adds a Courant halo of two planes that the face indices have to skip"""
+    for scheme in (lgrngn.as_t.euler, lgrngn.as_t.pred_corr):
+        oi = h.box_opts(*dims, 8, sedi_switch=dims[2] > 0, adve_scheme=scheme)
+        th, rv, rhod, C = h.box_fields(oi)
+        pr = make(oi)
+        pr.init(th, rv, rhod, **C)
+        pr.diag_vel_div()
+        div = 0
+        if dims[1]:
+            div = div + (C["Cy"][:, 1:, :] - C["Cy"][:, :-1, :]) / oi.dt
+        if dims[2]:
+            div = div + (C["Cz"][..., 1:] - C["Cz"][..., :-1]) / oi.dt
+        div = div + (C["Cx"][1:] - C["Cx"][:-1]) / oi.dt
+        np.testing.assert_array_equal(pr.outbuf_array(), div.ravel())
