@@ -59,6 +59,6 @@ namespace libcloudphxx { namespace lgrngn {
     int supstp_rlx = 1;
     // --- extensions of this backend (no reference counterpart, see include/lcx.h) ---
     bool strict_fp = true;     // false: contracted one-division form of the condensational growth rate
-    int reorder_every = 0;     // > 0: physical re-ordering of the storage into the cell-sorted order every so many steps
+    int reorder_every = 0;     // storage re-ordering into the cell-sorted order: every N steps and with every compaction (0: N = 64), -1 never (lcx.h)
   };
 } }

@@ -117,6 +117,7 @@ struct Particles : IParticles {
   struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
   // per-particle condensation substepping (exact_sstp_cond): the private rv, th, rhod(, p) of a super-droplet and rc2 are
   // further attributes (ext[]) that are compacted and migrate with it
+  bool replay_used = false;   // a parity run: storage stays in the reference's id order (see opts_init.reorder_every)
   bool no_cond_pre = getenv("LCX_NO_COND_PRE") != nullptr;   // test switch: evaluate the per-cell set-up per droplet instead
   uint64_t cells_version = 0, nobig_version = ~0ull;   // order_cells: "no cell above CELLRANK_MAX" is remembered per cell_start
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
@@ -389,6 +390,7 @@ struct Particles : IParticles {
   void release_replay_keep() { if (replay_keep_T.empty() && replay_keep_u.empty()) return; sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
   void rng_replay_push(int kind, const double *data, size_t n) override
   {
+    replay_used = true;
     Replay r; r.kind = kind; r.n = n;
     if (kind == 0 || kind == 2) {                        // 0: uniform [0,1), 2: standard normal
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(data[i]);
@@ -625,11 +627,16 @@ struct Particles : IParticles {
   {
     unsigned int dead = 0;
     read_back(&dead, d_dead.p, 1);
-    if (dead && (eager_compact || size_t(dead) * 32 > nphys)) { post_copy(opts, true); return; }
+    // reference storage order (stable compaction only) when asked for, and in every parity run (a replayed stream is indexed by id)
+    const bool strict_order = o.reorder_every < 0 || eager_compact || replay_used;
+    const bool compact_now = dead && (eager_compact || size_t(dead) * 32 > nphys);
+    if (compact_now && strict_order) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
     npart = nphys - dead;
     sort_from_hist(false);
-    if (o.reorder_every > 0 && ++steps_since_reorder >= o.reorder_every) reorder_storage();
+    // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
+    const int every = o.reorder_every > 0 ? o.reorder_every : 64;       // 0: the default period
+    if (compact_now || (!strict_order && ++steps_since_reorder >= every)) reorder_storage();
   }
   // opts_init.reorder_every: storage := cell-sorted order (ids renumbered, dead SDs dropped); needs the plain sorted order
   void reorder_storage()

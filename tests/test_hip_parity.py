@@ -712,9 +712,10 @@ def test_rcyc_matches_oracle(dims):
 def test_storage_reorder_is_a_permutation_of_the_same_state():
     """opts_init.reorder_every (extension): physically re-ordering the storage into the cell order renumbers the ids but
     must not change any super-droplet: with coalescence off (no id-keyed random numbers) a run that re-orders after every
-    step carries the same set of droplets as one that never does; th / rv agree to summation-order rounding"""
+    step carries the same set of droplets as one that never does (-1: stable compaction only, the reference's storage order);
+    th / rv agree to summation-order rounding"""
     runs = []
-    for every in (0, 1):
+    for every in (-1, 1):
         oi = h.box_opts(5, 4, 6, 40, reorder_every=every)
         fields = h.box_fields(oi)
         th, rv, rhod, C = fields
@@ -743,6 +744,40 @@ def test_storage_reorder_is_a_permutation_of_the_same_state():
     sid, sijk, ijk = b[5], b[6], b[7]
     exact(sid, np.arange(len(sid), dtype=sid.dtype), "sorted_id is the identity right after a re-order")
     exact(ijk, sijk, "ijk == sorted_ijk")
+
+
+def test_compaction_gathers_in_cell_order_by_default():
+    """opts_init.reorder_every == 0 (default): when enough super-droplets have died, the pass that drops them gathers the
+    survivors in the cell-sorted order; -1 keeps the reference's stable compaction.  Same droplets either way."""
+    runs = []
+    for every in (-1, 0):
+        oi = h.box_opts(5, 4, 6, 48, dx=30., coal_switch=False, reorder_every=every)
+        th, rv, rhod, C = h.box_fields(oi)
+        pr = h.hip_particles(oi)
+        pr.init(th.copy(), rv.copy(), rhod.copy(), **C)
+        n0 = pr.n_part
+        rw2 = pr.get_attr("rw2")
+        rw2[::5] = (1.2e-3) ** 2                      # mm-sized drops: a fifth of the SDs rains out within a few steps
+        pr.set_particles(pr.state_u64("n"), pr.state_real("rd3"), rw2, pr.state_real("kappa"), pr.state_real("vt"),
+                         pr.state_real("x"), pr.state_real("y"), pr.state_real("z"))
+        opts = lgrngn.opts_t()
+        opts.coal = opts.cond = False
+        for _ in range(8):
+            pr.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+            pr.step_async(opts)
+        assert pr.n_part < 0.96 * n0                  # more than the 1/32 that triggers a compaction
+        key = np.argsort(pr.get_attr("rd3"), kind="stable")
+        runs.append((pr.n_part, {a: pr.get_attr(a)[key] for a in ("rd3", "rw2", "x", "y", "z")}, pr.state_u64("n")[key],
+                     pr.state_u64("ijk"), pr.state_u64("sorted_ijk"), pr.state_u64("sorted_id")))
+    a, b = runs
+    assert a[0] == b[0]
+    exact(b[2], a[2], "multiplicities")
+    for k in a[1]:
+        exact(b[1][k], a[1][k], k)
+    assert not np.array_equal(a[3], a[4])                    # stable compaction: storage order is creation order
+    ijk, sijk, sid = b[3], b[4], b[5]
+    nondecreasing_from = int(np.argmax(np.diff(ijk.astype(np.int64)) < 0)) if np.any(np.diff(ijk.astype(np.int64)) < 0) else len(ijk)
+    assert nondecreasing_from > 0.5 * len(ijk)               # the last compaction left the storage cell-sorted (later steps moved a few)
 
 
 # ------------------------------------------------------------------ SGS turbulence (SURVEY 8f, f4)
