@@ -547,24 +547,36 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
                   const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims)
 {
   __shared__ T lds[CF_CAP];
+  __shared__ uint32_t cs[CF_CELLS + 1];
   const size_t c0 = size_t(blockIdx.x) * cfc;
   const size_t c1 = c0 + cfc < n_cell ? c0 + cfc : n_cell;
-  const uint32_t base = cell_start[c0], end = cell_start[c1];
-  const bool staged = (end - base) <= uint32_t(CF_CAP);
+  const int nc = int(c1 - c0);
+  if (int(threadIdx.x) <= nc) cs[threadIdx.x] = cell_start[c0 + threadIdx.x];
+  __syncthreads();
   const size_t c = c0 + threadIdx.x;
-  const bool mine = threadIdx.x < cfc && c < n_cell;
-  uint32_t s = 0, e = 0;
-  if (mine) { s = cell_start[c]; e = cell_start[c + 1]; }
+  const bool mine = int(threadIdx.x) < nc;
+  const uint32_t s = mine ? cs[threadIdx.x] : 0u, e = mine ? cs[threadIdx.x + 1] : 0u;
   const bool has = e > s;
   T after = 0, before = 0;
-  if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
-  __syncthreads();
-  if (mine && has) after = seg_sum(lds, m3_after, staged, base, s, e);
-  if (step == 0) {
+  // the workgroup's cells are taken in runs that fit the LDS stage (normally one run; crowded neighbourhoods split instead of
+  // falling back to uncoalesced global reads); a single cell above CF_CAP is summed from global memory
+  for (int cb = 0; cb < nc;) {
+    int ce = cb + 1;
+    while (ce < nc && cs[ce + 1] - cs[cb] <= uint32_t(CF_CAP)) ++ce;
+    const uint32_t base = cs[cb], end = cs[ce];
+    const bool staged = (end - base) <= uint32_t(CF_CAP);
+    const bool in_run = mine && has && int(threadIdx.x) >= cb && int(threadIdx.x) < ce;
+    if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
     __syncthreads();
-    if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
+    if (in_run) after = seg_sum(lds, m3_after, staged, base, s, e);
+    if (step == 0) {
+      __syncthreads();
+      if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
+      __syncthreads();
+      if (in_run) before = seg_sum(lds, m3_before, staged, base, s, e);
+    }
     __syncthreads();
-    if (mine && has) before = seg_sum(lds, m3_before, staged, base, s, e);
+    cb = ce;
   }
   if (!mine) return;
   T drw;
