@@ -319,6 +319,29 @@ __global__ void k_list_big_cells(size_t n_cell, const uint32_t *cell_start, uint
 // order, so only the compiler has to be kept from moving them across a pass (wave-scope fence); the four waves of a
 // workgroup sort four cells independently.
 constexpr int CELLSORT_WAVE_MAX = 1024;
+// one wave sorts a[0, cnt) in LDS ascending, cnt <= P = a power of two.  Bitonic network in its normalised form (every
+// comparator ascending; the first pass of a merge pairs i with its mirror in the block): comparators that reach beyond cnt
+// would only meet virtual +inf padding and are skipped.  No workgroup barrier: a wave executes its LDS instructions in order.
+template <class KEY>
+__device__ __forceinline__ void wave_bitonic(KEY *a, uint32_t cnt, uint32_t P, uint32_t lane)
+{
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    const uint32_t hk = k >> 1;
+    for (uint32_t t = lane; t < (P >> 1) && t < cnt; t += WAVE) {
+      const uint32_t base = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
+      const uint32_t lo = base | off, hi = base + (k - 1 - off);
+      if (hi < cnt) { const KEY u = a[lo], v = a[hi]; if (u > v) { a[lo] = v; a[hi] = u; } }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+      for (uint32_t t = lane; t < (P >> 1) && t < cnt; t += WAVE) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        if (hi < cnt) { const KEY u = a[lo], v = a[hi]; if (u > v) { a[lo] = v; a[hi] = u; } }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
 template <class KEY>
 __global__ void __launch_bounds__(BS)
 k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r)
@@ -331,18 +354,32 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
     const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
     if (cnt > uint32_t(CELLSORT_WAVE_MAX)) continue;         // k_cellsort_lds / k_cellsort_big take it
     uint32_t P = 2 * WAVE; while (P < cnt) P <<= 1;
-    for (uint32_t i = lane; i < P; i += WAVE) a[i] = i < cnt ? KEY(sort_key(sorted_id[start + i], shuffle, r)) : KEY(~KEY(0));
+    for (uint32_t i = lane; i < cnt; i += WAVE) a[i] = KEY(sort_key(sorted_id[start + i], shuffle, r));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    for (uint32_t k = 2; k <= P; k <<= 1)
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = lane; t < (P >> 1); t += WAVE) {
-          const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-          const KEY u = a[lo], v = a[hi];
-          if ((u > v) == ((lo & k) == 0)) { a[lo] = v; a[hi] = u; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const uint32_t H = P >> 1;
+    if (shuffle && H >= 2 * WAVE && cnt - H <= uint32_t(WAVE)) {
+      // (64-bit shuffle keys only: with 32-bit keys the passes are cheap enough that the merge's dependent look-ups cost more)
+      // a little more than a power of two (512 SDs per cell on average: half of the cells hold 513 ... 576): sort the first H
+      // keys and the short tail separately, then merge by rank (keys are unique) -- about half the passes of the 2H network
+      const uint32_t m = cnt - H;
+      wave_bitonic(a, H, H, lane);
+      wave_bitonic(a + H, m, uint32_t(WAVE), lane);
+      for (uint32_t i = lane; i < H; i += WAVE) {
+        const KEY key = a[i];
+        uint32_t lo = 0, hi = m;                                    // number of tail keys below `key`
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[H + mid] < key) lo = mid + 1; else hi = mid; }
+        sorted_id[start + i + lo] = uint32_t(key);
       }
-    for (uint32_t i = lane; i < cnt; i += WAVE) sorted_id[start + i] = uint32_t(a[i]);
+      if (lane < m) {
+        const KEY key = a[H + lane];
+        uint32_t lo = 0, hi = H;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+        sorted_id[start + lane + lo] = uint32_t(key);
+      }
+    } else {
+      wave_bitonic(a, cnt, P, lane);
+      for (uint32_t i = lane; i < cnt; i += WAVE) sorted_id[start + i] = uint32_t(a[i]);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   }
 }
@@ -358,17 +395,24 @@ k_cellsort_lds(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_st
     const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
     if (cnt > uint32_t(CELLSORT_LDS_MAX) || cnt <= uint32_t(CELLSORT_WAVE_MAX)) continue;   // k_cellsort_big / k_cellsort_wave take it
     uint32_t P = 2; while (P < cnt) P <<= 1;
-    for (uint32_t i = threadIdx.x; i < P; i += BS) a[i] = i < cnt ? KEY(sort_key(sorted_id[start + i], shuffle, r)) : KEY(~KEY(0));
+    for (uint32_t i = threadIdx.x; i < cnt; i += BS) a[i] = KEY(sort_key(sorted_id[start + i], shuffle, r));
     __syncthreads();
-    for (uint32_t k = 2; k <= P; k <<= 1)
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = threadIdx.x; t < (P >> 1); t += BS) {
+    for (uint32_t k = 2; k <= P; k <<= 1) {                   // normalised network, comparators beyond cnt skipped (see k_cellsort_wave)
+      const uint32_t hk = k >> 1;
+      for (uint32_t t = threadIdx.x; t < (P >> 1) && t < cnt; t += BS) {
+        const uint32_t base = (t & ~(hk - 1)) << 1, off = t & (hk - 1);
+        const uint32_t lo = base | off, hi = base + (k - 1 - off);
+        if (hi < cnt) { const KEY u = a[lo], v = a[hi]; if (u > v) { a[lo] = v; a[hi] = u; } }
+      }
+      __syncthreads();
+      for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+        for (uint32_t t = threadIdx.x; t < (P >> 1) && t < cnt; t += BS) {
           const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
-          const KEY u = a[lo], v = a[hi];
-          if ((u > v) == ((lo & k) == 0)) { a[lo] = v; a[hi] = u; }
+          if (hi < cnt) { const KEY u = a[lo], v = a[hi]; if (u > v) { a[lo] = v; a[hi] = u; } }
         }
         __syncthreads();
       }
+    }
     for (uint32_t i = threadIdx.x; i < cnt; i += BS) sorted_id[start + i] = uint32_t(a[i]);
     __syncthreads();
   }
