@@ -708,8 +708,12 @@ struct Particles : IParticles {
     }
     {
       Range r(this, "cond_cellfinish");
-      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
+      if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)        // crowded cells, fast arithmetic: one wave per cell
+        hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                           rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
+      else
+        hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                           rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
     }
   }
   // hskpng_rc2.ipp:14-32
