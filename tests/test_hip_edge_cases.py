@@ -1,0 +1,104 @@
+"""Edge cases of the hot path on the device against the oracle: empty and nearly empty populations, single cells / planes,
+one super-droplet per cell, everything switched off, all super-droplets raining out."""
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+
+
+def exact(a, b, what):
+    assert np.array_equal(a, b), what
+
+
+def run_pair(oi, steps, opts=None, fields=None, coal_replay=True):
+    fields = fields or h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = opts or lgrngn.opts_t()
+    th, rv, rhod, C = fields
+    for _ in range(steps):
+        tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()
+        orc.step_sync(opts, tho, rvo, rhod, **C)
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        if opts.coal and coal_replay:
+            h.push_coal_replay(orc, hip, oi.sstp_coal)
+        orc.step_async(opts)
+        hip.step_async(opts)
+        assert hip.n_part == orc.n_part
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+    return orc, hip
+
+
+@pytest.mark.parametrize("dims", [(1, 0, 0), (1, 0, 1), (1, 1, 1), (2, 1, 1), (1, 0, 7), (9, 0, 1)])
+def test_single_cells_and_planes(dims):
+    oi = h.box_opts(*dims, 32, sedi_switch=dims[2] > 0)
+    opts = lgrngn.opts_t()
+    opts.sedi = dims[2] > 0
+    orc, hip = run_pair(oi, 3, opts)
+    exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+    exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=2e-4)
+
+
+def test_one_super_droplet_per_cell():
+    """no pair anywhere: coalescence must be a no-op that still consumes its random numbers"""
+    oi = h.box_opts(4, 3, 5, 1)
+    orc, hip = run_pair(oi, 3)
+    exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+    assert np.all(orc.state_real("col")[:-1] == 0)
+
+
+def test_everything_switched_off():
+    oi = h.box_opts(3, 2, 4, 16)
+    opts = lgrngn.opts_t()
+    opts.adve = opts.sedi = opts.cond = opts.coal = False
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    before = {a: hip.get_attr(a) for a in ("rw2", "x", "y", "z")}
+    orc2, hip2 = run_pair(oi, 2, opts, fields)
+    exact(hip2.get_attr("rw2"), before["rw2"], "rw2")
+    for a in ("x", "y", "z"):               # the boundary condition is applied regardless (particles_step.ipp:480-481): the periodic
+        exact(hip2.get_attr(a), orc2.get_attr(a), a)                      # wrap a + fmod(x - a + 10 L, L) rounds, identically
+        np.testing.assert_allclose(hip2.get_attr(a), before[a], rtol=1e-11)
+
+
+def test_all_super_droplets_rain_out_and_the_steps_go_on():
+    """mm-sized drops in a shallow box: after a few steps no super-droplet is left; stepping and diagnosing an empty
+    population must work (and agree with the oracle)"""
+    oi = h.box_opts(3, 2, 3, 8, dx=10., coal_switch=False)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    g = lambda nm: orc.state_real(nm)
+    rw2 = np.full(orc.n_part, (2e-3) ** 2)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    th, rv, rhod, C = fields
+    for it in range(12):
+        for pr in (orc, hip):
+            pr.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+            pr.step_async(opts)
+        assert hip.n_part == orc.n_part
+    assert orc.n_part == 0
+    for pr in (orc, hip):
+        pr.diag_all(); pr.diag_sd_conc()
+    exact(hip.outbuf_array(), orc.outbuf_array(), "sd_conc of an empty population")
+    assert not hip.outbuf_array().any()
+    for pr in (orc, hip):
+        pr.diag_all(); pr.diag_wet_mom(3)
+    exact(hip.outbuf_array(), orc.outbuf_array(), "moment of an empty population")
+    po, ph = orc.diag_puddle(), hip.diag_puddle()
+    np.testing.assert_allclose(ph["particle_number"], po["particle_number"], rtol=1e-12)
+    assert len(hip.get_attr("rw2")) == 0
+
+
+def test_n_sd_max_is_enforced():
+    oi = h.box_opts(2, 2, 2, 16)
+    oi.n_sd_max = 16 * 8 - 1
+    th, rv, rhod, C = h.box_fields(oi)
+    with pytest.raises(RuntimeError, match="n_sd_max"):
+        h.hip_particles(oi).init(th, rv, rhod, **C)
