@@ -708,13 +708,23 @@ struct Particles : IParticles {
     }
     {
       Range r(this, "cond_cellfinish");
-      if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)        // crowded cells, fast arithmetic: one wave per cell
-        hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                           rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
-      else
-        hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                           rv.p, th.p, Tk.p, rw_mom3.p, step, sstp_cond, n_dims);
+      launch_cellfinish(step, sstp_cond);
     }
+  }
+  // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
+  // reference's summation order); fast: eight lanes per cell, or a whole wave per cell where cells are crowded
+  void launch_cellfinish(int step, int sstp)
+  {
+    if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)
+      hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
+    else if (!o.strict_fp) {
+      const int cfc = std::min(cf_cells(), BS / 8);
+      hipLaunchKernelGGL((k_cond_cellfinish<T, 8>), dim3(nblk(ncell, cfc)), dim3(BS), 0, st, ncell, cfc, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
+    } else
+      hipLaunchKernelGGL((k_cond_cellfinish<T, 1>), dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
   }
   // hskpng_rc2.ipp:14-32
   void hskpng_approximate_rc2_invalid()
@@ -752,8 +762,7 @@ struct Particles : IParticles {
       }
       // save_liq_ice_content_before_change + calc_liq_ice_content_change + update_th_rv: ordered per-cell sums of n rw^3
       Range r(this, "cond_cellfinish");
-      hipLaunchKernelGGL(k_cond_cellfinish<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p,
-                         dv.p, rhod.p, rv.p, th.p, Tk.p, rw_mom3.p, 0, 1, n_dims);
+      launch_cellfinish(0, 1);
       return;
     }
     Range r(this, "cond_perparticle_mix");

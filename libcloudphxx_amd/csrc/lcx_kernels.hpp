@@ -577,12 +577,13 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // straight from global memory touches 64 different cache lines per load instruction and ran 10x slower.)
 constexpr int CF_CELLS = 64;            // cells per workgroup at most; the host lowers it (cf_cells) when cells hold many SDs
 constexpr int CF_CAP = 2048;            // reals staged per workgroup (16 KiB of fp64 = 10 workgroups per CU; measured 6144: 1.05 ms, 2048: 0.64, 1024: 0.80)
-template <class T>
+template <class T, int G = 1>
 __device__ __forceinline__ T seg_sum(const T *lds, const T *glob, bool staged, uint32_t base, uint32_t s, uint32_t e)
 {
-  T acc;
-  if (staged) { acc = lds[s - base]; for (uint32_t q = s + 1; q < e; ++q) acc = acc + lds[q - base]; }
-  else        { acc = glob[s];       for (uint32_t q = s + 1; q < e; ++q) acc = acc + glob[q]; }
+  T acc = 0;
+  if (s >= e) return acc;                  // (G > 1: a lane beyond the end of a short segment)
+  if (staged) { acc = lds[s - base]; for (uint32_t q = s + G; q < e; q += G) acc = acc + lds[q - base]; }
+  else        { acc = glob[s];       for (uint32_t q = s + G; q < e; q += G) acc = acc + glob[q]; }
   return acc;
 }
 // moment bookkeeping across substeps + update_th_rv for one cell, given its sums of n rw^3 before / after the substep
@@ -609,7 +610,9 @@ __device__ __forceinline__ void cellfinish_apply(size_t c, bool has, T after, T 
   rv[c] = rv[c] - drw;
   th[c] = th[c] - drw * d_th_d_rv(Tk[c], th[c]);
 }
-template <class T>
+// G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
+// sums each 8th value of the staged segment and a fixed 3-step shuffle tree joins them (deterministic, different rounding)
+template <class T, int G>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
                   const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims)
@@ -621,9 +624,10 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
   const int nc = int(c1 - c0);
   if (int(threadIdx.x) <= nc) cs[threadIdx.x] = cell_start[c0 + threadIdx.x];
   __syncthreads();
-  const size_t c = c0 + threadIdx.x;
-  const bool mine = int(threadIdx.x) < nc;
-  const uint32_t s = mine ? cs[threadIdx.x] : 0u, e = mine ? cs[threadIdx.x + 1] : 0u;
+  const int cl = int(threadIdx.x) / G, sub = int(threadIdx.x) % G;
+  const size_t c = c0 + cl;
+  const bool mine = cl < nc;
+  const uint32_t s = mine ? cs[cl] : 0u, e = mine ? cs[cl + 1] : 0u;
   const bool has = e > s;
   T after = 0, before = 0;
   // the workgroup's cells are taken in runs that fit the LDS stage (normally one run; crowded neighbourhoods split instead of
@@ -633,20 +637,24 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     while (ce < nc && cs[ce + 1] - cs[cb] <= uint32_t(CF_CAP)) ++ce;
     const uint32_t base = cs[cb], end = cs[ce];
     const bool staged = (end - base) <= uint32_t(CF_CAP);
-    const bool in_run = mine && has && int(threadIdx.x) >= cb && int(threadIdx.x) < ce;
+    const bool in_run = mine && has && cl >= cb && cl < ce;
     if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
     __syncthreads();
-    if (in_run) after = seg_sum(lds, m3_after, staged, base, s, e);
+    if (in_run) after = seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
     if (step == 0) {
       __syncthreads();
       if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
       __syncthreads();
-      if (in_run) before = seg_sum(lds, m3_before, staged, base, s, e);
+      if (in_run) before = seg_sum<T, G>(lds, m3_before, staged, base, s + sub, e);
     }
     __syncthreads();
     cb = ce;
   }
-  if (!mine) return;
+  if (G > 1) {
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) { after = after + __shfl_xor(after, d); before = before + __shfl_xor(before, d); }
+  }
+  if (!mine || sub != 0) return;
   cellfinish_apply(c, has, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);
 }
 // Fast arithmetic, crowded cells (hundreds of SDs per cell): ONE WAVE per cell sums the segment with coalesced loads and a
