@@ -248,6 +248,13 @@ def main():
                     if t:
                         roof["traffic"] = t["hbm_bytes"]
                         roof["traffic_source"] = "profiles/" + os.path.basename(tf)
+                        if "valu_insts" in t:
+                            # what actually bounds this kernel: vector issue.  A wave64 VALU instruction occupies its SIMD for 4
+                            # cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
+                            slots = 1024 * 2.4e9 * avg_ms * 1e-3 / 4
+                            roof["valu"] = {"wave_insts_per_launch": t["valu_insts"], "issue_frac": t["valu_insts"] / slots,
+                                            "f64_arith_frac_of_insts": t.get("valu_f64_insts", 0) / t["valu_insts"],
+                                            "source": "profiles/" + os.path.basename(tf)}
         # attainable HBM bandwidth on this device (device-to-device copy of 1 GiB, read + write), SURVEY 8(d)
         a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev); b_ = torch.empty_like(a_)
         b_.copy_(a_); torch.cuda.synchronize()

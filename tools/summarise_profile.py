@@ -46,6 +46,10 @@ for k, v in sorted(agg.items()):
         rd = sum(v["FETCH_SIZE"][-2:]) / len(v["FETCH_SIZE"][-2:]) * 1024 * 2
         wr = sum(v["WRITE_SIZE"][-2:]) / len(v["WRITE_SIZE"][-2:]) * 1024
         traffic[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr}
+        if "SQ_INSTS_VALU" in v:      # wave-level vector instructions per launch (fp64 vector utilisation of the cond kernel)
+            traffic[k]["valu_insts"] = sum(v["SQ_INSTS_VALU"][-2:]) / len(v["SQ_INSTS_VALU"][-2:])
+            traffic[k]["valu_f64_insts"] = sum(sum(v[c][-2:]) / len(v[c][-2:]) for c in
+                                               ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64") if c in v)
 print()
 print("== HBM traffic per launch (FETCH_SIZE*2 KiB + WRITE_SIZE KiB)")
 for k, t in traffic.items():
