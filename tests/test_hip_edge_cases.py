@@ -102,3 +102,33 @@ def test_n_sd_max_is_enforced():
     th, rv, rhod, C = h.box_fields(oi)
     with pytest.raises(RuntimeError, match="n_sd_max"):
         h.hip_particles(oi).init(th, rv, rhod, **C)
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("turb_all", dict(turb_adve_switch=True, turb_cond_switch=True, turb_coal_switch=True, kernel=lgrngn.kernel_t.onishi_hall,
+                      kernel_parameters=np.array([66.]), SGS_mix_len=np.linspace(20., 40., 5))),
+    ("incloud_adaptive", dict(diag_incloud_time=True, exact_sstp_cond=True, sstp_cond=4, sstp_cond_act=8, sstp_cond_mix=False,
+                              adaptive_sstp_cond=True)),
+    ("pp_mix", dict(exact_sstp_cond=True, sstp_cond=3)),
+    ("pred_corr", dict(adve_scheme=lgrngn.as_t.pred_corr))])
+def test_float_build_tracks_double_with_the_widened_options(name, kw):
+    """particles_t<float>: every option family of SURVEY 8(f) steps in single precision and stays close to the double run"""
+    res = {}
+    for real in (np.float32, np.float64):
+        oi = h.box_opts(4, 3, 5, 32, **kw)
+        th, rv, rhod, C = h.box_fields(oi)
+        f = [a.astype(real) for a in (th, rv, rhod)]
+        Cf = {k: v.astype(real) for k, v in C.items()}
+        pr = lgrngn.particles_t(oi, real)
+        pr.init(*f, **Cf)
+        opts = lgrngn.opts_t()
+        opts.turb_adve = opts.turb_cond = opts.turb_coal = name == "turb_all"
+        extra = dict(diss_rate=(1e-3 * np.ones(th.shape)).astype(real)) if name == "turb_all" else {}
+        for _ in range(4):
+            pr.step_sync(opts, f[0].copy(), f[1].copy(), f[2], **extra, **Cf)
+            pr.step_async(opts)
+        pr.diag_all(); pr.diag_wet_mom(3)
+        res[real] = (pr.n_part, float(pr.outbuf_array().sum()))
+        assert np.isfinite(res[real][1]) and res[real][1] > 0
+    assert abs(res[np.float32][0] - res[np.float64][0]) <= 8
+    assert abs(res[np.float32][1] / res[np.float64][1] - 1) < 2e-2
