@@ -1334,7 +1334,8 @@ struct Particles : IParticles {
     n_before_unpack = nphys;
     if (fused && !distmem()) post_copy_after_fused_move(opts);
     else if (!distmem()) post_copy(opts);
-    sync();
+    // no host synchronisation here: step_async hands no array back, everything later is ordered on the object's stream and
+    // every call that returns data to the host synchronises itself -- the caller's next step_sync is queued while this one runs
     selected_before_counting = false;
   }
 
@@ -1617,7 +1618,6 @@ struct Particles : IParticles {
       fused_pending = false;
       post_copy_after_fused_move(opts);
     } else post_copy(opts);
-    sync();
   }
 };
 
