@@ -218,7 +218,7 @@ struct Particles : IParticles {
     if (use_rc2) hipLaunchKernelGGL(k_fill<T>, dim3(nblk(cap)), dim3(BS), 0, st, A.ext[ix_rc2].p, cap, T(-1));   // detail::invalid, particles_impl.ipp:490
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
-    tile_sums.alloc(std::max(cap, ncell) / SCAN_TILE + 2); scan_total.alloc(4);
+    tile_sums.alloc(2 * (std::max(cap, ncell) / SCAN_TILE + 2)); scan_total.alloc(4);   // (two halves for the two migrant lists)
     big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); big_meta.alloc(2);
     m3_before.alloc(cap); m3_after.alloc(cap);
     if (oi.coal_switch) col.alloc(cap);
@@ -896,11 +896,10 @@ struct Particles : IParticles {
   {
     const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     size_t *cnt[2] = {&lft_count, &rgt_count};
-    for (int side = 0; side < 2; ++side) {
-      hipLaunchKernelGGL(k_mig_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p);
-      hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p + side);
-      hipLaunchKernelGGL(k_mig_ids, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint8_t(side + 1), tile_sums.p, mig_ids[side].p);
-    }
+    if (!tiles) { lft_count = rgt_count = 0; return; }
+    hipLaunchKernelGGL(k_mig_tiles2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p);
+    hipLaunchKernelGGL(k_scan_sums2, dim3(2), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
+    hipLaunchKernelGGL(k_mig_ids2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p, mig_ids[0].p, mig_ids[1].p);
     uint32_t tot[2];
     read_back(tot, scan_total.p, 2);                  // one host sync for both directions
     *cnt[0] = tot[0]; *cnt[1] = tot[1];

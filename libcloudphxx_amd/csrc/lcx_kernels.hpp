@@ -1685,6 +1685,61 @@ __global__ void __launch_bounds__(BS) k_mig_ids(const uint8_t *mig, size_t n_par
     run += tot;
   }
 }
+// both directions in one pass each (three launches per step instead of six): tile_sums holds the left-going counts of all tiles,
+// then the right-going ones (offset n_tiles); k_scan_sums2 scans the two halves with two workgroups
+__global__ void __launch_bounds__(BS) k_mig_tiles2(const uint8_t *mig, size_t n_part, uint32_t n_tiles, uint32_t *tile_sums)
+{
+  __shared__ uint32_t lds[2][BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t cl = 0, cr = 0;
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    const uint8_t m = i < n_part ? mig[i] : uint8_t(0);
+    cl += __popcll(__ballot(m == 1)); cr += __popcll(__ballot(m == 2));
+  }
+  if (lane_id() == 0) { lds[0][wave_id()] = cl; lds[1][wave_id()] = cr; }
+  __syncthreads();
+  if (threadIdx.x < 2) { uint32_t s = 0; for (int w = 0; w < BS / WAVE; ++w) s += lds[threadIdx.x][w]; tile_sums[threadIdx.x * n_tiles + blockIdx.x] = s; }
+}
+__global__ void k_scan_sums2(uint32_t *sums, size_t m, uint32_t *total)
+{
+  __shared__ uint32_t lds[SCAN_MAX_WAVES];
+  uint32_t *a = sums + size_t(blockIdx.x) * m;
+  uint32_t run = 0;
+  for (size_t base = 0; base < m; base += blockDim.x) {
+    const size_t i = base + threadIdx.x;
+    const uint32_t v = i < m ? a[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_exclusive_scan(v, tot, lds);
+    if (i < m) a[i] = run + ex;
+    run += tot;
+  }
+  if (threadIdx.x == 0) total[blockIdx.x] = run;
+}
+__global__ void __launch_bounds__(BS) k_mig_ids2(const uint8_t *mig, size_t n_part, uint32_t n_tiles, const uint32_t *tile_offs, uint32_t *ids_l, uint32_t *ids_r)
+{
+  __shared__ uint32_t lds[2][BS / WAVE];
+  const size_t base = size_t(blockIdx.x) * SCAN_TILE;
+  uint32_t run_l = tile_offs[blockIdx.x], run_r = tile_offs[n_tiles + blockIdx.x];
+  for (int it = 0; it < SCAN_TILE / BS; ++it) {
+    const size_t i = base + size_t(it) * BS + threadIdx.x;
+    const uint8_t m = i < n_part ? mig[i] : uint8_t(0);
+    const unsigned long long bl = __ballot(m == 1), br = __ballot(m == 2);
+    const unsigned long long below = (1ull << lane_id()) - 1ull;
+    if (lane_id() == 0) { lds[0][wave_id()] = __popcll(bl); lds[1][wave_id()] = __popcll(br); }
+    __syncthreads();
+    uint32_t woff_l = 0, tot_l = 0, woff_r = 0, tot_r = 0;
+    for (unsigned w = 0; w < BS / WAVE; ++w) {
+      const uint32_t sl = lds[0][w], sr = lds[1][w];
+      if (w < wave_id()) { woff_l += sl; woff_r += sr; }
+      tot_l += sl; tot_r += sr;
+    }
+    __syncthreads();
+    if (m == 1) ids_l[size_t(run_l) + woff_l + __popcll(bl & below)] = uint32_t(i);
+    if (m == 2) ids_r[size_t(run_r) + woff_r + __popcll(br & below)] = uint32_t(i);
+    run_l += tot_l; run_r += tot_r;
+  }
+}
 // attribute-major record: n[count] | rd3,rw2,kpa,vt,x,(y),(z)[count] ; x re-based to the receiver's frame
 template <class T>
 __global__ void k_pack(size_t count, const uint32_t *ids, attr_set<T> s, grid_t g, T x_rmt, T x_lcl, n_t *nb, T *rb)
