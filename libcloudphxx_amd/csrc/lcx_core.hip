@@ -873,6 +873,7 @@ struct Particles : IParticles {
     const unsigned blocks = nblk(nphys);
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
     a.mig = mig.p;
+    if (do_bcnd && distmem()) HIPCHK(hipMemsetAsync(mig.p, 0, nphys, st));
     a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead.p;
     if (reindex) {
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));

@@ -1230,7 +1230,6 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   const size_t i = gid();
   double pl = 0, pd = 0, pn = 0, pp = 0;
   uint32_t c = i < a.n_part ? a.ijk[i] : DEAD_CELL;
-  if (c == DEAD_CELL && i < a.n_part && a.mig) a.mig[i] = 0;
   bool dead_now = false;         // counted in dead_count: was dead already, or dies in this pass
   uint32_t c_new = DEAD_CELL;
   if (a.reindex && i < a.n_part) {
@@ -1321,7 +1320,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
         uint8_t m = 0;
         if (x < a.x0) { m = 1; if (a.bcond_lft == 3) kill = true; }
         if (x >= a.x1) { m = 2; if (a.bcond_rgt == 3) kill = true; }
-        a.mig[i] = m;
+        if (m) a.mig[i] = m;                // (the flags are cleared before the launch: only the ~1 % that leave store a byte)
         emigrant = m != 0;
       }
       if (g.ndims == 3) {
