@@ -627,8 +627,10 @@ struct Particles : IParticles {
   {
     unsigned int dead = 0;
     read_back(&dead, d_dead.p, 1);
+    dead -= unsigned(std::min<size_t>(reused_total, dead));       // emigrants' slots that immigrants have taken over are alive again
+    reused_total = 0;
     // reference storage order (stable compaction only) when asked for, and in every parity run (a replayed stream is indexed by id)
-    const bool strict_order = o.reorder_every < 0 || eager_compact || replay_used;
+    const bool strict_order = this->strict_order();
     const bool compact_now = dead && (eager_compact || size_t(dead) * 32 > nphys);
     if (compact_now && strict_order) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
@@ -1560,8 +1562,14 @@ struct Particles : IParticles {
     sync();
   }
   // emigrants leave (n = 0) once they are packed: the protocol is pack (both sides) -> unpack -> finish
+  // emigrants leave (n = 0) once they are packed; their slots are offered to the immigrants of the same step (free_n / free_used)
+  size_t free_n[2] = {0, 0}, free_used = 0, reused_total = 0;
+  bool strict_order() const { return o.reorder_every < 0 || eager_compact || replay_used; }
   void flag_emigrants()
   {
+    if (lft_count || rgt_count) {
+      free_n[0] = strict_order() ? 0 : lft_count; free_n[1] = strict_order() ? 0 : rgt_count; free_used = 0;
+    }
     if (lft_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(lft_count)), dim3(BS), 0, st, lft_count, mig_ids[0].p, A.n.p);
     if (rgt_count) hipLaunchKernelGGL(k_flag_ids, dim3(nblk(rgt_count)), dim3(BS), 0, st, rgt_count, mig_ids[1].p, A.n.p);
     lft_count = rgt_count = 0;
@@ -1570,15 +1578,21 @@ struct Particles : IParticles {
   {
     if (!cnt) return;
     flag_emigrants();
-    if (nphys + cnt > cap) {                           // make room: compaction re-indexes everything, the fused histogram is void
+    const size_t n_free = free_n[0] + free_n[1];
+    size_t reuse = n_free > free_used ? std::min(cnt, n_free - free_used) : 0;
+    if (nphys + (cnt - reuse) > cap) {                  // make room: compaction re-indexes everything, the fused histogram is void
       ensure_compact_forced();
       fused_pending = false;
+      free_n[0] = free_n[1] = 0; free_used = 0; reuse = 0;
     }
-    check_npart(nphys + cnt);
+    check_npart(nphys + (cnt - reuse));
     Range r(this, "migrate_unpack");
     const n_t *nb = (const n_t *)buf; const T *rb = (const T *)((const n_t *)buf + cnt);
-    hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, nphys, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4));
-    nphys += cnt;
+    hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, nphys, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4),
+                       mig_ids[0].p, uint32_t(free_n[0]), mig_ids[1].p, uint32_t(free_n[1]), uint32_t(free_used),
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p);
+    free_used += reuse; reused_total += reuse;
+    nphys += cnt - reuse;
     sync();
   }
   // Courant halo of pred_corr on a decomposed domain (xchng_courants.ipp:15-160): element ranges inside the halo-extended
@@ -1610,14 +1624,12 @@ struct Particles : IParticles {
   void migrate_finish(const lcx_opts_t &opts) override
   {
     flag_emigrants();
+    free_n[0] = free_n[1] = 0; free_used = 0;
     if (fused_pending) {
-      // k_move left the histogram of the SDs that stayed; add the immigrants appended since, then scan/scatter/rank
-      if (nphys > n_before_unpack)
-        hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys - n_before_unpack)), dim3(BS), 0, st, n_before_unpack, nphys, g, A.n.p, A.x.p, A.y.p, A.z.p,
-                           ijk.p, cell_cnt.p, rank.p, 1);
+      // k_move left the histogram of the SDs that stayed and k_unpack added the immigrants': scan / scatter / rank remain
       fused_pending = false;
       post_copy_after_fused_move(opts);
-    } else post_copy(opts);
+    } else { reused_total = 0; post_copy(opts); }
   }
 };
 

@@ -1753,18 +1753,41 @@ __global__ void k_pack(size_t count, const uint32_t *ids, attr_set<T> s, grid_t 
   if (g.nz) rb[slab++ * count + i] = s.z[id];
   for (int e = 0; e < s.n_ext; ++e) rb[slab++ * count + i] = s.ext[e][id];
 }
+// free_l / free_r: storage slots the emigrants of this step have just vacated (their ids, already packed and flagged n = 0);
+// slots [free_used, n_free_l + n_free_r) are still unclaimed.  An immigrant takes the next free slot, or is appended behind
+// n_old when they are used up -- so a slab whose inflow balances its outflow keeps its storage extent and is not compacted every
+// few steps.  (Only where the storage order is free to differ from the reference's, see opts_init.reorder_every; else n_free = 0.)
+// cnt != nullptr: the step's re-indexing is fused into the passes over the positions (k_move for the SDs that stayed): cell index,
+// histogram and arrival rank of the immigrant are produced here as well.
 template <class T>
-__global__ void k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, const T *rb, T x0, T x1, T tol)
+__global__ void __launch_bounds__(BS)
+k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, const T *rb, T x0, T x1, T tol,
+         const uint32_t *free_l, uint32_t n_free_l, const uint32_t *free_r, uint32_t n_free_r, uint32_t free_used,
+         uint32_t *ijk, uint32_t *cnt, uint32_t *rank)
 {
-  const size_t i = gid(); if (i >= count) return;
-  const size_t d = n_old + i;
-  s.n[d] = nb[i];
-  size_t slab = 0;
-  s.rd3[d] = rb[slab++ * count + i]; s.rw2[d] = rb[slab++ * count + i]; s.kpa[d] = rb[slab++ * count + i]; s.vt[d] = rb[slab++ * count + i];
-  if (g.nx) { const T x = rb[slab++ * count + i]; s.x[d] = x >= x1 ? x - tol : x < x0 ? x + tol : x; }   // tolerance_away_from_bcond
-  if (g.ny) s.y[d] = rb[slab++ * count + i];
-  if (g.nz) s.z[d] = rb[slab++ * count + i];
-  for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = rb[slab++ * count + i];
+  const size_t i = gid();
+  const bool in = i < count;
+  uint32_t c = DEAD_CELL;
+  size_t d = 0;
+  if (in) {
+    const size_t j = size_t(free_used) + i, n_free = size_t(n_free_l) + n_free_r;
+    d = j < n_free_l ? size_t(free_l[j]) : j < n_free ? size_t(free_r[j - n_free_l]) : n_old + (j - (n_free > free_used ? n_free : size_t(free_used)));
+    const n_t nn = nb[i];
+    s.n[d] = nn;
+    size_t slab = 0;
+    s.rd3[d] = rb[slab++ * count + i]; s.rw2[d] = rb[slab++ * count + i]; s.kpa[d] = rb[slab++ * count + i]; s.vt[d] = rb[slab++ * count + i];
+    T x = 0, y = 0, z = 0;
+    if (g.nx) { x = rb[slab++ * count + i]; x = x >= x1 ? x - tol : x < x0 ? x + tol : x; s.x[d] = x; }   // tolerance_away_from_bcond
+    if (g.ny) { y = rb[slab++ * count + i]; s.y[d] = y; }
+    if (g.nz) { z = rb[slab++ * count + i]; s.z[d] = z; }
+    for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = rb[slab++ * count + i];
+    if (cnt) { c = nn == 0 ? DEAD_CELL : cell_of(g, x, y, z); ijk[d] = c; }
+  }
+  if (cnt) {                                           // every lane of the wave takes part (ballots inside)
+    const bool active = in && c != DEAD_CELL;
+    const uint32_t r = wave_hist_rank(cnt, c, active);
+    if (active) rank[d] = r;
+  }
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 
