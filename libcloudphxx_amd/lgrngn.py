@@ -76,6 +76,17 @@ class RH_formula_t(_bp_enum):       # lgrngn/RH_formula.hpp:8
     rv_tet = 3
 
 
+class chem_species_t(_bp_enum):        # common/chem.hpp via bindings/python/lib.cpp:257-265 (the chemistry itself is outside this library)
+    H = 0
+    SO2 = 1
+    O3 = 2
+    H2O2 = 3
+    CO2 = 4
+    NH3 = 5
+    HNO3 = 6
+    S_VI = 7
+
+
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8
     off = 0
     simple = 1
@@ -212,6 +223,12 @@ class opts_init_t:
         self.th_dry = True
         self.const_p = False
         self.diag_incloud_time = False
+        # fields of the parts that are outside this library (chemistry, aerosol sources / relaxation): kept so that scripts written
+        # for the reference can set and print them; the matching switches make the constructor throw
+        self.chem_rho = 0.
+        self.src_x0 = self.src_y0 = self.src_z0 = self.src_x1 = self.src_y1 = self.src_z1 = 0.
+        self.rlx_dry_distros = {}
+        self.rlx_bins, self.rlx_timescale, self.rlx_sd_per_bin, self.supstp_rlx = 0, 1., 0., 1
         # extensions (include/lcx.h)
         self.n_x_tot = 0
         self.n_x_bfr = 0
@@ -276,6 +293,9 @@ class opts_t:
         self.RH_max = 44.
         self.dt = -1.
         self.chem = False    # accepted for source compatibility with the reference's tests (no-op)
+        self.chem_gas = {}   # ambient trace gases, aerosol sources: holders only (chemistry / sources are outside this library)
+        self.src_dry_distros = {}
+        self.src_dry_sizes = {}
 
     def _to_c(self):
         c = _opts_c()

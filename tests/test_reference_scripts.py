@@ -42,3 +42,16 @@ def test_reference_cond_substepping_scripts_pass_on_the_oracle(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(HERE, "_ref_script_runner.py"), os.path.join(REF, script)], env=env,
                            capture_output=True, text=True, timeout=1800)
         assert r.returncode == 0, (script, r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_reference_api_script_runs_up_to_its_ice_section(tmp_path):
+    """unit/api_lgrngn.py cannot finish (it has ice-microphysics sections, outside this library), but everything before its
+    first one does: option printing, call-order checks, 0-D init modes (sd_conc, large tail, const_multi, dry_sizes and their
+    combinations), turbulent coalescence with diss_rate -- the script stops at '0D ice' with the constructor's out-of-scope error"""
+    env = dict(os.environ, LCX_REF_RUN_DIR=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_ref_script_runner.py"), os.path.join(REF, "unit/api_lgrngn.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    sections = [l for l in r.stdout.splitlines() if l[:2] in ("0D", "1D", "2D", "3D")]
+    assert sections[-1] == "0D ice" and "0D turb" in sections and "0D dry_sizes + const_multi" in sections, sections
+    assert "option outside the accelerated hot path" in r.stderr
