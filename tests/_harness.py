@@ -263,10 +263,13 @@ class LocalRing:
         for p in self.prts:
             p.step_async(opts)
         packs = []
+        open_walls = bool(self.oi.open_side_walls)           # no neighbour beyond the ends: what leaves there is gone (bcnd.ipp:160-205)
         for r, p in enumerate(self.prts):
             nl, nr = p.migrate_counts()
             rec = p.migrate_record_bytes()
             lft, rgt = (r - 1) % n, (r + 1) % n
+            if open_walls and r == 0: nl = 0
+            if open_walls and r == n - 1: nr = 0
             lft_x1 = self.prts[lft].opts_init.x1
             rgt_x0 = self.prts[rgt].opts_init.x0
             kl, pl = self.alloc(max(nl * rec, 8))
@@ -278,6 +281,8 @@ class LocalRing:
             lft, rgt = (r - 1) % n, (r + 1) % n
             n_from_l, p_from_l = packs[lft][3], packs[lft][4]      # left neighbour's right-going
             n_from_r, p_from_r = packs[rgt][0], packs[rgt][1]      # right neighbour's left-going
+            if open_walls and r == 0: n_from_l = 0
+            if open_walls and r == n - 1: n_from_r = 0
             if n_from_l: p.migrate_unpack(p_from_l, n_from_l)
             if n_from_r: p.migrate_unpack(p_from_r, n_from_r)
         for p in self.prts:

@@ -132,3 +132,22 @@ def test_float_build_tracks_double_with_the_widened_options(name, kw):
         assert np.isfinite(res[real][1]) and res[real][1] > 0
     assert abs(res[np.float32][0] - res[np.float64][0]) <= 8
     assert abs(res[np.float32][1] / res[np.float64][1] - 1) < 2e-2
+
+
+@pytest.mark.parametrize("walls", [dict(open_side_walls=True), dict(periodic_topbot_walls=True),
+                                   dict(open_side_walls=True, periodic_topbot_walls=True)])
+@pytest.mark.parametrize("dims", [(5, 0, 6), (4, 3, 5)])
+def test_wall_options_match_oracle(dims, walls):
+    """open side walls remove what leaves through x / y faces, periodic top and bottom wrap z instead of raining out
+    (bcnd.ipp:114-368); multiplicities, cell indices and positions against the oracle"""
+    oi = h.box_opts(*dims, 32, dx=15., coal_switch=False, **walls)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    orc, hip = run_pair(oi, 5, opts)
+    for nm in ("n", "ijk", "sorted_id"):
+        exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+    for a in ("x", "y", "z"):
+        if getattr(oi, "n" + a):
+            np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14, atol=1e-9)
+    po, ph = orc.diag_puddle(), hip.diag_puddle()
+    np.testing.assert_allclose(ph["particle_number"], po["particle_number"], rtol=1e-12)

@@ -180,3 +180,27 @@ def test_immigrants_reuse_the_slots_of_emigrants(dims, size):
         for p in ring_prts:
             p.diag_all(); p.diag_sd_conc(); out.append(p.outbuf_array().copy())
         return np.concatenate(out)
+
+
+@pytest.mark.parametrize("dims,size", [((8, 0, 5), 2), ((9, 3, 4), 3)])
+def test_open_side_walls_on_a_decomposed_domain(dims, size):
+    """opts_init.open_side_walls with slabs: the end ranks have no neighbour beyond the wall, what crosses it is removed
+    (bcond open, bcnd.ipp:160-205); interior faces exchange as usual.  Slab by slab against the oracle running the same protocol."""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False, open_side_walls=True)
+    oi.n_sd_max = 24 * max(nx, 1) * max(ny, 1) * nz * 3
+    fields = h.box_fields(oi)
+    orc, hip = ring_pair(oi, size, fields)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    n0 = sum(p.n_part for p in orc.prts)
+    for it in range(5):
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        hip.step(opts, th.copy(), rv.copy(), rhod, **C)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            np.testing.assert_allclose(ph.get_attr("x"), po.get_attr("x"), rtol=1e-14, atol=1e-9)
+    assert sum(p.n_part for p in hip.prts) < n0            # the walls did swallow super-droplets
