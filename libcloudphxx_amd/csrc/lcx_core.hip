@@ -117,6 +117,10 @@ struct Particles : IParticles {
   struct Attrs { DevBuf<n_t> n; DevBuf<T> rd3, rw2, kpa, vt, x, y, z, ext[MAX_EXT]; } A, B;
   // per-particle condensation substepping (exact_sstp_cond): the private rv, th, rhod(, p) of a super-droplet and rc2 are
   // further attributes (ext[]) that are compacted and migrate with it
+  // the initial sampling may have its own seed (opts_init.rng_seed_init_switch; particles_ctor.ipp / particles_init.ipp: the
+  // generator is re-seeded with rng_seed at the end of init)
+  bool in_init = false;
+  long long seed_now() const { return in_init && o.rng_seed_init_switch ? o.rng_seed_init : o.rng_seed; }
   bool replay_used = false;   // a parity run: storage stays in the reference's id order (see opts_init.reorder_every)
   bool no_cond_pre = getenv("LCX_NO_COND_PRE") != nullptr;   // test switch: evaluate the per-cell set-up per droplet instead
   uint64_t cells_version = 0, nobig_version = ~0ull;   // order_cells: "no cell above CELLRANK_MAX" is remembered per cell_start
@@ -374,7 +378,7 @@ struct Particles : IParticles {
       replay_keep_T.push_back(std::move(r.u01));
       return u01_src<T>{ptr, 0, 0};
     }
-    return u01_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+    return u01_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
   }
   rng_src rand_un(size_t n)
   {
@@ -385,7 +389,7 @@ struct Particles : IParticles {
       replay_keep_u.push_back(std::move(r.un));
       return rng_src{ptr, 0, 0};
     }
-    return rng_src{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+    return rng_src{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
   }
   void release_replay_keep() { if (replay_keep_T.empty() && replay_keep_u.empty()) return; sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
   void rng_replay_push(int kind, const double *data, size_t n) override
@@ -792,7 +796,7 @@ struct Particles : IParticles {
       replay_keep_T.push_back(std::move(r.u01));
       return normal_src<T>{ptr, 0, 0};
     }
-    return normal_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(o.rng_seed))};
+    return normal_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
   }
   // hskpng_tke + hskpng_turb_vel (+ hskpng_turb_dot_ss): particles_step.ipp:406-427
   void sgs_turbulence(const lcx_opts_t &opts)
@@ -1210,6 +1214,8 @@ struct Particles : IParticles {
             const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) override
   {
     sanity_init(th_, rv_, rhod_, p_, cx, cy, cz);
+    in_init = true;
+    struct Leave { bool &f; ~Leave() { f = false; } } leave{in_init};
     const int nxh = o.nx + 2 * halo;
     switch (n_dims) {                                                                    // init_sync.ipp:28-44, particles_impl.ipp:413-431
       case 3: n_cx = size_t(nxh + 1) * o.ny * o.nz; n_cy = size_t(nxh) * (o.ny + 1) * o.nz; n_cz = size_t(nxh) * o.ny * (o.nz + 1); break;

@@ -151,3 +151,66 @@ def test_wall_options_match_oracle(dims, walls):
             np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14, atol=1e-9)
     po, ph = orc.diag_puddle(), hip.diag_puddle()
     np.testing.assert_allclose(ph["particle_number"], po["particle_number"], rtol=1e-12)
+
+
+def test_subsidence_matches_oracle():
+    """opts.subs with a large-scale vertical velocity profile w_LS (subs.ipp:13-25; unit/lgrngn_subsidence.py runs on the oracle)"""
+    oi = h.box_opts(4, 3, 6, 24, dx=25., coal_switch=False, subs_switch=True, w_LS=np.linspace(0.5, 3., 6))
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    opts.subs = True
+    orc, hip = run_pair(oi, 4, opts)
+    for nm in ("n", "ijk", "sorted_id"):
+        exact(hip.state_u64(nm), orc.state_u64(nm), nm)
+    np.testing.assert_allclose(hip.get_attr("z"), orc.get_attr("z"), rtol=1e-14, atol=1e-9)
+
+
+@pytest.mark.parametrize("kw", [dict(aerosol_independent_of_rhod=True), dict(rd_min=5e-9, rd_max=2e-7),
+                                dict(aerosol_independent_of_rhod=True, aerosol_conc_factor=np.linspace(1.5, 0.5, 5))])
+def test_init_options_match_oracle(kw):
+    """initialisation variants: multiplicities independent of the air density, a vertical profile of the aerosol concentration,
+    manual bin edges, a separate seed for the initial sampling (init_n.ipp, init_count_num.ipp, particles_init.ipp)"""
+    oi = h.box_opts(3, 2, 5, 32, **kw)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields, force_state=False)
+    assert hip.n_part == orc.n_part
+    exact(hip.state_u64("n"), orc.state_u64("n"), "multiplicities")
+    np.testing.assert_allclose(hip.get_attr("rd3"), orc.get_attr("rd3"), rtol=1e-13)
+    np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-6)
+    for a in ("x", "y", "z"):
+        np.testing.assert_allclose(hip.get_attr(a), orc.get_attr(a), rtol=1e-14)
+
+
+def test_init_option_checks_and_the_separate_init_seed():
+    oi = h.box_opts(3, 2, 5, 16, aerosol_conc_factor=np.linspace(0.5, 1.5, 5))
+    th, rv, rhod, C = h.box_fields(oi)
+    with pytest.raises(RuntimeError, match="aerosol_independent_of_rhod"):          # init_sanity_check.ipp:123-127
+        h.hip_particles(oi).init(th, rv, rhod, **C)
+    # rng_seed_init_switch: the initial sampling has its own seed, the run's stream is seeded by rng_seed afterwards
+    def initial(seed, seed_init):
+        o = h.box_opts(3, 2, 5, 16, rng_seed=seed, rng_seed_init=seed_init, rng_seed_init_switch=True)
+        pr = h.hip_particles(o)
+        pr.init(th.copy(), rv.copy(), rhod.copy(), **C)
+        return pr.get_attr("rd3"), pr.get_attr("x")
+    a, b, c = initial(1, 7), initial(2, 7), initial(1, 8)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert not np.array_equal(a[0], c[0])
+
+
+def test_consecutive_range_selections_match_oracle():
+    """diag_*_rng_cons narrow a previous selection (particles_diag.ipp:300-345)"""
+    oi = h.box_opts(3, 2, 4, 48)
+    orc, hip = h.make_pair(oi, h.box_fields(oi))
+    for pr in (orc, hip):
+        pr.diag_dry_rng(0., 1.)
+        pr.diag_wet_rng_cons(1e-8, 2e-6)
+        pr.diag_kappa_rng_cons(.5, 1.)
+        pr.diag_dry_rng_cons(2e-8, 1e-7)
+        pr.diag_wet_mom(0)
+    exact(hip.outbuf_array(), orc.outbuf_array(), "concentration of the narrowed selection")
+    assert orc.outbuf_array().sum() > 0
+    with pytest.raises(RuntimeError):
+        fresh = h.hip_particles(oi)
+        th, rv, rhod, C = h.box_fields(oi)
+        fresh.init(th, rv, rhod, **C)
+        fresh.diag_dry_rng_cons(0., 1.)               # consecutive selection without a selection
