@@ -173,6 +173,10 @@ int lcx_diag_kappa_rng_cons(lcx_particles *, double k_mi, double k_mx);
 int lcx_diag_dry_mom(lcx_particles *, int k);
 int lcx_diag_wet_mom(lcx_particles *, int k);
 int lcx_diag_kappa_mom(lcx_particles *, int k);
+int lcx_diag_water_cons(lcx_particles *);                 /* particles_diag.ipp:346-349: rw2 > 0 among the selected */
+int lcx_diag_up_mom(lcx_particles *, int k);              /* :463-480: moments of the SGS velocity perturbations (turb_adve / turb_cond) */
+int lcx_diag_vp_mom(lcx_particles *, int k);
+int lcx_diag_wp_mom(lcx_particles *, int k);
 int lcx_diag_incloud_time_mom(lcx_particles *, int k);   /* particles_diag.ipp:482-490; needs opts_init.diag_incloud_time */
 /* selections by activation state (particles_diag.ipp:350-407): RH >= critical supersaturation / r_w >= critical radius */
 int lcx_diag_RH_ge_Sc(lcx_particles *);

@@ -50,6 +50,22 @@ namespace libcloudphxx { namespace lgrngn {
     virtual void diag_vel_div() { assert(false); }
     virtual void diag_kappa_mom(const int &) { assert(false); }
     virtual void diag_incloud_time_mom(const int &) { assert(false); }
+    virtual void diag_up_mom(const int &) { assert(false); }
+    virtual void diag_vp_mom(const int &) { assert(false); }
+    virtual void diag_wp_mom(const int &) { assert(false); }
+    virtual void diag_water_cons() { assert(false); }
+    // diagnostics of the parts outside this library (chemistry, ice): declared for source compatibility, never served
+    virtual void diag_chem(const int &) { assert(false); }
+    virtual void diag_ice() { assert(false); }
+    virtual void diag_ice_cons() { assert(false); }
+    virtual void diag_ice_a_rng(const real_t &, const real_t &) { assert(false); }
+    virtual void diag_ice_c_rng(const real_t &, const real_t &) { assert(false); }
+    virtual void diag_ice_a_rng_cons(const real_t &, const real_t &) { assert(false); }
+    virtual void diag_ice_c_rng_cons(const real_t &, const real_t &) { assert(false); }
+    virtual void diag_ice_a_mom(const int &) { assert(false); }
+    virtual void diag_ice_c_mom(const int &) { assert(false); }
+    virtual void diag_ice_mix_ratio() { assert(false); }
+    virtual void diag_precip_rate_ice_mass() { assert(false); }
     virtual void diag_max_rw() { assert(false); }
     virtual void diag_precip_rate() { assert(false); }
     virtual void diag_RH_ge_Sc() { assert(false); }
@@ -192,6 +208,10 @@ namespace libcloudphxx { namespace lgrngn {
     void diag_vel_div() override { detail::lcx_check(lcx_diag_vel_div(pimpl->h)); }
     void diag_kappa_mom(const int &k) override { detail::lcx_check(lcx_diag_kappa_mom(pimpl->h, k)); }
     void diag_incloud_time_mom(const int &k) override { detail::lcx_check(lcx_diag_incloud_time_mom(pimpl->h, k)); }
+    void diag_up_mom(const int &k) override { detail::lcx_check(lcx_diag_up_mom(pimpl->h, k)); }
+    void diag_vp_mom(const int &k) override { detail::lcx_check(lcx_diag_vp_mom(pimpl->h, k)); }
+    void diag_wp_mom(const int &k) override { detail::lcx_check(lcx_diag_wp_mom(pimpl->h, k)); }
+    void diag_water_cons() override { detail::lcx_check(lcx_diag_water_cons(pimpl->h)); }
     void diag_max_rw() override { detail::lcx_check(lcx_diag_max_rw(pimpl->h)); }
     void diag_precip_rate() override { detail::lcx_check(lcx_diag_precip_rate(pimpl->h)); }
     void diag_RH_ge_Sc() override { detail::lcx_check(lcx_diag_RH_ge_Sc(pimpl->h)); }

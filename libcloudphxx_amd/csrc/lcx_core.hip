@@ -1370,6 +1370,11 @@ struct Particles : IParticles {
       if (ix_ict < 0) throw lcx_error("libcloudph++: diag_incloud_time_mom called, but opts_init.diag_incloud_time==false");
       return A.ext[ix_ict].p;
     }
+    if (attr >= 5 && attr <= 7) {                                   // up, vp, wp
+      const int ix = attr == 5 ? ix_up : attr == 6 ? ix_vp : ix_wp;
+      if (ix < 0) throw lcx_error("libcloudph++: moment of an SGS velocity perturbation that this set-up does not carry (turb_adve_switch / turb_cond_switch, dimensions)");
+      return A.ext[ix].p;
+    }
     return attr == 0 ? A.rd3.p : attr == 1 ? A.rw2.p : attr == 2 ? A.kpa.p : A.vt.p;
   }
   void diag_select(int mode, int cons, int attr, double a, double b) override
@@ -1712,6 +1717,10 @@ int lcx_diag_dry_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(0, k / 3.)) 
 int lcx_diag_wet_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(1, k / 2.)) }
 int lcx_diag_kappa_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(2, k)) }
 int lcx_diag_incloud_time_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(4, k)) }
+int lcx_diag_up_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(5, k)) }
+int lcx_diag_vp_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(6, k)) }
+int lcx_diag_wp_mom(lcx_particles *h, int k) { LCX_TRY(H->diag_mom(7, k)) }
+int lcx_diag_water_cons(lcx_particles *h) { LCX_TRY(H->diag_select(2, 1, 1, 0, 0)) }
 int lcx_diag_RH_ge_Sc(lcx_particles *h) { LCX_TRY(H->diag_act(0)) }
 int lcx_diag_rw_ge_rc(lcx_particles *h) { LCX_TRY(H->diag_act(1)) }
 int lcx_diag_wet_mass_dens(lcx_particles *h, double rad, double sig0) { LCX_TRY(H->diag_wet_mass_dens(rad, sig0)) }

@@ -446,6 +446,10 @@ class particles_t:
     diag_wet_mom = _diagk("diag_wet_mom")
     diag_kappa_mom = _diagk("diag_kappa_mom")
     diag_incloud_time_mom = _diagk("diag_incloud_time_mom")
+    diag_up_mom = _diagk("diag_up_mom")
+    diag_vp_mom = _diagk("diag_vp_mom")
+    diag_wp_mom = _diagk("diag_wp_mom")
+    diag_water_cons = _diag0("diag_water_cons")
 
     def outbuf(self):
         """bytes-like view of n_cell reals (use numpy.frombuffer(..., dtype=real_t), default float64)."""

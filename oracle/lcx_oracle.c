@@ -1784,6 +1784,16 @@ int orc_diag_sd_conc(orc_particles *s)
 }
 int orc_diag_all(orc_particles *s) { moms_all(s); return 0; }
 int orc_diag_water(orc_particles *s) { moms_gt0(s, s->rw2, 0); return 0; }
+int orc_diag_water_cons(orc_particles *s) { moms_gt0(s, s->rw2, 1); return 0; }                  /* particles_diag.ipp:346-349 */
+static int diag_sgs_mom(orc_particles *s, const double *v, int k)                                /* particles_diag.ipp:463-480 */
+{
+  if (!v) FAIL("libcloudph++: moment of an SGS velocity perturbation that this set-up does not carry (turb_adve_switch / turb_cond_switch, dimensions)");
+  if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
+  moms_calc(s, v, k, 1); return 0;
+}
+int orc_diag_up_mom(orc_particles *s, int k) { return diag_sgs_mom(s, s->o.turb_adve_switch && s->o.nx ? s->up : NULL, k); }
+int orc_diag_vp_mom(orc_particles *s, int k) { return diag_sgs_mom(s, s->o.turb_adve_switch && s->o.ny ? s->vp : NULL, k); }
+int orc_diag_wp_mom(orc_particles *s, int k) { return diag_sgs_mom(s, (s->o.turb_adve_switch && s->o.nz) || s->o.turb_cond_switch ? s->wp : NULL, k); }
 int orc_diag_dry_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 0); return 0; }
 int orc_diag_wet_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 0); return 0; }
 int orc_diag_kappa_rng(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 0); return 0; }

@@ -214,3 +214,37 @@ def test_consecutive_range_selections_match_oracle():
         th, rv, rhod, C = h.box_fields(oi)
         fresh.init(th, rv, rhod, **C)
         fresh.diag_dry_rng_cons(0., 1.)               # consecutive selection without a selection
+
+
+def test_sgs_velocity_moments_and_water_selection():
+    """diag_up_mom / diag_vp_mom / diag_wp_mom (particles_diag.ipp:463-480) and diag_water_cons (:346-349) against the oracle"""
+    oi = h.box_opts(4, 3, 4, 24, coal_switch=False, turb_adve_switch=True, SGS_mix_len=np.linspace(20., 40., 4))
+    th, rv, rhod, C = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, (th, rv, rhod, C))
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    opts.turb_adve = True
+    diss = 1e-3 * np.ones(th.shape)
+    for _ in range(2):
+        for pr in (orc, hip):
+            pr.step_sync(opts, th.copy(), rv.copy(), rhod, diss_rate=diss, **C)
+        for arr in h.oracle_rng_preview(orc, [(2, orc.n_part)] * 3):
+            hip.rng_replay_push(2, arr)
+        orc.step_async(opts)
+        hip.step_async(opts)
+    for fn in ("diag_up_mom", "diag_vp_mom", "diag_wp_mom"):
+        for pr in (orc, hip):
+            pr.diag_all()
+            getattr(pr, fn)(2)
+        np.testing.assert_allclose(hip.outbuf_array(), orc.outbuf_array(), rtol=1e-9)
+        assert orc.outbuf_array().sum() > 0
+    for pr in (orc, hip):
+        pr.diag_dry_rng(2e-8, 1.)
+        pr.diag_water_cons()
+        pr.diag_wet_mom(0)
+    exact(hip.outbuf_array(), orc.outbuf_array(), "water among a dry-radius selection")
+    plain = h.hip_particles(h.box_opts(4, 3, 4, 8))
+    plain.init(th, rv, rhod, **C)
+    plain.diag_all()
+    with pytest.raises(RuntimeError, match="SGS velocity"):
+        plain.diag_up_mom(1)
