@@ -419,3 +419,39 @@ def test_diag_vel_div_is_the_courant_divergence(make, dims):
             div = div + (C["Cz"][..., 1:] - C["Cz"][..., :-1]) / oi.dt
         div = div + (C["Cx"][1:] - C["Cx"][:-1]) / oi.dt
         np.testing.assert_array_equal(pr.outbuf_array(), div.ravel())
+
+
+@pytest.mark.parametrize("make", MAKERS)
+@pytest.mark.parametrize("layout", ["padded", "kij"])
+def test_strided_eulerian_arrays(make, layout):
+    """arrinfo_t strides (arrinfo.hpp:11-49, init_e2l.ipp:59-102): arrays that are views into padded storage, or stored with
+    the two horizontal axes swapped (kij), give the same run as contiguous ones -- and th / rv are written back through the strides"""
+    oi = h.box_opts(4, 3, 5, 16, coal_switch=False)
+    th, rv, rhod, C = h.box_fields(oi)
+
+    def view(a):
+        if layout == "padded":
+            big = np.full(tuple(s + 2 for s in a.shape), np.nan)
+            v = big[1:-1, 1:-1, :-2]
+            assert not v.flags["C_CONTIGUOUS"] and v.strides[2] == a.itemsize
+        else:
+            v = np.empty((a.shape[1], a.shape[0], a.shape[2])).transpose(1, 0, 2)        # memory order j, i, k
+            assert v.strides[0] < v.strides[1]
+        v[...] = a
+        return v
+    res = []
+    for strided in (False, True):
+        f = (lambda a: view(a)) if strided else (lambda a: a.copy())
+        a_th, a_rv, a_rhod = f(th), f(rv), f(rhod)
+        Cs = {k: f(v) for k, v in C.items()}
+        pr = make(oi)
+        pr.init(a_th, a_rv, a_rhod, **Cs)
+        opts = lgrngn.opts_t()
+        opts.coal = False
+        for _ in range(2):
+            pr.step_sync(opts, a_th, a_rv, a_rhod, **Cs)
+            pr.step_async(opts)
+        res.append((np.array(a_th), np.array(a_rv), pr.get_attr("rw2"), pr.get_attr("x"), pr.get_attr("z")))
+    assert not np.array_equal(res[0][0], th)                       # condensation did write th back
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
