@@ -455,3 +455,54 @@ def test_strided_eulerian_arrays(make, layout):
     assert not np.array_equal(res[0][0], th)                       # condensation did write th back
     for a, b in zip(*res):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("make,alloc", [pytest.param(h.oracle_particles, h.host_alloc, id="oracle"),
+                                        pytest.param(h.hip_particles, h.dev_alloc, id="hip", marks=pytest.mark.gpu)])
+def test_slabs_indexing_the_global_arrays(make, alloc):
+    """The reference's multi_CUDA hands every GPU the GLOBAL Eulerian arrays and an offset of n_x_bfr planes
+    (init_e2l.ipp:44-46, distmem_opts.hpp:27); slabs that read / write their part of the global arrays through
+    opts_init.n_x_bfr / n_x_tot must run exactly like slabs that are given their own slices."""
+    from libcloudphxx_amd import multi
+    oi = h.box_opts(7, 3, 4, 16, coal_switch=False)
+    oi.n_sd_max = 16 * 7 * 3 * 4 * 3
+    th, rv, rhod, C = h.box_fields(oi)
+    size = 3
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    opts.adve = opts.sedi = False                # no exchange: this is about the array indexing only
+    res = []
+    for glob in (False, True):
+        out = []
+        thg, rvg = th.copy(), rv.copy()
+        for r in range(size):
+            o, bfr = multi.distmem_opts(oi, r, size)
+            o.rng_seed = oi.rng_seed + r
+            if not glob:
+                o.n_x_bfr, o.n_x_tot = 0, o.nx
+                sl = lambda a, ext=0: np.ascontiguousarray(a[bfr:bfr + o.nx + ext])
+                a_th, a_rv = sl(thg), sl(rvg)
+                args = (a_th, a_rv, sl(rhod))
+                kw = dict(Cx=sl(C["Cx"], 1), Cy=sl(C["Cy"]), Cz=sl(C["Cz"]))
+            else:
+                o.n_x_bfr, o.n_x_tot = bfr, oi.nx
+                a_th, a_rv = thg, rvg
+                args = (thg, rvg, rhod)
+                kw = dict(C)
+            pr = make(o)
+            pr.init(*args, **kw)
+            pr.step_sync(opts, *args, **kw)
+            # with adve and sedi off nobody leaves, but a decomposed object still expects the exchange protocol to be completed
+            pr.step_async(opts)
+            nl, nr = pr.migrate_counts()
+            assert nl == nr == 0
+            pr.migrate_finish(opts)
+            out.append((pr.get_attr("rw2"), pr.get_attr("x")))
+            if not glob:
+                thg[bfr:bfr + o.nx] = a_th
+                rvg[bfr:bfr + o.nx] = a_rv
+        res.append((out, thg.copy(), rvg.copy()))
+    for (a, b) in zip(res[0][0], res[1][0]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert not np.array_equal(res[1][1], th)
