@@ -24,3 +24,15 @@ def test_cxx_example_runs():
     th, rv, sd = float(vals["parcel"][1]), float(vals["parcel"][3]), float(vals["parcel"][5])
     assert abs(th - 307.78) < 1e-4 * 307.78 and abs(rv - 1.7e-2) < 1e-3 * 1.7e-2 and sd == 100   # lgrngn_cond.py:52-56
     assert float(vals["box"][1]) == 300 and int(vals["box"][3]) == 300
+
+
+@pytest.mark.gpu
+def test_cxx_ring_example_round_trip():
+    """examples/ring_cxx.cpp: two slabs of a periodic domain driven from C++ through the migration calls of the C ABI; Courant
+    number 1 for nx steps brings every super-droplet back (tests/mpi/mpi_adve_test.cpp:196-255)"""
+    exe = os.path.join(ROOT, "examples", "ring_cxx")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    out = subprocess.check_output([exe], env=dict(os.environ, LCX_DATA_DIR=os.path.join(ROOT, "libcloudphxx_amd", "data"))).decode().split()
+    assert out[:3] == ["ring", "round_trip_identical", "1"], out
+    assert float(out[4]) == 8 * 6 * 4 and int(out[6]) == 8 * 4 * 2 * 6      # every SD crosses one of the two faces every third step
