@@ -1,8 +1,10 @@
 // Construction-time options -- field names, types and defaults of the reference's opts_init_t
 // (reference: lgrngn/opts_init.hpp:29-253), written with default member initialisers.
-// Everything is forwarded to lcx_opts_init_t (include/lcx.h); switches of sub-systems that this backend
-// does not accelerate (chemistry, ice, sources, relaxation, SGS turbulence, per-particle substepping)
-// make the constructor throw instead of being ignored.
+// Everything is forwarded to lcx_opts_init_t (include/lcx.h).  Served: per-cell and per-particle condensation
+// substepping (exact_sstp_cond, sstp_cond_mix, adaptive_sstp_cond, sstp_cond_act), the SGS turbulence switches
+// (turb_adve / turb_cond / turb_coal), all initialisation modes, pred_corr advection, open side walls.  Switches of
+// sub-systems outside the accelerated path (chemistry, ice, aerosol sources, relaxation) make the constructor throw
+// instead of being ignored.
 #pragma once
 #include "kernel.hpp"
 #include "terminal_velocity.hpp"

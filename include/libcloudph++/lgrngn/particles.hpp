@@ -55,7 +55,7 @@ namespace libcloudphxx { namespace lgrngn {
     virtual void diag_wp_mom(const int &) { assert(false); }
     virtual void diag_water_cons() { assert(false); }
     // diagnostics of the parts outside this library (chemistry, ice): declared for source compatibility, never served
-    virtual void diag_chem(const int &) { assert(false); }
+    virtual void diag_chem(const enum common::chem::chem_species_t &) { assert(false); }
     virtual void diag_ice() { assert(false); }
     virtual void diag_ice_cons() { assert(false); }
     virtual void diag_ice_a_rng(const real_t &, const real_t &) { assert(false); }

@@ -5,6 +5,7 @@
 // as a sequence of kernel launches on one HIP stream.  The C ABI at the bottom is what the host-language
 // shims bind (C++: include/libcloudphxx_amd/lgrngn/particles.hpp, Python: libcloudphxx_amd/lgrngn.py).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -41,12 +42,23 @@ template <class T> struct DevBuf {
 };
 
 // ---- efficiency tables (numeric data files, see tools/extract_efficiency_tables.py) ----
-static bool load_efficiency_table(int kernel, std::vector<double> &tab, double &r_max)
+// looked up in $LCX_DATA_DIR if set, else in ../data next to this shared object (csrc/liblcx_hip.so -> data/), so that a
+// C / C++ consumer finds them from any working directory
+static std::string data_dir()
 {
-  const char *dir = getenv("LCX_DATA_DIR");
-  char path[1024];
-  snprintf(path, sizeof path, "%s/kernel_eff_%d.f64", dir ? dir : "libcloudphxx_amd/data", kernel);
-  FILE *f = fopen(path, "rb");
+  if (const char *dir = getenv("LCX_DATA_DIR")) return dir;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<const void *>(&data_dir), &info) && info.dli_fname) {
+    std::string so(info.dli_fname);
+    const size_t slash = so.rfind('/');
+    return (slash == std::string::npos ? std::string(".") : so.substr(0, slash)) + "/../data";
+  }
+  return "libcloudphxx_amd/data";
+}
+static bool load_efficiency_table(int kernel, std::vector<double> &tab, double &r_max, std::string &path)
+{
+  path = data_dir() + "/kernel_eff_" + std::to_string(kernel) + ".f64";
+  FILE *f = fopen(path.c_str(), "rb");
   if (!f) return false;
   double hdr[2];
   bool ok = fread(hdr, sizeof(double), 2, f) == 2;
@@ -698,39 +710,45 @@ struct Particles : IParticles {
   void cond_substep(double RH_max, int step, bool turb_cond = false)
   {
     hskpng_sort();
+    // fast arithmetic (no SGS supersaturation): per-cell set-up hoisted (k_cond_cellpre) and one scratch value per droplet (the
+    // change of n rw^3); strict arithmetic: n rw^3 before and after in position order + the ordered per-cell walk
+    const bool fast = !o.strict_fp && !turb_cond && !no_cond_pre;
     if (npart) {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
-      if (!o.strict_fp && !turb_cond && !no_cond_pre) {
+      const dim3 gr(nblk(npart)), bl(BS);
+      if (fast) {
         cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         hipLaunchKernelGGL(k_cond_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, rhod.p, rv.p, Tk.p, eta.p, RH.p, lambda_D.p, lambda_K.p,
                            T(RH_max), reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p));
+        hipLaunchKernelGGL((k_cond_fast<T>), gr, bl, 0, st, npart, a);
       }
-      if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
-      else hipLaunchKernelGGL((k_cond<T, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, a);
+      else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
+      else hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a);
     }
     {
       Range r(this, "cond_cellfinish");
-      launch_cellfinish(step, sstp_cond);
+      launch_cellfinish(step, sstp_cond, fast);
     }
   }
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
   // reference's summation order); fast: eight lanes per cell, or a whole wave per cell where cells are crowded
-  void launch_cellfinish(int step, int sstp)
+  void launch_cellfinish(int step, int sstp, bool delta = false)
   {
+    const int dl = delta ? 1 : 0;
     if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)
       hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
     else if (!o.strict_fp) {
       const int cfc = std::min(cf_cells(), BS / 8);
       hipLaunchKernelGGL((k_cond_cellfinish<T, 8>), dim3(nblk(ncell, cfc)), dim3(BS), 0, st, ncell, cfc, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
     } else
       hipLaunchKernelGGL((k_cond_cellfinish<T, 1>), dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
   }
   // hskpng_rc2.ipp:14-32
   void hskpng_approximate_rc2_invalid()
@@ -1151,8 +1169,10 @@ struct Particles : IParticles {
         const int eff = o.kernel == LCX_KERNEL_ONISHI_HALL ? LCX_KERNEL_HALL :
                         o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS ? LCX_KERNEL_HALL_DAVIS_NO_WAALS : o.kernel;
         std::vector<double> tab;
-        if (!load_efficiency_table(eff, tab, kernel_r_max))
-          throw lcx_error("libcloudph++: kernel " + std::to_string(o.kernel) + " not available in this backend");
+        std::string tried;
+        if (!load_efficiency_table(eff, tab, kernel_r_max, tried))
+          throw lcx_error("libcloudph++: collision efficiency table of kernel " + std::to_string(o.kernel) + " not found or unreadable (" + tried +
+                          "); set LCX_DATA_DIR to the directory that holds kernel_eff_*.f64");
         params.insert(params.end(), tab.begin(), tab.end());                             // user parameters first, then the efficiencies
       }
     }

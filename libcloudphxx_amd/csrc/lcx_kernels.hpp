@@ -545,8 +545,9 @@ __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const 
   const size_t c = gid(); if (c >= n_cell) return;
   pre[c] = make_cond_cell_fast(rhod[c], rv[c], Tk[c], eta[c], lambda_D[c], lambda_K[c], RH[c], RH_max);
 }
-// Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms, 4 waves with 24 B of scratch per
-// lane: 10.1 ms, 5 waves: 13.0 ms).
+// Strict arithmetic, and the fast arithmetic with an SGS supersaturation perturbation per droplet (turb_cond); the production
+// fast path is k_cond_fast below.  Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms,
+// 4 waves with 24 B of scratch per lane: 10.1 ms, 5 waves: 13.0 ms).
 template <class T, bool FAST>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond(size_t n_part, cond_args<T> a)
 {
@@ -555,17 +556,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const T rw2_old = a.rw2[id];
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
   if (a.first) a.m3_before[pos] = rw2_old >= 0 ? nn * (rw2_old * T(sqrt(rw2_old))) : nn * rw2_old;
-  T r;
-  if (FAST && a.pre) {
-    r = rw2_old;
-    if (rw2_old > 0) {
-      cond_fun_fast<T> ff;
-      const T rd3 = a.rd3[id];
-      ff.setup_cell(a.pre[c], rw2_old, a.dt_sub, rd3, a.kpa[id], a.vt[id]);
-      r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-    }
-  } else
-    r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
+  const T r = advance_rw2<T, FAST>(rw2_old, a.dt_sub, a.rhod[c], a.rv[c], a.Tk[c], a.eta[c], a.rd3[id], a.kpa[id], a.vt[id],
                              a.lambda_D[c], a.lambda_K[c], a.ssp ? T(a.RH[c] + a.ssp[id]) : a.RH[c], a.RH_max, a.eps, a.cond_mlt, a.n_iter);
   a.rw2[id] = r;
   a.m3_after[pos] = r >= 0 ? nn * (r * T(sqrt(r))) : nn * r;
@@ -610,13 +601,43 @@ __device__ __forceinline__ void cellfinish_apply(size_t c, bool has, T after, T 
   rv[c] = rv[c] - drw;
   th[c] = th[c] - drw * d_th_d_rv(Tk[c], th[c]);
 }
+// ---- fast arithmetic (opts_init.strict_fp == 0, no SGS supersaturation): the production form of the condensation kernel.
+// Per-cell set-up hoisted (k_cond_cellpre); ONE scratch value per droplet, delta[pos] = n (rw_new^3 - rw_old^3), instead of the
+// strict path's two (n rw^3 before and after): the cell's change of the third moment is the sum of the deltas, so the finishing
+// pass reads half as much, nothing is carried between substeps (rw_mom3) and the difference of two large sums is never formed.
+// Measured on C3 (MI355X, fp64, cond + cond_cellfinish per step): round-1 pair 8.45 + 0.62 ms; this form 8.42 + 0.42; with the
+// root finder's reciprocals at one Newton step (OPT bit 0) 8.20; with the cube-root series (bit 1) 8.35; both 8.15 + 0.42.
+// Also measured and dropped: the per-cell sums fused in as a wave-shuffle segmented scan with one store per (wave, cell)
+// fragment (each scan of 6 shuffle steps costs 0.35-0.4 ms, more than the 0.2 ms of stores + 0.4 ms finishing pass it
+// replaces: 9.2-9.4 + 0.05 ms); the cell's nine constants re-read from LDS at every evaluation instead of living in 18 VGPRs
+// (no scratch, but 9.4 ms); 3 waves per SIMD without scratch 10.2 ms, 5 waves with 116 B of scratch 10.8 ms.
+template <class T> __device__ __forceinline__ T rw2_to_rw3_signed(T x) { return x >= 0 ? x * T(sqrt(x)) : x; }
+template <class T, int OPT = 3>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond_fast(size_t n_part, cond_args<T> a)
+{
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  const T rw2_old = a.rw2[id];
+  T r = rw2_old;
+  if (rw2_old > 0) {
+    cond_fun_fast<T, OPT> ff;
+    const T rd3 = a.rd3[id];
+    ff.setup_cell(a.pre[c], rw2_old, a.dt_sub, rd3, a.kpa[id], a.vt[id]);
+    r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    a.rw2[id] = r;
+  }
+  a.m3_after[pos] = T(a.n[id]) * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+}
+
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
 // sums each 8th value of the staged segment and a fixed 3-step shuffle tree joins them (deterministic, different rounding)
 template <class T, int G>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
-                  const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims)
+                  const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0)
 {
+  // delta: m3_after holds the droplets' CHANGES n (rw_new^3 - rw_old^3) (k_cond_fast): their sum is the whole answer of every substep
+  if (delta) { step = 0; sstp = 1; }
   __shared__ T lds[CF_CAP];
   __shared__ uint32_t cs[CF_CELLS + 1];
   const size_t c0 = size_t(blockIdx.x) * cfc;
@@ -641,7 +662,7 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
     __syncthreads();
     if (in_run) after = seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
-    if (step == 0) {
+    if (step == 0 && !delta) {
       __syncthreads();
       if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
       __syncthreads();
@@ -664,13 +685,14 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
 template <class T>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish_wave(size_t n_cell, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
-                       const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims)
+                       const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0)
 {
   const size_t c = size_t(blockIdx.x) * (BS / WAVE) + wave_id();
   if (c >= n_cell) return;
+  if (delta) { step = 0; sstp = 1; }
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T after = 0, before = 0;
-  for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[q]; if (step == 0) before = before + m3_before[q]; }
+  for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[q]; if (step == 0 && !delta) before = before + m3_before[q]; }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) { after = after + __shfl_down(after, d); before = before + __shfl_down(before, d); }
   if (lane_id() == 0) cellfinish_apply(c, e > s, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);
@@ -1312,6 +1334,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     if (a.do_sedi) z = z - a.dt * a.vt[i];
     if (a.do_subs) z = z - a.dt * a.w_LS[k_subs];
     bool kill = false, emigrant = false;
+    uint8_t mig_flag = 0;
     if (a.do_bcnd && g.ndims > 0) {
       if (!a.distmem) {
         if (!a.open_side_walls) x = periodic(x, a.x0, a.x1);
@@ -1320,8 +1343,10 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
         uint8_t m = 0;
         if (x < a.x0) { m = 1; if (a.bcond_lft == 3) kill = true; }
         if (x >= a.x1) { m = 2; if (a.bcond_rgt == 3) kill = true; }
-        if (m) a.mig[i] = m;                // (the flags are cleared before the launch: only the ~1 % that leave store a byte)
+        // an SD that an open wall removes on its way out is not a migrant (it would travel with n == 0 only to be dropped
+        // by the receiver); one that also precipitates or leaves through the top in this pass is decided below
         emigrant = m != 0;
+        mig_flag = m;
       }
       if (g.ndims == 3) {
         if (!a.open_side_walls) y = periodic(y, a.y0, a.y1);
@@ -1346,6 +1371,10 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     if (g.nx) a.x[i] = x;
     if (g.ny) a.y[i] = y;
     if (g.nz) a.z[i] = z;
+    // (the flags are cleared before the launch: only the ~1 % that leave store a byte.)  An SD that dies in this very pass
+    // -- open wall, top, precipitation -- is not shipped: the reference sends it with n == 0 and the receiver's
+    // hskpng_remove_n0 drops it, so the neighbour never sees it either way, and its puddle contribution stays on this slab
+    if (mig_flag && !kill) a.mig[i] = mig_flag;
     if (kill) { a.n[i] = 0; dead_now = true; }
     else if (a.reindex) {
       // an emigrant leaves the cell-sorted order at once (it is packed by id and its multiplicity zeroed in migrate_finish)
@@ -1877,7 +1906,8 @@ __global__ void k_math_probe(int which, double *v, size_t n)
   const size_t i = gid();
   if (i >= n) return;
   const double x = v[i];
-  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : which == 5 ? log_lean(x) : exp(x);
+  v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : which == 5 ? log_lean(x) :
+         which == 6 ? rcp_newton1(x) : which == 7 ? cbrt1p<true>(x) : exp(x);
 }
 
 } // namespace lcx

@@ -118,8 +118,9 @@ template <class T> LCX_HD bool tol_reached(T eps, T a, T b) { return fabs(a - b)
 // v_rcp_f64, 6 FMA, v_div_fmas, v_div_fixup).  A reciprocal refined by two Newton steps (<= 1 ulp, math probe 4) times the
 // numerator is half of that, and denominators shared between quotients are inverted once.  Quotients differ from the IEEE
 // ones by <= 2 ulp, i.e. like the growth rate itself in this mode; the strict mode keeps the IEEE divisions.
-template <class F, class = void> struct fastdiv : std::false_type {};
-template <class F> struct fastdiv<F, std::void_t<decltype(F::fast_div)>> : std::true_type {};
+// fast_div level of a functor: 0 none (IEEE divisions), 1 reciprocal + two Newton steps, 2 reciprocal + one Newton step
+template <class F, class = void> struct fastdiv { static constexpr int value = 0; };
+template <class F> struct fastdiv<F, std::void_t<decltype(F::fast_div)>> { static constexpr int value = int(F::fast_div); };
 LCX_HD double rcp_refined(double y)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -131,28 +132,41 @@ LCX_HD double rcp_refined(double y)
 #endif
 }
 LCX_HD float rcp_refined(float y) { return 1.f / y; }
-template <bool FD, class T> LCX_HD T dvd(T x, T y)
+// one Newton step on the hardware reciprocal (v_rcp_f64 delivers ~2^-25: one step squares that -- measured <= 11 ulp, math
+// probe 6).  Used for the interpolated abscissae of the fast-mode root finder only, never for a function value.
+LCX_HD double rcp_newton1(double y)
 {
-  if constexpr (FD) return x * rcp_refined(y);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double r0 = __builtin_amdgcn_rcp(y);
+  return __builtin_fma(__builtin_fma(-y, r0, 1.0), r0, r0);
+#else
+  return 1.0 / y;
+#endif
+}
+LCX_HD float rcp_newton1(float y) { return 1.f / y; }
+template <int FD, class T> LCX_HD T rcp_fd(T y) { if constexpr (FD == 2) return rcp_newton1(y); else return rcp_refined(y); }
+template <int FD, class T> LCX_HD T dvd(T x, T y)
+{
+  if constexpr (FD != 0) return x * rcp_fd<FD>(y);
   else return x / y;
 }
 
 namespace t748 {
 template <class T> struct st { T a, b, fa, fb, d, fd; };
 
-template <bool FD = false, class T> LCX_HD T safe_div(T num, T den, T r)
+template <int FD = 0, class T> LCX_HD T safe_div(T num, T den, T r)
 {                                                                  // :124-138
   if (fabs(den) < 1 && fabs(den * lim<T>::max) <= fabs(num)) return r;
   return dvd<FD>(num, den);
 }
-template <bool FD = false, class T> LCX_HD T secant(T a, T b, T fa, T fb)
+template <int FD = 0, class T> LCX_HD T secant(T a, T b, T fa, T fb)
 {                                                                  // :140-160
   const T tol = lim<T>::eps * 5;
   const T c = a - dvd<FD>(fa, T(fb - fa)) * (b - a);
   if (c <= a + fabs(a) * tol || c >= b - fabs(b) * tol) return (a + b) / 2;
   return c;
 }
-template <bool FD = false, class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb, T fd, unsigned count)
+template <int FD = 0, class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb, T fd, unsigned count)
 {                                                                  // :162-222
   T B = safe_div<FD>(T(fb - fa), T(b - a), lim<T>::max);
   T A = safe_div<FD>(T(fd - fb), T(d - b), lim<T>::max);
@@ -164,11 +178,11 @@ template <bool FD = false, class T> LCX_HD T quadratic(T a, T b, T d, T fa, T fb
   if (c <= a || c >= b) c = secant<FD>(a, b, fa, fb);
   return c;
 }
-template <bool FD = false, class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T fd, T fe)
+template <int FD = 0, class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T fd, T fe)
 {                                                                  // :224-262
-  if constexpr (FD) {                                              // six distinct denominators among the nine quotients
-    const T r_ed = rcp_refined(T(fe - fd)), r_db = rcp_refined(T(fd - fb)), r_ba = rcp_refined(T(fb - fa)),
-            r_eb = rcp_refined(T(fe - fb)), r_da = rcp_refined(T(fd - fa)), r_ea = rcp_refined(T(fe - fa));
+  if constexpr (FD != 0) {                                         // six distinct denominators among the nine quotients
+    const T r_ed = rcp_fd<FD>(T(fe - fd)), r_db = rcp_fd<FD>(T(fd - fb)), r_ba = rcp_fd<FD>(T(fb - fa)),
+            r_eb = rcp_fd<FD>(T(fe - fb)), r_da = rcp_fd<FD>(T(fd - fa)), r_ea = rcp_fd<FD>(T(fe - fa));
     const T q11 = (d - e) * fd * r_ed;
     const T q21 = (b - d) * fb * r_db;
     const T q31 = (a - b) * fa * r_ba;
@@ -222,7 +236,7 @@ template <class T, class F>
 LCX_HD bool toms748_head(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned max_iter, toms_carry<T> &k, T &root)
 {                                                                  // returns true when `root` is final
   using namespace t748;
-  constexpr bool FD = fastdiv<F>::value;
+  constexpr int FD = fastdiv<F>::value;
   k.count = max_iter;
   k.s = st<T>{ax, bx, fax, fbx, T(0), T(0)};
   st<T> &s = k.s;
@@ -253,7 +267,7 @@ template <class T, class F>
 LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
 {
   using namespace t748;
-  constexpr bool FD = fastdiv<F>::value;
+  constexpr int FD = fastdiv<F>::value;
   st<T> &s = k.s;
   T c, u, fu, a0, b0, &e = k.e, &fe = k.fe;
   unsigned &count = k.count;
@@ -388,10 +402,8 @@ LCX_HD double cbrt_seeded(double x)
 }
 LCX_HD float cbrt_seeded(float x) { return cbrt(x); }
 
-LCX_HD double exp_reduced(double x)
+LCX_HD double exp_reduced_core(double x)            // |x| < 700 is the caller's business
 {
-#if defined(__HIP_DEVICE_COMPILE__)
-  if (!(x > -700. && x < 700.)) return exp(x);
   const double k = __builtin_rint(x * 1.4426950408889634);
   double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);                           // ln2 hi / lo (fdlibm split)
   r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
@@ -410,6 +422,12 @@ LCX_HD double exp_reduced(double x)
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, int(k));
+}
+LCX_HD double exp_reduced(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x > -700. && x < 700.)) return exp(x);
+  return exp_reduced_core(x);
 #else
   return exp(x);
 #endif
@@ -419,10 +437,9 @@ LCX_HD float exp_reduced(float x) { return exp(x); }
 // natural logarithm of a positive normal double for the fast-arithmetic terminal-velocity pass (only the index of a
 // ln(r)-uniform table is taken from it): mantissa in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) as an odd series.
 // <= 2 ulp (math probe 5); the library call costs about twice as many instructions.
-LCX_HD double log_lean(double x)
-{
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (!(x >= 2.3e-308 && x < 1.7e308)) return log(x);
+LCX_HD double log_lean_core(double x)               // positive normal x is the caller's business
+{
   int e = __builtin_amdgcn_frexp_exp(x);
   double m = __builtin_amdgcn_frexp_mant(x);                     // [0.5, 1)
   if (m < 0.70710678118654752) { m = m + m; e -= 1; }
@@ -443,11 +460,32 @@ LCX_HD double log_lean(double x)
   const double lm = __builtin_fma(two_s * z, p, two_s);
   const double ed = double(e);
   return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+}
+#endif
+LCX_HD double log_lean(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x >= 2.3e-308 && x < 1.7e308)) return log(x);
+  return log_lean_core(x);
 #else
   return log(x);
 #endif
 }
 LCX_HD float log_lean(float x) { return log(x); }
+
+// x^y for x > 1 and a small positive exponent (the ventilation factor's Re^0.077 of drops above ~50 um): exp(y ln x) from the two
+// lean functions above, <= 2 ulp here because |y ln x| stays below a few units; the library pow is ~10x the instructions and
+// two dozen scalar constants, all of it inlined into every copy of the growth rate.
+LCX_HD double pow_lean(double x, double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!(x < 1e300)) return pow(x, y);               // (x > 1 is the caller's; inf / NaN take the library's way)
+  return exp_reduced_core(y * log_lean_core(x));
+#else
+  return pow(x, y);
+#endif
+}
+LCX_HD float pow_lean(float x, float y) { return pow(x, y); }
 
 // The same growth rate as cond_fun, algebraically collected into ONE rational expression (one IEEE division
 // instead of fifteen) with FMA contraction allowed.  Selected by opts_init.strict_fp = 0.  It is the counterpart
@@ -458,8 +496,19 @@ LCX_HD float log_lean(float x) { return log(x); }
 // with beta(Kn) = n/d, a_w = na/da, c1 = 2/(D_0 rho_v), c2 = 2 l_v (l_v/(R_v T) - 1)/(K_0 RH T).
 // droplet-independent part of the collected growth rate's set-up
 template <class T> struct cond_cell_fast { T Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w, rhod, eta, pad_; };
-template <class T> struct cond_fun_fast {
-  static constexpr bool fast_div = true;      // the root finder may use refined reciprocals (t748 above)
+// cbrt(1 + x) for x >= 0: below 2^-8 (Re Sc of droplets up to ~8 um) the Taylor series to x^5 (next term 0.023 x^6 < 1e-16)
+template <bool SERIES, class T> LCX_HD T cbrt1p(T x)
+{
+  if constexpr (SERIES && sizeof(T) == 8) {
+    if (x < T(0x1p-8))
+      return T(1) + x * (T(1. / 3) + x * (T(-1. / 9) + x * (T(5. / 81) + x * (T(-10. / 243) + x * T(22. / 729)))));
+  }
+  return cbrt_seeded(T(1) + x);
+}
+// OPT (measurement / tuning switches, all inside the fast arithmetic's few-ulp envelope): bit 0 the root finder's reciprocals
+// with one Newton step instead of two; bit 1 the ventilation factors' cube roots by series for small arguments
+template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
+  static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
   T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
   LCX_HD void setup(const cond_fun<T> &f)
   {
@@ -488,8 +537,8 @@ template <class T> struct cond_fun_fast {
     const T rw3 = rw2 * rw;
     const T Re = c_Re * rw;
     const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
-    const T Sh = T(1) + cbrt_seeded(T(1) + Re * Sc) * m;
-    const T Nu = T(1) + cbrt_seeded(T(1) + Re * Pr) * m;
+    const T Sh = T(1) + cbrt1p<(OPT & 2) != 0>(Re * Sc) * m;
+    const T Nu = T(1) + cbrt1p<(OPT & 2) != 0>(Re * Pr) * m;
     const T KnD = lambda_D * irw, KnK = lambda_K * irw;
     const T nD = T(1) + KnD, dD = T(1) + KnD * (T(1.71) + T(1.33) * KnD);
     const T nK = T(1) + KnK, dK = T(1) + KnK * (T(1.71) + T(1.33) * KnK);
@@ -498,7 +547,7 @@ template <class T> struct cond_fun_fast {
     const T nDSh = nD * Sh, nKNu = nK * Nu;
     const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
     const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);
-    return T(2) * dvd<true>(num, den);
+    return T(2) * dvd<1>(num, den);
   }
   LCX_HD T operator()(T rw2) const
   {
@@ -525,7 +574,7 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
   const T drw2 = dt * f.drw2_dt(rw2_old);
   if (drw2 == 0) { result = rw2_old; return true; }
   T rd;
-  if constexpr (fastdiv<F>::value) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
+  if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
   const T a = mx(rd2, rw2_old + mn(T(0), cond_mlt * drw2)),
           b = rw2_old + mx(T(0), cond_mlt * drw2);
@@ -546,7 +595,7 @@ LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k)
 {
   T rw2_new = toms748_tail(f, k, eps);
   T rd;
-  if constexpr (fastdiv<F>::value) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
+  if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
@@ -663,7 +712,7 @@ template <class T> LCX_HD T vt_beard77_fact_pre(T r, const beard77_cell<T> &b)
 template <class T> LCX_HD T vt_beard77_fact_pre_small_fast(T inv_r, const beard77_cell<T> &b)
 {
   const T l_0 = T(6.62e-8);
-  return dvd<true>(T(b.e0e * (1 + T(1.255) * (b.l * inv_r))), T(1 + T(1.255) * (l_0 * inv_r)));
+  return dvd<1>(T(b.e0e * (1 + T(1.255) * (b.l * inv_r))), T(1 + T(1.255) * (l_0 * inv_r)));
 }
 template <class T> LCX_HD T vt_beard77_fact(T r, T p, T rhoa, T eta)
 {

@@ -22,10 +22,13 @@ BCOND_SHAREDMEM, BCOND_DISTMEM, BCOND_OPEN = 0, 1, 3      # src/detail/bcond.hpp
 
 
 def get_dev_nx(nx, rank, size):
-    """distmem_opts.hpp:10-16"""
-    if rank < size - 1:
-        return int(nx / size + .5)
-    return nx - rank * int(nx / size + .5)
+    """distmem_opts.hpp:10-16.  `opts_init.nx / size + .5` is an INTEGER division there (both operands are int), so every
+    rank but the last gets floor(nx / size) planes and the last one the remainder."""
+    per = nx // size
+    n = per if rank < size - 1 else nx - rank * per
+    if n <= 0:
+        raise RuntimeError("libcloudph++: number of devices exceeds nx")
+    return n
 
 
 def distmem_opts(opts_init, rank, size):

@@ -204,3 +204,41 @@ def test_open_side_walls_on_a_decomposed_domain(dims, size):
                 assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
             np.testing.assert_allclose(ph.get_attr("x"), po.get_attr("x"), rtol=1e-14, atol=1e-9)
     assert sum(p.n_part for p in hip.prts) < n0            # the walls did swallow super-droplets
+
+
+def test_precipitating_super_droplets_that_also_cross_a_slab_face():
+    """A super-droplet that falls out of the bottom (or leaves through the top) in the very pass that takes it across a slab
+    face dies on the slab it left: it is neither shipped nor counted.  Both engines must agree on n_part, on the sorted order
+    and on the puddle, slab by slab, and the device's CSR end must equal its n_part (a stale slot there once let k_cellrank
+    run over garbage)."""
+    nx, ny, nz, size = 8, 0, 4, 2
+    oi = h.box_opts(nx, ny, nz, 32, dx=20., coal_switch=False)
+    oi.n_sd_max = 32 * nx * nz * 3
+    th, rv, rhod, C = h.box_fields(oi, supersat=False)
+    C["Cx"] = 0.9 * np.ones_like(C["Cx"])                 # nine in ten of the SDs of an edge column change slabs
+    C["Cz"] = np.zeros_like(C["Cz"])
+    orc, hip = ring_pair(oi, size, (th, rv, rhod, C))
+    # rain drops just above the floor: r = 1 mm falls ~6.5 m per step, z in [0, 3) m
+    for po, ph in zip(orc.prts, hip.prts):
+        g = lambda nm: po.state_real(nm)
+        z = g("z").copy(); rw2 = g("rw2").copy()
+        low = z < oi.dz                                    # the bottom row of cells
+        z[low] = 3. * (z[low] / oi.dz)
+        rw2[low] = 1e-6
+        for p in (po, ph):
+            p.set_particles(po.state_u64("n"), g("rd3"), rw2, g("kappa"), g("vt"), g("x"), None, z)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    n0 = sum(p.n_part for p in orc.prts)
+    for it in range(3):
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        hip.step(opts, th.copy(), rv.copy(), rhod, **C)
+        for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
+            assert ph.n_part == po.n_part, (it, r)
+            assert int(ph.state_u64("cell_start")[-1]) == ph.n_part, (it, r)
+            for nm in ("n", "ijk", "sorted_id"):
+                assert np.array_equal(ph.state_u64(nm), po.state_u64(nm)), (it, r, nm)
+            pud_o, pud_h = po.diag_puddle(), ph.diag_puddle()
+            for k in pud_o:
+                np.testing.assert_allclose(pud_h[k], pud_o[k], rtol=1e-12, err_msg="%s slab %d" % (k, r))
+    assert sum(p.n_part for p in hip.prts) < n0            # it did rain

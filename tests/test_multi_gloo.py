@@ -21,8 +21,11 @@ def free_port():
 
 def test_distmem_opts_follow_reference_split():
     from libcloudphxx_amd import lgrngn, multi
-    # src/detail/distmem_opts.hpp:10-16: round(nx/size) to all but the last rank, remainder to the last
-    assert [multi.get_dev_nx(5, r, 2) for r in range(2)] == [3, 2]
+    # src/detail/distmem_opts.hpp:10-16: `nx / size + .5` with an INTEGER division = floor(nx/size) to all but the last rank,
+    # the remainder to the last
+    assert [multi.get_dev_nx(5, r, 2) for r in range(2)] == [2, 3]
+    assert [multi.get_dev_nx(6, r, 4) for r in range(4)] == [1, 1, 1, 3]
+    assert [multi.get_dev_nx(9, r, 6) for r in range(6)] == [1, 1, 1, 1, 1, 4]
     assert [multi.get_dev_nx(128, r, 8) for r in range(8)] == [16] * 8
     assert [multi.get_dev_nx(7, r, 3) for r in range(3)] == [2, 2, 3]
     oi = lgrngn.opts_init_t()
