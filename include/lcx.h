@@ -123,8 +123,10 @@ typedef struct {
 } lcx_opts_t;
 
 /* arrinfo_t (arrinfo.hpp:11-49): data == NULL <=> "not provided".  strides in elements.
- * on_device != 0: data is a device pointer (extension: lets a GPU-resident host model
- * skip the PCIe round trip of particles_impl_sync.ipp:15-68). */
+ * on_device (extension: lets a GPU-resident host model skip the PCIe round trip of particles_impl_sync.ipp:15-68):
+ *   0 host array; 1 data is a device pointer (for a multi-device object: the global array on a device every slab's device can read);
+ *   2 multi-device objects only: data is a host table of dev_count device pointers (void *[]), entry i = the planes of slab i as an
+ *     array of its own on slab i's device, same strides for all (a host model decomposed the same way keeps its fields like that). */
 typedef struct {
   void *data;
   const ptrdiff_t *strides;
@@ -141,6 +143,22 @@ const char *lcx_version(void);
 /* factory<real_t>(backend, opts_init)  (factory.hpp:12-15, src/lib.cpp:13-40) + ctor (particles_ctor.ipp:22-75) */
 int lcx_create(const lcx_opts_init_t *, int real_kind, lcx_particles **out);
 void lcx_destroy(lcx_particles *);
+/* factory<real_t>(multi_CUDA | multi_HIP, opts_init): ONE object that drives opts_init.dev_count devices of this process (0: all
+ * visible ones) -- replaces particles_t<real_t, multi_CUDA> (particles.hpp:246-340, src/particles_multi_gpu_*.ipp,
+ * src/impl_multi_gpu/particles_multi_gpu_impl.ipp:17-227).  The domain is cut into x-slabs (src/detail/distmem_opts.hpp:10-52), one
+ * per device; the arrays passed to init / sync_in / step_cond are the GLOBAL ones (each device reads and writes its planes), outbuf()
+ * is gathered into one host array, diag_puddle() is summed; get_attr throws as in the reference; opts.rcyc is refused as there.
+ * step_async exchanges the super-droplets that crossed a slab face between neighbouring devices: packed on the device straight into
+ * the neighbour's buffer over the peer mapping (xGMI), count in the message header, one host synchronisation per step
+ * (replaces impl_multi_gpu/particles_multi_gpu_impl_step_async_and_copy.ipp:28-206).  Every other entry point of this header takes
+ * the handle unchanged.  LCX_MULTI_DEVICE_MAP="0,0,1,1" (environment) maps slabs to devices explicitly; several slabs may share one. */
+int lcx_create_multi(const lcx_opts_init_t *, int real_kind, lcx_particles **out);
+/* number of slabs of a handle (1 for a single-device object) */
+int lcx_multi_dev_count(lcx_particles *, int *n);
+/* handle of slab i of a multi-device object, for the calls that address one device's storage (state getters, set_particles, random
+ * replay: what the reference exposes as the public pimpl->particles[i], particles_multi_gpu_impl.ipp:21); owned by the parent, valid
+ * until the parent is destroyed, not to be destroyed itself */
+int lcx_multi_slab(lcx_particles *, int i, lcx_particles **slab);
 
 /* particles_t::init (particles_init.ipp:16-131) */
 int lcx_init(lcx_particles *, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,

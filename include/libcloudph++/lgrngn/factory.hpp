@@ -7,15 +7,12 @@ namespace libcloudphxx { namespace lgrngn {
   inline particles_proto_t<real_t> *factory(const backend_t backend, opts_init_t<real_t> opts_init)
   {
     switch (backend) {
-      case HIP:
-      case CUDA:              // "the GPU backend" of a driver written for the reference
-        return new particles_t<real_t, HIP>(opts_init);
-      case multi_HIP:
-      case multi_CUDA:
-        throw std::runtime_error("libcloudph++: the multi-GPU backend of this library is one process per GPU "
-                                 "(libcloudphxx_amd.multi + torch.distributed/RCCL); see INTEGRATION.md");
+      case HIP: return new particles_t<real_t, HIP>(opts_init);
+      case CUDA: return new particles_t<real_t, CUDA>(opts_init);               // "the GPU backend" of a driver written for the reference
+      case multi_HIP: return new particles_t<real_t, multi_HIP>(opts_init);     // one object, opts_init.dev_count devices (0: all)
+      case multi_CUDA: return new particles_t<real_t, multi_CUDA>(opts_init);
       default:
-        throw std::runtime_error(std::string("libcloudph++: backend ") + backend_str(backend) + " is not part of the HIP library (available: HIP)");
+        throw std::runtime_error(std::string("libcloudph++: backend ") + backend_str(backend) + " is not part of the HIP library (available: HIP, multi_HIP)");
     }
   }
 } }

@@ -110,7 +110,8 @@ namespace libcloudphxx { namespace lgrngn {
     struct impl { lcx_particles *h = nullptr; opts_init_t<real_t> opts_init; std::vector<real_t> outbuf_copy; ~impl() { if (h) lcx_destroy(h); } };
     std::unique_ptr<impl> pimpl;
 
-    explicit particles_t(opts_init_t<real_t> oi, int n_x_tot = 0) : pimpl(new impl)
+    // multi: the object spans opts_init.dev_count devices (lcx_create_multi) -- used by the multi_HIP specialisation below
+    explicit particles_t(opts_init_t<real_t> oi, int n_x_tot = 0, bool multi = false) : pimpl(new impl)
     {
       if (!oi.rlx_dry_distros.empty()) throw std::runtime_error("libcloudph++: option outside the accelerated hot path (rlx)");
       pimpl->opts_init = oi;
@@ -154,7 +155,7 @@ namespace libcloudphxx { namespace lgrngn {
       for (const auto &kv : o.dry_sizes) for (const auto &rc : kv.second)
         ds.push_back(lcx_dry_size_t{double(kv.first.kappa), double(kv.first.rd_insol), double(rc.first), double(rc.second.first), rc.second.second});
       c.dry_sizes = ds.data(); c.n_dry_sizes = int(ds.size());
-      detail::lcx_check(lcx_create(&c, int(sizeof(real_t)), &pimpl->h));
+      detail::lcx_check(multi ? lcx_create_multi(&c, int(sizeof(real_t)), &pimpl->h) : lcx_create(&c, int(sizeof(real_t)), &pimpl->h));
     }
     ~particles_t() override {}
 
@@ -252,4 +253,27 @@ namespace libcloudphxx { namespace lgrngn {
       return c;
     }
   };
+
+  // particles_t<real_t, multi_HIP>: one object over all (or opts_init.dev_count) devices of the process, the reference's
+  // particles_t<real_t, multi_CUDA> (reference: lgrngn/particles.hpp:246-340, src/particles_multi_gpu_*.ipp).  Same virtuals;
+  // arrays are the GLOBAL ones, outbuf() the global field, get_attr() throws (particles_multi_gpu_ctor.ipp:53-57), opts.rcyc is
+  // refused (particles_multi_gpu_step.ipp:63-65).  The slabs, worker threads and the device-driven exchange live inside the
+  // library (libcloudphxx_amd/csrc/lcx_multi.hpp).
+  template <typename real_t>
+  struct particles_t<real_t, multi_HIP> : particles_t<real_t, HIP>
+  {
+    explicit particles_t(opts_init_t<real_t> oi) : particles_t<real_t, HIP>(oi, 0, true)
+    {
+      int n = 0;
+      detail::lcx_check(lcx_multi_dev_count(this->pimpl->h, &n));
+      this->pimpl->opts_init.dev_count = n;              // the reference stores the actual count in the live copy
+    }
+  };
+  // the reference's own backend names: a driver that instantiates or dynamic_casts to them gets the HIP objects
+  template <typename real_t>
+  struct particles_t<real_t, CUDA> : particles_t<real_t, HIP>
+  { explicit particles_t(opts_init_t<real_t> oi, int n_x_tot = 0) : particles_t<real_t, HIP>(oi, n_x_tot) {} };
+  template <typename real_t>
+  struct particles_t<real_t, multi_CUDA> : particles_t<real_t, multi_HIP>
+  { explicit particles_t(opts_init_t<real_t> oi) : particles_t<real_t, multi_HIP>(oi) {} };
 } }

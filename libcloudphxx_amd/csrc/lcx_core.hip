@@ -69,6 +69,7 @@ static bool load_efficiency_table(int kernel, std::vector<double> &tab, double &
 
 struct IParticles {
   virtual ~IParticles() {}
+  virtual void bind() {}      // make the object's device current on the calling thread
   virtual int real_kind() const = 0;
   virtual void init(const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *p,
                     const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) = 0;
@@ -173,6 +174,7 @@ struct Particles : IParticles {
   std::map<std::string, double> prof_ms; std::vector<std::string> prof_order;
 
   int real_kind() const override { return int(sizeof(T)); }
+  void bind() override { if (o.dev_id >= 0) (void)hipSetDevice(o.dev_id); }
   bool distmem() const { return o.bcond_lft == 1 || o.bcond_rgt == 1; }
   static int m1(int n) { return n == 0 ? 1 : n; }
 
@@ -337,10 +339,13 @@ struct Particles : IParticles {
     if (is_null(a)) return;
     int n1, n2; long s0, s1, s2;
     arr_geom(a, ex, ey, ez, n1, n2, s0, s1, s2);
-    const long wrap = halo_planes ? long(o.n_x_tot) + ex : 0;
+    // on_device == 3 (set by the multi-device front end for per-slab arrays): a device array of THIS slab, indexed from 0; its
+    // Courant halo wraps inside the slab and is then overwritten by the halo exchange
+    const bool local = a->on_device == 3;
+    const long wrap = halo_planes ? (local ? long(o.nx) : long(o.n_x_tot)) + ex : 0;
     if (a->on_device) {
       hipLaunchKernelGGL(k_gather_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, to.p, (const T *)a->data, n, n_dims, n1, n2, s0, s1, s2,
-                         long(o.n_x_bfr) - halo_planes, wrap);
+                         (local ? 0l : long(o.n_x_bfr)) - halo_planes, wrap);
       return;
     }
     stage_host.resize(n);
@@ -362,7 +367,8 @@ struct Particles : IParticles {
     int n1, n2; long s0, s1, s2;
     arr_geom(a, 0, 0, 0, n1, n2, s0, s1, s2);
     if (a->on_device) {
-      hipLaunchKernelGGL(k_scatter_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, (T *)a->data, (const T *)from.p, n, n_dims, n1, n2, s0, s1, s2, long(o.n_x_bfr));
+      hipLaunchKernelGGL(k_scatter_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, (T *)a->data, (const T *)from.p, n, n_dims, n1, n2, s0, s1, s2,
+                         a->on_device == 3 ? 0l : long(o.n_x_bfr));
       return;
     }
     stage_host.resize(n);
@@ -639,11 +645,14 @@ struct Particles : IParticles {
     sort_from_hist(false);
   }
   // post_copy when k_move has already produced ijk / histogram / ranks / the dead count
-  void post_copy_after_fused_move(const lcx_opts_t &opts)
+  void post_copy_after_fused_move(const lcx_opts_t &opts, long dead_known = -1)
   {
     unsigned int dead = 0;
-    read_back(&dead, d_dead.p, 1);
-    dead -= unsigned(std::min<size_t>(reused_total, dead));       // emigrants' slots that immigrants have taken over are alive again
+    if (dead_known >= 0) dead = unsigned(dead_known);             // (multi_HIP: came with the exchange's single read-back)
+    else {
+      read_back(&dead, d_dead.p, 1);
+      dead -= unsigned(std::min<size_t>(reused_total, dead));     // emigrants' slots that immigrants have taken over are alive again
+    }
     reused_total = 0;
     // reference storage order (stable compaction only) when asked for, and in every parity run (a replayed stream is indexed by id)
     const bool strict_order = this->strict_order();
@@ -877,7 +886,10 @@ struct Particles : IParticles {
   // reindex: also produce the new cell index / histogram / rank / dead count (single-device post_copy fused in)
   void move(bool do_adve, bool do_sedi, bool do_subs, bool do_bcnd, bool reindex = false)
   {
-    if (n_dims == 0 || nphys == 0) { if (do_bcnd) { lft_count = rgt_count = 0; } return; }
+    if (n_dims == 0 || nphys == 0) {
+      if (do_bcnd) { lft_count = rgt_count = 0; if (dev_exchange) HIPCHK(hipMemsetAsync(scan_total.p, 0, 2 * sizeof(uint32_t), st)); }
+      return;
+    }
     Range r(this, "move(adve+sedi+bcnd)");
     move_args<T> a;
     a.n_part = nphys; a.g = g;
@@ -908,23 +920,31 @@ struct Particles : IParticles {
     else if (pc) hipLaunchKernelGGL((k_move<T, true, false>), dim3(blocks), dim3(BS), 0, st, a);
     else if (tb) hipLaunchKernelGGL((k_move<T, false, true>), dim3(blocks), dim3(BS), 0, st, a);
     else hipLaunchKernelGGL((k_move<T, false, false>), dim3(blocks), dim3(BS), 0, st, a);
-    if (want_puddle) {
+    if (want_puddle && dev_exchange) puddle_pending_blocks = blocks;      // (reduced after the emigrants are on their way, see lcx_multi.hpp)
+    else if (want_puddle) puddle_reduce(blocks);
+    if (do_bcnd && distmem()) build_migrant_lists();
+  }
+  unsigned puddle_pending_blocks = 0;
+  void puddle_reduce_deferred() { if (puddle_pending_blocks) puddle_reduce(puddle_pending_blocks); puddle_pending_blocks = 0; }
+  void puddle_reduce(unsigned blocks)
+  {
+    {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
       hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
       hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_sum.p + 4, slices, slices, puddle_sum.p);
       // running totals stay on the device (same additions in the same order as on the host); diag_puddle reads them
       hipLaunchKernelGGL(k_accumulate4, dim3(1), dim3(64), 0, st, puddle_sum.p, puddle_acc.p);
     }
-    if (do_bcnd && distmem()) build_migrant_lists();
   }
   void build_migrant_lists()
   {
     const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
     size_t *cnt[2] = {&lft_count, &rgt_count};
-    if (!tiles) { lft_count = rgt_count = 0; return; }
+    if (!tiles) { lft_count = rgt_count = 0; if (dev_exchange) HIPCHK(hipMemsetAsync(scan_total.p, 0, 2 * sizeof(uint32_t), st)); return; }
     hipLaunchKernelGGL(k_mig_tiles2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p);
     hipLaunchKernelGGL(k_scan_sums2, dim3(2), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
     hipLaunchKernelGGL(k_mig_ids2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p, mig_ids[0].p, mig_ids[1].p);
+    if (dev_exchange) return;                         // multi_HIP: the counts stay on the device (scan_total[0..1]), see exch_*
     uint32_t tot[2];
     read_back(tot, scan_total.p, 2);                  // one host sync for both directions
     *cnt[0] = tot[0]; *cnt[1] = tot[1];
@@ -1652,6 +1672,59 @@ struct Particles : IParticles {
     else      HIPCHK(hipMemcpyAsync(a + off[2 + side], buf, cnt * sizeof(T), hipMemcpyDeviceToDevice, st));
     sync();
   }
+  // ---- device-driven neighbour exchange (multi_HIP, lcx_multi.hpp): the three steps of migrate_pack / _unpack / _finish without
+  // a host round trip for the counts.  inbox[0] receives from the left neighbour, inbox[1] from the right one.
+  bool dev_exchange = false;
+  DevBuf<uint8_t> inbox[2], outbox[2]; size_t inbox_cap_rec = 0;
+  DevBuf<uint32_t> xcnt;
+  void exch_alloc()
+  {
+    dev_exchange = true;
+    // the reference sizes its buffers to half an x-plane of n_sd_max (reserve_hskpng_npart.ipp:84-94, config.hpp:25); a Courant
+    // number of 1 (the ring test) moves a whole plane, pred_corr allows 2
+    inbox_cap_rec = std::min<size_t>(cap, 2 * cap / size_t(std::max(o.nx, 1)) + 1024);
+    for (auto &b : inbox) { b.alloc(EXCH_HDR + inbox_cap_rec * migrate_record_bytes()); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
+    xcnt.alloc_zero(8, st);
+    if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
+    sync();
+  }
+  // emigrants of `side` -> the neighbour's inbox (a pointer this device can write: peer-mapped, or an inbox on this very device)
+  void exch_pack(int side, double x_rmt, uint8_t *remote_inbox)
+  {
+    hipLaunchKernelGGL(k_pack_dev<T>, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + side, uint32_t(inbox_cap_rec), mig_ids[side].p, aset(A), g,
+                       T(x_rmt), T(side == 0 ? o.x0 : o.x1), remote_inbox);
+  }
+  void exch_flag(bool lft, bool rgt)
+  {
+    if (lft) hipLaunchKernelGGL(k_flag_ids_dev, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + 0, mig_ids[0].p, A.n.p);
+    if (rgt) hipLaunchKernelGGL(k_flag_ids_dev, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + 1, mig_ids[1].p, A.n.p);
+  }
+  void exch_unpack(bool from_l, bool from_r)
+  {
+    Range r(this, "exchange_unpack");
+    HIPCHK(hipMemsetAsync(xcnt.p + 7, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr, nphys, cap,
+                       aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, strict_order() ? (const uint32_t *)nullptr : scan_total.p,
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 7);
+    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, d_dead.p, scan_total.p, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr,
+                       xcnt.p + 7, xcnt.p);
+  }
+  size_t exch_moved = 0;       // super-droplets this slab has sent so far (bench / diagnostics)
+  void exch_finish(const lcx_opts_t &opts)
+  {
+    uint32_t h[6];
+    read_back(h, xcnt.p, 6);                            // the step's one host synchronisation
+    if (h[5] & 1u) throw lcx_error("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (" +
+                                    std::to_string(inbox_cap_rec) + " records); raise opts_init.n_sd_max");
+    if (h[5] & 2u) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part after the neighbour exchange");
+    const size_t n_in = size_t(h[3]) + h[4], n_free = strict_order() ? 0 : size_t(h[1]) + h[2], reuse = std::min(n_in, n_free);
+    exch_moved += size_t(h[1]) + h[2];
+    nphys += n_in - reuse;
+    lft_count = rgt_count = 0; free_n[0] = free_n[1] = 0; free_used = 0; reused_total = 0;
+    if (fused_pending) { fused_pending = false; post_copy_after_fused_move(opts, long(h[0]) - long(reuse)); }
+    else post_copy(opts);
+  }
+
   void migrate_finish(const lcx_opts_t &opts) override
   {
     flag_emigrants();
@@ -1666,15 +1739,36 @@ struct Particles : IParticles {
 
 } // namespace lcx
 
+#include "lcx_multi.hpp"
+
 // =================================================================================================
 // C ABI
 // =================================================================================================
 using lcx::IParticles;
 static thread_local std::string g_err;
-struct lcx_particles { std::unique_ptr<IParticles> impl; };
+// a handle owns its object, except the per-slab handles of a multi-device object (lcx_multi_slab), which the parent keeps
+struct lcx_particles {
+  IParticles *p = nullptr; bool own = true;
+  std::vector<std::unique_ptr<lcx_particles>> slabs;
+  ~lcx_particles() { slabs.clear(); if (own) delete p; }
+};
+static inline IParticles *bound(lcx_particles *h) { h->p->bind(); return h->p; }
 
 #define LCX_TRY(body) try { body; return 0; } catch (const std::exception &e) { g_err = e.what(); return 1; } catch (...) { g_err = "libcloudph++: unknown error"; return 1; }
-#define H (h->impl)
+#define H (bound(h))
+
+template <class T> static bool multi_slabs(lcx_particles *h, int *n, int i, lcx_particles **out)
+{
+  auto *m = dynamic_cast<lcx::MultiParticles<T> *>(h->p);
+  if (!m) return false;
+  if (n) *n = m->D;
+  if (out) {
+    if (i < 0 || i >= m->D) throw std::runtime_error("libcloudph++: no such slab");
+    if (h->slabs.empty()) for (int k = 0; k < m->D; ++k) { h->slabs.emplace_back(new lcx_particles); h->slabs[k]->p = m->slab[k].get(); h->slabs[k]->own = false; }
+    *out = h->slabs[i].get();
+  }
+  return true;
+}
 
 extern "C" {
 
@@ -1704,13 +1798,35 @@ int lcx_create(const lcx_opts_init_t *oi, int real_kind, lcx_particles **out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
       throw std::runtime_error("libcloudph++: no HIP device available (this backend has no CPU fallback)");
     std::unique_ptr<lcx_particles> h(new lcx_particles);
-    if (real_kind == 8) h->impl.reset(new lcx::Particles<double>(*oi));
-    else if (real_kind == 4) h->impl.reset(new lcx::Particles<float>(*oi));
+    if (real_kind == 8) h->p = new lcx::Particles<double>(*oi);
+    else if (real_kind == 4) h->p = new lcx::Particles<float>(*oi);
     else throw std::runtime_error("libcloudph++: real_kind must be 4 (float) or 8 (double)");
     *out = h.release();
   })
 }
-void lcx_destroy(lcx_particles *h) { delete h; }
+int lcx_create_multi(const lcx_opts_init_t *oi, int real_kind, lcx_particles **out)
+{
+  LCX_TRY({
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+      throw std::runtime_error("libcloudph++: no HIP device available (this backend has no CPU fallback)");
+    std::unique_ptr<lcx_particles> h(new lcx_particles);
+    if (real_kind == 8) h->p = new lcx::MultiParticles<double>(*oi);
+    else if (real_kind == 4) h->p = new lcx::MultiParticles<float>(*oi);
+    else throw std::runtime_error("libcloudph++: real_kind must be 4 (float) or 8 (double)");
+    *out = h.release();
+  })
+}
+int lcx_multi_dev_count(lcx_particles *h, int *n)
+{ LCX_TRY({ if (!multi_slabs<double>(h, n, 0, nullptr) && !multi_slabs<float>(h, n, 0, nullptr)) *n = 1; }) }
+int lcx_multi_slab(lcx_particles *h, int i, lcx_particles **slab)
+{
+  LCX_TRY({
+    if (!multi_slabs<double>(h, nullptr, i, slab) && !multi_slabs<float>(h, nullptr, i, slab))
+      throw std::runtime_error("libcloudph++: not a multi-device object");
+  })
+}
+void lcx_destroy(lcx_particles *h) { if (h && h->own) delete h; }
 int lcx_init(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *p,
              const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) { LCX_TRY(H->init(th, rv, rhod, p, cx, cy, cz)) }
 int lcx_sync_in(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,

@@ -1820,6 +1820,85 @@ k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, con
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 
+// ---- the same three steps driven from the device (multi_HIP, lcx_multi.hpp): the migrant counts never visit the host.  A message is
+// an "inbox" on the RECEIVING device -- header {count, overflow} in the first EXCH_HDR bytes, then the attribute-major record of
+// k_pack -- that the sender's pack kernel writes straight through the peer mapping (xGMI): one message per direction, no count
+// round trip, no staging copy.  Kernels are launched over the inbox capacity and read the counts from device memory.
+constexpr size_t EXCH_HDR = 256;
+template <class T>
+__global__ void __launch_bounds__(BS)
+k_pack_dev(const uint32_t *count_p, uint32_t cap_rec, const uint32_t *ids, attr_set<T> s, grid_t g, T x_rmt, T x_lcl, uint8_t *inbox)
+{
+  const uint32_t count = *count_p;
+  const size_t i = gid();
+  if (i == 0) { reinterpret_cast<uint32_t *>(inbox)[0] = count; reinterpret_cast<uint32_t *>(inbox)[1] = count > cap_rec ? 1u : 0u; }
+  if (count > cap_rec || i >= count) return;          // overflow: nothing is shipped, the hosts of both slabs raise
+  n_t *nb = reinterpret_cast<n_t *>(inbox + EXCH_HDR);
+  T *rb = reinterpret_cast<T *>(nb + count);
+  const uint32_t id = ids[i];
+  nb[i] = s.n[id];
+  size_t slab = 0;
+  rb[slab++ * count + i] = s.rd3[id]; rb[slab++ * count + i] = s.rw2[id]; rb[slab++ * count + i] = s.kpa[id]; rb[slab++ * count + i] = s.vt[id];
+  if (g.nx) { const T xn = x_rmt + s.x[id] - x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
+  if (g.ny) rb[slab++ * count + i] = s.y[id];
+  if (g.nz) rb[slab++ * count + i] = s.z[id];
+  for (int e = 0; e < s.n_ext; ++e) rb[slab++ * count + i] = s.ext[e][id];
+}
+__global__ void k_flag_ids_dev(const uint32_t *count_p, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < *count_p) n[ids[i]] = 0; }
+// immigrants of both inboxes in one launch, the left neighbour's first (the reference unpacks lft, then rgt); slots as in k_unpack
+template <class T>
+__global__ void __launch_bounds__(BS)
+k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, size_t n_old, size_t cap, attr_set<T> s, grid_t g, T x0, T x1, T tol,
+             const uint32_t *free_l, const uint32_t *free_r, const uint32_t *n_free /* [2] on the device, nullptr: no slot re-use */,
+             uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *overflow)
+{
+  auto hdr_count = [](const uint8_t *b) { const uint32_t *h = reinterpret_cast<const uint32_t *>(b); return b && !h[1] ? h[0] : 0u; };
+  const uint32_t cl = hdr_count(inbox_l), cr = hdr_count(inbox_r);
+  const size_t i = gid();
+  bool in = i < size_t(cl) + cr;
+  uint32_t c = DEAD_CELL;
+  size_t d = 0;
+  if (in) {
+    const bool from_l = i < cl;
+    const uint8_t *box = from_l ? inbox_l : inbox_r;
+    const size_t count = from_l ? cl : cr, k = from_l ? i : i - cl;
+    const n_t *nb = reinterpret_cast<const n_t *>(box + EXCH_HDR);
+    const T *rb = reinterpret_cast<const T *>(nb + count);
+    const size_t n_free_l = n_free ? n_free[0] : 0, n_free_all = n_free_l + (n_free ? n_free[1] : 0);
+    d = i < n_free_l ? size_t(free_l[i]) : i < n_free_all ? size_t(free_r[i - n_free_l]) : n_old + (i - n_free_all);
+    if (d >= cap) { *overflow = 1u; in = false; }
+    else {
+      const n_t nn = nb[k];
+      s.n[d] = nn;
+      size_t slab = 0;
+      s.rd3[d] = rb[slab++ * count + k]; s.rw2[d] = rb[slab++ * count + k]; s.kpa[d] = rb[slab++ * count + k]; s.vt[d] = rb[slab++ * count + k];
+      T x = 0, y = 0, z = 0;
+      if (g.nx) { x = rb[slab++ * count + k]; x = x >= x1 ? x - tol : x < x0 ? x + tol : x; s.x[d] = x; }   // tolerance_away_from_bcond
+      if (g.ny) { y = rb[slab++ * count + k]; s.y[d] = y; }
+      if (g.nz) { z = rb[slab++ * count + k]; s.z[d] = z; }
+      for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = rb[slab++ * count + k];
+      if (cnt) { c = nn == 0 ? DEAD_CELL : cell_of(g, x, y, z); ijk[d] = c; }
+    }
+  }
+  if (cnt) {                                           // every lane of the wave takes part (ballots inside)
+    const bool active = in && c != DEAD_CELL;
+    const uint32_t r = wave_hist_rank(cnt, c, active);
+    if (active) rank[d] = r;
+  }
+}
+// the step's counts in one small record for ONE host read-back: dead, out_l, out_r, in_l, in_r, flags (1 my inbox overflowed at a
+// sender, 2 storage full)
+__global__ void k_collect_counts(const unsigned int *dead, const uint32_t *out_cnt, const uint8_t *inbox_l, const uint8_t *inbox_r,
+                                 const uint32_t *overflow, uint32_t *rec)
+{
+  if (threadIdx.x != 0) return;
+  const uint32_t *hl = reinterpret_cast<const uint32_t *>(inbox_l), *hr = reinterpret_cast<const uint32_t *>(inbox_r);
+  rec[0] = *dead; rec[1] = out_cnt[0]; rec[2] = out_cnt[1];
+  rec[3] = hl ? hl[0] : 0u; rec[4] = hr ? hr[0] : 0u;
+  rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | (*overflow ? 2u : 0u);
+}
+
+
 // ============================================================================================
 // recycling (housekeeping/particles_impl_rcyc.ipp:44-140): SDs with n == 0 become halves of the SDs with the highest
 // multiplicities.  The reference sorts ALL multiplicities; here the k largest are found by a radix select (one 256-bin

@@ -321,17 +321,47 @@ class DeviceArray:
         self.strides = tuple(strides)
 
 
+class DeviceArrays:
+    """The field of a multi-device object kept as one device array per slab (extension: lcx_arrinfo_t.on_device == 2):
+    ptrs[i] = raw address of slab i's planes on slab i's device, shape = the shape of ONE slab's array (all alike)."""
+
+    def __init__(self, ptrs, shape, strides=None):
+        self.ptrs = [int(p) for p in ptrs]
+        one = DeviceArray(0, shape, strides)
+        self.shape, self.strides = one.shape, one.strides
+
+
 class particles_t:
-    def __init__(self, opts_init, real_t=np.float64, lib=None, prefix="lcx_"):
+    """particles_t<real_t, HIP>; with multi=True particles_t<real_t, multi_HIP>: one object over opts_init.dev_count devices of
+    this process (lcx_create_multi, include/lcx.h) -- same calls, global arrays."""
+
+    def __init__(self, opts_init, real_t=np.float64, lib=None, prefix="lcx_", multi=False, _borrowed=None):
         self._lib = lib if lib is not None else _lib.load()
         self._px = prefix
         self._keep = []
         self.real_t = np.dtype(real_t)
         self.opts_init = opts_init
+        self._arr_keep = []
+        self._owner = None
+        if _borrowed is not None:                  # a slab of a multi-device object: the parent owns the handle
+            self._h, self._owner = _borrowed
+            return
         c = opts_init._to_c(self._keep)
         self._h = C.c_void_p()
-        self._chk(self._f("create")(C.byref(c), C.c_int(self.real_t.itemsize), C.byref(self._h)))
-        self._arr_keep = []
+        self._chk(self._f("create_multi" if multi else "create")(C.byref(c), C.c_int(self.real_t.itemsize), C.byref(self._h)))
+
+    # -- multi-device objects
+    @property
+    def dev_count(self):
+        n = C.c_int()
+        self._chk(self._f("multi_dev_count")(self._h, C.byref(n)))
+        return n.value
+
+    def slab(self, i):
+        """particles_t view of slab i of a multi-device object (state getters, set_particles, random replay), owned by the parent"""
+        h = C.c_void_p()
+        self._chk(self._f("multi_slab")(self._h, C.c_int(i), C.byref(h)))
+        return particles_t(self.opts_init, self.real_t, lib=self._lib, prefix=self._px, _borrowed=(h, self))
 
     # -- plumbing
     def _f(self, name):
@@ -346,6 +376,8 @@ class particles_t:
 
     def __del__(self):
         try:
+            if getattr(self, "_owner", None) is not None:
+                return
             if getattr(self, "_h", None) and self._h.value:
                 self._f("destroy")(self._h)
                 self._h = C.c_void_p()
@@ -356,6 +388,12 @@ class particles_t:
         if a is None:
             return None
         ai = _arrinfo_c()
+        if isinstance(a, DeviceArrays):
+            st = (C.c_ssize_t * max(1, len(a.strides)))(*a.strides) if a.strides else (C.c_ssize_t * 1)(1)
+            tab = (C.c_void_p * len(a.ptrs))(*a.ptrs)
+            ai.data, ai.strides, ai.on_device = C.cast(tab, C.c_void_p).value, C.cast(st, C.POINTER(C.c_ssize_t)), 2
+            self._arr_keep.append((st, tab))
+            return ai
         if isinstance(a, DeviceArray):
             st = (C.c_ssize_t * max(1, len(a.strides)))(*a.strides) if a.strides else (C.c_ssize_t * 1)(1)
             ai.data, ai.strides, ai.on_device = a.ptr, C.cast(st, C.POINTER(C.c_ssize_t)), 1
@@ -574,6 +612,7 @@ def factory(backend, opts_init, real_t=np.float64):
     if backend == backend_t.HIP or backend == backend_t.CUDA:
         return particles_t(opts_init, real_t)
     if backend in (backend_t.multi_HIP, backend_t.multi_CUDA):
-        from .multi import particles_multi_t
-        return particles_multi_t(opts_init, real_t)
+        # one object, opts_init.dev_count devices of this process (0: all visible) -- the reference's multi_CUDA.  The SPMD flavour
+        # (one process per GPU, torch.distributed) is libcloudphxx_amd.multi.particles_multi_t.
+        return particles_t(opts_init, real_t, multi=True)
     raise RuntimeError("libcloudph++: backend %s not compiled in this library (available: HIP, multi_HIP)" % backend.name)
