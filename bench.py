@@ -3,14 +3,16 @@
 coalescence, advection, sedimentation, boundary, re-sort) on the BASELINE workload:
 3-D stratocumulus-like box 128^3 cells x 64 super-droplets per cell (BASELINE.json configs[2]).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
+    python bench.py --gpus N ...                      # ONE process, N devices: the native multi_HIP object (lcx_create_multi)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # one process per GPU (SPMD wrapper libcloudphxx_amd/multi.py over RCCL)
 
 A "step" is one full pass of the hot path over all super-droplets.  Inputs (th, rv, rhod, Courant numbers) are
-device-resident when the timed region starts.  Rank 0 prints ONE JSON line.  N > 1: the SAME box is split into N
-slabs along x (strong scaling, as BASELINE.json's metric asks: one problem at 1/2/4/8 GPUs); migrating
-super-droplets are exchanged with the two neighbours over RCCL point-to-point (no collective).
+device-resident when the timed region starts (N > 1: every slab's planes on its own device).  Rank 0 prints ONE JSON line.
+N > 1: the SAME box is split into N slabs along x (strong scaling, as BASELINE.json's metric asks: one problem at 1/2/4/8
+GPUs); super-droplets that cross a slab face are handed to the neighbouring device (no collective).
+--oversubscribe maps all N slabs to device 0 (what a one-GPU box can measure of the N-slab protocol).
 """
 import argparse
 import json
@@ -43,8 +45,7 @@ def make_opts_init(nx, ny, nz, sd_conc, dx, sstp_cond, sstp_coal, seed):
     oi.sd_conc = sd_conc
     oi.n_sd_max = int(nx * ny * nz * sd_conc * 1.15) + 1024
     oi.dry_distros = {(.61, 0.): bimodal()}
-    oi.kernel = lgrngn.kernel_t.hall_pinsky_stratocumulus if os.path.exists(
-        os.path.join(ROOT, "libcloudphxx_amd", "data", "kernel_eff_10.f64")) else lgrngn.kernel_t.Long
+    oi.kernel = lgrngn.kernel_t.hall_pinsky_stratocumulus       # (init fails loudly if its efficiency table is missing)
     oi.terminal_velocity = lgrngn.vt_t.beard77fast
     oi.adve_scheme = lgrngn.as_t.euler
     oi.sstp_cond, oi.sstp_coal = sstp_cond, sstp_coal
@@ -80,8 +81,31 @@ def make_fields(nx_loc, ny, nz, x_off, nx_tot, xp, dtype):
     return [a.contiguous() if hasattr(a, "contiguous") else np.ascontiguousarray(a) for a in (th, rv, rhod, Cx, Cy, Cz)]
 
 
+def host_cpu():
+    """model string and physical core count of the host (printed next to the CPU baseline)"""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not line.strip():
+                if core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return model, len(cores) or (os.cpu_count() or 1)
+
+
 def cpu_baseline(args):
-    """the CPU oracle (a serial port of the reference path) timed on a bounded sample of the same workload"""
+    """the CPU oracle (a port of the reference path, OpenMP on its elementwise loops) timed on a bounded sample of the same workload"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _harness as h
     from libcloudphxx_amd import lgrngn
@@ -89,7 +113,8 @@ def cpu_baseline(args):
     oi = make_opts_init(n, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44)
     th, rv, rhod, Cx, Cy, Cz = make_fields(n, n, n, 0, n, np, np.float64)
     pr = h.oracle_omp_particles(oi)
-    cores = int(h.oracle_omp_lib().orc_num_threads())
+    threads = int(h.oracle_omp_lib().orc_num_threads())
+    model, phys = host_cpu()
     pr.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
     opts = lgrngn.opts_t()
     pr.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
@@ -101,16 +126,21 @@ def cpu_baseline(args):
         pr.step_async(opts)
         done += pr.n_part
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "super-droplets/s", "cores": cores, "kind": "port",
-            "sample": "%d^3 cells x %d SD/cell, %d full steps (cond+coal+adve+sedi), C oracle with OpenMP elementwise loops on %d threads, %.1f s"
-                      % (n, args.sd_conc, args.cpu_sample_steps, cores, dt)}
+    return {"value": done / dt, "unit": "super-droplets/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "physical_cores": phys,
+            "sample": "%d^3 cells x %d SD/cell, %d full steps (cond+coal+adve+sedi), C oracle with OpenMP elementwise loops on %d threads "
+                      "(%s, %d physical cores), %.1f s" % (n, args.sd_conc, args.cpu_sample_steps, threads, model, phys, dt),
+            # the reference's OWN OpenMP backend, timed during the survey in the build container: the anchor
+            # that says what reference code does per core; the port above is what can run on the GPU box
+            "reference_openmp_anchor": {"value": 2.56e6, "unit": "super-droplets/s", "cores": 8, "kind": "reference",
+                                        "sample": "the reference's thrust::omp backend, 64^3-class box, build container, BASELINE.md section 2"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=128, help="cells per dimension (BASELINE: 128)")
     ap.add_argument("--nx", type=int, default=0, help="override the number of x-planes (emulates one slab of a decomposed run)")
     ap.add_argument("--sd-conc", type=int, default=64)
@@ -130,19 +160,29 @@ def main():
                          "many steps (0 = the library default, every 64 steps and with every compaction; -1 = never, the reference's "
                          "storage order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=48)
-    ap.add_argument("--cpu-sample-steps", type=int, default=12)
+    ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    ap.add_argument("--oversubscribe", action="store_true", help="--gpus N in one process with all N slabs on device 0")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))          # > 1: launched by torch.distributed.run, one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    native_multi = world == 1 and args.gpus > 1               # ONE process over args.gpus devices: the native multi_HIP object
+    n_slabs = args.gpus if native_multi else world
+    if world > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
+    if native_multi:
+        if args.oversubscribe:
+            os.environ["LCX_MULTI_DEVICE_MAP"] = ",".join(["0"] * args.gpus)
+        dmap = os.environ.get("LCX_MULTI_DEVICE_MAP")
+        slab_dev = [int(x) for x in dmap.split(",")][:args.gpus] if dmap else list(range(args.gpus))
+        if max(slab_dev) >= torch.cuda.device_count():
+            raise SystemExit("--gpus %d: only %d device(s) visible (use --oversubscribe to put every slab on device 0)"
+                             % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -154,11 +194,11 @@ def main():
     real_t = np.float64 if args.real == "f64" else np.float32
     tdtype = torch.float64 if args.real == "f64" else torch.float32
     n = args.n
-    nx_tot = n * world if args.scaling == "weak" else n
+    nx_tot = n * n_slabs if args.scaling == "weak" else n
     if args.nx:
         nx_tot = args.nx
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
-    oi.dev_id = local_rank
+    oi.dev_id = -1 if native_multi else local_rank
     oi.strict_fp = args.strict_fp
     oi.reorder_every = args.reorder_every
     if args.cond_mode != "percell":
@@ -166,34 +206,54 @@ def main():
         oi.sstp_cond_mix = args.cond_mode == "pp_mix"
         oi.adaptive_sstp_cond = args.cond_mode == "pp_adaptive"
         oi.n_sd_max = int(oi.n_sd_max)
-    if world > 1:
-        prt = multi.particles_multi_t(oi, real_t, device=dev)
-        nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
-    else:
-        prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
-        nx_loc, x_off = nx_tot, 0
 
-    class TorchXP:                      # the tiny subset of the numpy namespace make_fields uses, on the device
-        @staticmethod
-        def arange(m, dtype=None):
-            return torch.arange(m, dtype=tdtype, device=dev)
-        sin, cos, exp, log = staticmethod(torch.sin), staticmethod(torch.cos), staticmethod(torch.exp), staticmethod(torch.log)
-    fields_t = make_fields(nx_loc, n, n, x_off, nx_tot, TorchXP, tdtype)
-    shapes = [(nx_loc, n, n)] * 3 + [(nx_loc + 1, n, n), (nx_loc, n + 1, n), (nx_loc, n, n + 1)]
-    fields_t = [f.expand(s).contiguous() for f, s in zip(fields_t, shapes)]
-    th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in fields_t]
-    torch.cuda.synchronize()
+    def device_fields(nx_loc, x_off, d):
+        class TorchXP:                      # the tiny subset of the numpy namespace make_fields uses, on the device
+            @staticmethod
+            def arange(m, dtype=None):
+                return torch.arange(m, dtype=tdtype, device=d)
+            sin, cos, exp, log = staticmethod(torch.sin), staticmethod(torch.cos), staticmethod(torch.exp), staticmethod(torch.log)
+        f = make_fields(nx_loc, n, n, x_off, nx_tot, TorchXP, tdtype)
+        shapes = [(nx_loc, n, n)] * 3 + [(nx_loc + 1, n, n), (nx_loc, n + 1, n), (nx_loc, n, n + 1)]
+        return [t.expand(sh).contiguous() for t, sh in zip(f, shapes)]
+
+    if native_multi:
+        oi.dev_count = args.gpus
+        oi.n_sd_max = int(oi.n_sd_max * 1.1)            # (per slab: n_sd_max / dev_count + 1, distmem_opts.hpp:47)
+        prt = lgrngn.factory(lgrngn.backend_t.multi_HIP, oi, real_t)
+        per = nx_tot // args.gpus
+        parts = [device_fields(per if r < args.gpus - 1 else nx_tot - r * per, r * per, torch.device("cuda", slab_dev[r]))
+                 for r in range(args.gpus)]
+        fields_t = parts                                   # keep the tensors alive
+        th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArrays([parts[r][k].data_ptr() for r in range(args.gpus)], parts[0][k].shape)
+                                    for k in range(6)]
+        devices = sorted(set(slab_dev))
+    else:
+        if world > 1:
+            prt = multi.particles_multi_t(oi, real_t, device=dev)
+            nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
+        else:
+            prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
+            nx_loc, x_off = nx_tot, 0
+        fields_t = device_fields(nx_loc, x_off, dev)
+        th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in fields_t]
+        devices = [local_rank]
+
+    def sync_all():
+        for d in devices:
+            torch.cuda.synchronize(d)
+    sync_all()
 
     t_init = time.perf_counter()
     prt.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
-    torch.cuda.synchronize()
+    sync_all()
     t_init = time.perf_counter() - t_init
     opts = lgrngn.opts_t()
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync_all()
 
     def one_step():
         prt.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
@@ -222,13 +282,14 @@ def main():
         elapsed, sd_total = float(tmax[0]), float(tsum[1])
     else:
         sd_total = float(sd_done)
+    world_out = n_slabs
 
     if rank == 0:
         R = 8 if args.real == "f64" else 4
         # ALGORITHMIC bytes of the dominant kernel (k_cond), SURVEY 8(d): 5R (rw2,rd3,kpa,vt read + rw2 write)
         # + I (sorted_id + sorted_ijk, two u32 = 8 B) + N (multiplicity, 8 B) per super-droplet per substep
         cond_bytes_per_sd = 5 * R + 8 + 8
-        n_local = sd_done / max(args.steps, 1)
+        n_local = sd_done / max(args.steps, 1) / (n_slabs if native_multi else 1)      # super-droplets per device and step
         roof = None
         if "cond" in stage_ms and args.cond_mode == "percell":
             launches = args.steps * args.sstp_cond
@@ -237,24 +298,32 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
-            # HBM bytes per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE, KiB; they
-            # cannot be collected inside a timed run): reported only for the configuration they were measured on
-            default_cfg = (world == 1 and n == 128 and not args.nx and args.sd_conc == 64 and args.real == "f64"
+            # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
+            # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
+            default_cfg = (world_out == 1 and n == 128 and not args.nx and args.sd_conc == 64 and args.real == "f64"
                            and not args.strict_fp and args.sstp_cond == 1)
             if default_cfg:
                 import glob
-                for tf in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))[-1:]:
-                    t = json.load(open(tf)).get("lcx::k_cond<double, true>")
+                for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1:]:
+                    tj = json.load(open(tf))
+                    t = next((v for k_, v in tj.items() if k_.startswith("lcx::k_cond_fast<double")), None)
                     if t:
+                        src = "profiles/" + os.path.basename(tf)
                         roof["traffic"] = t["hbm_bytes"]
-                        roof["traffic_source"] = "profiles/" + os.path.basename(tf)
+                        roof["traffic_source"] = src
                         if "valu_insts" in t:
-                            # what actually bounds this kernel: vector issue.  A wave64 VALU instruction occupies its SIMD for 4
-                            # cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)
-                            slots = 1024 * 2.4e9 * avg_ms * 1e-3 / 4
-                            roof["valu"] = {"wave_insts_per_launch": t["valu_insts"], "issue_frac": t["valu_insts"] / slots,
-                                            "f64_arith_frac_of_insts": t.get("valu_f64_insts", 0) / t["valu_insts"],
-                                            "source": "profiles/" + os.path.basename(tf)}
+                            # the second roof: fp64 vector arithmetic.  78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 x 2.4 GHz.
+                            # A wave64 fp64 instruction occupies its SIMD for 4 cycles, any other VALU instruction for 2
+                            # (MI355X_MICROARCH.md); lane_util = share of the 64 lanes that were active per VALU instruction
+                            f64 = t.get("valu_f64_insts", 0)
+                            cyc = 4 * f64 + 2 * (t["valu_insts"] - f64)
+                            flop = (2 * t.get("valu_fma_f64", 0) + t.get("valu_mul_f64", 0) + t.get("valu_add_f64", 0) + t.get("valu_trans_f64", 0)) * 64
+                            lane = t["thread_cycles_valu"] / (t["valu_insts"] * 64) if t.get("thread_cycles_valu") else None
+                            roof["fp64_valu"] = {"achieved_tflops": flop / (avg_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
+                                                 "frac": flop / (avg_ms * 1e-3) / 1e12 / 78.6,
+                                                 "useful_tflops": (flop * lane / (avg_ms * 1e-3) / 1e12) if lane else None,
+                                                 "issue_frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3), "lane_util": lane,
+                                                 "wave_insts_per_launch": t["valu_insts"], "f64_insts_per_launch": f64, "source": src}
         # attainable HBM bandwidth on this device (device-to-device copy of 1 GiB, read + write), SURVEY 8(d)
         a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev); b_ = torch.empty_like(a_)
         b_.copy_(a_); torch.cuda.synchronize()
@@ -267,7 +336,7 @@ def main():
         del a_, b_
         # per-stage achieved algorithmic bandwidth (bytes per SD from SURVEY 8(d) with 4-byte indices: I = 4)
         I = 4
-        stage_bytes = {"cond": 5 * R + 2 * I + 8, "cond_cellfinish": 2 * R, "hskpng_vterm_all": 2 * R + I,
+        stage_bytes = {"cond": 5 * R + 2 * I + 8, "cond_cellfinish": (1 if not args.strict_fp else 2) * R, "hskpng_vterm_all": 2 * R + I,
                        "hskpng_shuffle_and_sort": 2 * I, "coal": 2 * I + R / 2 + 8 + 3 * R,
                        "move(adve+sedi+bcnd)": 7 * R + 2 * I, "post_copy": 3 * I}
         stage_roof = {}
@@ -281,7 +350,7 @@ def main():
             "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
             "value": sd_total / elapsed,
             "unit": "super-droplets/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world_out, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": args.scaling,
@@ -290,14 +359,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
                                    % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
-                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d" % world, "cond_mode": args.cond_mode,
+                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, " (one process, native multi_HIP%s)" % (", all slabs on device 0" if args.oversubscribe else "") if native_multi else (" (one process per GPU, RCCL)" if world > 1 else "")), "cond_mode": args.cond_mode,
                        "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
                        "init_s": t_init},
             "roofline": roof,
             "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
             "stage_roofline": stage_roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world_out == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:

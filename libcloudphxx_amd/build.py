@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "liblcx_hip.so")
 SRCS = ["lcx_core.hip"]
-DEPS = ["lcx_core.hip", "lcx_kernels.hpp", "lcx_math.hpp", os.path.join("..", "..", "include", "lcx.h")]
+DEPS = ["lcx_core.hip", "lcx_kernels.hpp", "lcx_math.hpp", "lcx_multi.hpp", os.path.join("..", "..", "include", "lcx.h")]
 
 
 def needs_build():

@@ -136,7 +136,7 @@ struct Particles : IParticles {
   long long seed_now() const { return in_init && o.rng_seed_init_switch ? o.rng_seed_init : o.rng_seed; }
   bool replay_used = false;   // a parity run: storage stays in the reference's id order (see opts_init.reorder_every)
   bool no_cond_pre = getenv("LCX_NO_COND_PRE") != nullptr;   // test switch: evaluate the per-cell set-up per droplet instead
-  uint64_t cells_version = 0, nobig_version = ~0ull;   // order_cells: "no cell above CELLRANK_MAX" is remembered per cell_start
+  uint64_t cells_version = 0;   // order_cells: the list of cells above CELLRANK_MAX is remembered per cell_start
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
   int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
@@ -144,7 +144,7 @@ struct Particles : IParticles {
   std::vector<double> SGS_mix_len_h; DevBuf<T> SGS_mix_len, diss_rate, tau_cell, tau_rlx;
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
-  DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, big_meta, mig_ids[2];
+  DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, step_cnt, mig_ids[2];
   DevBuf<uint8_t> mig, cond_pre;
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
@@ -154,7 +154,10 @@ struct Particles : IParticles {
   size_t n_cx = 0, n_cy = 0, n_cz = 0;
   DevBuf<T> stage_dev; std::vector<T> stage_host, outbuf_h;
   DevBuf<double> puddle_partial, puddle_sum, puddle_acc;
-  DevBuf<int> d_flag; DevBuf<unsigned int> d_dead;
+  DevBuf<int> d_flag;
+  // step_cnt: [0] dead SDs counted by the fused move, [1] number of crowded cells, [2] largest cell occupancy -- one read-back
+  unsigned int *d_dead_p() { return step_cnt.p; }
+  uint32_t *big_meta_p() { return step_cnt.p + 1; }
   void *pinned = nullptr;      // 256 B of page-locked host memory for the small per-step read-backs (counts, sums)
   double puddle[LCX_OUT_COUNT];
   bool count_mom_valid_all = true;
@@ -235,14 +238,14 @@ struct Particles : IParticles {
     }
     if (use_rc2) hipLaunchKernelGGL(k_fill<T>, dim3(nblk(cap)), dim3(BS), 0, st, A.ext[ix_rc2].p, cap, T(-1));   // detail::invalid, particles_impl.ipp:490
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
-    cell_cnt.alloc(ncell); cell_start.alloc_zero(ncell + 1, st);
+    cell_cnt.alloc_zero(ncell, st); cell_start.alloc_zero(ncell + 1, st);
     tile_sums.alloc(2 * (std::max(cap, ncell) / SCAN_TILE + 2)); scan_total.alloc(4);   // (two halves for the two migrant lists)
-    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); big_meta.alloc(2);
+    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); step_cnt.alloc_zero(4, st);
     m3_before.alloc(cap); m3_after.alloc(cap);
     if (oi.coal_switch) col.alloc(cap);
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
       b->alloc_zero(ncell, st);
-    d_flag.alloc_zero(1, st); d_dead.alloc_zero(1, st);
+    d_flag.alloc_zero(1, st);
     puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4); puddle_acc.alloc_zero(4, st);
     outbuf_h.assign(ncell, T(0));
     if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
@@ -308,13 +311,14 @@ struct Particles : IParticles {
   }
 
   // ---- device exclusive scan: out[0..m) = exclusive scan of in, out[m] (if out_last) = total; returns nothing (async) ----
-  void exclusive_scan(const uint32_t *in, uint32_t *out, size_t m, uint32_t *out_last)
+  void exclusive_scan(const uint32_t *in, uint32_t *out, size_t m, uint32_t *out_last, uint32_t *zero_in = nullptr, uint32_t *zero_words = nullptr,
+                      int n_zero_words = 0)
   {
     const size_t tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) { if (out_last) HIPCHK(hipMemsetAsync(out_last, 0, sizeof(uint32_t), st)); HIPCHK(hipMemsetAsync(scan_total.p, 0, sizeof(uint32_t), st)); return; }
     hipLaunchKernelGGL(k_scan_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, in, out, tile_sums.p, m);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblk(m)), dim3(BS), 0, st, out, tile_sums.p, m, scan_total.p, out_last);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblk(m)), dim3(BS), 0, st, out, tile_sums.p, m, scan_total.p, out_last, zero_in, zero_words, n_zero_words);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -334,6 +338,22 @@ struct Particles : IParticles {
   }
   // halo_planes > 0 (Courant numbers with pred_corr): the device array starts that many x-planes left of the user's array;
   // planes outside it wrap around the n_x_tot + ex planes cyclically (init_e2l.ipp:44-46,109-113)
+  // device-resident caller arrays are gathered / scattered by ONE launch per call (flush_sync_jobs)
+  sync_jobs<T> jobs_in{}, jobs_out{};
+  void add_job(sync_jobs<T> &J, T *lib, const T *user, size_t n, int n1, int n2, long s0, long s1, long s2, long i_off, long wrap)
+  {
+    const int j = J.n_jobs++;
+    if (j == 0) J.first_block[0] = 0;
+    J.ndims = n_dims;
+    J.dst[j] = lib; J.src[j] = user; J.n[j] = n; J.n1[j] = n1; J.n2[j] = n2; J.s0[j] = s0; J.s1[j] = s1; J.s2[j] = s2; J.i_off[j] = i_off; J.wrap[j] = wrap;
+    J.first_block[j + 1] = J.first_block[j] + nblk(n);
+  }
+  void flush_sync_jobs()
+  {
+    if (jobs_in.n_jobs) hipLaunchKernelGGL((k_sync_multi<T, true>), dim3(jobs_in.first_block[jobs_in.n_jobs]), dim3(BS), 0, st, jobs_in);
+    if (jobs_out.n_jobs) hipLaunchKernelGGL((k_sync_multi<T, false>), dim3(jobs_out.first_block[jobs_out.n_jobs]), dim3(BS), 0, st, jobs_out);
+    jobs_in.n_jobs = jobs_out.n_jobs = 0;
+  }
   void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0)
   {
     if (is_null(a)) return;
@@ -344,8 +364,8 @@ struct Particles : IParticles {
     const bool local = a->on_device == 3;
     const long wrap = halo_planes ? (local ? long(o.nx) : long(o.n_x_tot)) + ex : 0;
     if (a->on_device) {
-      hipLaunchKernelGGL(k_gather_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, to.p, (const T *)a->data, n, n_dims, n1, n2, s0, s1, s2,
-                         (local ? 0l : long(o.n_x_bfr)) - halo_planes, wrap);
+      if (jobs_in.n_jobs == MAX_SYNC_JOBS) flush_sync_jobs();
+      add_job(jobs_in, to.p, (const T *)a->data, n, n1, n2, s0, s1, s2, (local ? 0l : long(o.n_x_bfr)) - halo_planes, wrap);
       return;
     }
     stage_host.resize(n);
@@ -367,8 +387,8 @@ struct Particles : IParticles {
     int n1, n2; long s0, s1, s2;
     arr_geom(a, 0, 0, 0, n1, n2, s0, s1, s2);
     if (a->on_device) {
-      hipLaunchKernelGGL(k_scatter_strided<T>, dim3(nblk(n)), dim3(BS), 0, st, (T *)a->data, (const T *)from.p, n, n_dims, n1, n2, s0, s1, s2,
-                         a->on_device == 3 ? 0l : long(o.n_x_bfr));
+      if (jobs_out.n_jobs == MAX_SYNC_JOBS) flush_sync_jobs();
+      add_job(jobs_out, from.p, (const T *)a->data, n, n1, n2, s0, s1, s2, a->on_device == 3 ? 0l : long(o.n_x_bfr), 0);
       return;
     }
     stage_host.resize(n);
@@ -430,11 +450,21 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   // housekeeping
   // ------------------------------------------------------------------------------------------
-  void hskpng_Tpr()
+  bool vtpre_valid = false;       // vt_pre (the cell part of beard77) matches the current T, p, eta
+  // with_vtpre: the cell pass of step_async -- hskpng_Tpr and the cell part of the beard77 terminal velocity in one launch
+  void hskpng_Tpr(bool with_vtpre = false)
   {
     Range r(this, "hskpng_Tpr");
+    if (with_vtpre && (vtc.formula == LCX_VT_BEARD77 || vtc.formula == LCX_VT_BEARD77FAST)) {
+      vt_pre.alloc(ncell);
+      hipLaunchKernelGGL(k_cell_Tpr_vtpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p,
+                         o.th_dry, o.const_p, o.RH_formula, n_dims, vt_pre.p);
+      vtpre_valid = true;
+      return;
+    }
     hipLaunchKernelGGL(k_cell_Tpr<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p,
                        o.th_dry, o.const_p, o.RH_formula, n_dims);
+    vtpre_valid = false;
   }
   void hskpng_mfp()
   {
@@ -450,10 +480,15 @@ struct Particles : IParticles {
   }
   void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(2, false); sorted = false; }
   // finish a sort given cell_cnt/rank: scan -> scatter -> per-cell order
-  void sort_from_hist(bool shuffle)
+  // meta_known: {number of cells above CELLRANK_MAX, largest occupancy} already on the host (listed from the histogram ahead of the
+  // step's read-back), else order_cells lists them from the CSR offsets and pays a host round trip of its own
+  uint32_t big_n = 0, big_mx = 0; uint64_t meta_version = ~0ull;
+  void sort_from_hist(bool shuffle, const uint32_t *meta_known = nullptr)
   {
-    exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell);
+    // (the scan leaves the histogram and the step's counters cleared for the next fused move)
+    exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, cell_cnt.p, step_cnt.p, 3);
     ++cells_version;
+    if (meta_known) { big_n = meta_known[0]; big_mx = meta_known[1]; meta_version = cells_version; }
     if (nphys)
       hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
     order_cells(shuffle);
@@ -466,22 +501,22 @@ struct Particles : IParticles {
       if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
       else {
-        // the list of cells too big for k_cellrank costs a host round trip; the in-cell shuffle of coalescence re-orders the
-        // SAME segments as the sort before it, so "none" is remembered until cell_start changes
-        const bool known_nobig = nobig_version == cells_version;
-        if (!known_nobig) {
-          HIPCHK(hipMemsetAsync(big_meta.p, 0, 2 * sizeof(uint32_t), st));
-          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p,
-                             uint32_t(shuffle ? cellrank_max<uint64_t> : cellrank_max<uint32_t>), big_list.p, big_meta.p, big_meta.p + 1);
+        // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
+        // the in-cell shuffle of coalescence re-orders the SAME segments as the sort before it, so the list is kept until cell_start changes
+        if (meta_version != cells_version) {
+          HIPCHK(hipMemsetAsync(big_meta_p(), 0, 2 * sizeof(uint32_t), st));
+          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, uint32_t(CELLRANK_MAX), big_list.p, big_meta_p(), big_meta_p() + 1,
+                             (const uint32_t *)nullptr);
         }
         if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
-        uint32_t meta[2] = {0, 0};
-        if (!known_nobig) {
-          read_back(meta, big_meta.p, 2);
-          if (!meta[0]) nobig_version = cells_version;
+        if (meta_version != cells_version) {
+          uint32_t m2[2];
+          read_back(m2, big_meta_p(), 2);
+          big_n = m2[0]; big_mx = m2[1]; meta_version = cells_version;
         }
+        const uint32_t meta[2] = {big_n, big_mx};
         if (meta[0]) {
           const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
           if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
@@ -517,8 +552,11 @@ struct Particles : IParticles {
     Range r(this, only_invalid ? "hskpng_vterm_invalid" : "hskpng_vterm_all");
     if (!nphys) return;
     if (vtc.formula == LCX_VT_BEARD77 || vtc.formula == LCX_VT_BEARD77FAST) {
-      vt_pre.alloc(ncell);
-      hipLaunchKernelGGL(k_vterm_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, p.p, rhod.p, eta.p, vt_pre.p);
+      if (!vtpre_valid) {
+        vt_pre.alloc(ncell);
+        hipLaunchKernelGGL(k_vterm_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, p.p, rhod.p, eta.p, vt_pre.p);
+        vtpre_valid = true;
+      }
       if (o.strict_fp) hipLaunchKernelGGL((k_vterm_b77<T, false>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
       else             hipLaunchKernelGGL((k_vterm_b77<T, true>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
       return;
@@ -645,14 +683,26 @@ struct Particles : IParticles {
     sort_from_hist(false);
   }
   // post_copy when k_move has already produced ijk / histogram / ranks / the dead count
+  bool listed_from_hist = false, meta_known_valid = false; uint32_t meta_known_v[2] = {0, 0};
+  void list_big_from_hist()
+  {   // (big_meta was cleared behind the previous sort's scan)
+    hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p, big_meta_p(), big_meta_p() + 1,
+                       (const uint32_t *)cell_cnt.p);
+    listed_from_hist = true;
+  }
   void post_copy_after_fused_move(const lcx_opts_t &opts, long dead_known = -1)
   {
     unsigned int dead = 0;
-    if (dead_known >= 0) dead = unsigned(dead_known);             // (multi_HIP: came with the exchange's single read-back)
+    uint32_t meta[2] = {0, 0}; const uint32_t *meta_p = nullptr;
+    if (dead_known >= 0) { dead = unsigned(dead_known); if (meta_known_valid) { meta[0] = meta_known_v[0]; meta[1] = meta_known_v[1]; meta_p = meta; } }
     else {
-      read_back(&dead, d_dead.p, 1);
+      uint32_t h[3];
+      read_back(h, step_cnt.p, 3);                                // dead count (+ the crowded cells, if the move listed them)
+      dead = h[0];
+      if (listed_from_hist) { meta[0] = h[1]; meta[1] = h[2]; meta_p = meta; }
       dead -= unsigned(std::min<size_t>(reused_total, dead));     // emigrants' slots that immigrants have taken over are alive again
     }
+    listed_from_hist = meta_known_valid = false;
     reused_total = 0;
     // reference storage order (stable compaction only) when asked for, and in every parity run (a replayed stream is indexed by id)
     const bool strict_order = this->strict_order();
@@ -660,7 +710,7 @@ struct Particles : IParticles {
     if (compact_now && strict_order) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
     npart = nphys - dead;
-    sort_from_hist(false);
+    sort_from_hist(false, meta_p);
     // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
     const int every = o.reorder_every > 0 ? o.reorder_every : 64;       // 0: the default period
     if (compact_now || (!strict_order && ++steps_since_reorder >= every)) reorder_storage();
@@ -722,6 +772,16 @@ struct Particles : IParticles {
     // fast arithmetic (no SGS supersaturation): per-cell set-up hoisted (k_cond_cellpre) and one scratch value per droplet (the
     // change of n rw^3); strict arithmetic: n rw^3 before and after in position order + the ordered per-cell walk
     const bool fast = !o.strict_fp && !turb_cond && !no_cond_pre;
+    {
+      // the substep's cell pass in one launch: mean free paths (substep 0, from the previous T and p as the reference's hskpng_mfp
+      // ahead of the loop), hskpng_Tpr, and in fast arithmetic the droplet-independent set-up of the growth rate
+      Range r(this, "hskpng_Tpr");
+      if (fast) cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
+      hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p,
+                         lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
+                         fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr);
+      vtpre_valid = false;
+    }
     if (npart) {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
@@ -729,10 +789,7 @@ struct Particles : IParticles {
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       if (fast) {
-        cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
-        hipLaunchKernelGGL(k_cond_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, rhod.p, rv.p, Tk.p, eta.p, RH.p, lambda_D.p, lambda_K.p,
-                           T(RH_max), reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p));
         hipLaunchKernelGGL((k_cond_fast<T>), gr, bl, 0, st, npart, a);
       }
       else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
@@ -909,17 +966,14 @@ struct Particles : IParticles {
     const unsigned blocks = nblk(nphys);
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
     a.mig = mig.p;
-    if (do_bcnd && distmem()) HIPCHK(hipMemsetAsync(mig.p, 0, nphys, st));
-    a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead.p;
-    if (reindex) {
-      HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
-      HIPCHK(hipMemsetAsync(d_dead.p, 0, sizeof(unsigned int), st));
-    }
+    // (no memsets: every lane stores its migrant flag, and the histogram and the dead count are cleared behind each sort's scan)
+    a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead_p();
     const bool pc = adve_scheme == LCX_ADVE_PRED_CORR, tb = a.up != nullptr;
     if (pc && tb) hipLaunchKernelGGL((k_move<T, true, true>), dim3(blocks), dim3(BS), 0, st, a);
     else if (pc) hipLaunchKernelGGL((k_move<T, true, false>), dim3(blocks), dim3(BS), 0, st, a);
     else if (tb) hipLaunchKernelGGL((k_move<T, false, true>), dim3(blocks), dim3(BS), 0, st, a);
     else hipLaunchKernelGGL((k_move<T, false, false>), dim3(blocks), dim3(BS), 0, st, a);
+    if (reindex && !distmem()) list_big_from_hist();                    // (with neighbours: after their immigrants are in, exch_unpack)
     if (want_puddle && dev_exchange) puddle_pending_blocks = blocks;      // (reduced after the emigrants are on their way, see lcx_multi.hpp)
     else if (want_puddle) puddle_reduce(blocks);
     if (do_bcnd && distmem()) build_migrant_lists();
@@ -930,10 +984,9 @@ struct Particles : IParticles {
   {
     {
       const size_t slices = 256, per = (size_t(blocks) + slices - 1) / slices;
-      hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4);
-      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_sum.p + 4, slices, slices, puddle_sum.p);
+      hipLaunchKernelGGL(k_sum_partials, dim3(unsigned(slices)), dim3(BS), 0, st, puddle_partial.p, size_t(blocks), per, puddle_sum.p + 4, (double *)nullptr);
       // running totals stay on the device (same additions in the same order as on the host); diag_puddle reads them
-      hipLaunchKernelGGL(k_accumulate4, dim3(1), dim3(64), 0, st, puddle_sum.p, puddle_acc.p);
+      hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, st, puddle_sum.p + 4, slices, slices, puddle_sum.p, puddle_acc.p);
     }
   }
   void build_migrant_lists()
@@ -1269,6 +1322,7 @@ struct Particles : IParticles {
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     sync_in_arr(p_, p, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
+    flush_sync_jobs();
     if (n_dims > 0)
       hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
                          T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
@@ -1306,6 +1360,7 @@ struct Particles : IParticles {
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     if (turb_any()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
+    flush_sync_jobs();
     if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
       HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
       hipLaunchKernelGGL(k_flag_outside<T>, dim3(nblk(n_cx)), dim3(BS), 0, st, courant_x.p, n_cx, T(-2.), T(2.), d_flag.p);
@@ -1325,17 +1380,15 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_incloud_time<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, A.rd3.p, A.kpa.p, A.rw2.p, Tk.p, T(dt), A.ext[ix_ict].p);
     if (opts.cond) {
       hskpng_sort();
-      hskpng_mfp();
-      if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) cond_perparticle(opts.RH_max, opts.turb_cond);
+      if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) { hskpng_mfp(); cond_perparticle(opts.RH_max, opts.turb_cond); }
       else for (int step = 0; step < sstp_cond; ++step) {
         sstp_percell_step(step);
         if (opts.turb_cond && nphys)                                                     // apply_perparticle_sgs_supersat.ipp
           hipLaunchKernelGGL(k_sgs_supersat<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, T(T(dt) / sstp_cond), A.ext[ix_dot_ssp].p, A.ext[ix_ssp].p);
-        hskpng_Tpr();
-        cond_substep(opts.RH_max, step, opts.turb_cond);
+        cond_substep(opts.RH_max, step, opts.turb_cond);                                 // (hskpng_mfp at substep 0 and hskpng_Tpr inside)
       }
       sstp_save();
-      { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); }
+      { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); flush_sync_jobs(); }
     }
     sync();
     should_now_run_async = true;
@@ -1355,7 +1408,7 @@ struct Particles : IParticles {
     if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
     adjust_timesteps(opts.dt);
-    hskpng_Tpr();
+    hskpng_Tpr(opts.sedi || opts.coal || opts.cond);
     if (opts.sedi || opts.coal || opts.cond) hskpng_vterm(false);
     if (opts.coal) {
       for (int step = 0; step < sstp_coal; ++step) {
@@ -1684,36 +1737,34 @@ struct Particles : IParticles {
     // number of 1 (the ring test) moves a whole plane, pred_corr allows 2
     inbox_cap_rec = std::min<size_t>(cap, 2 * cap / size_t(std::max(o.nx, 1)) + 1024);
     for (auto &b : inbox) { b.alloc(EXCH_HDR + inbox_cap_rec * migrate_record_bytes()); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
-    xcnt.alloc_zero(8, st);
+    xcnt.alloc_zero(12, st);
     if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
     sync();
   }
-  // emigrants of `side` -> the neighbour's inbox (a pointer this device can write: peer-mapped, or an inbox on this very device)
-  void exch_pack(int side, double x_rmt, uint8_t *remote_inbox)
+  // emigrants of both faces -> the neighbours' inboxes (pointers this device can write: peer-mapped, or inboxes on this very device;
+  // nullptr: no neighbour behind that face), their multiplicities cleared in the same launch
+  void exch_pack(uint8_t *inbox_of_lft, double lft_x1, uint8_t *inbox_of_rgt, double rgt_x0)
   {
-    hipLaunchKernelGGL(k_pack_dev<T>, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + side, uint32_t(inbox_cap_rec), mig_ids[side].p, aset(A), g,
-                       T(x_rmt), T(side == 0 ? o.x0 : o.x1), remote_inbox);
-  }
-  void exch_flag(bool lft, bool rgt)
-  {
-    if (lft) hipLaunchKernelGGL(k_flag_ids_dev, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + 0, mig_ids[0].p, A.n.p);
-    if (rgt) hipLaunchKernelGGL(k_flag_ids_dev, dim3(nblk(inbox_cap_rec)), dim3(BS), 0, st, scan_total.p + 1, mig_ids[1].p, A.n.p);
+    const unsigned half = nblk(inbox_cap_rec);
+    hipLaunchKernelGGL(k_pack_dev<T>, dim3(2 * half), dim3(BS), 0, st, scan_total.p, uint32_t(inbox_cap_rec), half,
+                       pack_side<T>{mig_ids[0].p, inbox_of_lft, T(lft_x1), T(o.x0)}, pack_side<T>{mig_ids[1].p, inbox_of_rgt, T(rgt_x0), T(o.x1)}, aset(A), g);
   }
   void exch_unpack(bool from_l, bool from_r)
   {
     Range r(this, "exchange_unpack");
-    HIPCHK(hipMemsetAsync(xcnt.p + 7, 0, sizeof(uint32_t), st));
+    HIPCHK(hipMemsetAsync(xcnt.p + 8, 0, sizeof(uint32_t), st));
     hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr, nphys, cap,
                        aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, strict_order() ? (const uint32_t *)nullptr : scan_total.p,
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 7);
-    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, d_dead.p, scan_total.p, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr,
-                       xcnt.p + 7, xcnt.p);
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 8);
+    if (fused_pending) list_big_from_hist();            // the histogram is complete now: crowded cells for order_cells, same read-back
+    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, step_cnt.p, scan_total.p, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr,
+                       xcnt.p + 8, xcnt.p);
   }
   size_t exch_moved = 0;       // super-droplets this slab has sent so far (bench / diagnostics)
   void exch_finish(const lcx_opts_t &opts)
   {
-    uint32_t h[6];
-    read_back(h, xcnt.p, 6);                            // the step's one host synchronisation
+    uint32_t h[8];
+    read_back(h, xcnt.p, 8);                            // the step's one host synchronisation
     if (h[5] & 1u) throw lcx_error("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (" +
                                     std::to_string(inbox_cap_rec) + " records); raise opts_init.n_sd_max");
     if (h[5] & 2u) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part after the neighbour exchange");
@@ -1721,7 +1772,11 @@ struct Particles : IParticles {
     exch_moved += size_t(h[1]) + h[2];
     nphys += n_in - reuse;
     lft_count = rgt_count = 0; free_n[0] = free_n[1] = 0; free_used = 0; reused_total = 0;
-    if (fused_pending) { fused_pending = false; post_copy_after_fused_move(opts, long(h[0]) - long(reuse)); }
+    if (fused_pending) {
+      fused_pending = false;
+      meta_known_valid = listed_from_hist; meta_known_v[0] = h[6]; meta_known_v[1] = h[7];
+      post_copy_after_fused_move(opts, long(h[0]) - long(reuse));
+    }
     else post_copy(opts);
   }
 

@@ -63,6 +63,35 @@ __global__ void k_scatter_strided(T *dst, const T *src, size_t n, int ndims, int
   dst[off] = src[c];
 }
 
+// several fields in ONE launch (sync_in moves up to seven arrays per step; on a slab of a decomposed domain seven launches of a few
+// microseconds each were a measurable share of a 2 ms step): job j owns the blocks [first_block[j], first_block[j+1])
+constexpr int MAX_SYNC_JOBS = 8;
+template <class T> struct sync_jobs {
+  int n_jobs, ndims;
+  T *dst[MAX_SYNC_JOBS]; const T *src[MAX_SYNC_JOBS]; size_t n[MAX_SYNC_JOBS];
+  int n1[MAX_SYNC_JOBS], n2[MAX_SYNC_JOBS]; long s0[MAX_SYNC_JOBS], s1[MAX_SYNC_JOBS], s2[MAX_SYNC_JOBS], i_off[MAX_SYNC_JOBS], wrap[MAX_SYNC_JOBS];
+  unsigned first_block[MAX_SYNC_JOBS + 1];
+};
+template <class T, bool GATHER>          // GATHER: strided caller array -> contiguous library array; else the reverse (sync out)
+__global__ void k_sync_multi(sync_jobs<T> J)
+{
+  int j = 0;
+  while (j + 1 < J.n_jobs && blockIdx.x >= J.first_block[j + 1]) ++j;
+  const size_t c = size_t(blockIdx.x - J.first_block[j]) * blockDim.x + threadIdx.x;
+  if (c >= J.n[j]) return;
+  const int n1 = J.n1[j], n2 = J.n2[j];
+  long i = J.ndims == 0 ? 0 : J.ndims == 1 ? long(c) : J.ndims == 2 ? long(c / n2) : long(c / (size_t(n2) * n1));
+  i += J.i_off[j];
+  if (J.wrap[j] > 0) { if (i >= J.wrap[j]) i -= J.wrap[j]; else if (i < 0) i += J.wrap[j]; }
+  long off;
+  if (J.ndims == 0) off = 0;
+  else if (J.ndims == 1) off = i * J.s0[j];
+  else if (J.ndims == 2) off = i * J.s0[j] + long(c % n2) * J.s1[j];
+  else off = i * J.s0[j] + long((c / n2) % n1) * J.s1[j] + long(c % n2) * J.s2[j];
+  if (GATHER) J.dst[j][c] = J.src[j][off];
+  else const_cast<T *>(J.src[j])[off] = J.dst[j][c];     // (sync out: `src` is the caller's array, `dst` the library's)
+}
+
 // ---- exclusive scan of u32 (three launches: per-tile scan, scan of tile sums, add) ----
 constexpr int SCAN_TILE = 2048;         // 256 threads x 8 items, items interleaved for coalescing
 
@@ -111,11 +140,15 @@ __global__ void k_scan_sums(uint32_t *sums, size_t m, uint32_t *total)
   }
   if (threadIdx.x == 0) *total = run;
 }
-__global__ void k_scan_add(uint32_t *out, const uint32_t *tile_offs, size_t n, const uint32_t *total, uint32_t *out_last)
+// zero_in: the scanned input is cleared behind the scan (the cell histogram is all zeros whenever no sort is in flight, so the
+// passes that fill it need no memset of their own); zero_words: a few single counters cleared on the same occasion
+__global__ void k_scan_add(uint32_t *out, const uint32_t *tile_offs, size_t n, const uint32_t *total, uint32_t *out_last,
+                           uint32_t *zero_in = nullptr, uint32_t *zero_words = nullptr, int n_zero_words = 0)
 {
   const size_t i = gid();
-  if (i < n) out[i] += tile_offs[i / SCAN_TILE];
+  if (i < n) { out[i] += tile_offs[i / SCAN_TILE]; if (zero_in) zero_in[i] = 0u; }
   if (i == 0 && out_last) *out_last = *total;        // out[n] = total (CSR end)
+  if (i < size_t(n_zero_words)) zero_words[i] = 0u;
 }
 
 // ============================================================================================
@@ -142,6 +175,27 @@ __global__ void k_cell_mfp(size_t n_cell, const T *Tk, const T *p, T *lambda_D, 
   const size_t c = gid(); if (c >= n_cell) return;
   lambda_D[c] = lambda_D_of(Tk[c]);
   lambda_K[c] = lambda_K_of(Tk[c], p[c]);
+}
+// condensation substep's cell pass in one launch: (substep 0) the mean free paths from the temperature and pressure of the PREVIOUS
+// housekeeping, as the reference's hskpng_mfp placed ahead of the substep loop (particles_step.ipp:193-196) -- then hskpng_Tpr --
+// then (fast arithmetic) the droplet-independent set-up of the growth rate.  Same expressions as the three kernels it replaces.
+template <class T>
+__global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv, T *lambda_D, T *lambda_K,
+                                int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  T lD, lK;
+  if (do_mfp) { lD = lambda_D_of(Tk[c]); lK = lambda_K_of(Tk[c], p[c]); lambda_D[c] = lD; lambda_K[c] = lK; }
+  else { lD = lambda_D[c]; lK = lambda_K[c]; }
+  const T t = th_dry ? theta_dry_T(th[c], rhod[c]) : T(th[c] * exner(p[c]));
+  Tk[c] = t;
+  T pp = p[c];
+  if (!const_p) { pp = theta_dry_p(rhod[c], rv[c], t); p[c] = pp; }
+  const T rh = RH_of(RH_formula, pp, rv[c], t), et = visc(t);
+  RH[c] = rh;
+  eta[c] = et;
+  if (ndims == 0) dv[c] = T(1) / rhod[c];
+  if (pre) pre[c] = make_cond_cell_fast(rhod[c], rv[c], t, et, lD, lK, rh, RH_max);
 }
 // sstp_percell_step.ipp:7-48 for one field
 template <class T>
@@ -298,11 +352,13 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
 }
 // the cells with more than `thr` SDs: wave-aggregated append (one atomic per wave of 64 cells, not one per cell -- with
 // 512 SDs in every cell a per-cell atomicAdd on one counter cost more than the sort itself)
-__global__ void k_list_big_cells(size_t n_cell, const uint32_t *cell_start, uint32_t thr, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max)
+// counts != nullptr: straight from the cell histogram (before the scan: the fused move has just produced it), else from the CSR offsets
+__global__ void k_list_big_cells(size_t n_cell, const uint32_t *cell_start, uint32_t thr, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max,
+                                 const uint32_t *counts = nullptr)
 {
   const size_t c = gid();
   uint32_t cnt = 0;
-  if (c < n_cell) cnt = cell_start[c + 1] - cell_start[c];
+  if (c < n_cell) cnt = counts ? counts[c] : cell_start[c + 1] - cell_start[c];
   const bool big = cnt > thr;
   const unsigned long long bal = __ballot(big);
   if (!bal) return;
@@ -483,6 +539,22 @@ __device__ __forceinline__ T vt_eval(const vt_cfg &v, T rw2, T Tk, T p, T rhod, 
 template <class T>
 __global__ void k_vterm_cellpre(size_t n_cell, const T *p, const T *rhod, const T *eta, beard77_cell<T> *out)
 { const size_t c = gid(); if (c < n_cell) out[c] = vt_beard77_cellpart(p[c], rhod[c], eta[c]); }
+// hskpng_Tpr of step_async + the cell part of beard77 in one launch
+template <class T>
+__global__ void k_cell_Tpr_vtpre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv,
+                                 int th_dry, int const_p, int RH_formula, int ndims, beard77_cell<T> *out)
+{
+  const size_t c = gid(); if (c >= n_cell) return;
+  const T t = th_dry ? theta_dry_T(th[c], rhod[c]) : T(th[c] * exner(p[c]));
+  Tk[c] = t;
+  T pp = p[c];
+  if (!const_p) { pp = theta_dry_p(rhod[c], rv[c], t); p[c] = pp; }
+  RH[c] = RH_of(RH_formula, pp, rv[c], t);
+  const T et = visc(t);
+  eta[c] = et;
+  if (ndims == 0) dv[c] = T(1) / rhod[c];
+  out[c] = vt_beard77_cellpart(pp, rhod[c], et);
+}
 // FAST (opts_init.strict_fp == 0): reciprocal square root, refined-reciprocal division and the lean logarithm (<= 2 ulp each)
 template <class T, bool FAST>
 __global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const beard77_cell<T> *pre, const T *vt_0, T *vt)
@@ -1371,16 +1443,17 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     if (g.nx) a.x[i] = x;
     if (g.ny) a.y[i] = y;
     if (g.nz) a.z[i] = z;
-    // (the flags are cleared before the launch: only the ~1 % that leave store a byte.)  An SD that dies in this very pass
+    // (every living SD stores its flag byte, dead slots are cleared at the end of the pass: no memset ahead of the launch.)  An SD that dies in this very pass
     // -- open wall, top, precipitation -- is not shipped: the reference sends it with n == 0 and the receiver's
     // hskpng_remove_n0 drops it, so the neighbour never sees it either way, and its puddle contribution stays on this slab
-    if (mig_flag && !kill) a.mig[i] = mig_flag;
+    if (a.distmem && a.do_bcnd) a.mig[i] = kill ? uint8_t(0) : mig_flag;
     if (kill) { a.n[i] = 0; dead_now = true; }
     else if (a.reindex) {
       // an emigrant leaves the cell-sorted order at once (it is packed by id and its multiplicity zeroed in migrate_finish)
       if (emigrant) dead_now = true; else c_new = cell_of(g, x, y, z);
     }
   }
+  if (c == DEAD_CELL && a.distmem && a.do_bcnd && i < a.n_part) a.mig[i] = 0;       // a dead slot is nobody's migrant
   if (a.reindex) {                                    // every lane of the wave takes part (ballots inside)
     const bool live = c_new != DEAD_CELL;
     const uint32_t r = wave_hist_rank(a.cnt, c_new, live);
@@ -1406,7 +1479,8 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
 // workgroup g of the first launch reduces the contiguous slice [g*per, (g+1)*per) of the partials into out[g][4];
 // the second launch (one workgroup, nblocks = number of slices, per = 1) reduces those.
 __global__ void k_accumulate4(const double *s4, double *acc) { if (threadIdx.x < 4) acc[threadIdx.x] = acc[threadIdx.x] + s4[threadIdx.x]; }
-__global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, size_t per, double *out)
+// running != nullptr (the final launch): the running totals are advanced by the result as well
+__global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, size_t nblocks, size_t per, double *out, double *running = nullptr)
 {
   __shared__ double red[4][BS];
   const size_t b0 = size_t(blockIdx.x) * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
@@ -1419,7 +1493,10 @@ __global__ void __launch_bounds__(BS) k_sum_partials(const double *partials, siz
     if (int(threadIdx.x) < d) for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + d];
     __syncthreads();
   }
-  if (threadIdx.x < 4) out[size_t(blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
+  if (threadIdx.x < 4) {
+    out[size_t(blockIdx.x) * 4 + threadIdx.x] = red[threadIdx.x][0];
+    if (running && blockIdx.x == 0) running[threadIdx.x] = running[threadIdx.x] + red[threadIdx.x][0];
+  }
 }
 
 // ============================================================================================
@@ -1825,26 +1902,32 @@ __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const si
 // k_pack -- that the sender's pack kernel writes straight through the peer mapping (xGMI): one message per direction, no count
 // round trip, no staging copy.  Kernels are launched over the inbox capacity and read the counts from device memory.
 constexpr size_t EXCH_HDR = 256;
+template <class T> struct pack_side { const uint32_t *ids; uint8_t *inbox; T x_rmt, x_lcl; };
+// blocks [0, half) pack the left-going emigrants, [half, 2 half) the right-going ones (inbox == nullptr: that face has no neighbour);
+// the multiplicity of a packed SD is cleared in the same pass (flag_lft / flag_rgt of the reference)
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_pack_dev(const uint32_t *count_p, uint32_t cap_rec, const uint32_t *ids, attr_set<T> s, grid_t g, T x_rmt, T x_lcl, uint8_t *inbox)
+k_pack_dev(const uint32_t *counts, uint32_t cap_rec, unsigned half, pack_side<T> L, pack_side<T> R, attr_set<T> s, grid_t g)
 {
-  const uint32_t count = *count_p;
-  const size_t i = gid();
-  if (i == 0) { reinterpret_cast<uint32_t *>(inbox)[0] = count; reinterpret_cast<uint32_t *>(inbox)[1] = count > cap_rec ? 1u : 0u; }
+  const int side = blockIdx.x >= half;
+  const pack_side<T> &P = side ? R : L;
+  if (!P.inbox) return;
+  const uint32_t count = counts[side];
+  const size_t i = size_t(blockIdx.x - (side ? half : 0u)) * blockDim.x + threadIdx.x;
+  if (i == 0) { reinterpret_cast<uint32_t *>(P.inbox)[0] = count; reinterpret_cast<uint32_t *>(P.inbox)[1] = count > cap_rec ? 1u : 0u; }
   if (count > cap_rec || i >= count) return;          // overflow: nothing is shipped, the hosts of both slabs raise
-  n_t *nb = reinterpret_cast<n_t *>(inbox + EXCH_HDR);
+  n_t *nb = reinterpret_cast<n_t *>(P.inbox + EXCH_HDR);
   T *rb = reinterpret_cast<T *>(nb + count);
-  const uint32_t id = ids[i];
+  const uint32_t id = P.ids[i];
   nb[i] = s.n[id];
+  s.n[id] = 0;
   size_t slab = 0;
   rb[slab++ * count + i] = s.rd3[id]; rb[slab++ * count + i] = s.rw2[id]; rb[slab++ * count + i] = s.kpa[id]; rb[slab++ * count + i] = s.vt[id];
-  if (g.nx) { const T xn = x_rmt + s.x[id] - x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
+  if (g.nx) { const T xn = P.x_rmt + s.x[id] - P.x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
   if (g.ny) rb[slab++ * count + i] = s.y[id];
   if (g.nz) rb[slab++ * count + i] = s.z[id];
   for (int e = 0; e < s.n_ext; ++e) rb[slab++ * count + i] = s.ext[e][id];
 }
-__global__ void k_flag_ids_dev(const uint32_t *count_p, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < *count_p) n[ids[i]] = 0; }
 // immigrants of both inboxes in one launch, the left neighbour's first (the reference unpacks lft, then rgt); slots as in k_unpack
 template <class T>
 __global__ void __launch_bounds__(BS)
@@ -1887,13 +1970,13 @@ k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, size_t n_old, size_
   }
 }
 // the step's counts in one small record for ONE host read-back: dead, out_l, out_r, in_l, in_r, flags (1 my inbox overflowed at a
-// sender, 2 storage full)
-__global__ void k_collect_counts(const unsigned int *dead, const uint32_t *out_cnt, const uint8_t *inbox_l, const uint8_t *inbox_r,
+// sender, 2 storage full), number of crowded cells and the largest occupancy (order_cells)
+__global__ void k_collect_counts(const uint32_t *step_cnt /* dead, n_big, max_big */, const uint32_t *out_cnt, const uint8_t *inbox_l, const uint8_t *inbox_r,
                                  const uint32_t *overflow, uint32_t *rec)
 {
   if (threadIdx.x != 0) return;
   const uint32_t *hl = reinterpret_cast<const uint32_t *>(inbox_l), *hr = reinterpret_cast<const uint32_t *>(inbox_r);
-  rec[0] = *dead; rec[1] = out_cnt[0]; rec[2] = out_cnt[1];
+  rec[0] = step_cnt[0]; rec[1] = out_cnt[0]; rec[2] = out_cnt[1]; rec[6] = step_cnt[1]; rec[7] = step_cnt[2];
   rec[3] = hl ? hl[0] : 0u; rec[4] = hr ? hr[0] : 0u;
   rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | (*overflow ? 2u : 0u);
 }

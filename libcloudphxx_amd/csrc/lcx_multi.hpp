@@ -184,6 +184,7 @@ struct MultiParticles : IParticles {
     }
     pool.reset(new WorkerPool(D));
     barrier.reset(new HostBarrier(D));
+    if (serialize) fprintf(stderr, "libcloudph++ (multi_HIP): LCX_MULTI_SERIALIZE is set -- the %d slabs take turns (measurement mode)\n", D);
     pool->run([this](int i) { HIPCHK(hipSetDevice(dev[i])); });                    // each worker stays on its device
   }
   ~MultiParticles() override
@@ -198,10 +199,26 @@ struct MultiParticles : IParticles {
   int real_kind() const override { return int(sizeof(T)); }
 
   // ---- fan-out helpers ----
+  // LCX_MULTI_SERIALIZE=1 (measurement only): the slab threads take turns, so that with all slabs on ONE device the wall time of a
+  // call is the SUM of what each slab would spend alone on a device of its own (kernels + its host round trips), not their overlap
+  std::mutex serial_mx;
+  const bool serialize = getenv("LCX_MULTI_SERIALIZE") != nullptr;
   template <class F> void each(F f)
   {
     barrier->reset();
-    pool->run([&](int i) { try { f(i, *slab[i]); } catch (...) { barrier->brk(); throw; } });
+    pool->run([&](int i) {
+      std::unique_lock<std::mutex> lk(serial_mx, std::defer_lock);
+      if (serialize) lk.lock();
+      try { f(i, *slab[i]); if (serialize) slab[i]->sync(); } catch (...) { barrier->brk(); throw; }
+    });
+  }
+  void rendezvous(int i)
+  {
+    if (!serialize) { barrier->wait(); return; }
+    slab[i]->sync();                              // (this slab's queue drains while it still has the device to itself)
+    serial_mx.unlock(); 
+    try { barrier->wait(); } catch (...) { serial_mx.lock(); throw; }
+    serial_mx.lock();
   }
   // per-slab view of a caller's array: on_device == 2 means `data` is a table of D device pointers, one slab-local array each
   struct Arr {
@@ -270,27 +287,24 @@ struct MultiParticles : IParticles {
         typename Particles<T>::Range r(&s, "exchange_pack");
         if (lft >= 0) HIPCHK(hipStreamWaitEvent(s.st, ev_consumed[lft], 0));
         if (rgt >= 0 && rgt != lft) HIPCHK(hipStreamWaitEvent(s.st, ev_consumed[rgt], 0));
-        if (peer_ok[i]) {
-          if (lft >= 0) s.exch_pack(0, slab[lft]->o.x1, slab[lft]->inbox[1].p);
-          if (rgt >= 0) s.exch_pack(1, slab[rgt]->o.x0, slab[rgt]->inbox[0].p);
-        } else {
+        const double lft_x1 = lft >= 0 ? slab[lft]->o.x1 : 0., rgt_x0 = rgt >= 0 ? slab[rgt]->o.x0 : 0.;
+        if (peer_ok[i]) s.exch_pack(lft >= 0 ? slab[lft]->inbox[1].p : nullptr, lft_x1, rgt >= 0 ? slab[rgt]->inbox[0].p : nullptr, rgt_x0);
+        else {
           // no peer mapping between the two devices: pack at home, then a peer copy of exactly the bytes used (one extra host
           // synchronisation for the two counts -- what the reference always does)
           const size_t rec = s.migrate_record_bytes();
           for (auto &b : s.outbox) b.alloc(EXCH_HDR + s.inbox_cap_rec * rec);
-          if (lft >= 0) s.exch_pack(0, slab[lft]->o.x1, s.outbox[0].p);
-          if (rgt >= 0) s.exch_pack(1, slab[rgt]->o.x0, s.outbox[1].p);
+          s.exch_pack(lft >= 0 ? s.outbox[0].p : nullptr, lft_x1, rgt >= 0 ? s.outbox[1].p : nullptr, rgt_x0);
           uint32_t out[2] = {0, 0};
           s.read_back(out, s.scan_total.p, 2);
           auto bytes = [&](uint32_t c) { return EXCH_HDR + (c <= s.inbox_cap_rec ? size_t(c) * rec : 0); };
           if (lft >= 0) HIPCHK(hipMemcpyPeerAsync(slab[lft]->inbox[1].p, dev[lft], s.outbox[0].p, dev[i], bytes(out[0]), s.st));
           if (rgt >= 0) HIPCHK(hipMemcpyPeerAsync(slab[rgt]->inbox[0].p, dev[rgt], s.outbox[1].p, dev[i], bytes(out[1]), s.st));
         }
-        s.exch_flag(lft >= 0, rgt >= 0);
       }
       HIPCHK(hipEventRecord(ev_sent[i], s.st));
       s.puddle_reduce_deferred();                 // work that does not depend on the neighbours runs while the messages travel
-      barrier->wait();                            // every slab's `sent` event is recorded
+      rendezvous(i);                              // every slab's `sent` event is recorded
       // 2) the neighbours' messages -> append, histogram; 3) counts to the host, scan / scatter / rank
       {
         typename Particles<T>::Range r(&s, "exchange_wait");

@@ -6,7 +6,7 @@ import json
 import sys
 
 out = sys.argv[1]
-print("== rocprofv3 --kernel-trace --stats : python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline")
+print("== rocprofv3 --kernel-trace --stats : python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline")
 for f in glob.glob(out + "/trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     print("%-60s %8s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "%"))
@@ -21,7 +21,7 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         per[r["Kernel_Name"].replace("void ", "").split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, d in sorted(per.items(), key=lambda kv: -sum(kv[1][-10:])):
-        if len(d) >= 13 and k.startswith("lcx::") and sum(d[-10:]) > 1000:
+        if len(d) >= 20 and k.startswith("lcx::") and sum(d[-10:]) > 1000:
             print("%-60s avg_us(last 10) %10.2f   min %10.2f  max %10.2f" % (k[:60], sum(d[-10:]) / 10, min(d[-10:]), max(d[-10:])))
 try:
     print("bench line under trace:", open(out + "/bench_under_trace.json").read().strip()[:400])
@@ -50,6 +50,16 @@ for k, v in sorted(agg.items()):
             traffic[k]["valu_insts"] = sum(v["SQ_INSTS_VALU"][-2:]) / len(v["SQ_INSTS_VALU"][-2:])
             traffic[k]["valu_f64_insts"] = sum(sum(v[c][-2:]) / len(v[c][-2:]) for c in
                                                ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64") if c in v)
+            for c, nm in (("SQ_INSTS_VALU_FMA_F64", "valu_fma_f64"), ("SQ_INSTS_VALU_MUL_F64", "valu_mul_f64"), ("SQ_INSTS_VALU_ADD_F64", "valu_add_f64"),
+                          ("SQ_INSTS_VALU_TRANS_F64", "valu_trans_f64"), ("SQ_THREAD_CYCLES_VALU", "thread_cycles_valu"), ("SQ_INSTS_SALU", "salu_insts"),
+                          ("SQ_INSTS_VMEM_RD", "vmem_rd_insts"), ("SQ_INSTS_VMEM_WR", "vmem_wr_insts"), ("SQ_INSTS_LDS", "lds_insts"),
+                          ("SQ_INSTS_BRANCH", "branch_insts"), ("SQ_INSTS_VALU_INT32", "valu_int32"), ("SQ_INSTS_VALU_INT64", "valu_int64"),
+                          ("SQ_INSTS_VALU_CVT", "valu_cvt"), ("SQ_INSTS_VALU_TRANS_F32", "valu_trans_f32"), ("SQ_INSTS_VALU_FMA_F32", "valu_fma_f32"),
+                          ("SQ_INSTS_VALU_MUL_F32", "valu_mul_f32"), ("SQ_INSTS_VALU_ADD_F32", "valu_add_f32"), ("SQ_WAVES", "waves"),
+                          ("SQ_WAVE_CYCLES", "wave_cycles"), ("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"),
+                          ("SQ_ACTIVE_INST_ANY", "active_inst_any"), ("SQ_ACTIVE_INST_VALU", "active_inst_valu"), ("GRBM_GUI_ACTIVE", "grbm_gui_active")):
+                if c in v:
+                    traffic[k][nm] = sum(v[c][-2:]) / len(v[c][-2:])
 print()
 print("== HBM traffic per launch (FETCH_SIZE*2 KiB + WRITE_SIZE KiB)")
 for k, t in traffic.items():
