@@ -2,7 +2,9 @@
 migrating super-droplets with torch.distributed point-to-point operations (backend "nccl" == RCCL over
 xGMI on ROCm; "gloo" in the CPU tests).
 
-This replaces the reference's multi_CUDA backend (src/particles_multi_gpu_*.ipp,
+This is the SPMD flavour (one PROCESS per GPU, e.g. under torch.distributed.run or next to an MPI host model); the reference's
+multi_CUDA object -- ONE process, all GPUs of the node -- is native in the C library (lcx_create_multi, csrc/lcx_multi.hpp) and is
+what factory(multi_CUDA | multi_HIP) returns.  It replaces the reference's multi_CUDA backend (src/particles_multi_gpu_*.ipp,
 src/impl_multi_gpu/particles_multi_gpu_impl_step_async_and_copy.ipp:28-206: one std::thread per GPU,
 cudaMemcpyPeerAsync of two packed buffers, five thread barriers per step) and its MPI twin
 (src/impl/distributed_memory/particles_impl_mpi_exchange.ipp:20-330).  There is no collective on the data
@@ -84,6 +86,13 @@ class particles_multi_t:
             oi.n_x_bfr = 0
             oi.n_x_tot = oi.nx        # slab-local arrays: a Courant halo wraps inside the slab, the exchange below overwrites it
         self.opts_init = oi
+        if device is None and make_particles is None:
+            # the HIP engine works on device buffers: with the default engine the rank's current GPU is the device (a host tensor's
+            # address handed to the pack / unpack kernels would fault)
+            if not torch.cuda.is_available():
+                raise RuntimeError("libcloudph++: multi_HIP needs a GPU per process (pass make_particles / device for another engine)")
+            device = torch.device("cuda", torch.cuda.current_device())
+            oi.dev_id = device.index
         self.device = device
         if make_particles is None:
             make_particles = lambda o: lgrngn.particles_t(o, real_t)

@@ -36,7 +36,8 @@ def test_oracle_exports_the_same_surface():
     lib = oracle_lib()
     # the oracle mirrors the ABI (prefix orc_) for everything the tests drive through the shared harness
     skip = {"lcx_dev_alloc", "lcx_dev_free", "lcx_dev_copy", "lcx_dev_sync", "lcx_timings", "lcx_set_profiling",
-            "lcx_rng_replay_push", "lcx_rng_replay_pending", "lcx_math_probe"}
+            "lcx_rng_replay_push", "lcx_rng_replay_pending", "lcx_math_probe",
+            "lcx_create_multi", "lcx_multi_dev_count", "lcx_multi_slab"}     # (the oracle's ring is LocalRing in tests/_harness.py)
     missing = [s for s in declared_symbols() if s not in skip and not hasattr(lib, "orc_" + s[4:])]
     assert not missing, missing
 
@@ -51,6 +52,19 @@ def test_no_gpu_means_loud_failure():
     oi.dt, oi.sd_conc, oi.n_sd_max = 1, 10, 10
     with pytest.raises(RuntimeError):
         lgrngn.factory(lgrngn.backend_t.HIP, oi)
+
+
+def test_multi_backend_without_gpu_fails_loudly():
+    """factory(multi_CUDA) is the native multi-device object; without a device it raises like the single-device one"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from libcloudphxx_amd import lgrngn
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.x1, oi.dt, oi.sd_conc, oi.n_sd_max = 4, 4., 1, 10, 100
+    for b in (lgrngn.backend_t.multi_CUDA, lgrngn.backend_t.multi_HIP):
+        with pytest.raises(RuntimeError):
+            lgrngn.factory(b, oi)
 
 
 def test_unavailable_backends_raise():
