@@ -321,34 +321,49 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
   const uint32_t u = r.un ? r.un[id] : philox::un(id, r.call, r.seed);
   return (uint64_t(u) << 32) | id;
 }
-// KEY = uint32_t for the plain order (key == id), uint64_t for the shuffled order ((un << 32) | id)
+// KEY = uint32_t for the plain order (key == id), uint64_t for the shuffled order ((un << 32) | id).
+// The kernel is bound by the latency of its dependent loads (three quarters of its wave-cycles are waits), so every lane
+// fetches its own cell index, id and segment bounds up front (two dependent levels: sorted_ijk / in, then cell_start) and the
+// workgroup only adds the overhang of its first and last cell before the one barrier ahead of the ranking loop (C3: 1.17 -> 1.04 ms
+// for the ids, 1.41 -> 1.32 ms for the shuffle keys).  Tried and dropped: 32-bit shuffle keys (un alone) with the position in the
+// plain order as tie-break -- lane-dependent loop bounds, 1.9 ms; a cell-major form (a workgroup owns a few whole cells, no
+// overhang, no sorted_ijk) -- ragged ranges and the cell look-up cost more than the saved load level, 1.49 ms.
 template <class KEY>
 __global__ void __launch_bounds__(BS)
 k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
   __shared__ KEY lds[cr_cap<KEY>];
+  __shared__ uint32_t bounds[2];
   const size_t p0 = size_t(blockIdx.x) * BS;
   const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
-  const uint32_t lo = cell_start[sorted_ijk[p0]], hi = cell_start[sorted_ijk[plast] + 1];
-  const bool staged = (hi - lo) <= uint32_t(cr_cap<KEY>);
-  if (staged) for (uint32_t q = lo + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));
-  __syncthreads();
   const size_t p = p0 + threadIdx.x;
-  if (p >= n) return;
-  const uint32_t c = sorted_ijk[p], s = cell_start[c], e = cell_start[c + 1], cnt = e - s;
-  if (cnt > uint32_t(cellrank_max<KEY>)) { out[p] = in[p]; return; }      // listed by k_list_big_cells, sorted by a bitonic network
-  uint32_t rank = 0;
-  KEY mine;
+  const bool active = p < n;
+  uint32_t c = 0, s = 0, e = 0, id = 0;
+  if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
+  const KEY mine = active ? KEY(sort_key(id, shuffle, r)) : KEY(0);
+  if (threadIdx.x == 0) bounds[0] = s;
+  if (p == plast) bounds[1] = e;
+  __syncthreads();
+  const uint32_t lo = bounds[0], hi = bounds[1];
+  const bool staged = (hi - lo) <= uint32_t(cr_cap<KEY>);
   if (staged) {
-    mine = lds[p - lo];
+    if (active) lds[p - lo] = mine;
+    for (size_t q = size_t(lo) + threadIdx.x; q < p0; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));            // the first cell's part before the block
+    for (size_t q = plast + 1 + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));             // the last cell's part behind it
+  }
+  __syncthreads();
+  if (!active) return;
+  const uint32_t cnt = e - s;
+  if (cnt > uint32_t(cellrank_max<KEY>)) { out[p] = id; return; }      // listed by k_list_big_cells, sorted by a bitonic network
+  uint32_t rank = 0;
+  if (staged) {
     const KEY *seg = lds + (s - lo);
     for (uint32_t q = 0; q < cnt; ++q) rank += seg[q] < mine;
   } else {
-    mine = KEY(sort_key(in[p], shuffle, r));
     for (uint32_t q = s; q < e; ++q) rank += KEY(sort_key(in[q], shuffle, r)) < mine;
   }
-  out[s + rank] = uint32_t(mine);
+  out[s + rank] = id;
 }
 // the cells with more than `thr` SDs: wave-aggregated append (one atomic per wave of 64 cells, not one per cell -- with
 // 512 SDs in every cell a per-cell atomicAdd on one counter cost more than the sort itself)
@@ -679,6 +694,13 @@ __device__ __forceinline__ void cellfinish_apply(size_t c, bool has, T after, T 
 // pass reads half as much, nothing is carried between substeps (rw_mom3) and the difference of two large sums is never formed.
 // Measured on C3 (MI355X, fp64, cond + cond_cellfinish per step): round-1 pair 8.45 + 0.62 ms; this form 8.42 + 0.42; with the
 // root finder's reciprocals at one Newton step (OPT bit 0) 8.20; with the cube-root series (bit 1) 8.35; both 8.15 + 0.42.
+// HBM traffic of this kernel (PMC, r02): 13.0 GB read + 5.4 GB written per launch against 6.4 + 2.1 algorithmic.  The excess is
+// NOT the 28 B of scratch (a variant with 12 B of scratch -- three cell constants re-read from lane-private LDS slots -- moves the
+// same bytes and takes 8.06 ms instead of 7.92): it is the 40 B gathered and 8 B scattered per droplet through sorted_id, which
+// touch whole 64-B lines once droplets have drifted from their storage neighbours (half of them after two steps at |C| = 0.3).
+// Walking the STORAGE order instead (unit-stride attributes, only the 8-B delta gathered by the finishing pass) removes that
+// traffic and was measured as well: 9.28 + 0.63 ms -- the lanes of a wave then sit in different cells, their root finders need
+// different numbers of iterations, and the kernel is bound by exactly that (fp64 issue and divergence), not by HBM.
 // Also measured and dropped: the per-cell sums fused in as a wave-shuffle segmented scan with one store per (wave, cell)
 // fragment (each scan of 6 shuffle steps costs 0.35-0.4 ms, more than the 0.2 ms of stores + 0.4 ms finishing pass it
 // replaces: 9.2-9.4 + 0.05 ms); the cell's nine constants re-read from LDS at every evaluation instead of living in 18 VGPRs

@@ -269,11 +269,11 @@ LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
   using namespace t748;
   constexpr int FD = fastdiv<F>::value;
   st<T> &s = k.s;
-  T c, u, fu, a0, b0, &e = k.e, &fe = k.fe;
+  T c, u, fu, w0, &e = k.e, &fe = k.fe;
   unsigned &count = k.count;
   const T mu = 0.5f;
   while (count && s.fa != 0 && !tol_reached(eps, s.a, s.b)) {
-    a0 = s.a; b0 = s.b;
+    w0 = s.b - s.a;                                // (b0 - a0 of the reference: only the width is used below)
     c = prof(s, fe) ? quadratic<FD>(s.a, s.b, s.d, s.fa, s.fb, s.fd, 2) : cubic<FD>(s.a, s.b, s.d, e, s.fa, s.fb, s.fd, fe);
     e = s.d; fe = s.fd;
     bracket(f, s, c);
@@ -287,7 +287,7 @@ LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
     e = s.d; fe = s.fd;
     bracket(f, s, c);
     if (0 == --count || s.fa == 0 || tol_reached(eps, s.a, s.b)) break;
-    if ((s.b - s.a) < mu * (b0 - a0)) continue;
+    if ((s.b - s.a) < mu * w0) continue;
     e = s.d; fe = s.fd;
     bracket(f, s, T(s.a + (s.b - s.a) / 2));
     --count;
@@ -576,9 +576,17 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
   T rd;
   if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
-  const T a = mx(rd2, rw2_old + mn(T(0), cond_mlt * drw2)),
+  const T a_un = rw2_old + mn(T(0), cond_mlt * drw2);
+  const T a = mx(rd2, a_un),
           b = rw2_old + mx(T(0), cond_mlt * drw2);
   if (a == b) { result = rw2_old; return true; }
+  if constexpr (fastdiv<F>::value != 0) {
+    // Fast arithmetic: a bracket that already meets the root finder's tolerance (a droplet near equilibrium) is answered with its
+    // midpoint WITHOUT the function value at its far end.  The reference evaluates f there first and then returns either that very
+    // midpoint (toms748's entry check, toms748.hpp:296-305) or rw2_old + drw2 (no sign change) -- the same number, the midpoint of
+    // [rw2_old, rw2_old + 2 drw2], to the last bit or the one before it.  Not taken when the dry radius clamps the lower end.
+    if (a == a_un && tol_reached(eps, a, b)) { result = (a + b) / 2; return true; }
+  }
   T fa, fb;
   // the reference takes f(rw2_old) == drw2 at the near end of the bracket (cond_common.ipp:296-305)
   if (drw2 > 0) { fa = drw2; fb = f(b); }
