@@ -268,6 +268,11 @@ int lcx_dev_sync(void);
  * (which: 0 seeded cbrt, 1 reduced exp [the fast-mode growth rate uses these], 2 library cbrt, 3 library exp,
  *  4 refined reciprocal [the fast-mode root finder divides with it], 5 lean logarithm [fast-mode terminal velocities]) */
 int lcx_math_probe(int which, const double *x_host, double *y_host, size_t n);
+/* parity hook: raw output blocks of the library's counter-based generator, Philox4x32-10 (Salmon et al. 2011; what the reference
+ * draws from cuRAND / mt19937 in src/detail/urand.hpp:24-86 is drawn here inside the consuming kernel).  ics = n triples
+ * (index, call, seed): counter = {index lo, index hi, call lo, call hi}, key = {seed lo, seed hi}; out = 4 n words.
+ * on_device = 0 evaluates the same routine on the host (needs no GPU). */
+int lcx_philox_probe(const unsigned long long *ics, size_t n, unsigned int *out, int on_device);
 /* host-side scalar evaluation of the formula library, = the functions the reference's Python module exposes as
  * libcloudphxx.common (ref: bindings/python/common.hpp:19-172, lib.cpp:129-144): name is one of
  *   th_dry2std(th_dry,r) th_std2dry(th_std,r) exner(p) p_v(p,r) p_vs(T) r_vs(T,p) p_vs_tet(T) l_v(T) T(th,rhod)

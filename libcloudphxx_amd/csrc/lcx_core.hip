@@ -1964,6 +1964,24 @@ int lcx_math_probe(int which, const double *x, double *y, size_t n)
   })
 }
 
+int lcx_philox_probe(const unsigned long long *ics, size_t n, unsigned int *out, int on_device)
+{
+  LCX_TRY({
+    if (!on_device) {
+      for (size_t i = 0; i < n; ++i) { uint32_t r[4]; lcx::philox::gen(ics[3 * i], ics[3 * i + 1], ics[3 * i + 2], r); for (int k = 0; k < 4; ++k) out[4 * i + k] = r[k]; }
+    } else {
+      uint64_t *d_in = nullptr; uint32_t *d_out = nullptr;
+      if (hipMalloc(&d_in, (n ? n : 1) * 3 * sizeof(uint64_t)) != hipSuccess || hipMalloc(&d_out, (n ? n : 1) * 4 * sizeof(uint32_t)) != hipSuccess)
+        throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed");
+      (void)hipMemcpy(d_in, ics, n * 3 * sizeof(uint64_t), hipMemcpyHostToDevice);
+      if (n) hipLaunchKernelGGL(lcx::k_philox_probe, dim3((n + 255) / 256), dim3(256), 0, 0, d_in, n, d_out);
+      const hipError_t e = hipMemcpy(out, d_out, n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+      (void)hipFree(d_in); (void)hipFree(d_out);
+      if (e != hipSuccess) throw std::runtime_error(std::string("libcloudph++ (HIP): philox probe failed: ") + hipGetErrorString(e));
+    }
+  })
+}
+
 int lcx_common_eval(const char *name, const double *a, int n, double *out)
 {
   LCX_TRY({

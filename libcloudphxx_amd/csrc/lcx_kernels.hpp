@@ -2085,6 +2085,14 @@ __global__ void k_vel_div(size_t n_cell, grid_t g, int halo, T dt, const T *cx, 
   d = d + (cx[rgt] - cx[ce]) / dt;
   out[c] = d;
 }
+// parity hook (lcx_philox_probe): raw Philox4x32-10 blocks for given (index, call, seed) triples
+__global__ void k_philox_probe(const uint64_t *ics, size_t n, uint32_t *out)
+{
+  const size_t i = gid(); if (i >= n) return;
+  uint32_t r[4];
+  philox::gen(ics[3 * i], ics[3 * i + 1], ics[3 * i + 2], r);
+  for (int k = 0; k < 4; ++k) out[4 * i + k] = r[k];
+}
 __global__ void k_math_probe(int which, double *v, size_t n)
 {
   const size_t i = gid();

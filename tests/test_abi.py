@@ -37,7 +37,7 @@ def test_oracle_exports_the_same_surface():
     # the oracle mirrors the ABI (prefix orc_) for everything the tests drive through the shared harness
     skip = {"lcx_dev_alloc", "lcx_dev_free", "lcx_dev_copy", "lcx_dev_sync", "lcx_timings", "lcx_set_profiling",
             "lcx_rng_replay_push", "lcx_rng_replay_pending", "lcx_math_probe",
-            "lcx_create_multi", "lcx_multi_dev_count", "lcx_multi_slab"}     # (the oracle's ring is LocalRing in tests/_harness.py)
+            "lcx_create_multi", "lcx_multi_dev_count", "lcx_multi_slab", "lcx_philox_probe"}     # (the oracle's ring is LocalRing in tests/_harness.py)
     missing = [s for s in declared_symbols() if s not in skip and not hasattr(lib, "orc_" + s[4:])]
     assert not missing, missing
 
@@ -73,3 +73,66 @@ def test_unavailable_backends_raise():
     for b in (lgrngn.backend_t.serial, lgrngn.backend_t.OpenMP):
         with pytest.raises(RuntimeError):
             lgrngn.factory(b, oi)
+
+
+# Philox4x32-10 known answers: Random123's kat_vectors (philox4x32 10 <counter x4> <key x2> -> <out x4>), re-derived for this
+# test from the round function published in Salmon et al. 2011 (tests/test_abi.py::philox_reference below reproduces them)
+PHILOX_KAT = [
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def philox_reference(ctr, key, rounds=10):
+    """Philox4x32-R as published (multipliers 0xD2511F53 / 0xCD9E8D57, Weyl key increments 0x9E3779B9 / 0xBB67AE85)"""
+    c, k = list(ctr), list(key)
+    for _ in range(rounds):
+        p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xffffffff, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xffffffff]
+        k = [(k[0] + 0x9E3779B9) & 0xffffffff, (k[1] + 0xBB67AE85) & 0xffffffff]
+    return tuple(c)
+
+
+def philox_probe(triples, on_device):
+    import numpy as np
+    from libcloudphxx_amd import _lib
+    lib = _lib.load()
+    ics = np.ascontiguousarray(triples, dtype=np.uint64).reshape(-1)
+    out = np.zeros(4 * (len(ics) // 3), dtype=np.uint32)
+    rc = lib.lcx_philox_probe(ics.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(ics) // 3), out.ctypes.data_as(ctypes.c_void_p),
+                              ctypes.c_int(int(on_device)))
+    assert rc == 0
+    return out.reshape(-1, 4)
+
+
+def kat_triples():
+    return [(c[0] | (c[1] << 32), c[2] | (c[3] << 32), k[0] | (k[1] << 32)) for c, k, _ in PHILOX_KAT]
+
+
+def test_philox_known_answers_host():
+    """the library's generator IS Philox4x32-10: Random123's known-answer vectors through the host build of the very routine the
+    kernels inline (csrc/lcx_math.hpp philox::gen)"""
+    for c, k, want in PHILOX_KAT:
+        assert philox_reference(c, k) == want
+    got = philox_probe(kat_triples(), on_device=False)
+    for row, (_, _, want) in zip(got, PHILOX_KAT):
+        assert tuple(int(x) for x in row) == want
+
+
+@pytest.mark.gpu
+def test_philox_known_answers_device():
+    """the same on the GPU, plus 1e5 random (index, call, seed) triples against the reference round function"""
+    import numpy as np
+    got = philox_probe(kat_triples(), on_device=True)
+    for row, (_, _, want) in zip(got, PHILOX_KAT):
+        assert tuple(int(x) for x in row) == want
+    rng = np.random.default_rng(3)
+    tri = rng.integers(0, 2 ** 63, size=(100000, 3), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(100000, 3), dtype=np.uint64)
+    dev = philox_probe(tri, on_device=True)
+    host = philox_probe(tri, on_device=False)
+    assert np.array_equal(dev, host)
+    for t, row in list(zip(tri, dev))[:200]:
+        i, c, s = (int(x) for x in t)
+        want = philox_reference((i & 0xffffffff, i >> 32, c & 0xffffffff, c >> 32), (s & 0xffffffff, s >> 32))
+        assert tuple(int(x) for x in row) == want

@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 N, SD = 128, 64
 
 
-@pytest.fixture(scope="module")
-def big():
+@pytest.fixture(scope="module", params=[True, False], ids=["strict_fp", "fast_fp"])
+def big(request):
+    """strict_fp = False is exactly what bench.py runs (the benchmarked configuration is a tested configuration)"""
     oi = bench.make_opts_init(N, N, N, SD, 40., 1, 1, 44)
+    oi.strict_fp = request.param
     fields = bench.make_fields(N, N, N, 0, N, np, np.float64)
     pr = lgrngn.factory(lgrngn.backend_t.HIP, oi)
     th, rv, rhod, Cx, Cy, Cz = fields
