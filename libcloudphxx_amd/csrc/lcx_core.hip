@@ -123,6 +123,12 @@ struct Particles : IParticles {
   // ---- order-of-operation flags (particles_impl.ipp:32) ----
   bool init_called = false, should_now_run_async = false, should_now_run_cond = false, selected_before_counting = false;
   bool var_rho = false, sorted = false, sorted_shuffled = false;
+  // production order (no replayed stream): the re-sort at the end of step_async ranks the cells straight by the NEXT coalescence's
+  // random keys (un[id], id) -- nothing between the two needs ids ascending inside a cell (condensation treats a droplet on its
+  // own, the fast per-cell sums take any fixed order, and this one is as deterministic as the other), so the ascending-id ranking
+  // of every step (1.0 of 17.3 ms on C3) is not run at all and coalescence finds its shuffled order ready.  The reference's order
+  // (plain sort, then shuffle at coalescence) stays in every parity run and with opts_init.reorder_every < 0.
+  bool shuffle_fresh = false, last_async_coal = false;
   int sstp_cond, sstp_coal; bool allow_sstp_cond, pure_const_multi; double dt;
   int adve_scheme, halo = 0;      // halo: x-planes of Courant halo on each side (pred_corr)
   hipStream_t st = nullptr;
@@ -536,11 +542,12 @@ struct Particles : IParticles {
         }
       }
     }
-    sorted = true; sorted_shuffled = shuffle;
+    sorted = true; sorted_shuffled = shuffle; shuffle_fresh = false;
   }
   void hskpng_sort_helper(bool shuffle)
   {
     Range r(this, shuffle ? "hskpng_shuffle_and_sort" : "hskpng_sort");
+    if (sorted && shuffle && sorted_shuffled && shuffle_fresh && replay.empty()) { shuffle_fresh = false; return; }   // post_copy has shuffled for us already
     if (sorted && shuffle) { order_cells(true); return; }   // cells unchanged since the last sort: re-order the segments only
     ijk_and_hist(0, true);
     sort_from_hist(shuffle);
@@ -710,7 +717,11 @@ struct Particles : IParticles {
     if (compact_now && strict_order) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
     npart = nphys - dead;
-    sort_from_hist(false, meta_p);
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : 64;
+    const bool reorder_due = compact_now || (!strict_order && steps_since_reorder + 1 >= every_);     // (the re-ordering wants the plain order)
+    const bool preshuffle = !strict_order && last_async_coal && o.coal_switch && !reorder_due && npart >= 2;
+    sort_from_hist(preshuffle, meta_p);
+    shuffle_fresh = preshuffle;
     // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
     const int every = o.reorder_every > 0 ? o.reorder_every : 64;       // 0: the default period
     if (compact_now || (!strict_order && ++steps_since_reorder >= every)) reorder_storage();
@@ -1408,6 +1419,7 @@ struct Particles : IParticles {
     if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
     adjust_timesteps(opts.dt);
+    last_async_coal = opts.coal != 0;
     hskpng_Tpr(opts.sedi || opts.coal || opts.cond);
     if (opts.sedi || opts.coal || opts.cond) hskpng_vterm(false);
     if (opts.coal) {
@@ -1564,7 +1576,11 @@ struct Particles : IParticles {
     std::vector<unsigned long long> v;
     if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }
-    else if (s == "sorted_id") { hskpng_sort(); auto h = d2h(sorted_id.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "sorted_id") {
+      hskpng_sort();
+      if (sorted_shuffled) order_cells(false);      // the getter shows the reference's sorted_id: ids ascending inside a cell
+      auto h = d2h(sorted_id.p, npart); v.assign(h.begin(), h.end());
+    }
     else if (s == "sorted_ijk") { hskpng_sort(); auto h = d2h(sorted_ijk.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "cell_start") { hskpng_sort(); auto h = d2h(cell_start.p, ncell + 1); v.assign(h.begin(), h.end()); }
     else if (s == "count_ijk" || s == "count_num") {
