@@ -129,6 +129,9 @@ struct Particles : IParticles {
   // of every step (1.0 of 17.3 ms on C3) is not run at all and coalescence finds its shuffled order ready.  The reference's order
   // (plain sort, then shuffle at coalescence) stays in every parity run and with opts_init.reorder_every < 0.
   bool shuffle_fresh = false, last_async_coal = false;
+  // an SD that coalescence uses up is marked in ijk by k_coal when the step ends in the fused move + re-index (which then reads no
+  // multiplicities: 8 B per SD less); zero multiplicities of other origin (initialisation, set_particles) make the next move look
+  bool coal_marks_dead = false, zero_n_unmarked = true;
   int sstp_cond, sstp_coal; bool allow_sstp_cond, pure_const_multi; double dt;
   int adve_scheme, halo = 0;      // halo: x-planes of Courant halo on each side (pred_corr)
   hipStream_t st = nullptr;
@@ -941,7 +944,7 @@ struct Particles : IParticles {
     auto launch = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
                          A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
-                         ix_ict >= 0 ? A.ext[ix_ict].p : nullptr);
+                         ix_ict >= 0 ? A.ext[ix_ict].p : nullptr, coal_marks_dead ? ijk.p : nullptr);
     };
     if (onishi) launch(k_coal<T, true>); else launch(k_coal<T, false>);
     if (o.n_dry_distros + n_size_keys > 1)
@@ -979,6 +982,8 @@ struct Particles : IParticles {
     a.mig = mig.p;
     // (no memsets: every lane stores its migrant flag, and the histogram and the dead count are cleared behind each sort's scan)
     a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead_p();
+    a.check_n = !coal_marks_dead || zero_n_unmarked;
+    if (reindex) zero_n_unmarked = false;
     const bool pc = adve_scheme == LCX_ADVE_PRED_CORR, tb = a.up != nullptr;
     if (pc && tb) hipLaunchKernelGGL((k_move<T, true, true>), dim3(blocks), dim3(BS), 0, st, a);
     else if (pc) hipLaunchKernelGGL((k_move<T, true, false>), dim3(blocks), dim3(BS), 0, st, a);
@@ -1420,6 +1425,8 @@ struct Particles : IParticles {
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
     adjust_timesteps(opts.dt);
     last_async_coal = opts.coal != 0;
+    coal_marks_dead = n_dims > 0 && nphys > 0 && !opts.rcyc && sstp_coal == 1;   // (= the fused move below; with coalescence
+                                                       // substeps a used-up SD still takes part in the later ones and keeps its cell)
     hskpng_Tpr(opts.sedi || opts.coal || opts.cond);
     if (opts.sedi || opts.coal || opts.cond) hskpng_vterm(false);
     if (opts.coal) {
@@ -1578,7 +1585,8 @@ struct Particles : IParticles {
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "sorted_id") {
       hskpng_sort();
-      if (sorted_shuffled) order_cells(false);      // the getter shows the reference's sorted_id: ids ascending inside a cell
+      if (sorted_shuffled && shuffle_fresh) order_cells(false);   // (production order: post_copy has pre-shuffled for the next coalescence;
+                                                                  //  the getter shows the reference's state at this point, ids ascending inside a cell)
       auto h = d2h(sorted_id.p, npart); v.assign(h.begin(), h.end());
     }
     else if (s == "sorted_ijk") { hskpng_sort(); auto h = d2h(sorted_ijk.p, npart); v.assign(h.begin(), h.end()); }
@@ -1630,6 +1638,7 @@ struct Particles : IParticles {
   {
     check_npart(n);
     npart = nphys = n;
+    zero_n_unmarked = true;
     auto up = [&](DevBuf<T> &b, const double *src) {
       if (!src || !b.p || !n) return;
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(src[i]);
@@ -1648,6 +1657,7 @@ struct Particles : IParticles {
   void stage(const char *name, const lcx_opts_t *opts) override
   {
     const std::string s(name);
+    coal_marks_dead = false; zero_n_unmarked = true;                   // (single stages: nothing is fused)
     if (s == "hskpng_Tpr") hskpng_Tpr();
     else if (s == "hskpng_mfp") hskpng_mfp();
     else if (s == "hskpng_ijk") hskpng_ijk();

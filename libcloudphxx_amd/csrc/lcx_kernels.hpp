@@ -1224,7 +1224,7 @@ template <class T, bool ONISHI>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
-       int pure_const_multi, int *increase_sstp_coal, T *rc2, T *ict)
+       int pure_const_multi, int *increase_sstp_coal, T *rc2, T *ict, uint32_t *ijk_mark)
 {
   const size_t p0 = 2 * gid();
   if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
@@ -1258,6 +1258,8 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
   if (na >= nb) {                                                            // collide<>, coal.ipp:110-143
     if (nb > 0) { const n_t q = na / nb; if (q < col_no) col_no = q; }
     n[a] = na - col_no * nb;
+    if (ijk_mark && na == col_no * nb) ijk_mark[a] = DEAD_CELL;                // used up: out of the cell histogram at the next re-index (the fused move
+                                                                               // then needs no look at n; the sorted order of this step still holds it)
     const T rw_b = cbrt(col_no * rw2a * sqrt(rw2a) + rw2b * sqrt(rw2b));
     rw2[b] = rw_b * rw_b;
     rd3[b] = col_no * rd3[a] + rd3[b];
@@ -1268,6 +1270,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
   } else {
     if (na > 0) { const n_t q = nb / na; if (q < col_no) col_no = q; }
     n[b] = nb - col_no * na;
+    if (ijk_mark && nb == col_no * na) ijk_mark[b] = DEAD_CELL;
     const T rw_a = cbrt(col_no * rw2b * sqrt(rw2b) + rw2a * sqrt(rw2a));
     rw2[a] = rw_a * rw_a;
     rd3[a] = col_no * rd3[b] + rd3[a];
@@ -1314,6 +1317,7 @@ struct move_args {
   // fused re-indexing (single-device runs): the new cell index, the cell histogram with per-SD rank and the number of
   // dead SDs come out of the same pass, so post_copy needs no further sweep over the positions
   int reindex; uint32_t *ijk_out, *cnt, *rank; unsigned int *dead_count;
+  int check_n;                 // look at n for SDs that have n == 0 without being marked dead (first move after init / set_particles)
 };
 template <class T>
 __device__ __forceinline__ T adve_1d(int scheme, T x, uint32_t fl, T C_l, T C_r, T dx)
@@ -1349,8 +1353,8 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   bool dead_now = false;         // counted in dead_count: was dead already, or dies in this pass
   uint32_t c_new = DEAD_CELL;
   if (a.reindex && i < a.n_part) {
-    if (c == DEAD_CELL) dead_now = true;
-    else if (a.n[i] == 0) { dead_now = true; c = DEAD_CELL; }          // multiplicity went to zero in coalescence
+    if (c == DEAD_CELL) dead_now = true;                               // (incl. those that coalescence has just used up: k_coal marks them)
+    else if (a.check_n && a.n[i] == 0) { dead_now = true; c = DEAD_CELL; }   // zero multiplicities from the initialisation / set_particles
   }
   if (c != DEAD_CELL) {
     const grid_t &g = a.g;
