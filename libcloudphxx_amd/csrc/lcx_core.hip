@@ -166,7 +166,8 @@ struct Particles : IParticles {
   DevBuf<int> d_flag;
   // step_cnt: [0] dead SDs counted by the fused move, [1] number of crowded cells, [2] largest cell occupancy -- one read-back
   unsigned int *d_dead_p() { return step_cnt.p; }
-  uint32_t *big_meta_p() { return step_cnt.p + 1; }
+  uint32_t *big_meta_p() { return step_cnt.p + 1; }      // filled by list_big_from_hist only (cleared behind every scan)
+  uint32_t *big_meta_own_p() { return step_cnt.p + 4; }  // order_cells' own listing (cleared by itself)
   void *pinned = nullptr;      // 256 B of page-locked host memory for the small per-step read-backs (counts, sums)
   double puddle[LCX_OUT_COUNT];
   bool count_mom_valid_all = true;
@@ -249,7 +250,7 @@ struct Particles : IParticles {
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc_zero(ncell, st); cell_start.alloc_zero(ncell + 1, st);
     tile_sums.alloc(2 * (std::max(cap, ncell) / SCAN_TILE + 2)); scan_total.alloc(4);   // (two halves for the two migrant lists)
-    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); step_cnt.alloc_zero(4, st);
+    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); step_cnt.alloc_zero(8, st);
     m3_before.alloc(cap); m3_after.alloc(cap);
     if (oi.coal_switch) col.alloc(cap);
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
@@ -513,16 +514,16 @@ struct Particles : IParticles {
         // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
         // the in-cell shuffle of coalescence re-orders the SAME segments as the sort before it, so the list is kept until cell_start changes
         if (meta_version != cells_version) {
-          HIPCHK(hipMemsetAsync(big_meta_p(), 0, 2 * sizeof(uint32_t), st));
-          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, uint32_t(CELLRANK_MAX), big_list.p, big_meta_p(), big_meta_p() + 1,
-                             (const uint32_t *)nullptr);
+          HIPCHK(hipMemsetAsync(big_meta_own_p(), 0, 2 * sizeof(uint32_t), st));
+          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, uint32_t(CELLRANK_MAX), big_list.p, big_meta_own_p(),
+                             big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
           uint32_t m2[2];
-          read_back(m2, big_meta_p(), 2);
+          read_back(m2, big_meta_own_p(), 2);
           big_n = m2[0]; big_mx = m2[1]; meta_version = cells_version;
         }
         const uint32_t meta[2] = {big_n, big_mx};
