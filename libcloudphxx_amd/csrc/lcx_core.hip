@@ -38,6 +38,17 @@ template <class T> struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
   void alloc(size_t m) { if (m <= n && p) return; release(); HIPCHK(hipMalloc((void **)&p, std::max<size_t>(m, 1) * sizeof(T))); n = std::max<size_t>(m, 1); }
   void alloc_zero(size_t m, hipStream_t s) { alloc(m); HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
+  // fine-grained device memory: coherent with writes that arrive from ANOTHER device while kernels of this one run before and
+  // after them (the exchange inboxes that a neighbour's pack kernel fills over xGMI); plain hipMalloc if the runtime refuses
+  void alloc_finegrained(size_t m)
+  {
+    release();
+    if (hipExtMallocWithFlags((void **)&p, std::max<size_t>(m, 1) * sizeof(T), hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError(); p = nullptr;
+      HIPCHK(hipMalloc((void **)&p, std::max<size_t>(m, 1) * sizeof(T)));
+    }
+    n = std::max<size_t>(m, 1);
+  }
   void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
 
@@ -1763,7 +1774,7 @@ struct Particles : IParticles {
     // the reference sizes its buffers to half an x-plane of n_sd_max (reserve_hskpng_npart.ipp:84-94, config.hpp:25); a Courant
     // number of 1 (the ring test) moves a whole plane, pred_corr allows 2
     inbox_cap_rec = std::min<size_t>(cap, 2 * cap / size_t(std::max(o.nx, 1)) + 1024);
-    for (auto &b : inbox) { b.alloc(EXCH_HDR + inbox_cap_rec * migrate_record_bytes()); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
+    for (auto &b : inbox) { b.alloc_finegrained(EXCH_HDR + inbox_cap_rec * migrate_record_bytes()); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
     xcnt.alloc_zero(12, st);
     if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
     sync();

@@ -144,7 +144,7 @@ struct MultiParticles : IParticles {
     dev.resize(D); nx_loc.resize(D); n_x_bfr.resize(D);
     for (int i = 0; i < D; ++i) dev[i] = map.empty() ? i : map[i];
     // peer access between neighbouring devices (particles_multi_gpu_impl.ipp:100-125)
-    peer_ok.assign(D, 1);
+    peer_ok.assign(D, getenv("LCX_MULTI_NO_PEER") ? 0 : 1);      // (LCX_MULTI_NO_PEER: tests drive the staged path on one device)
     if (D > 1)
       for (int i = 0; i < D; ++i)
         for (int nb : {lft_of(i), rgt_of(i)}) {

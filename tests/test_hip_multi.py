@@ -281,3 +281,22 @@ def test_multi_device_api_rules(monkeypatch):
     oi3.dev_count = 64
     with pytest.raises(RuntimeError, match="number of available GPUs"):
         lgrngn.factory(lgrngn.backend_t.multi_HIP, oi3)
+
+
+def test_multi_device_without_peer_mapping(monkeypatch):
+    """devices that cannot map each other's memory (LCX_MULTI_NO_PEER forces it here): emigrants are packed at home and moved by a
+    peer copy of exactly the bytes used -- same slabs as the direct path, against the oracle ring"""
+    monkeypatch.setenv("LCX_MULTI_NO_PEER", "1")
+    nx, ny, nz, size = 9, 3, 4, 3
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False)
+    oi.n_sd_max = 24 * nx * ny * nz * 3
+    fields = h.box_fields(oi)
+    orc, mul, slabs = multi_pair(oi, size, fields, monkeypatch)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    for it in range(4):
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_async(opts)
+        compare_slabs(orc, slabs, oi, it, attrs=("x", "y", "z", "rw2"))
