@@ -579,8 +579,11 @@ struct Particles : IParticles {
         hipLaunchKernelGGL(k_vterm_cellpre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, p.p, rhod.p, eta.p, vt_pre.p);
         vtpre_valid = true;
       }
-      if (o.strict_fp) hipLaunchKernelGGL((k_vterm_b77<T, false>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
-      else             hipLaunchKernelGGL((k_vterm_b77<T, true>), dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p);
+      const dim3 gv(nblk(nphys, 2 * BS * VT_CHUNKS));                   // VT_CHUNKS pairs of super-droplets per lane
+      auto launch = [&](auto kern) { hipLaunchKernelGGL(kern, gv, dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, vt_pre.p, vt_0.p, A.vt.p); };
+      const bool table = vtc.formula == LCX_VT_BEARD77FAST;
+      if (o.strict_fp) { if (table) launch(k_vterm_b77<T, false, true>); else launch(k_vterm_b77<T, false, false>); }
+      else             { if (table) launch(k_vterm_b77<T, true, true>); else launch(k_vterm_b77<T, true, false>); }
       return;
     }
     hipLaunchKernelGGL(k_vterm<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, int(only_invalid), vtc, A.rw2.p, ijk.p, Tk.p, p.p, rhod.p, eta.p, vt_0.p, A.vt.p);

@@ -290,6 +290,8 @@ k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const 
   }
   if (cnt) { const uint32_t r = wave_hist_rank(cnt, c, active); if (active) rank[i] = r; }
 }
+// (measured: several super-droplets per lane -- four consecutive ids, or one from each of four chunks -- do not help here, 2.13-2.43
+// against 2.07 ms for the whole re-sort: the pass is bound by its scattered 4-byte stores, not by the latency of its loads)
 __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
                                  uint32_t *sorted_id, uint32_t *sorted_ijk)
 {
@@ -571,15 +573,11 @@ __global__ void k_cell_Tpr_vtpre(size_t n_cell, const T *th, const T *rhod, cons
   out[c] = vt_beard77_cellpart(pp, rhod[c], et);
 }
 // FAST (opts_init.strict_fp == 0): reciprocal square root, refined-reciprocal division and the lean logarithm (<= 2 ulp each)
-template <class T, bool FAST>
-__global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const beard77_cell<T> *pre, const T *vt_0, T *vt)
+// one super-droplet of the pass below
+template <class T, bool FAST, bool TABLE>
+__device__ __forceinline__ bool vterm_b77_one(const vt_cfg &v, T r2, uint32_t c, const beard77_cell<T> *pre, const T *vt_0, T &out)
 {
-  const size_t i = gid(); if (i >= n) return;
-  const T r2 = rw2[i];
-  if (!(r2 > T(0))) return;
-  if (only_invalid && !(vt[i] == T(-1))) return;
-  const uint32_t c = ijk[i];
-  if (c == DEAD_CELL) return;
+  if (!(r2 > T(0)) || c == DEAD_CELL) return false;
   T r, f;
   if (FAST) {
     const T irw = rsqrt(r2);
@@ -589,11 +587,47 @@ __global__ void k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, 
     r = sqrt(r2);
     f = vt_beard77_fact_pre(r, pre[c]);
   }
-  if (v.formula == LCX_VT_BEARD77) { vt[i] = f * T(vt_beard77_v0(double(r))); return; }
-  const T lnmin = T(v.ln_r_min), lnmax = T(v.ln_r_max), dlnr = (lnmax - lnmin) / v.n_bin;
-  const T lnr = .5 * (FAST ? log_lean(r2) : T(log(r2)));
-  const int bin = lnr <= lnmin ? 0 : lnr >= lnmax ? v.n_bin - 1 : int((lnr - lnmin) / dlnr);
-  vt[i] = f * vt_0[bin];
+  if constexpr (!TABLE) { out = f * T(vt_beard77_v0(double(r))); return true; }      // beard77: the polynomial itself
+  else {                                                                            // beard77fast: its table over ln r
+    const T lnmin = T(v.ln_r_min), lnmax = T(v.ln_r_max), dlnr = (lnmax - lnmin) / v.n_bin;
+    const T lnr = .5 * (FAST ? log_lean(r2) : T(log(r2)));
+    const int bin = lnr <= lnmin ? 0 : lnr >= lnmax ? v.n_bin - 1 : int((lnr - lnmin) / dlnr);
+    out = f * vt_0[bin];
+    return true;
+  }
+}
+// Several super-droplets per lane, all of their loads issued before the arithmetic: the pass is bound by memory latency (81 % of its
+// wave-cycles were waits with one 8-byte element per lane).  A lane takes VT_CHUNKS pairs of neighbours, one pair from each
+// 2*BS-element chunk of its workgroup's range, so that every load instruction of a wave is one contiguous 1 KiB (rw2, vt) or 512 B (ijk).
+// C3: 1.05 ms with one element per lane, 0.82 ms with one pair, 1.31 ms with four CONSECUTIVE elements (strided lanes).
+constexpr int VT_CHUNKS = 2;
+template <class T, bool FAST, bool TABLE>
+__global__ void __launch_bounds__(BS)
+k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const beard77_cell<T> *pre, const T *vt_0, T *vt)
+{
+  struct alignas(2 * sizeof(T)) pairT { T a, b; };
+  struct alignas(8) pairU { uint32_t a, b; };
+  const size_t base = size_t(blockIdx.x) * (2 * BS * VT_CHUNKS) + 2 * threadIdx.x;
+  pairT r2[VT_CHUNKS], o[VT_CHUNKS]; pairU c[VT_CHUNKS];
+#pragma unroll
+  for (int k = 0; k < VT_CHUNKS; ++k) {
+    const size_t i = base + size_t(k) * 2 * BS;
+    if (i + 1 < n) {
+      r2[k] = *reinterpret_cast<const pairT *>(rw2 + i); c[k] = *reinterpret_cast<const pairU *>(ijk + i); o[k] = *reinterpret_cast<const pairT *>(vt + i);
+    } else if (i < n) { r2[k] = pairT{rw2[i], T(0)}; c[k] = pairU{ijk[i], DEAD_CELL}; o[k] = pairT{vt[i], T(0)}; }
+    else { r2[k] = pairT{T(0), T(0)}; c[k] = pairU{DEAD_CELL, DEAD_CELL}; o[k] = r2[k]; }
+  }
+#pragma unroll
+  for (int k = 0; k < VT_CHUNKS; ++k) {
+    const size_t i = base + size_t(k) * 2 * BS;
+    if (i >= n) break;
+    T va = o[k].a, vb = o[k].b;
+    const bool wa = !(only_invalid && !(va == T(-1))) && vterm_b77_one<T, FAST, TABLE>(v, r2[k].a, c[k].a, pre, vt_0, va);
+    const bool wb = i + 1 < n && !(only_invalid && !(vb == T(-1))) && vterm_b77_one<T, FAST, TABLE>(v, r2[k].b, c[k].b, pre, vt_0, vb);
+    if (wa && wb) *reinterpret_cast<pairT *>(vt + i) = pairT{va, vb};
+    else if (wa) vt[i] = va;
+    else if (wb) vt[i + 1] = vb;
+  }
 }
 template <class T>
 __global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *ijk, const T *Tk, const T *p,
