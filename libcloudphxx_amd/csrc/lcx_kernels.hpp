@@ -743,18 +743,27 @@ template <class T> __device__ __forceinline__ T rw2_to_rw3_signed(T x) { return 
 template <class T, int OPT = 3>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond_fast(size_t n_part, cond_args<T> a)
 {
+  __shared__ T stash[BS];                                  // the multiplicity waits here while the root finder has the registers
   const size_t pos = gid(); if (pos >= n_part) return;
   const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
-  const T rw2_old = a.rw2[id];
+  // Every gather of the droplet is issued HERE, in one batch behind the two index loads: left to itself the compiler sinks them
+  // into the branch below and the wave walks five dependent memory levels (sorted_id -> rw2 -> sorted_ijk, rd3, kpa, vt -> the
+  // cell's constants ... -> n at the very end), a third of its lifetime at four waves per SIMD.  The empty asm pins the values.
+  T rw2_old = a.rw2[id], rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
+  T nn = T(a.n[id]);
+  cond_cell_fast<T> cc = a.pre[c];
+  asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+  volatile T *my = &stash[threadIdx.x];
+  *my = nn;
   T r = rw2_old;
   if (rw2_old > 0) {
     cond_fun_fast<T, OPT> ff;
-    const T rd3 = a.rd3[id];
-    ff.setup_cell(a.pre[c], rw2_old, a.dt_sub, rd3, a.kpa[id], a.vt[id]);
+    ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
     r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     a.rw2[id] = r;
   }
-  a.m3_after[pos] = T(a.n[id]) * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+  a.m3_after[pos] = *my * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
 }
 
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
@@ -1262,28 +1271,34 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
 {
   const size_t p0 = 2 * gid();
   if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
+  // The three positions a lane may need (2t, 2t+1, 2t+2) and the CSR bounds of their first two cells are fetched up front, in two
+  // dependent levels; then the pair's attributes in one batch.  (Written as the decision tree reads, the kernel walked six or seven
+  // dependent loads, and 70 % of its wave-cycles were waits.)
+  const bool has2 = p0 + 2 < n_part;
+  const uint32_t c0 = sorted_ijk[p0], c1 = sorted_ijk[p0 + 1], c2 = has2 ? sorted_ijk[p0 + 2] : DEAD_CELL;
+  const uint32_t i0 = sorted_id[p0], i1 = sorted_id[p0 + 1], i2 = has2 ? sorted_id[p0 + 2] : 0u;
+  const uint32_t off0 = cell_start[c0], end0 = cell_start[c0 + 1], off1 = cell_start[c1], end1 = cell_start[c1 + 1];
   size_t p = p0;
-  uint32_t ca = sorted_ijk[p];
-  uint32_t off = cell_start[ca];
+  uint32_t ca = c0, off = off0, end = end0, a = i0, b = i1;
   {
     const bool even0 = ((uint32_t(p) - off) & 1u) == 0;
-    const uint32_t cb = sorted_ijk[p + 1];
-    if (!(even0 && cb == ca)) {
+    if (!(even0 && c1 == ca)) {
       if (even0) col[p] = T(0);                        // last SD of a cell with an odd count: no partner
       p = p0 + 1;
-      if (p + 1 >= n_part) return;
-      if (cb != ca) { ca = cb; off = cell_start[ca]; }
+      if (!has2) return;
+      if (c1 != ca) { ca = c1; off = off1; end = end1; }
       if ((uint32_t(p) - off) & 1u) return;            // odd offset: this SD is the b of the previous lane's pair
-      if (sorted_ijk[p + 1] != ca) { col[p] = T(0); return; }
+      if (c2 != ca) { col[p] = T(0); return; }
+      a = i1; b = i2;
     }
   }
-  const uint32_t cnt = cell_start[ca + 1] - off;
+  const uint32_t cnt = end - off;
   const n_t nn = cnt;
   const T scl = nn > 1 ? (T(nn * (nn - 1)) / 2) / (nn / 2) : T(0);           // scale_factor, coal.ipp:99-107
-  const uint32_t a = sorted_id[p], b = sorted_id[p + 1];
   n_t na = n[a], nb = n[b];
-  const T rw2a = rw2[a], rw2b = rw2[b];
-  const T prob = dt / dv[ca] * scl * kernel_calc<T, ONISHI>(kc, na, nb, rw2a, rw2b, vt[a], vt[b], ca);
+  T rw2a = rw2[a], rw2b = rw2[b], vta = vt[a], vtb = vt[b], dvc = dv[ca];
+  asm volatile("" : "+v"(rw2a), "+v"(rw2b), "+v"(vta), "+v"(vtb), "+v"(dvc), "+v"(na), "+v"(nb));   // (one batch, not a chain)
+  const T prob = dt / dvc * scl * kernel_calc<T, ONISHI>(kc, na, nb, rw2a, rw2b, vta, vtb, ca);
   n_t col_no = n_t(prob);
   if (pure_const_multi && col_no >= 1) *increase_sstp_coal = 1;
   const T u = rs.arr ? rs.arr[p] : philox::u01<T>(p, rs.call, rs.seed);
