@@ -165,7 +165,7 @@ struct Particles : IParticles {
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, step_cnt, mig_ids[2];
-  DevBuf<uint8_t> mig, cond_pre;
+  DevBuf<uint8_t> mig, cond_pre; DevBuf<uint32_t> defer_cnt;
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
   // ---- cell fields ----
@@ -805,10 +805,12 @@ struct Particles : IParticles {
       // the substep's cell pass in one launch: mean free paths (substep 0, from the previous T and p as the reference's hskpng_mfp
       // ahead of the loop), hskpng_Tpr, and in fast arithmetic the droplet-independent set-up of the growth rate
       Range r(this, "hskpng_Tpr");
-      if (fast) cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
-      hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p,
-                         lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
-                         fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr);
+      if (fast) { cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>)); defer_cnt.alloc(DEFER_SHARDS * DEFER_CNT_STRIDE); }
+      const int n_defer_words = DEFER_SHARDS * DEFER_CNT_STRIDE;
+      hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(std::max(nblk(ncell), nblk(size_t(n_defer_words)))), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p,
+                         Tk.p, RH.p, eta.p, dv.p, lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
+                         fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr,
+                         fast ? defer_cnt.p : (uint32_t *)nullptr, fast ? n_defer_words : 0);
       vtpre_valid = false;
     }
     if (npart) {
@@ -819,7 +821,16 @@ struct Particles : IParticles {
       const dim3 gr(nblk(npart)), bl(BS);
       if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
-        hipLaunchKernelGGL((k_cond_fast<T>), gr, bl, 0, st, npart, a);
+        // two passes: a short iteration budget first, the droplets that need more in a dense second launch (k_cond_fast)
+        static const int budget_env = getenv("LCX_COND_BUDGET") ? atoi(getenv("LCX_COND_BUDGET")) : 6;
+        // (`rank` is free between the sorts; part s holds at most the positions of the workgroups b with b % DEFER_SHARDS == s)
+        cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget_env)};
+        if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
+        hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
+        if (df.budget) {
+          const unsigned per_shard = std::max(1u, std::min(nblk(npart / 8 + 1), 256u * 64u) / DEFER_SHARDS);
+          hipLaunchKernelGGL((k_cond_fast<T, 3, true>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, npart, a, df);
+        }
       }
       else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
       else hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a);

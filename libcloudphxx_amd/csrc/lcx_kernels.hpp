@@ -181,8 +181,10 @@ __global__ void k_cell_mfp(size_t n_cell, const T *Tk, const T *p, T *lambda_D, 
 // then (fast arithmetic) the droplet-independent set-up of the growth rate.  Same expressions as the three kernels it replaces.
 template <class T>
 __global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv, T *lambda_D, T *lambda_K,
-                                int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre)
+                                int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre,
+                                uint32_t *zero_words = nullptr, int n_zero_words = 0)
 {
+  if (gid() < size_t(n_zero_words)) zero_words[gid()] = 0u;         // (the straggler counters of the condensation kernel that follows)
   const size_t c = gid(); if (c >= n_cell) return;
   T lD, lK;
   if (do_mfp) { lD = lambda_D_of(Tk[c]); lK = lambda_K_of(Tk[c], p[c]); lambda_D[c] = lD; lambda_K[c] = lK; }
@@ -740,11 +742,22 @@ __device__ __forceinline__ void cellfinish_apply(size_t c, bool has, T after, T 
 // replaces: 9.2-9.4 + 0.05 ms); the cell's nine constants re-read from LDS at every evaluation instead of living in 18 VGPRs
 // (no scratch, but 9.4 ms); 3 waves per SIMD without scratch 10.2 ms, 5 waves with 116 B of scratch 10.8 ms.
 template <class T> __device__ __forceinline__ T rw2_to_rw3_signed(T x) { return x >= 0 ? x * T(sqrt(x)) : x; }
-template <class T, int OPT = 3>
-__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond_fast(size_t n_part, cond_args<T> a)
+// Stragglers.  A wave is as slow as its slowest lane: the root finder needs 4.0 growth-rate evaluations per droplet on average,
+// but 7.3 per wave (C3, step 12: 3 evaluations 28 %, 4: 34 %, 5: 16 %, 6: 10 %, 7: 3.5 %, more: 0.7 %).  The first pass therefore
+// runs the root finder with a short iteration budget; a droplet that has not converged inside it is left untouched and its position
+// appended to a list (one atomic per wave), and a second, dense pass solves the listed droplets from scratch with the reference's
+// budget of 100.  Same arithmetic per droplet either way, hence the same results; the list lives in the `rank` scratch.
+// Measured on C3 (ms per launch pair): no deferral 7.69; budget 6 (= 8 evaluations, 0.7 % deferred) 7.39; 7 and 8: 7.56; 5 (4 % deferred)
+// 7.99; 4 (14 %) 8.69 -- dense waves of stragglers pay the maximum over 64 hard droplets, so only the far tail is worth deferring.
+// The list is kept in DEFER_SHARDS parts, workgroup b appending to part b % DEFER_SHARDS with the part's own counter (one counter
+// for everybody saturates at ~90 appends per microsecond -- with a few per cent of stragglers nearly every wave appends, and the
+// first pass went from 7.8 to 25 ms); part s can hold every position of the workgroups that feed it, so it cannot overflow.
+constexpr int DEFER_SHARDS = 64, DEFER_CNT_STRIDE = 16;               // counters 64 B apart
+struct cond_defer { uint32_t *list, *count; size_t shard_cap; unsigned budget; };      // budget 0: no deferral (a single pass with the full budget)
+// one droplet; returns true when it was set aside for the second pass
+template <class T, int OPT, bool SECOND>
+__device__ __forceinline__ bool cond_fast_one(size_t pos, const cond_args<T> &a, unsigned budget, volatile T *my)
 {
-  __shared__ T stash[BS];                                  // the multiplicity waits here while the root finder has the registers
-  const size_t pos = gid(); if (pos >= n_part) return;
   const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
   // Every gather of the droplet is issued HERE, in one batch behind the two index loads: left to itself the compiler sinks them
   // into the branch below and the wave walks five dependent memory levels (sorted_id -> rw2 -> sorted_ijk, rd3, kpa, vt -> the
@@ -754,16 +767,45 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   cond_cell_fast<T> cc = a.pre[c];
   asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
                "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
-  volatile T *my = &stash[threadIdx.x];
-  *my = nn;
+  *my = nn;                                                // the multiplicity waits in LDS while the root finder has the registers
   T r = rw2_old;
+  bool deferred = false;
   if (rw2_old > 0) {
     cond_fun_fast<T, OPT> ff;
     ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
-    r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-    a.rw2[id] = r;
+    unsigned left = 1;
+    const bool budgeted = !SECOND && budget != 0;
+    r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, budgeted ? budget : a.n_iter, &left);
+    deferred = budgeted && left == 0;
+    if (!deferred) a.rw2[id] = r;
   }
-  a.m3_after[pos] = *my * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+  if (!deferred) a.m3_after[pos] = *my * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+  return deferred;
+}
+template <class T, int OPT = 3, bool SECOND = false>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond_fast(size_t n_part, cond_args<T> a, cond_defer df)
+{
+  __shared__ T stash[BS];
+  volatile T *my = &stash[threadIdx.x];
+  if (SECOND) {                                            // the listed droplets: workgroup b walks part b % DEFER_SHARDS with the stride
+    const unsigned shard = blockIdx.x % DEFER_SHARDS;      // of the workgroups that share it (the host does not know the counts)
+    const size_t count = df.count[shard * DEFER_CNT_STRIDE];
+    const uint32_t *part = df.list + size_t(shard) * df.shard_cap;
+    for (size_t q = size_t(blockIdx.x / DEFER_SHARDS) * BS + threadIdx.x; q < count; q += size_t(gridDim.x / DEFER_SHARDS) * BS)
+      cond_fast_one<T, OPT, true>(part[q], a, 0u, my);
+    return;
+  }
+  const size_t pos = gid(); if (pos >= n_part) return;
+  const bool deferred = cond_fast_one<T, OPT, false>(pos, a, df.budget, my);
+  const unsigned long long bal = __ballot(deferred);       // (lanes behind n_part have left: the ballot covers the rest)
+  if (bal) {
+    const int leader = __ffsll((long long)bal) - 1;
+    uint32_t base = 0;
+    const unsigned shard = blockIdx.x % DEFER_SHARDS;
+    if (int(lane_id()) == leader) base = atomicAdd(df.count + shard * DEFER_CNT_STRIDE, uint32_t(__popcll(bal)));
+    base = __shfl(base, leader);
+    if (deferred) df.list[size_t(shard) * df.shard_cap + base + __popcll(bal & ((1ull << lane_id()) - 1ull))] = uint32_t(pos);
+  }
 }
 
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane

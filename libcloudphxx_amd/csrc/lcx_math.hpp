@@ -264,7 +264,7 @@ LCX_HD bool toms748_head(const F &f, T ax, T bx, T fax, T fbx, T eps, unsigned m
   return true;
 }
 template <class T, class F>
-LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
+LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps, unsigned *iters_left = nullptr)
 {
   using namespace t748;
   constexpr int FD = fastdiv<F>::value;
@@ -292,6 +292,7 @@ LCX_HD T toms748_tail(const F &f, toms_carry<T> k, T eps)
     bracket(f, s, T(s.a + (s.b - s.a) / 2));
     --count;
   }
+  if (iters_left) *iters_left = count;
   if (s.fa == 0) s.b = s.a; else if (s.fb == 0) s.a = s.b;
   return (s.a + s.b) / 2;
 }
@@ -599,22 +600,25 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
   return true;
 }
 template <class T, class F>
-LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k)
+LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k, unsigned *iters_left = nullptr)
 {
-  T rw2_new = toms748_tail(f, k, eps);
+  T rw2_new = toms748_tail(f, k, eps, iters_left);
   T rd;
   if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
   const T rd2 = rd * rd;
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
 }
+// iters_left (optional): the root finder's remaining iteration budget on return -- 0 says that n_iter ran out (the answer is then
+// NOT the reference's unless n_iter is its 100; k_cond_fast uses a short budget to set the slowest droplets aside, see there)
 template <class T, class F>
-LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, unsigned *iters_left = nullptr)
 {                                                                  // cond_common.ipp:197-337
   toms_carry<T> k;
+  k.count = n_iter;
   T r;
-  if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) return r;
-  return advance_rw2_tail_with(f, rd3, eps, k);
+  if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) { if (iters_left) *iters_left = k.count; return r; }
+  return advance_rw2_tail_with(f, rd3, eps, k, iters_left);
 }
 // per-cell part of with_cond_fun + cond_fun_fast::setup (same expressions, same order)
 template <class T>
