@@ -22,6 +22,7 @@ with tempfile.TemporaryDirectory() as d:
 names = sorted(set(m.group(1) for m in re.finditer(r"^(_Z\S+):\s", s, re.M)))
 demangled = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
 pick = [(n, dm) for n, dm in zip(names, demangled) if pat in dm and "double" in dm]
+pick.sort(key=lambda nd: 0 if "<double, 3, false>" in nd[1] else 1)          # the production instantiation of k_cond_fast first
 if not pick:
     sys.exit("no kernel matches " + pat)
 name, dm = pick[0]
@@ -71,7 +72,8 @@ for k, n in groups.most_common():
 print("   most frequent opcodes: " + ", ".join("%s %d" % kv for kv in cnt.most_common(14)))
 if tj:
     t = json.load(open(tj))
-    key = next((k for k in t if pat in k and "double" in k), None)
+    keys = [k for k in t if pat in k and "double" in k]
+    key = next((k for k in keys if k.split("(")[0] in dm), keys[0] if keys else None)
     if key:
         v = t[key]
         w = v.get("waves", 1)
