@@ -164,31 +164,45 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
     ap.add_argument("--oversubscribe", action="store_true", help="--gpus N in one process with all N slabs on device 0")
+    ap.add_argument("--spmd", action="store_true",
+                    help="under torch.distributed.run: one single-device object per rank with the migrants over RCCL "
+                         "(libcloudphxx_amd.multi) instead of the native multi_HIP object driven by rank 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))          # > 1: launched by torch.distributed.run, one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    native_multi = world == 1 and args.gpus > 1               # ONE process over args.gpus devices: the native multi_HIP object
-    n_slabs = args.gpus if native_multi else world
     if world > 1 and world != args.gpus:
         raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
-    if native_multi:
+    # --gpus N > 1 runs the library's native multi_HIP object (ONE process, one host thread per device, migrants written straight
+    # into the neighbour's memory over xGMI) -- also under torch.distributed.run, where rank 0 drives all N devices and the other
+    # ranks only join the barriers and the timing reduction (they never touch a GPU).  --spmd, or a launcher that shows each rank
+    # fewer than N devices, selects the one-object-per-rank path over RCCL instead.
+    spmd = world > 1 and (args.spmd or (torch.cuda.device_count() < args.gpus and not args.oversubscribe))
+    native_multi = args.gpus > 1 and not spmd
+    idle = native_multi and rank > 0
+    n_slabs = args.gpus
+    if native_multi and not idle:
         if args.oversubscribe:
             os.environ["LCX_MULTI_DEVICE_MAP"] = ",".join(["0"] * args.gpus)
         dmap = os.environ.get("LCX_MULTI_DEVICE_MAP")
         slab_dev = [int(x) for x in dmap.split(",")][:args.gpus] if dmap else list(range(args.gpus))
-        if max(slab_dev) >= torch.cuda.device_count():
+        if max(slab_dev) >= torch.cuda.device_count() and world == 1:      # (under a launcher: the per-rank fallback below)
             raise SystemExit("--gpus %d: only %d device(s) visible (use --oversubscribe to put every slab on device 0)"
                              % (args.gpus, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if spmd else 0
+    if not idle:
+        torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # host-side collectives (barriers, the timing reduction) over gloo, so that a waiting rank sleeps on the host instead of
+        # spinning in a kernel on a GPU that rank 0 is driving; device tensors (the SPMD path's migrants) go over RCCL
+        dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(minutes=60))
 
     from libcloudphxx_amd import lgrngn, multi
     real_t = np.float64 if args.real == "f64" else np.float32
@@ -198,7 +212,7 @@ def main():
     if args.nx:
         nx_tot = args.nx
     oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
-    oi.dev_id = -1 if native_multi else local_rank
+    oi.dev_id = -1 if native_multi else dev_index
     oi.strict_fp = args.strict_fp
     oi.reorder_every = args.reorder_every
     if args.cond_mode != "percell":
@@ -217,72 +231,116 @@ def main():
         shapes = [(nx_loc, n, n)] * 3 + [(nx_loc + 1, n, n), (nx_loc, n + 1, n), (nx_loc, n, n + 1)]
         return [t.expand(sh).contiguous() for t, sh in zip(f, shapes)]
 
-    if native_multi:
-        oi.dev_count = args.gpus
-        oi.n_sd_max = int(oi.n_sd_max * 1.1)            # (per slab: n_sd_max / dev_count + 1, distmem_opts.hpp:47)
+    n_sd_max0 = oi.n_sd_max
+
+    def setup_native():
+        """ONE object over args.gpus devices; the Eulerian arrays live in per-slab pieces on the slabs' own devices"""
+        oi.dev_count, oi.dev_id = args.gpus, -1
+        oi.n_sd_max = int(n_sd_max0 * 1.1)              # (per slab: n_sd_max / dev_count + 1, distmem_opts.hpp:47)
         prt = lgrngn.factory(lgrngn.backend_t.multi_HIP, oi, real_t)
         per = nx_tot // args.gpus
         parts = [device_fields(per if r < args.gpus - 1 else nx_tot - r * per, r * per, torch.device("cuda", slab_dev[r]))
                  for r in range(args.gpus)]
-        fields_t = parts                                   # keep the tensors alive
-        th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArrays([parts[r][k].data_ptr() for r in range(args.gpus)], parts[0][k].shape)
-                                    for k in range(6)]
-        devices = sorted(set(slab_dev))
-    else:
+        arrays = [lgrngn.DeviceArrays([parts[r][k].data_ptr() for r in range(args.gpus)], parts[0][k].shape) for k in range(6)]
+        return prt, parts, arrays, sorted(set(slab_dev))
+
+    def setup_local():
+        """a single-device object: the whole domain, or this rank's slab of the one-object-per-rank run"""
+        oi.dev_count, oi.dev_id, oi.n_sd_max = 0, dev_index, n_sd_max0
         if world > 1:
             prt = multi.particles_multi_t(oi, real_t, device=dev)
             nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
         else:
             prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
             nx_loc, x_off = nx_tot, 0
-        fields_t = device_fields(nx_loc, x_off, dev)
-        th, rv, rhod, Cx, Cy, Cz = [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in fields_t]
-        devices = [local_rank]
+        fields = device_fields(nx_loc, x_off, dev)
+        return prt, fields, [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in fields], [dev_index]
+
+    def setup_and_init(setup):
+        prt, keep, arrays, devices = setup()
+        for d in devices:
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        prt.init(arrays[0], arrays[1], arrays[2], Cx=arrays[3], Cy=arrays[4], Cz=arrays[5])
+        for d in devices:
+            torch.cuda.synchronize(d)
+        return prt, keep, arrays, devices, time.perf_counter() - t0
+
+    state, fallback_reason = None, None
+    if native_multi:
+        if not idle:
+            try:
+                if max(slab_dev) >= torch.cuda.device_count():
+                    raise RuntimeError("slab devices %s: only %d device(s) visible" % (slab_dev, torch.cuda.device_count()))
+                state = setup_and_init(setup_native)
+            except RuntimeError as e:
+                if world == 1:
+                    raise
+                fallback_reason = str(e)
+        if world > 1:                                   # every rank learns whether rank 0 got its multi-device object
+            ok = torch.tensor([0 if fallback_reason else 1])
+            dist.broadcast(ok, 0)
+            if not int(ok.item()):
+                if rank == 0:
+                    print("bench.py: native multi_HIP object failed (%s); falling back to one object per rank over RCCL"
+                          % fallback_reason, file=sys.stderr, flush=True)
+                spmd, native_multi, idle, state = True, False, False, None
+                dev_index = local_rank % torch.cuda.device_count()
+                torch.cuda.set_device(dev_index)
+                dev = torch.device("cuda", dev_index)
+    if state is None and not idle:
+        state = setup_and_init(setup_local)
+    if idle:
+        prt, fields_t, devices, t_init = None, None, [], 0.
+        th = rv = rhod = Cx = Cy = Cz = None
+    else:
+        prt, fields_t, (th, rv, rhod, Cx, Cy, Cz), devices, t_init = state
 
     def sync_all():
         for d in devices:
             torch.cuda.synchronize(d)
-    sync_all()
-
-    t_init = time.perf_counter()
-    prt.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
-    sync_all()
-    t_init = time.perf_counter() - t_init
     opts = lgrngn.opts_t()
 
     def barrier():
+        sync_all()
         if world > 1:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))             # (gloo: a host barrier)
         sync_all()
 
     def one_step():
         prt.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
         prt.step_async(opts)
 
-    for _ in range(args.warmup):
-        one_step()
-    p1 = prt.prt if world > 1 else prt
-    if not args.no_stage_timers:
-        p1.set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
     sd_done = 0
-    for _ in range(args.steps):
-        one_step()
-        sd_done += p1.n_part
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stage_ms = p1.timings() if not args.no_stage_timers else {}
-    tt = torch.tensor([elapsed, float(sd_done)], dtype=torch.float64, device=dev)
+    if idle:                                            # rank 0 drives this rank's device: only the barriers and the reduction
+        barrier()
+        t0 = time.perf_counter()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stage_ms = {}
+    else:
+        for _ in range(args.warmup):
+            one_step()
+        p1 = prt.prt if spmd else prt
+        if not args.no_stage_timers:
+            p1.set_profiling(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+            sd_done += p1.n_part
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stage_ms = p1.timings() if not args.no_stage_timers else {}
     if world > 1:
-        tmax = tt.clone()
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone()
+        tsum = torch.tensor([float(sd_done)], dtype=torch.float64)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, sd_total = float(tmax[0]), float(tsum[1])
+        elapsed, sd_total = float(tmax[0]), float(tsum[0])
     else:
         sd_total = float(sd_done)
-    world_out = n_slabs
+    world_out = n_slabs if (native_multi or spmd) else 1
 
     if rank == 0:
         R = 8 if args.real == "f64" else 4
@@ -354,6 +412,15 @@ def main():
                 stage_roof[k_] = {"bytes_per_sd": bsd, "GB/s": gbs, "frac_of_8TB/s": gbs / HBM_PEAK_GBS}
         if roof is not None:
             roof["peak_measured_copy_GBs"] = copy_gbs
+        if native_multi:
+            decomposition_note = " (native multi_HIP object: one process, one host thread per device, migrants written into the neighbour's memory%s%s)" % (
+                "; all slabs on device 0" if args.oversubscribe else "",
+                "; driven by rank 0 of the launcher, ranks 1..%d idle" % (world - 1) if world > 1 else "")
+        elif spmd:
+            decomposition_note = " (one single-device object per rank, migrants over RCCL%s)" % (
+                "; fallback: " + fallback_reason if fallback_reason else "")
+        else:
+            decomposition_note = ""
         out = {
             "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
             "value": sd_total / elapsed,
@@ -367,7 +434,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
                                    % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
-                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, " (one process, native multi_HIP%s)" % (", all slabs on device 0" if args.oversubscribe else "") if native_multi else (" (one process per GPU, RCCL)" if world > 1 else "")), "cond_mode": args.cond_mode,
+                       "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, decomposition_note), "cond_mode": args.cond_mode,
                        "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
                        "init_s": t_init},
             "roofline": roof,
@@ -378,7 +445,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 
