@@ -822,9 +822,13 @@ struct Particles : IParticles {
       if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         // two passes: a short iteration budget first, the droplets that need more in a dense second launch (k_cond_fast)
-        static const int budget_env = getenv("LCX_COND_BUDGET") ? atoi(getenv("LCX_COND_BUDGET")) : 6;
+        // The second launch costs what its slowest wave costs (~60 us) however few droplets it holds, and the first pass saves ~2.3 us
+        // per million droplets: one pass below 2^25 droplets (a 16-plane slab of C3, 16.7e6 SDs: 0.96 ms in two passes, 0.91 in one).
+        // LCX_COND_BUDGET: test / measurement switch (the parity tests force the two-pass form at their small sizes with it)
+        const char *budget_env = getenv("LCX_COND_BUDGET");
+        const int budget = budget_env ? atoi(budget_env) : (npart >= (size_t(1) << 25) ? 6 : 0);
         // (`rank` is free between the sorts; part s holds at most the positions of the workgroups b with b % DEFER_SHARDS == s)
-        cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget_env)};
+        cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
         hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
         if (df.budget) {

@@ -686,6 +686,31 @@ def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-8)
 
 
+@pytest.mark.parametrize("budget", ["6", "3", "1"])
+def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget):
+    """k_cond_fast with a short iteration budget + the dense second launch over the droplets that ran out of it (the production
+    form from 2^25 super-droplets upwards; LCX_COND_BUDGET forces it here) does the same arithmetic per droplet as the single pass:
+    identical bits in rw2, th and rv.  Budget 6 defers the far tail, 3 and 1 defer most of the droplets that iterate at all."""
+    oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for b in ("0", budget):
+        monkeypatch.setenv("LCX_COND_BUDGET", b)
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        opts.coal = opts.adve = opts.sedi = False
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(2):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    assert np.abs(res[0][2] - rv).max() > 0                       # (condensation did happen)
+
+
 @pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
 def test_rcyc_matches_oracle(dims):
     """opts.rcyc: the SDs freed by coalescence / precipitation are re-used as halves of the SDs with the highest

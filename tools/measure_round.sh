@@ -1,0 +1,37 @@
+#!/bin/bash
+# The round's side measurements (everything DESIGN.md quotes besides the default bench line and the rocprof profile):
+#   gpurun -- 'bash tools/measure_round.sh r02d'   ->  gpurun_out/meas_<tag>/*.json   (copy into profiles/<tag>_measurements.json with
+#   tools/measure_round.sh's last step, which merges the one-line results)
+tag=${1:-r02}
+ulimit -c 0
+out=gpurun_out/meas_$tag
+mkdir -p $out
+B="python3 bench.py --no-cpu-baseline"
+# one slab of the strong-scaling split of C3 on a device of its own (what each GPU of an N-GPU run computes, without exchange)
+for nx in 64 32 16; do $B --nx $nx --steps 100 > $out/slab_nx$nx.json 2> $out/slab_nx$nx.err; done
+# the native multi_HIP object with all slabs on this one device: concurrent (exchange overlapped) and one slab at a time
+for N in 2 4 8; do
+  $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_concurrent.json 2> $out/multi_${N}_concurrent.err
+  LCX_MULTI_SERIALIZE=1 $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_serialized.json 2> $out/multi_${N}_serialized.err
+done
+# C4's slab (256 x 256 x 128 over 8 devices = 32 x-planes of 256 x 128 cells) does not fit bench.py's cubic grid options: weak-scaling slab instead
+$B --scaling weak --gpus 2 --oversubscribe --n 64 --steps 40 > $out/weak_2x64.json 2> $out/weak_2x64.err
+# C5: 128^3 x 512 SD/cell
+$B --sd-conc 512 --steps 10 --warmup 2 > $out/c5.json 2> $out/c5.err
+python3 - "$out" "$tag" <<'PY'
+import glob, json, os, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {}
+for f in sorted(glob.glob(os.path.join(out, "*.json"))):
+    try:
+        d = json.loads(open(f).read().strip().split("\n")[-1])
+    except Exception as e:
+        res[os.path.basename(f)[:-5]] = {"error": str(e)}
+        continue
+    res[os.path.basename(f)[:-5]] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "n_gpus": d["n_gpus"], "steps": d["steps"],
+                                      "workload": d["config"]["workload"], "decomposition": d["config"]["decomposition"],
+                                      "stage_ms_per_step": d.get("stage_ms_per_step")}
+json.dump(res, open(os.path.join(out, "measurements.json"), "w"), indent=1)
+for k, v in res.items():
+    print(k, v.get("ms_per_step"), v.get("value"))
+PY
