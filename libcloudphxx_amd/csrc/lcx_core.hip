@@ -529,8 +529,9 @@ struct Particles : IParticles {
           hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, uint32_t(CELLRANK_MAX), big_list.p, big_meta_own_p(),
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
-        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
-        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs);
+        const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
+        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
+        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
           uint32_t m2[2];
@@ -817,6 +818,7 @@ struct Particles : IParticles {
       Range r(this, "cond");
       cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
+                     xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       if (fast) {

@@ -23,12 +23,17 @@ __device__ __forceinline__ size_t gid() { return size_t(blockIdx.x) * blockDim.x
 // (droplets that changed cell since the storage was last put in cell order sit in the neighbours' ranges) meet in ONE L2.
 // Measured on k_cond_fast, C3 (ms): plain order 7.60; groups of 4: 7.77, 16: 7.31, 64: 7.15, 128..1024: 7.11..7.13, 8192: 7.22, one
 // contiguous eighth per XCD: 7.33.  k_coal, k_move and k_scatter_sorted gain nothing (+-1 %; k_coal loses 17 % with eighths).
-constexpr unsigned XCD_GROUP = 256;
-__device__ __forceinline__ size_t gid_xcd()
+// The run length follows the cells: xcd_group() = the workgroups of ~2048 cells (C3: 512 workgroups; C5, 512 SDs per cell: 4096).
+__host__ __device__ __forceinline__ unsigned xcd_group(size_t n_part, size_t n_cell)
 {
-  constexpr unsigned W = 8u * XCD_GROUP;
+  const size_t g = (n_part / (n_cell ? n_cell : 1) + 1) * 2048 / BS;
+  return unsigned(g < 64 ? 64 : g > 8192 ? 8192 : g);
+}
+__device__ __forceinline__ size_t gid_xcd(unsigned group)
+{
+  const unsigned W = 8u * group;
   const unsigned b = blockIdx.x, w = b / W;
-  const unsigned t = (w + 1) * W <= gridDim.x ? w * W + (b % 8u) * XCD_GROUP + (b % W) / 8u : b;      // (the ragged tail keeps its order)
+  const unsigned t = (w + 1) * W <= gridDim.x ? w * W + (b % 8u) * group + (b % W) / 8u : b;      // (the ragged tail keeps its order)
   return size_t(t) * blockDim.x + threadIdx.x;
 }
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (WAVE - 1); }
@@ -347,7 +352,7 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // overhang, no sorted_ijk) -- ragged ranges and the cell look-up cost more than the saved load level, 1.49 ms.
 template <class KEY>
 __global__ void __launch_bounds__(BS)
-k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r)
+k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
   __shared__ KEY lds[cr_cap<KEY>];
@@ -358,6 +363,9 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   const bool active = p < n;
   uint32_t c = 0, s = 0, e = 0, id = 0;
   if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
+  // a workgroup that sees only crowded cells (every cell of C5) has nothing to rank: the listed-cell sorts take the ids as they are.
+  // `crowded`: the host's guess from the mean SDs per cell -- the vote is a barrier behind the loads, 0.15 ms on C3 where it never hits
+  if (crowded && __syncthreads_and(!active || (e - s) > uint32_t(cellrank_max<KEY>))) { if (active) out[p] = id; return; }
   const KEY mine = active ? KEY(sort_key(id, shuffle, r)) : KEY(0);
   if (threadIdx.x == 0) bounds[0] = s;
   if (p == plast) bounds[1] = e;
@@ -430,45 +438,80 @@ __device__ __forceinline__ void wave_bitonic(KEY *a, uint32_t cnt, uint32_t P, u
     }
   }
 }
+// Shuffle keys ((un << 32) | id, un uniform in 32 bits) are ranked by BUCKETS instead of a network: the top 9 bits of un spread a
+// cell's keys over 512 buckets (one or two keys each at 512 SDs per cell); an LDS histogram + one wave scan give every bucket its
+// first rank, and a key's rank is that plus the number of smaller keys in its own bucket.  ~12 LDS operations per key against ~90
+// for the bitonic network of 512..1024 keys (C5: 18.5 -> see DESIGN.md); keys are unique, so the order does not depend on the
+// arrival order of the atomics.  A degenerate un (a replayed constant array) only makes the in-bucket loop long, never wrong.
+constexpr int CSW_BUCKETS = 512;
 template <class KEY>
 __global__ void __launch_bounds__(BS)
 k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
+  constexpr int PER = CELLSORT_WAVE_MAX / WAVE;
   __shared__ KEY lds[BS / WAVE][CELLSORT_WAVE_MAX];
+  __shared__ uint32_t bkt[shuffle ? BS / WAVE : 1][shuffle ? CSW_BUCKETS : 1];
+  __shared__ uint16_t idx[shuffle ? BS / WAVE : 1][shuffle ? CELLSORT_WAVE_MAX : 1];
   KEY *a = lds[wave_id()];
   const uint32_t lane = lane_id();
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
   for (uint32_t b = blockIdx.x * (BS / WAVE) + wave_id(); b < n_big; b += gridDim.x * (BS / WAVE)) {
     const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
     if (cnt > uint32_t(CELLSORT_WAVE_MAX)) continue;         // k_cellsort_lds / k_cellsort_big take it
-    uint32_t P = 2 * WAVE; while (P < cnt) P <<= 1;
-    for (uint32_t i = lane; i < cnt; i += WAVE) a[i] = KEY(sort_key(sorted_id[start + i], shuffle, r));
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    const uint32_t H = P >> 1;
-    if (shuffle && H >= 2 * WAVE && cnt - H <= uint32_t(WAVE)) {
-      // (64-bit shuffle keys only: with 32-bit keys the passes are cheap enough that the merge's dependent look-ups cost more)
-      // a little more than a power of two (512 SDs per cell on average: half of the cells hold 513 ... 576): sort the first H
-      // keys and the short tail separately, then merge by rank (keys are unique) -- about half the passes of the 2H network
-      const uint32_t m = cnt - H;
-      wave_bitonic(a, H, H, lane);
-      wave_bitonic(a + H, m, uint32_t(WAVE), lane);
-      for (uint32_t i = lane; i < H; i += WAVE) {
-        const KEY key = a[i];
-        uint32_t lo = 0, hi = m;                                    // number of tail keys below `key`
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[H + mid] < key) lo = mid + 1; else hi = mid; }
-        sorted_id[start + i + lo] = uint32_t(key);
+    if constexpr (shuffle) {
+      uint32_t *cb = bkt[wave_id()];
+      uint16_t *ix = idx[wave_id()];
+      constexpr int CPL = CSW_BUCKETS / WAVE;                // counters per lane in the scan
+      constexpr int SH = 64 - 9;
+      static_assert(CSW_BUCKETS == 512, "the bucket is the key's top 9 bits");
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) cb[lane + j * WAVE] = 0u;
+      wave_sync();
+      uint32_t slot[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t i = lane + k * WAVE;
+        if (i < cnt) { const KEY key = KEY(sort_key(sorted_id[start + i], shuffle, r)); a[i] = key; slot[k] = atomicAdd(&cb[uint32_t(key >> SH)], 1u); }
       }
-      if (lane < m) {
-        const KEY key = a[H + lane];
-        uint32_t lo = 0, hi = H;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-        sorted_id[start + lane + lo] = uint32_t(key);
+      wave_sync();
+      uint32_t loc[CPL], sum = 0;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { loc[j] = cb[lane * CPL + j]; sum += loc[j]; }
+      uint32_t incl = sum;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane) >= d) incl += t; }
+      uint32_t run = incl - sum;
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { cb[lane * CPL + j] = run; run += loc[j]; }       // first rank of every bucket
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t i = lane + k * WAVE;
+        if (i < cnt) ix[cb[uint32_t(a[i] >> SH)] + slot[k]] = uint16_t(i);
       }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t i = lane + k * WAVE;
+        if (i < cnt) {
+          const KEY key = a[i];
+          const uint32_t bk = uint32_t(key >> SH), s = cb[bk], e = bk + 1 < uint32_t(CSW_BUCKETS) ? cb[bk + 1] : cnt;
+          uint32_t rank = s;
+          for (uint32_t q = s; q < e; ++q) rank += a[ix[q]] < key;
+          sorted_id[start + rank] = uint32_t(key);
+        }
+      }
+      wave_sync();
     } else {
+      uint32_t P = 2 * WAVE; while (P < cnt) P <<= 1;
+      for (uint32_t i = lane; i < cnt; i += WAVE) a[i] = KEY(sort_key(sorted_id[start + i], shuffle, r));
+      wave_sync();
       wave_bitonic(a, cnt, P, lane);
       for (uint32_t i = lane; i < cnt; i += WAVE) sorted_id[start + i] = uint32_t(a[i]);
+      wave_sync();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
   }
 }
 // listed segments of up to CELLSORT_LDS_MAX keys: one workgroup per segment, bitonic network
@@ -671,6 +714,7 @@ struct cond_args {
   const T *rhod, *rv, *Tk, *eta, *RH, *lambda_D, *lambda_K;
   T *m3_before, *m3_after;
   T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
+  unsigned xcd_group;     // workgroups per XCD run (gid_xcd)
   const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
   const cond_cell_fast<T> *pre;   // fast arithmetic without turb_cond: the droplet-independent set-up, per cell (k_cond_cellpre)
 };
@@ -687,7 +731,7 @@ __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const 
 template <class T, bool FAST>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond(size_t n_part, cond_args<T> a)
 {
-  const size_t pos = gid_xcd(); if (pos >= n_part) return;
+  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
   const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
   const T rw2_old = a.rw2[id];
   const T nn = T(a.n[id]);                                            // n_filtered is a real_t copy of n (moms.ipp:55-61)
@@ -808,7 +852,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
       cond_fast_one<T, OPT, true>(part[q], a, 0u, my);
     return;
   }
-  const size_t pos = gid_xcd(); if (pos >= n_part) return;
+  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
   const bool deferred = cond_fast_one<T, OPT, false>(pos, a, df.budget, my);
   const unsigned long long bal = __ballot(deferred);       // (lanes behind n_part have left: the ballot covers the rest)
   if (bal) {
