@@ -350,6 +350,9 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // for the ids, 1.41 -> 1.32 ms for the shuffle keys).  Tried and dropped: 32-bit shuffle keys (un alone) with the position in the
 // plain order as tie-break -- lane-dependent loop bounds, 1.9 ms; a cell-major form (a workgroup owns a few whole cells, no
 // overhang, no sorted_ijk) -- ragged ranges and the cell look-up cost more than the saved load level, 1.49 ms.
+// Also tried: ranking by buckets as k_cellsort_wave does for crowded cells (bucket = the key's expected rank in its cell, LDS histogram +
+// workgroup scan + in-bucket compares instead of 64 compares per key) -- a third of the instructions but five barriers instead of
+// two: post_copy 2.03 against 2.09 ms on C3, not worth a second kernel.
 template <class KEY>
 __global__ void __launch_bounds__(BS)
 k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded)
