@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=128, help="cells per dimension (BASELINE: 128)")
     ap.add_argument("--nx", type=int, default=0, help="override the number of x-planes (emulates one slab of a decomposed run)")
+    ap.add_argument("--ny", type=int, default=0, help="override the number of cells in y (C4: --nx 256 --ny 256 --nz 128)")
+    ap.add_argument("--nz", type=int, default=0, help="override the number of cells in z")
     ap.add_argument("--sd-conc", type=int, default=64)
     ap.add_argument("--dx", type=float, default=40.)
     ap.add_argument("--sstp-cond", type=int, default=1)
@@ -211,7 +213,8 @@ def main():
     nx_tot = n * n_slabs if args.scaling == "weak" else n
     if args.nx:
         nx_tot = args.nx
-    oi = make_opts_init(nx_tot, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
+    ny, nz = args.ny or n, args.nz or n
+    oi = make_opts_init(nx_tot, ny, nz, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = -1 if native_multi else dev_index
     oi.strict_fp = args.strict_fp
     oi.reorder_every = args.reorder_every
@@ -227,8 +230,8 @@ def main():
             def arange(m, dtype=None):
                 return torch.arange(m, dtype=tdtype, device=d)
             sin, cos, exp, log = staticmethod(torch.sin), staticmethod(torch.cos), staticmethod(torch.exp), staticmethod(torch.log)
-        f = make_fields(nx_loc, n, n, x_off, nx_tot, TorchXP, tdtype)
-        shapes = [(nx_loc, n, n)] * 3 + [(nx_loc + 1, n, n), (nx_loc, n + 1, n), (nx_loc, n, n + 1)]
+        f = make_fields(nx_loc, ny, nz, x_off, nx_tot, TorchXP, tdtype)
+        shapes = [(nx_loc, ny, nz)] * 3 + [(nx_loc + 1, ny, nz), (nx_loc, ny + 1, nz), (nx_loc, ny, nz + 1)]
         return [t.expand(sh).contiguous() for t, sh in zip(f, shapes)]
 
     n_sd_max0 = oi.n_sd_max
@@ -358,7 +361,7 @@ def main():
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
             # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
-            default_cfg = (world_out == 1 and n == 128 and not args.nx and args.sd_conc == 64 and args.real == "f64"
+            default_cfg = (world_out == 1 and n == 128 and not (args.nx or args.ny or args.nz) and args.sd_conc == 64 and args.real == "f64"
                            and not args.strict_fp and args.sstp_cond == 1)
             if default_cfg:
                 import glob
@@ -433,7 +436,7 @@ def main():
             "dtype": args.real,
             "data": "synthetic",
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
-                                   % (nx_tot, n, n, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
+                                   % (nx_tot, ny, nz, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
                        "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, decomposition_note), "cond_mode": args.cond_mode,
                        "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
                        "init_s": t_init},

@@ -14,8 +14,12 @@ for N in 2 4 8; do
   $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_concurrent.json 2> $out/multi_${N}_concurrent.err
   LCX_MULTI_SERIALIZE=1 $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_serialized.json 2> $out/multi_${N}_serialized.err
 done
-# C4's slab (256 x 256 x 128 over 8 devices = 32 x-planes of 256 x 128 cells) does not fit bench.py's cubic grid options: weak-scaling slab instead
-$B --scaling weak --gpus 2 --oversubscribe --n 64 --steps 40 > $out/weak_2x64.json 2> $out/weak_2x64.err
+# C4 at full size (256 x 256 x 128 x 64 = 5.4e8 SDs, 8 slabs of 32 x-planes), all slabs on this device: concurrently, and one slab at a time
+C4="--nx 256 --ny 256 --nz 128 --gpus 8 --oversubscribe --steps 10 --warmup 2"
+$B $C4 > $out/c4_8slabs_concurrent.json 2> $out/c4_8slabs_concurrent.err
+LCX_MULTI_SERIALIZE=1 $B $C4 > $out/c4_8slabs_serialized.json 2> $out/c4_8slabs_serialized.err
+# one C4 slab alone on the device (no neighbours)
+$B --nx 32 --ny 256 --nz 128 --steps 40 > $out/c4_slab_alone.json 2> $out/c4_slab_alone.err
 # C5: 128^3 x 512 SD/cell
 $B --sd-conc 512 --steps 10 --warmup 2 > $out/c5.json 2> $out/c5.err
 python3 - "$out" "$tag" <<'PY'
