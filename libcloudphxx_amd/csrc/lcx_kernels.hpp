@@ -807,6 +807,11 @@ template <class T> __device__ __forceinline__ T rw2_to_rw3_signed(T x) { return 
 // runs the root finder with a short iteration budget; a droplet that has not converged inside it is left untouched and its position
 // appended to a list (one atomic per wave), and a second, dense pass solves the listed droplets from scratch with the reference's
 // budget of 100.  Same arithmetic per droplet either way, hence the same results; the list lives in the `rank` scratch.
+// Root-finder iterations per droplet on C3 (bracket updates behind the two end evaluations): 0: 8 %, 1: 30 %, 2: 25 %, 3: 26 %, 4: 7 %,
+// 5: 3.7 %, 6+: 0.2 % -- mean 2.1, but 92 % of the waves hold a droplet that needs 5.  Dealing a workgroup's droplets to its waves by the
+// count each needed in the PREVIOUS step (a byte per droplet, counting sort in LDS) was built and measured: the count repeats for only
+// 51 % of the droplets (83 % within +-1), so the waves stay as uneven as before, and the three barriers + the hint's gather and
+// byte-wide scatter cost 0.66 ms (cond 7.30 -> 8.02 ms).
 // Measured on C3 (ms per launch pair): no deferral 7.69; budget 6 (= 8 evaluations, 0.7 % deferred) 7.39; 7 and 8: 7.56; 5 (4 % deferred)
 // 7.99; 4 (14 %) 8.69 -- dense waves of stragglers pay the maximum over 64 hard droplets, so only the far tail is worth deferring.
 // The list is kept in DEFER_SHARDS parts, workgroup b appending to part b % DEFER_SHARDS with the part's own counter (one counter
