@@ -356,7 +356,7 @@ def main():
             launches = args.steps * args.sstp_cond
             avg_ms = stage_ms["cond"] / launches
             ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_cond_fast (first pass + straggler pass)" if not args.strict_fp else "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roof = {"bound": "hbm", "kernel": "k_cond_fast_fold + k_cond_fast (first pass + straggler pass)" if not args.strict_fp else "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
@@ -369,7 +369,7 @@ def main():
                     tj = json.load(open(tf))
                     # the condensation kernel runs as two launches per substep (first pass + deferred stragglers): the stage timer and the
                     # counters below cover the pair
-                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_fast<double")]
+                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_fast") and "<double" in k_]     # k_cond_fast_fold + k_cond_fast<.., true>
                     t = {k_: sum(v.get(k_, 0) for v in both) for k_ in set().union(*both) if isinstance(both[0].get(k_, 0), (int, float))} if both else None
                     if t:
                         src = "profiles/" + os.path.basename(tf)

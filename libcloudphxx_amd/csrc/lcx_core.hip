@@ -832,7 +832,9 @@ struct Particles : IParticles {
         // (`rank` is free between the sorts; part s holds at most the positions of the workgroups b with b % DEFER_SHARDS == s)
         cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
-        hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
+        const bool fold = getenv("LCX_COND_NO_FOLD") == nullptr;                             // (test / measurement switch)
+        if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 3>), gr, bl, 0, st, npart, a, df);
+        else hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
         if (df.budget) {
           const unsigned per_shard = std::max(1u, std::min(nblk(npart / 8 + 1), 256u * 64u) / DEFER_SHARDS);
           hipLaunchKernelGGL((k_cond_fast<T, 3, true>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, npart, a, df);

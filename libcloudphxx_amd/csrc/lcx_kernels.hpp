@@ -873,6 +873,88 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 }
 
+// The first pass with the workgroup FOLDED at the root finder's loop entry: every lane runs the head (the two end evaluations, the secant
+// and the first quadratic step: uniform work); the ~37 % of the droplets that enter the loop hand their state (bracket, function values,
+// the droplet's own constants: 13 reals + 4 words) through LDS to the lowest lanes of the workgroup, the emptied waves leave, and the
+// remaining one or two run the loop densely.  Same arithmetic per droplet, same results as k_cond_fast.
+// Measured on C3: 6.96-7.06 ms against 7.22-7.26 for the pair of launches.  The wave-evaluations drop by a fifth (4 waves x 4 + 2 x 3.3
+// against 4 x 7), the time by 3-4 %: at four waves per SIMD the kernel runs at the latency of its dependent fp64 chains, and the folded
+// workgroups leave their SIMDs with fewer waves to interleave.  Variants: the droplet's own values gathered again instead of moved
+// (22 KB of LDS instead of 31): no gain at all; a 160-slot stage with an unfolded fallback (values live across the barrier): 7.34.
+template <class T, int OPT = 3>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond_fast_fold(size_t n_part, cond_args<T> a, cond_defer df)
+{
+  constexpr int NR = 13;
+  __shared__ T xr[NR][BS];                                     // [12] doubles as the lanes' own stash of the multiplicity
+  __shared__ uint32_t xw[4][BS];
+  __shared__ uint32_t wcnt[BS / WAVE];
+  const size_t pos0 = gid_xcd(a.xcd_group);
+  const unsigned budget = df.budget ? df.budget : a.n_iter;
+  bool need = false;
+  toms_carry<T> k;
+  k.count = budget;
+  T rw2_old = 0, rd3 = 0, kpa = 0, vt = 0;
+  uint32_t id = 0, c = 0;
+  if (pos0 < n_part) {
+    id = a.sorted_id[pos0]; c = a.sorted_ijk[pos0];
+    rw2_old = a.rw2[id]; rd3 = a.rd3[id]; kpa = a.kpa[id]; vt = a.vt[id];
+    T nn = T(a.n[id]);
+    cond_cell_fast<T> cc = a.pre[c];
+    asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+                 "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+    volatile T *my = &xr[12][threadIdx.x];
+    *my = nn;                                                  // (the multiplicity waits in LDS while the root finder has the registers)
+    T r = rw2_old;
+    if (rw2_old > 0) {
+      cond_fun_fast<T, OPT> ff;
+      ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+      need = !advance_rw2_head_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, budget, k, r);
+      if (df.budget && k.count == 0) need = true;              // (a budget the head itself exhausts: the loop below defers it)
+      if (!need) a.rw2[id] = r;
+    }
+    if (!need) a.m3_after[pos0] = *my * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+  }
+  // fold: the droplets still in the root finder move to lanes 0 .. total-1 of the workgroup
+  const unsigned long long bal = __ballot(need);
+  if (lane_id() == 0) wcnt[wave_id()] = uint32_t(__popcll(bal));
+  const T nn_move = need ? xr[12][threadIdx.x] : T(0);         // (slot and threadIdx.x index the same array: read before anybody writes)
+  __syncthreads();
+  uint32_t first = 0, total = 0;
+#pragma unroll
+  for (unsigned w = 0; w < BS / WAVE; ++w) { const uint32_t n_w = wcnt[w]; if (w < wave_id()) first += n_w; total += n_w; }
+  if (need) {
+    const uint32_t slot = first + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)));
+    xw[0][slot] = id; xw[1][slot] = c; xw[2][slot] = uint32_t(pos0); xw[3][slot] = k.count;
+    xr[0][slot] = k.s.a; xr[1][slot] = k.s.b; xr[2][slot] = k.s.fa; xr[3][slot] = k.s.fb; xr[4][slot] = k.s.d; xr[5][slot] = k.s.fd;
+    xr[6][slot] = k.e; xr[7][slot] = k.fe; xr[8][slot] = rw2_old; xr[9][slot] = rd3; xr[10][slot] = kpa; xr[11][slot] = vt;
+    xr[12][slot] = nn_move;
+  }
+  __syncthreads();
+  if (threadIdx.x >= total) return;
+  const uint32_t t = threadIdx.x;
+  id = xw[0][t]; c = xw[1][t];
+  const size_t pos = xw[2][t];
+  k.count = xw[3][t];
+  k.s.a = xr[0][t]; k.s.b = xr[1][t]; k.s.fa = xr[2][t]; k.s.fb = xr[3][t]; k.s.d = xr[4][t]; k.s.fd = xr[5][t];
+  k.e = xr[6][t]; k.fe = xr[7][t]; rw2_old = xr[8][t]; rd3 = xr[9][t]; kpa = xr[10][t]; vt = xr[11][t];
+  const cond_cell_fast<T> cc = a.pre[c];
+  cond_fun_fast<T, OPT> ff;
+  ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+  unsigned left = 1;
+  const T r = advance_rw2_tail_with(ff, rd3, a.eps, k, &left);
+  const bool deferred = df.budget != 0 && left == 0;
+  if (!deferred) { a.rw2[id] = r; a.m3_after[pos] = xr[12][t] * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old)); }
+  const unsigned long long dbal = __ballot(deferred);
+  if (dbal) {
+    const int leader = __ffsll((long long)dbal) - 1;
+    uint32_t base = 0;
+    const unsigned shard = blockIdx.x % DEFER_SHARDS;
+    if (int(lane_id()) == leader) base = atomicAdd(df.count + shard * DEFER_CNT_STRIDE, uint32_t(__popcll(dbal)));
+    base = __shfl(base, leader);
+    if (deferred) df.list[size_t(shard) * df.shard_cap + base + __popcll(dbal & ((1ull << lane_id()) - 1ull))] = uint32_t(pos);
+  }
+}
+
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
 // sums each 8th value of the staged segment and a fixed 3-step shuffle tree joins them (deterministic, different rounding)
 template <class T, int G>

@@ -711,6 +711,31 @@ def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget)
     assert np.abs(res[0][2] - rv).max() > 0                       # (condensation did happen)
 
 
+@pytest.mark.parametrize("budget", ["0", "6", "2"])
+def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatch, budget):
+    """k_cond_fast_fold (the workgroup's droplets that enter the root finder's loop handed through LDS to its lowest lanes; the
+    production first pass) against k_cond_fast (LCX_COND_NO_FOLD=1): the same arithmetic per droplet on another lane"""
+    oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
+    fields = h.box_fields(oi)
+    monkeypatch.setenv("LCX_COND_BUDGET", budget)
+    res = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("LCX_COND_NO_FOLD", "1")
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        opts.coal = opts.adve = opts.sedi = False
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(2):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
 def test_rcyc_matches_oracle(dims):
     """opts.rcyc: the SDs freed by coalescence / precipitation are re-used as halves of the SDs with the highest
