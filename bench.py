@@ -159,7 +159,7 @@ def main():
                          "the collected one-division form with FMA contraction, parity-tested at the same tolerances")
     ap.add_argument("--reorder-every", type=int, default=0,
                     help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
-                         "many steps (0 = the library default, every 64 steps and with every compaction; -1 = never, the reference's "
+                         "many steps (0 = the library default, every 64 steps -- 32 for slabs with neighbours -- and with every compaction; -1 = never, the reference's "
                          "storage order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=64)
