@@ -388,6 +388,21 @@ template <class T> struct cond_fun {
 // precision hardware seed (v_log_f32 / v_exp_f32 / v_rcp_f32) refined in double does the same job in ~15/~20.
 // Both are accurate to <= 1 ulp on their domain (tests/test_hip_parity.py::test_fast_math_accuracy) and fall back
 // to the library call outside it.
+LCX_HD double cbrt_seeded_core(double x)            // 0.125 <= x < 1e30 is the caller's business
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float xf = float(x);
+  const float y0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (1.f / 3.f));
+  const double inv = double(__builtin_amdgcn_rcpf(3.f * y0 * y0));
+  double y = double(y0);
+  y = __builtin_fma(-inv, __builtin_fma(y * y, y, -x), y);
+  y = __builtin_fma(-inv, __builtin_fma(y * y, y, -x), y);
+  return y;
+#else
+  return cbrt(x);
+#endif
+}
+LCX_HD float cbrt_seeded_core(float x) { return cbrt(x); }
 LCX_HD double cbrt_seeded(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -519,6 +534,17 @@ LCX_HD double pow_lean(double x, double y)
 #endif
 }
 LCX_HD float pow_lean(float x, float y) { return pow(x, y); }
+// the same without the library fallback (1 < x < 1e300 is the caller's business): the growth rate's Re^0.077 sits in a rarely taken
+// branch of every inlined copy, where the library pow is ~220 instructions of code each -- a third of the condensation kernel
+LCX_HD double pow_core(double x, double y)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return exp_kelvin(y * log_lean_core(x));
+#else
+  return pow(x, y);
+#endif
+}
+LCX_HD float pow_core(float x, float y) { return pow(x, y); }
 
 // The same growth rate as cond_fun, algebraically collected into ONE rational expression (one IEEE division
 // instead of fifteen) with FMA contraction allowed.  Selected by opts_init.strict_fp = 0.  It is the counterpart
@@ -586,8 +612,9 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       klv = exp_kelvin(A * irw);
       Sh = T(1) + cS; Nu = T(1) + cN;
       if (!(mx(xS, xN) < T(0x1p-8))) {
-        cS = cbrt_seeded(T(1) + xS); cN = cbrt_seeded(T(1) + xN);
-        const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+        // (1 + Re Sc >= 1, and below 1e30 for anything that is a droplet: no range check, whose library fallback is code in every copy)
+        cS = cbrt_seeded_core(T(1) + xS); cN = cbrt_seeded_core(T(1) + xN);
+        const T m = (Re > T(1)) ? mx(T(1), T(pow_core(Re, T(.077)))) : T(1);
         Sh = T(1) + cS * m; Nu = T(1) + cN * m;
       }
     } else {
