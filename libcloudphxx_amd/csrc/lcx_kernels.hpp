@@ -790,10 +790,12 @@ __device__ __forceinline__ void cellfinish_apply(size_t c, bool has, T after, T 
 // pass reads half as much, nothing is carried between substeps (rw_mom3) and the difference of two large sums is never formed.
 // Measured on C3 (MI355X, fp64, cond + cond_cellfinish per step): round-1 pair 8.45 + 0.62 ms; this form 8.42 + 0.42; with the
 // root finder's reciprocals at one Newton step (OPT bit 0) 8.20; with the cube-root series (bit 1) 8.35; both 8.15 + 0.42.
-// HBM traffic of this kernel (PMC, r02): 13.0 GB read + 5.4 GB written per launch against 6.4 + 2.1 algorithmic.  The excess is
-// NOT the 28 B of scratch (a variant with 12 B of scratch -- three cell constants re-read from lane-private LDS slots -- moves the
-// same bytes and takes 8.06 ms instead of 7.92): it is the 40 B gathered and 8 B scattered per droplet through sorted_id, which
-// touch whole 64-B lines once droplets have drifted from their storage neighbours (half of them after two steps at |C| = 0.3).
+// HBM traffic of this kernel (PMC): 13.0 GB read + 5.4 GB written per launch against 6.4 + 2.1 algorithmic at the start of round 2,
+// 11.2 + 3.3 at its end.  2.7 GB of the writes were the 28-36 B of scratch per lane: they went when the library pow left the growth
+// rate's rare branch (lcx_math.hpp pow_core) and the kernel fitted 114 VGPRs.  (A variant with 12 B of scratch had moved the same bytes
+// as the 28-B one and taken 8.06 instead of 7.92 ms, which is why the scratch was acquitted for a while.)  The rest of the excess is
+// the 40 B gathered and 8 B scattered per droplet through sorted_id, which touch whole 64-B lines once droplets have drifted from their
+// storage neighbours (half of them after two steps at |C| = 0.3).
 // Walking the STORAGE order instead (unit-stride attributes, only the 8-B delta gathered by the finishing pass) removes that
 // traffic and was measured as well: 9.28 + 0.63 ms -- the lanes of a wave then sit in different cells, their root finders need
 // different numbers of iterations, and the kernel is bound by exactly that (fp64 issue and divergence), not by HBM.
