@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round profile: kernel trace statistics of the default bench command, then two PMC passes (HBM read / write bytes)
-# of the dominant kernels.  Run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r01c'
+# of the dominant kernels.  Run on the GPU box:  gpurun -- 'bash tools/profile_round.sh r02f'   (then copy summary.txt, traffic.json,
+# bench_under_trace.json and the trace's kernel_stats.csv into profiles/<tag>_*, and run tools/isa_histogram.py on the traffic file)
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
