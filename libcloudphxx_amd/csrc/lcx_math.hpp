@@ -668,8 +668,16 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
   }
   T fa, fb;
   // the reference takes f(rw2_old) == drw2 at the near end of the bracket (cond_common.ipp:296-305)
-  if (drw2 > 0) { fa = drw2; fb = f(b); }
-  else          { fa = f(a); fb = drw2; }
+  if constexpr (fastdiv<F>::value != 0) {
+    // ONE evaluation site for the far end: growing and evaporating droplets of a wave (the haze of a subsaturated cell hovers around
+    // drw2 = 0) would otherwise run the two inlined copies one after the other
+    const bool grows = drw2 > 0;
+    const T f_far = f(grows ? b : a);
+    fa = grows ? drw2 : f_far; fb = grows ? f_far : drw2;
+  } else {
+    if (drw2 > 0) { fa = drw2; fb = f(b); }
+    else          { fa = f(a); fb = drw2; }
+  }
   T rw2_new;
   if (fa * fb > 0) rw2_new = rw2_old + drw2;
   else if (!toms748_head(f, a, b, fa, fb, eps, n_iter, k, rw2_new)) return false;
