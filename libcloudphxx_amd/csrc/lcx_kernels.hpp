@@ -366,11 +366,19 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   const size_t p = p0 + threadIdx.x;
   const bool active = p < n;
   uint32_t c = 0, s = 0, e = 0, id = 0;
+  // SPEC positions on either side of the workgroup's range are fetched together with its own ids, before the cell bounds are known: the
+  // overhang of the first and last cell (half a cell on average) is then staged without a third dependent load level
+  constexpr int SPEC = BS / 2;
+  const size_t pe = threadIdx.x < SPEC ? p0 - SPEC + threadIdx.x : p0 + BS + (threadIdx.x - SPEC);      // (wraps below zero: caught by pe < n)
+  const bool have_e = (threadIdx.x < SPEC ? p0 >= size_t(SPEC) - threadIdx.x : true) && pe < n;
+  uint32_t id_e = 0;
+  if (have_e) id_e = in[pe];
   if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
   // a workgroup that sees only crowded cells (every cell of C5) has nothing to rank: the listed-cell sorts take the ids as they are.
   // `crowded`: the host's guess from the mean SDs per cell -- the vote is a barrier behind the loads, 0.15 ms on C3 where it never hits
   if (crowded && __syncthreads_and(!active || (e - s) > uint32_t(cellrank_max<KEY>))) { if (active) out[p] = id; return; }
   const KEY mine = active ? KEY(sort_key(id, shuffle, r)) : KEY(0);
+  const KEY key_e = have_e ? KEY(sort_key(id_e, shuffle, r)) : KEY(0);
   if (threadIdx.x == 0) bounds[0] = s;
   if (p == plast) bounds[1] = e;
   __syncthreads();
@@ -378,8 +386,11 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   const bool staged = (hi - lo) <= uint32_t(cr_cap<KEY>);
   if (staged) {
     if (active) lds[p - lo] = mine;
-    for (size_t q = size_t(lo) + threadIdx.x; q < p0; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));            // the first cell's part before the block
-    for (size_t q = plast + 1 + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));             // the last cell's part behind it
+    if (have_e && pe >= lo && pe < hi) lds[pe - lo] = key_e;
+    // what the speculative window does not cover (cells above SPEC super-droplets)
+    if (p0 >= size_t(SPEC))
+      for (size_t q = size_t(lo) + threadIdx.x; q < p0 - SPEC; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));  // the first cell's part before the block
+    for (size_t q = p0 + BS + SPEC + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));         // the last cell's part behind it
   }
   __syncthreads();
   if (!active) return;
