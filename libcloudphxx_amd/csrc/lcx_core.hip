@@ -1023,6 +1023,18 @@ struct Particles : IParticles {
     if (pc && tb) hipLaunchKernelGGL((k_move<T, true, true>), dim3(blocks), dim3(BS), 0, st, a);
     else if (pc) hipLaunchKernelGGL((k_move<T, true, false>), dim3(blocks), dim3(BS), 0, st, a);
     else if (tb) hipLaunchKernelGGL((k_move<T, false, true>), dim3(blocks), dim3(BS), 0, st, a);
+    else if (n_dims == 3) {
+      const bool full = do_adve && do_sedi && !do_subs && do_bcnd && reindex && halo == 0 && !o.open_side_walls && !o.periodic_topbot_walls &&
+                        (adve_scheme == LCX_ADVE_EULER || adve_scheme == LCX_ADVE_IMPLICIT);
+      const int spec = !full ? MOVE_3D : MOVE_3D | MOVE_FULL | (a.distmem ? MOVE_DISTMEM : 0) | (adve_scheme == LCX_ADVE_IMPLICIT ? MOVE_IMPLICIT : 0);
+      switch (spec) {
+        case MOVE_3D | MOVE_FULL: hipLaunchKernelGGL((k_move<T, false, false, MOVE_3D | MOVE_FULL>), dim3(blocks), dim3(BS), 0, st, a); break;
+        case MOVE_3D | MOVE_FULL | MOVE_DISTMEM: hipLaunchKernelGGL((k_move<T, false, false, MOVE_3D | MOVE_FULL | MOVE_DISTMEM>), dim3(blocks), dim3(BS), 0, st, a); break;
+        case MOVE_3D | MOVE_FULL | MOVE_IMPLICIT: hipLaunchKernelGGL((k_move<T, false, false, MOVE_3D | MOVE_FULL | MOVE_IMPLICIT>), dim3(blocks), dim3(BS), 0, st, a); break;
+        case MOVE_3D | MOVE_FULL | MOVE_DISTMEM | MOVE_IMPLICIT: hipLaunchKernelGGL((k_move<T, false, false, MOVE_3D | MOVE_FULL | MOVE_DISTMEM | MOVE_IMPLICIT>), dim3(blocks), dim3(BS), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_move<T, false, false, MOVE_3D>), dim3(blocks), dim3(BS), 0, st, a);
+      }
+    }
     else hipLaunchKernelGGL((k_move<T, false, false>), dim3(blocks), dim3(BS), 0, st, a);
     if (reindex && !distmem()) list_big_from_hist();                    // (with neighbours: after their immigrants are in, exch_unpack)
     if (want_puddle && dev_exchange) puddle_pending_blocks = blocks;      // (reduced after the emigrants are on their way, see lcx_multi.hpp)

@@ -1595,9 +1595,19 @@ template <class T> __device__ __forceinline__ T periodic(T x, T a, T b) { return
 
 // PC / TURB: the predictor-corrector scheme and the SGS velocity perturbations are separate instantiations (their extra
 // live state costs the plain first-order pass 8..12 %)
-template <class T, bool PC, bool TURB>
+// SPEC: the common configurations compiled for themselves -- a uniform branch costs this kernel far more than its instruction count
+// says (k_move on C3: 2.52 ms generic, 2.22 with the dimension tests folded away, see DESIGN.md for the full profile).
+//   bit 0: three-dimensional;  bit 1: the full step's pass (advection + sedimentation + boundary + re-indexing, no subsidence, no
+//   Courant halo, periodic side walls, closed bottom / top);  with bit 1 -- bit 2: a slab with neighbours, bit 3: implicit scheme (else Euler)
+constexpr int MOVE_3D = 1, MOVE_FULL = 2, MOVE_DISTMEM = 4, MOVE_IMPLICIT = 8;
+template <class T, bool PC, bool TURB, int SPEC = 0>
 __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
 {
+  if (SPEC & MOVE_3D) { a.g.ndims = 3; __builtin_assume(a.g.nx > 0); __builtin_assume(a.g.ny > 0); __builtin_assume(a.g.nz > 0); }
+  if (SPEC & MOVE_FULL) {
+    a.do_adve = a.do_sedi = a.do_bcnd = a.reindex = 1; a.do_subs = 0; a.halo = 0; a.open_side_walls = 0; a.periodic_topbot = 0;
+    a.distmem = (SPEC & MOVE_DISTMEM) ? 1 : 0; a.scheme = (SPEC & MOVE_IMPLICIT) ? LCX_ADVE_IMPLICIT : LCX_ADVE_EULER;
+  }
   __shared__ double red[4][BS / WAVE];
   const size_t i = gid();
   double pl = 0, pd = 0, pn = 0, pp = 0;
