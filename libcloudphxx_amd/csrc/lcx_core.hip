@@ -530,7 +530,8 @@ struct Particles : IParticles {
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
-        if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
+        if (shuffle && !rs.un && !crowded) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
+        else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
@@ -981,7 +982,10 @@ struct Particles : IParticles {
                          A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
                          ix_ict >= 0 ? A.ext[ix_ict].p : nullptr, coal_marks_dead ? ijk.p : nullptr);
     };
-    if (onishi) launch(k_coal<T, true>); else launch(k_coal<T, false>);
+    const bool tabulated = o.kernel != LCX_KERNEL_GOLOVIN && o.kernel != LCX_KERNEL_GEOMETRIC && o.kernel != LCX_KERNEL_LONG;
+    if (onishi) launch(k_coal<T, true>);
+    else if (tabulated && !pure_const_multi && !rs.arr && !use_rc2 && ix_ict < 0 && coal_marks_dead) launch(k_coal<T, false, true>);
+    else launch(k_coal<T, false>);
     if (o.n_dry_distros + n_size_keys > 1)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
   }

@@ -354,11 +354,12 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // Also tried: ranking by buckets as k_cellsort_wave does for crowded cells (bucket = the key's expected rank in its cell, LDS histogram +
 // workgroup scan + in-bucket compares instead of 64 compares per key) -- a third of the instructions but five barriers instead of
 // two: post_copy 2.03 against 2.09 ms on C3, not worth a second kernel.
-template <class KEY>
+template <class KEY, bool PROD = false>      // PROD: keys from Philox (no replayed array), no crowded cells expected -- the uniform tests folded away
 __global__ void __launch_bounds__(BS)
 k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded)
 {
   constexpr int shuffle = sizeof(KEY) == 8;
+  if (PROD) { r.un = nullptr; crowded = 0; }
   __shared__ KEY lds[cr_cap<KEY>];
   __shared__ uint32_t bounds[2];
   const size_t p0 = size_t(blockIdx.x) * BS;
@@ -1466,12 +1467,15 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // owned by exactly one lane and all 64 lanes of a wave carry work.  Pairs are disjoint, so the read-modify-write
 // of the two SDs needs no atomics.  The collision count / who-was-bigger flags go to col[] exactly as in the
 // reference (coal.ipp:209,233-267) because the kappa update (and tests) read them.
-template <class T, bool ONISHI>
+// TAB (as k_move's SPEC: uniform branches are dear): the production configuration compiled for itself -- a tabulated-efficiency
+// kernel (hall*, vohl*), random numbers from Philox, no per-particle rc2 / in-cloud time, used-up super-droplets marked in ijk
+template <class T, bool ONISHI, bool TAB = false>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
        n_t *n, T *rw2, T *vt, T *rd3, T *col, const T *dv, T dt, coal_kernel_cfg<T> kc, u01_src<T> rs,
        int pure_const_multi, int *increase_sstp_coal, T *rc2, T *ict, uint32_t *ijk_mark)
 {
+  if (TAB) { kc.kernel = LCX_KERNEL_HALL; pure_const_multi = 0; rs.arr = nullptr; rc2 = nullptr; ict = nullptr; __builtin_assume(ijk_mark != nullptr); }
   const size_t p0 = 2 * gid();
   if (p0 + 1 >= n_part) return;                       // the reference's range is [0, n_part-1)
   // The three positions a lane may need (2t, 2t+1, 2t+2) and the CSR bounds of their first two cells are fetched up front, in two
