@@ -213,6 +213,26 @@ template <int FD = 0, class T> LCX_HD T cubic(T a, T b, T d, T e, T fa, T fb, T 
 }
 template <class T, class F> LCX_HD void bracket(const F &f, st<T> &s, T c)
 {                                                                  // :60-122
+  if constexpr (fastdiv<F>::value != 0) {
+    // fast arithmetic: the same decisions as below through selects -- every `if` in divergent code is an exec-mask save / branch /
+    // restore (a few dozen cycles of a wave that has only three others to hide behind), and these bodies are single assignments
+    const T tol = lim<T>::eps * 2;
+    const T w = s.b - s.a;
+    T cc = c;
+    cc = (c >= s.b - fabs(s.b) * tol) ? s.b - fabs(s.a) * tol : cc;
+    cc = (c <= s.a + fabs(s.a) * tol) ? s.a + fabs(s.a) * tol : cc;
+    cc = (w < 2 * tol * s.a) ? s.a + w / 2 : cc;
+    const T fc = f(cc);
+    const bool zero = fc == 0, neg = !zero && copysign(T(1), s.fa * fc) < 0, pos = !zero && !neg;
+    const T a0 = s.a, fa0 = s.fa, b0 = s.b, fb0 = s.fb;
+    s.d = zero ? T(0) : neg ? b0 : a0;
+    s.fd = zero ? T(0) : neg ? fb0 : fa0;
+    s.a = neg ? a0 : cc;
+    s.fa = zero ? T(0) : pos ? fc : fa0;
+    s.b = neg ? cc : b0;
+    s.fb = neg ? fc : fb0;
+    return;
+  }
   const T tol = lim<T>::eps * 2;
   if ((s.b - s.a) < 2 * tol * s.a) c = s.a + (s.b - s.a) / 2;
   else if (c <= s.a + fabs(s.a) * tol) c = s.a + fabs(s.a) * tol;
