@@ -270,6 +270,17 @@ def main():
         return prt, keep, arrays, devices, time.perf_counter() - t0
 
     state, fallback_reason = None, None
+    if native_multi and not idle and len(set(slab_dev)) > 1:
+        # several real devices in one process, never run on this hardware before this bench: a cross-device wait that never returns
+        # must not hold the launcher for its whole time-out -- give up loudly after 30 minutes (a default run takes about one)
+        import threading
+
+        def _give_up():
+            print("bench.py: the multi-device run did not finish within 1800 s; giving up", file=sys.stderr, flush=True)
+            os._exit(3)
+        _watchdog = threading.Timer(1800., _give_up)
+        _watchdog.daemon = True
+        _watchdog.start()
     if native_multi:
         if not idle:
             try:
