@@ -179,6 +179,37 @@ def test_cond_step(sstp, strict_fp):
 
 
 @pytest.mark.parametrize("strict_fp", [True, False])
+def test_cond_step_with_drizzle_and_rain_drops(strict_fp):
+    """the ventilated branch of the growth rate (Re Sc above 2^-8: drops above ~8 um; Re > 1 with its Re^0.077: above ~40 um), which
+    the fast form keeps out of its straight-line path (cube roots without range check, pow as exp(y ln x)): wet radii from 5 um to
+    1 mm with their terminal velocities, one and four substeps, against the oracle at the bars of test_cond_step"""
+    oi = h.box_opts(4, 4, 6, 64, sstp_cond=1, strict_fp=strict_fp)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    g = orc.state_real
+    rw2 = orc.get_attr("rw2")
+    rw2[::2] = np.geomspace(5e-6, 1e-3, len(rw2[::2])) ** 2
+    vt = np.minimum(1.2e8 * rw2, 9.)                              # (Stokes-like fall speeds up to 9 m/s: Re from 1e-4 to ~1000)
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), vt, g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+    for it in range(2):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
+        assert (orc.state_real("vt") > 0.3).sum() > 100           # drops with Re > 1 are there
+        np.testing.assert_allclose(rh, ro, rtol=1e-4)
+        # millimetre drops at the multiplicities of aerosol particles hold far more water than the vapour: where the fast form's
+        # last-ulp differences end the root search on a neighbouring bracket (2^-15 wide), one cell's rv shows it at 1e-6
+        np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 1e-6)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-5)
+        big = ro > (8e-6) ** 2
+        assert np.median(np.abs(rh[big] / ro[big] - 1)) < 1e-10
+        h.copy_state(orc, hip)
+
+
+@pytest.mark.parametrize("strict_fp", [True, False])
 @pytest.mark.parametrize("mode", ["nomix", "mix", "adaptive", "adaptive_act"])
 def test_perparticle_cond_step(mode, strict_fp):
     """per-particle substepping (exact_sstp_cond) on a 3-D box against the oracle, advection on so that droplets carry
