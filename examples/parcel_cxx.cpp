@@ -20,6 +20,14 @@ struct lognormal : libcloudphxx::common::unary_function<real_t>
 
 int main()
 {
+  // ---- a driver that prints its options (as UWLCM / icicle do at start-up) needs the `<enum>_name` tables of the option headers
+  {
+    opts_init_t<real_t> oi;
+    std::printf("options backend=%s kernel=%s vt=%s adve=%s RH=%s src=%s n_kernels=%zu\n", backend_name.at(HIP).c_str(),
+                kernel_name.at(kernel_t::hall_pinsky_stratocumulus).c_str(), vt_name.at(vt_t::beard77fast).c_str(),
+                as_name.at(oi.adve_scheme).c_str(), RH_formula_name.at(oi.RH_formula).c_str(), src_name.at(src_t::off).c_str(),
+                kernel_name.size());
+  }
   // ---- 0-D parcel: condensation only
   {
     opts_init_t<real_t> oi;

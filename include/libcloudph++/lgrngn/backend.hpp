@@ -2,8 +2,7 @@
 // CUDA / multi_CUDA are accepted as aliases of HIP / multi_HIP by factory() so that a driver that asks for
 // "the GPU backend" keeps working; serial / OpenMP are not part of this library.
 #pragma once
-#include <string>
-#include <unordered_map>
+#include "enum_names.hpp"
 namespace libcloudphxx { namespace lgrngn {
   enum backend_t { undefined, serial, OpenMP, CUDA, multi_CUDA, HIP, multi_HIP };
   inline const char *backend_str(backend_t b)
@@ -11,6 +10,7 @@ namespace libcloudphxx { namespace lgrngn {
     switch (b) { case serial: return "serial"; case OpenMP: return "OpenMP"; case CUDA: return "CUDA"; case multi_CUDA: return "multi_CUDA";
                  case HIP: return "HIP"; case multi_HIP: return "multi_HIP"; default: return "undefined"; }
   }
-  static const std::unordered_map<int, std::string> backend_name = {
-    {undefined, "undefined"}, {serial, "serial"}, {OpenMP, "OpenMP"}, {CUDA, "CUDA"}, {multi_CUDA, "multi_CUDA"}, {HIP, "HIP"}, {multi_HIP, "multi_HIP"}};
+  // keyed by the enum like the reference's table (backend.hpp:10-16); an unscoped enum hashes through std::hash<backend_t> (C++14)
+  const std::unordered_map<backend_t, std::string> backend_name = detail::enum_names<backend_t>(
+    {"undefined", "serial", "OpenMP", "CUDA", "multi_CUDA", "HIP", "multi_HIP"});
 } }

@@ -76,7 +76,7 @@ def oracle_rng_preview(prt, calls):
     lens = (ctypes.c_size_t * len(calls))(*[n for _, n in calls])
     tot = sum(n for _, n in calls)
     out = np.empty(tot, dtype=np.float64)
-    f = oracle_lib().orc_rng_preview
+    f = prt._lib.orc_rng_preview           # (the library the object was made by: serial, fast-math or OpenMP build)
     rc = f(prt._h, kinds, lens, ctypes.c_int(len(calls)), out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     assert rc == 0
     res, o = [], 0
@@ -177,11 +177,12 @@ def init_replay_calls(oi):
     return [(0, n_new)] * (1 + ndim)
 
 
-def make_pair(oi, fields, force_state=True):
-    """oracle and HIP objects initialised from the same inputs and the same (oracle) random stream"""
+def make_pair(oi, fields, force_state=True, make_oracle=None, real_t=np.float64):
+    """oracle and HIP objects initialised from the same inputs and the same (oracle) random stream
+    (make_oracle: another build of the oracle, e.g. oracle_omp_particles for the large cases)"""
     th, rv, rhod, C = fields
-    orc = oracle_particles(oi)
-    hip = hip_particles(oi)
+    orc = (make_oracle or oracle_particles)(oi)
+    hip = hip_particles(oi, real_t)
     for arr in oracle_rng_preview(orc, init_replay_calls(oi)):
         hip.rng_replay_push(0, arr)
     orc.init(th.copy(), rv.copy(), rhod.copy(), **C)

@@ -21,6 +21,8 @@ def test_cxx_example_runs():
     out = subprocess.check_output([EXE], env=dict(os.environ, LCX_DATA_DIR=os.path.join(ROOT, "libcloudphxx_amd", "data"))).decode()
     vals = {l.split()[0]: l.split()[1:] for l in out.strip().splitlines()}
     assert vals["call_order_exception"] == ["1"]
+    # the `<enum>_name` tables of the option headers (reference lgrngn/kernel.hpp:11-24 etc.), as a driver prints them
+    assert vals["options"] == ["backend=HIP", "kernel=hall_pinsky_stratocumulus", "vt=beard77fast", "adve=implicit", "RH=pv_cc", "src=off", "n_kernels=12"]
     th, rv, sd = float(vals["parcel"][1]), float(vals["parcel"][3]), float(vals["parcel"][5])
     assert abs(th - 307.78) < 1e-4 * 307.78 and abs(rv - 1.7e-2) < 1e-3 * 1.7e-2 and sd == 100   # lgrngn_cond.py:52-56
     assert float(vals["box"][1]) == 300 and int(vals["box"][3]) == 300
