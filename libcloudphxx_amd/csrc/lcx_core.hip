@@ -39,15 +39,19 @@ template <class T> struct DevBuf {
   void alloc(size_t m) { if (m <= n && p) return; release(); HIPCHK(hipMalloc((void **)&p, std::max<size_t>(m, 1) * sizeof(T))); n = std::max<size_t>(m, 1); }
   void alloc_zero(size_t m, hipStream_t s) { alloc(m); HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), s)); }
   // fine-grained device memory: coherent with writes that arrive from ANOTHER device while kernels of this one run before and
-  // after them (the exchange inboxes that a neighbour's pack kernel fills over xGMI); plain hipMalloc if the runtime refuses
-  void alloc_finegrained(size_t m)
+  // after them (the exchange inboxes that a neighbour's pack kernel fills over xGMI).  Returns false when the runtime refuses and
+  // plain (coarse-grained) memory was taken instead: such an inbox must only be filled by copies (hipMemcpyPeerAsync), never by a
+  // neighbour's kernel -- the caller routes its senders through the staged path then (lcx_multi.hpp)
+  bool alloc_finegrained(size_t m)
   {
     release();
+    bool fine = true;
     if (hipExtMallocWithFlags((void **)&p, std::max<size_t>(m, 1) * sizeof(T), hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError(); p = nullptr;
+      (void)hipGetLastError(); p = nullptr; fine = false;
       HIPCHK(hipMalloc((void **)&p, std::max<size_t>(m, 1) * sizeof(T)));
     }
     n = std::max<size_t>(m, 1);
+    return fine;
   }
   void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
 };
@@ -1802,46 +1806,62 @@ struct Particles : IParticles {
     else      HIPCHK(hipMemcpyAsync(a + off[2 + side], buf, cnt * sizeof(T), hipMemcpyDeviceToDevice, st));
     sync();
   }
-  // ---- device-driven neighbour exchange (multi_HIP, lcx_multi.hpp): the three steps of migrate_pack / _unpack / _finish without
-  // a host round trip for the counts.  inbox[0] receives from the left neighbour, inbox[1] from the right one.
-  bool dev_exchange = false;
+  // ---- device-driven neighbour exchange (multi_HIP: lcx_multi.hpp; one process per GPU: lcx_exch_* of the C ABI): the three steps of
+  // migrate_pack / _unpack / _finish without a host round trip for the counts.  inbox[0] receives from the left neighbour, inbox[1]
+  // from the right one; outbox[0] / [1] hold what goes to the left / right when the transport is a copy (no peer mapping, RCCL).
+  bool dev_exchange = false, inbox_finegrained = true;
   DevBuf<uint8_t> inbox[2], outbox[2]; size_t inbox_cap_rec = 0;
-  DevBuf<uint32_t> xcnt;
-  void exch_alloc()
+  DevBuf<uint32_t> xcnt;                 // [0..11] the step's record (k_collect_counts), [16] flags, [17] shift of the sorted order
+  uint32_t exch_rec_h[12] = {0};         // the last step's record on the host
+  int n_attr() const { return 4 + n_dims + n_ext; }
+  size_t exch_bytes(size_t n_rec) const { return exch_msg_bytes<T>(n_rec, n_attr()); }
+  // ONE capacity for every slab of a decomposition (a sender checks its count against the RECEIVER's inbox): two x-planes of the
+  // thinnest slab's share of n_sd_max -- the reference sizes its buffers to half a plane (reserve_hskpng_npart.ipp:84-94,
+  // config.hpp:25); a Courant number of 1 (the ring test) moves a whole plane, pred_corr allows 2 -- in whole tiles
+  static size_t exch_capacity(size_t cap_sd, int nx_min)
+  {
+    const size_t c = std::min<size_t>(cap_sd, 2 * cap_sd / size_t(std::max(nx_min, 1)) + 1024);
+    return (c + EXCH_TILE - 1) / EXCH_TILE * EXCH_TILE;
+  }
+  void exch_alloc(size_t cap_rec, bool with_outbox = false)
   {
     dev_exchange = true;
-    // the reference sizes its buffers to half an x-plane of n_sd_max (reserve_hskpng_npart.ipp:84-94, config.hpp:25); a Courant
-    // number of 1 (the ring test) moves a whole plane, pred_corr allows 2
-    inbox_cap_rec = std::min<size_t>(cap, 2 * cap / size_t(std::max(o.nx, 1)) + 1024);
-    for (auto &b : inbox) { b.alloc_finegrained(EXCH_HDR + inbox_cap_rec * migrate_record_bytes()); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
-    xcnt.alloc_zero(12, st);
+    inbox_cap_rec = cap_rec;
+    for (auto &b : inbox) { inbox_finegrained = b.alloc_finegrained(exch_bytes(inbox_cap_rec)) && inbox_finegrained; HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
+    if (with_outbox) for (auto &b : outbox) { b.alloc(exch_bytes(inbox_cap_rec)); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
+    xcnt.alloc_zero(24, st);
     if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
     sync();
   }
-  // emigrants of both faces -> the neighbours' inboxes (pointers this device can write: peer-mapped, or inboxes on this very device;
-  // nullptr: no neighbour behind that face), their multiplicities cleared in the same launch
-  void exch_pack(uint8_t *inbox_of_lft, double lft_x1, uint8_t *inbox_of_rgt, double rgt_x0)
+  // emigrants of both faces -> the neighbours' inboxes (pointers this device can write: peer-mapped, inboxes on this very device, or
+  // this slab's own outboxes; nullptr: no neighbour behind that face), their multiplicities cleared in the same launch.
+  // cap_l / cap_r: the capacity of the inbox behind each pointer; next_l / next_r: header word 2 (see k_pack_dev)
+  void exch_pack(uint8_t *dst_l, double lft_x1, size_t cap_l, uint8_t *dst_r, double rgt_x0, size_t cap_r, uint32_t next_l = 0, uint32_t next_r = 0)
   {
-    const unsigned half = nblk(inbox_cap_rec);
-    hipLaunchKernelGGL(k_pack_dev<T>, dim3(2 * half), dim3(BS), 0, st, scan_total.p, uint32_t(inbox_cap_rec), half,
-                       pack_side<T>{mig_ids[0].p, inbox_of_lft, T(lft_x1), T(o.x0)}, pack_side<T>{mig_ids[1].p, inbox_of_rgt, T(rgt_x0), T(o.x1)}, aset(A), g);
+    const unsigned half = nblk(std::max(cap_l, cap_r));
+    hipLaunchKernelGGL(k_pack_dev<T>, dim3(2 * half), dim3(BS), 0, st, scan_total.p, half,
+                       pack_side<T>{mig_ids[0].p, dst_l, T(lft_x1), T(o.x0), uint32_t(cap_l), next_l},
+                       pack_side<T>{mig_ids[1].p, dst_r, T(rgt_x0), T(o.x1), uint32_t(cap_r), next_r}, aset(A), g);
   }
-  void exch_unpack(bool from_l, bool from_r)
+  // have_l / have_r: records of each message that have arrived (all of it unless the transport ships in two parts)
+  void exch_unpack(bool from_l, bool from_r, uint32_t have_l = ~0u, uint32_t have_r = ~0u)
   {
     Range r(this, "exchange_unpack");
-    HIPCHK(hipMemsetAsync(xcnt.p + 8, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr, nphys, cap,
-                       aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, strict_order() ? (const uint32_t *)nullptr : scan_total.p,
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 8);
+    HIPCHK(hipMemsetAsync(xcnt.p + 16, 0, 2 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr, have_l, have_r,
+                       nphys, cap, aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, strict_order() ? (const uint32_t *)nullptr : scan_total.p,
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, (const uint32_t *)nullptr, 0u, 0u);
     if (fused_pending) list_big_from_hist();            // the histogram is complete now: crowded cells for order_cells, same read-back
     hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, step_cnt.p, scan_total.p, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr,
-                       xcnt.p + 8, xcnt.p);
+                       xcnt.p + 16, (const uint32_t *)nullptr, xcnt.p);
   }
   size_t exch_moved = 0;       // super-droplets this slab has sent so far (bench / diagnostics)
-  void exch_finish(const lcx_opts_t &opts)
+  // returns false when a message had not arrived in full (nothing was unpacked: ship the rest, call exch_unpack and this again)
+  bool exch_finish(const lcx_opts_t &opts)
   {
-    uint32_t h[8];
-    read_back(h, xcnt.p, 8);                            // the step's one host synchronisation
+    uint32_t *h = exch_rec_h;
+    read_back(h, xcnt.p, 12);                           // the step's one host synchronisation
+    if (h[5] & 4u) return false;
     if (h[5] & 1u) throw lcx_error("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (" +
                                     std::to_string(inbox_cap_rec) + " records); raise opts_init.n_sd_max");
     if (h[5] & 2u) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part after the neighbour exchange");
@@ -1855,6 +1875,7 @@ struct Particles : IParticles {
       post_copy_after_fused_move(opts, long(h[0]) - long(reuse));
     }
     else post_copy(opts);
+    return true;
   }
 
   void migrate_finish(const lcx_opts_t &opts) override

@@ -2195,88 +2195,118 @@ k_unpack(size_t count, size_t n_old, attr_set<T> s, grid_t g, const n_t *nb, con
 }
 __global__ void k_flag_ids(size_t count, const uint32_t *ids, n_t *n) { const size_t i = gid(); if (i < count) n[ids[i]] = 0; }
 
-// ---- the same three steps driven from the device (multi_HIP, lcx_multi.hpp): the migrant counts never visit the host.  A message is
-// an "inbox" on the RECEIVING device -- header {count, overflow} in the first EXCH_HDR bytes, then the attribute-major record of
-// k_pack -- that the sender's pack kernel writes straight through the peer mapping (xGMI): one message per direction, no count
-// round trip, no staging copy.  Kernels are launched over the inbox capacity and read the counts from device memory.
+// ---- the same three steps driven from the device (multi_HIP, lcx_multi.hpp; one process per GPU: libcloudphxx_amd/multi.py): the
+// migrant counts never visit the host.  A message is an "inbox" on the RECEIVING device -- a header {count, overflow flag, the capacity
+// the sender will use NEXT step} in its first EXCH_HDR bytes, then the records in TILES of EXCH_TILE super-droplets, each tile
+// attribute-major (n[256] | rd3[256] | rw2 | kpa | vt | x (| y | z | ext...)) -- that the sender's pack kernel writes straight through
+// the peer mapping (xGMI), or into an outbox that RCCL ships: one message per direction, no count round trip.  Tiles make any prefix
+// of a message self-contained, so a transport that must fix the message size before the count is known (RCCL send / recv) ships the
+// first K tiles and the rest only in the rare step that needs it.  A tile is one workgroup's worth: 2 KiB contiguous per attribute.
+// Kernels are launched over the inbox capacity and read the counts from device memory.
 constexpr size_t EXCH_HDR = 256;
-template <class T> struct pack_side { const uint32_t *ids; uint8_t *inbox; T x_rmt, x_lcl; };
+constexpr uint32_t EXCH_TILE = 256;
+static_assert(EXCH_TILE == uint32_t(BS), "one workgroup packs one tile");
+template <class T> __host__ __device__ __forceinline__ size_t exch_rec_bytes(int n_attr) { return sizeof(n_t) + sizeof(T) * size_t(n_attr); }
+template <class T> __host__ __device__ __forceinline__ size_t exch_msg_bytes(size_t n_rec, int n_attr)
+{ return EXCH_HDR + ((n_rec + EXCH_TILE - 1) / EXCH_TILE) * EXCH_TILE * exch_rec_bytes<T>(n_attr); }
+// record r of a message: its multiplicity and its attribute `a`
+template <class T> struct exch_tile {
+  uint8_t *base; uint32_t j;
+  __device__ __forceinline__ exch_tile(uint8_t *msg, size_t r, int n_attr) : base(msg + EXCH_HDR + (r / EXCH_TILE) * (EXCH_TILE * exch_rec_bytes<T>(n_attr))), j(uint32_t(r % EXCH_TILE)) {}
+  __device__ __forceinline__ n_t &n() const { return reinterpret_cast<n_t *>(base)[j]; }
+  __device__ __forceinline__ T &at(int a) const { return reinterpret_cast<T *>(base + EXCH_TILE * sizeof(n_t))[size_t(a) * EXCH_TILE + j]; }
+};
+// cap_rec: what the RECEIVER's inbox holds; next_cap: the records the sender will ship in the first part of its NEXT message (header word 2)
+template <class T> struct pack_side { const uint32_t *ids; uint8_t *inbox; T x_rmt, x_lcl; uint32_t cap_rec, next_cap; };
 // blocks [0, half) pack the left-going emigrants, [half, 2 half) the right-going ones (inbox == nullptr: that face has no neighbour);
 // the multiplicity of a packed SD is cleared in the same pass (flag_lft / flag_rgt of the reference)
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_pack_dev(const uint32_t *counts, uint32_t cap_rec, unsigned half, pack_side<T> L, pack_side<T> R, attr_set<T> s, grid_t g)
+k_pack_dev(const uint32_t *counts, unsigned half, pack_side<T> L, pack_side<T> R, attr_set<T> s, grid_t g)
 {
   const int side = blockIdx.x >= half;
   const pack_side<T> &P = side ? R : L;
   if (!P.inbox) return;
   const uint32_t count = counts[side];
   const size_t i = size_t(blockIdx.x - (side ? half : 0u)) * blockDim.x + threadIdx.x;
-  if (i == 0) { reinterpret_cast<uint32_t *>(P.inbox)[0] = count; reinterpret_cast<uint32_t *>(P.inbox)[1] = count > cap_rec ? 1u : 0u; }
-  if (count > cap_rec || i >= count) return;          // overflow: nothing is shipped, the hosts of both slabs raise
-  n_t *nb = reinterpret_cast<n_t *>(P.inbox + EXCH_HDR);
-  T *rb = reinterpret_cast<T *>(nb + count);
+  if (i == 0) { uint32_t *h = reinterpret_cast<uint32_t *>(P.inbox); h[0] = count; h[1] = count > P.cap_rec ? 1u : 0u; h[2] = P.next_cap; }
+  if (count > P.cap_rec || i >= count) return;        // overflow: nothing is shipped, the hosts of both slabs raise
+  const int n_attr = 4 + g.ndims + s.n_ext;
+  const exch_tile<T> t(P.inbox, i, n_attr);
   const uint32_t id = P.ids[i];
-  nb[i] = s.n[id];
+  t.n() = s.n[id];
   s.n[id] = 0;
-  size_t slab = 0;
-  rb[slab++ * count + i] = s.rd3[id]; rb[slab++ * count + i] = s.rw2[id]; rb[slab++ * count + i] = s.kpa[id]; rb[slab++ * count + i] = s.vt[id];
-  if (g.nx) { const T xn = P.x_rmt + s.x[id] - P.x_lcl; s.x[id] = xn; rb[slab++ * count + i] = xn; }     // detail::remote, pack.ipp:14-26
-  if (g.ny) rb[slab++ * count + i] = s.y[id];
-  if (g.nz) rb[slab++ * count + i] = s.z[id];
-  for (int e = 0; e < s.n_ext; ++e) rb[slab++ * count + i] = s.ext[e][id];
+  int a = 0;
+  t.at(a++) = s.rd3[id]; t.at(a++) = s.rw2[id]; t.at(a++) = s.kpa[id]; t.at(a++) = s.vt[id];
+  if (g.nx) { const T xn = P.x_rmt + s.x[id] - P.x_lcl; s.x[id] = xn; t.at(a++) = xn; }     // detail::remote, pack.ipp:14-26
+  if (g.ny) t.at(a++) = s.y[id];
+  if (g.nz) t.at(a++) = s.z[id];
+  for (int e = 0; e < s.n_ext; ++e) t.at(a++) = s.ext[e][id];
 }
-// immigrants of both inboxes in one launch, the left neighbour's first (the reference unpacks lft, then rgt); slots as in k_unpack
+// immigrants of both inboxes in one launch, the left neighbour's first (the reference unpacks lft, then rgt); slots as in k_unpack.
+// have_l / have_r: how many records of each message have ARRIVED (a transport that ships a message in two parts, see above): a message
+// that is not complete is not touched at all -- flag bit 2 asks the host for the rest and a second call.
+// stay_start != nullptr (the overlapped re-sort, lcx_core.hip exch_*): the immigrant's rank in its cell continues behind the SDs that
+// stayed there, whose number the CSR offsets of the stayers' scan still hold; cells [c_lo, c_hi) are the slab's interior, where no
+// immigrant may land (flag bit 4).
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, size_t n_old, size_t cap, attr_set<T> s, grid_t g, T x0, T x1, T tol,
+k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, uint32_t have_l, uint32_t have_r, size_t n_old, size_t cap, attr_set<T> s, grid_t g, T x0, T x1, T tol,
              const uint32_t *free_l, const uint32_t *free_r, const uint32_t *n_free /* [2] on the device, nullptr: no slot re-use */,
-             uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *overflow)
+             uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *flags, const uint32_t *stay_start, uint32_t c_lo, uint32_t c_hi)
 {
   auto hdr_count = [](const uint8_t *b) { const uint32_t *h = reinterpret_cast<const uint32_t *>(b); return b && !h[1] ? h[0] : 0u; };
   const uint32_t cl = hdr_count(inbox_l), cr = hdr_count(inbox_r);
+  if (cl > have_l || cr > have_r) { if (gid() == 0) atomicOr(flags, 4u); return; }      // (uniform over the launch)
   const size_t i = gid();
   bool in = i < size_t(cl) + cr;
   uint32_t c = DEAD_CELL;
   size_t d = 0;
   if (in) {
     const bool from_l = i < cl;
-    const uint8_t *box = from_l ? inbox_l : inbox_r;
-    const size_t count = from_l ? cl : cr, k = from_l ? i : i - cl;
-    const n_t *nb = reinterpret_cast<const n_t *>(box + EXCH_HDR);
-    const T *rb = reinterpret_cast<const T *>(nb + count);
+    const size_t k = from_l ? i : i - cl;
+    const int n_attr = 4 + g.ndims + s.n_ext;
+    const exch_tile<T> t(const_cast<uint8_t *>(from_l ? inbox_l : inbox_r), k, n_attr);
     const size_t n_free_l = n_free ? n_free[0] : 0, n_free_all = n_free_l + (n_free ? n_free[1] : 0);
     d = i < n_free_l ? size_t(free_l[i]) : i < n_free_all ? size_t(free_r[i - n_free_l]) : n_old + (i - n_free_all);
-    if (d >= cap) { *overflow = 1u; in = false; }
+    if (d >= cap) { atomicOr(flags, 1u); in = false; }
     else {
-      const n_t nn = nb[k];
+      const n_t nn = t.n();
       s.n[d] = nn;
-      size_t slab = 0;
-      s.rd3[d] = rb[slab++ * count + k]; s.rw2[d] = rb[slab++ * count + k]; s.kpa[d] = rb[slab++ * count + k]; s.vt[d] = rb[slab++ * count + k];
+      int a = 0;
+      s.rd3[d] = t.at(a++); s.rw2[d] = t.at(a++); s.kpa[d] = t.at(a++); s.vt[d] = t.at(a++);
       T x = 0, y = 0, z = 0;
-      if (g.nx) { x = rb[slab++ * count + k]; x = x >= x1 ? x - tol : x < x0 ? x + tol : x; s.x[d] = x; }   // tolerance_away_from_bcond
-      if (g.ny) { y = rb[slab++ * count + k]; s.y[d] = y; }
-      if (g.nz) { z = rb[slab++ * count + k]; s.z[d] = z; }
-      for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = rb[slab++ * count + k];
+      if (g.nx) { x = t.at(a++); x = x >= x1 ? x - tol : x < x0 ? x + tol : x; s.x[d] = x; }   // tolerance_away_from_bcond
+      if (g.ny) { y = t.at(a++); s.y[d] = y; }
+      if (g.nz) { z = t.at(a++); s.z[d] = z; }
+      for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = t.at(a++);
       if (cnt) { c = nn == 0 ? DEAD_CELL : cell_of(g, x, y, z); ijk[d] = c; }
     }
   }
   if (cnt) {                                           // every lane of the wave takes part (ballots inside)
     const bool active = in && c != DEAD_CELL;
-    const uint32_t r = wave_hist_rank(cnt, c, active);
-    if (active) rank[d] = r;
+    uint32_t r = wave_hist_rank(cnt, c, active);
+    if (active) {
+      if (stay_start) { r += stay_start[c + 1] - stay_start[c]; if (c >= c_lo && c < c_hi) atomicOr(flags, 8u); }
+      rank[d] = r;
+    }
   }
 }
 // the step's counts in one small record for ONE host read-back: dead, out_l, out_r, in_l, in_r, flags (1 my inbox overflowed at a
-// sender, 2 storage full), number of crowded cells and the largest occupancy (order_cells)
+// sender, 2 storage full, 4 a message has not arrived in full yet, 8 an immigrant landed beyond the boundary planes), number of crowded
+// cells and the largest occupancy (order_cells), [8] immigrants that joined the left boundary planes (the overlapped re-sort's shift of
+// the sorted order, exch_*), [9] / [10] the capacity each neighbour will use for its NEXT message (header word 2; RCCL transport)
 __global__ void k_collect_counts(const uint32_t *step_cnt /* dead, n_big, max_big */, const uint32_t *out_cnt, const uint8_t *inbox_l, const uint8_t *inbox_r,
-                                 const uint32_t *overflow, uint32_t *rec)
+                                 const uint32_t *flags, const uint32_t *shift, uint32_t *rec)
 {
   if (threadIdx.x != 0) return;
   const uint32_t *hl = reinterpret_cast<const uint32_t *>(inbox_l), *hr = reinterpret_cast<const uint32_t *>(inbox_r);
   rec[0] = step_cnt[0]; rec[1] = out_cnt[0]; rec[2] = out_cnt[1]; rec[6] = step_cnt[1]; rec[7] = step_cnt[2];
   rec[3] = hl ? hl[0] : 0u; rec[4] = hr ? hr[0] : 0u;
-  rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | (*overflow ? 2u : 0u);
+  const uint32_t f = *flags;
+  rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | ((f & 1u) ? 2u : 0u) | (f & 4u) | (f & 8u);
+  rec[8] = shift ? *shift : 0u;
+  rec[9] = hl ? hl[2] : 0u; rec[10] = hr ? hr[2] : 0u;
 }
 
 

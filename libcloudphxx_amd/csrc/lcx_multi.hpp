@@ -157,6 +157,9 @@ struct MultiParticles : IParticles {
           if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) peer_ok[i] = 0;
           (void)hipGetLastError();
         }
+    // one inbox capacity for all slabs: the last slab takes the remainder of nx / D and would size its inbox smaller than what its
+    // neighbours, with fewer planes, may send (and check against)
+    const size_t exch_cap = Particles<T>::exch_capacity(size_t(oi.n_sd_max / D + 1), get_dev_nx(oi.nx, 0, D));
     slab.resize(D); n_rendezvous.assign(D, 0); n_rendezvous_hidden.assign(D, 0);
     ev_sent.assign(D, nullptr); ev_consumed.assign(D, nullptr);
     for (int i = 0; i < D; ++i) {
@@ -170,19 +173,28 @@ struct MultiParticles : IParticles {
         const bool first = i == 0, last = i == D - 1;
         o.bcond_lft = first && !periodic ? 3 : 1;                                  // particles_multi_gpu_impl.ipp:158-179
         o.bcond_rgt = last && !periodic ? 3 : 1;
-        o.rng_seed = oi.rng_seed + i;      // (the reference seeds every device alike; distinct streams per slab cost nothing here)
+        // the reference seeds every device alike (particles_multi_gpu_impl.ipp: the same opts_init on every device): distinct streams
+        // per slab cost nothing here.  rng_seed_init (the initial sampling's own seed, if switched on) stays common as in the
+        // reference: a caller who asks for a reproducible initial condition gets the same draws per slab on any device count
+        o.rng_seed = oi.rng_seed + i;
       }
       o.n_x_tot = oi.nx; o.n_x_bfr = bfr; o.dev_id = dev[i]; o.dev_count = D;
       nx_loc[i] = o.nx; n_x_bfr[i] = bfr;
       HIPCHK(hipSetDevice(dev[i]));
       slab[i].reset(new Particles<T>(o));
       if (D > 1) {
-        slab[i]->exch_alloc();
+        slab[i]->exch_alloc(exch_cap);
         HIPCHK(hipEventCreateWithFlags(&ev_sent[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_consumed[i], hipEventDisableTiming));
         HIPCHK(hipEventRecord(ev_consumed[i], slab[i]->st));
       }
     }
+    // an inbox that could not be had as fine-grained memory must not be written by a neighbour's kernel from another device (its
+    // receiver could read stale cache lines): those senders pack at home and copy
+    if (D > 1)
+      for (int i = 0; i < D; ++i)
+        for (int nb : {lft_of(i), rgt_of(i)})
+          if (nb >= 0 && dev[nb] != dev[i] && !slab[nb]->inbox_finegrained) peer_ok[i] = 0;
     pool.reset(new WorkerPool(D));
     barrier.reset(new HostBarrier(D));
     if (serialize) fprintf(stderr, "libcloudph++ (multi_HIP): LCX_MULTI_SERIALIZE is set -- the %d slabs take turns (measurement mode)\n", D);
@@ -289,18 +301,18 @@ struct MultiParticles : IParticles {
         if (lft >= 0) HIPCHK(hipStreamWaitEvent(s.st, ev_consumed[lft], 0));
         if (rgt >= 0 && rgt != lft) HIPCHK(hipStreamWaitEvent(s.st, ev_consumed[rgt], 0));
         const double lft_x1 = lft >= 0 ? slab[lft]->o.x1 : 0., rgt_x0 = rgt >= 0 ? slab[rgt]->o.x0 : 0.;
-        if (peer_ok[i]) s.exch_pack(lft >= 0 ? slab[lft]->inbox[1].p : nullptr, lft_x1, rgt >= 0 ? slab[rgt]->inbox[0].p : nullptr, rgt_x0);
+        const size_t cap_l = lft >= 0 ? slab[lft]->inbox_cap_rec : 0, cap_r = rgt >= 0 ? slab[rgt]->inbox_cap_rec : 0;
+        if (peer_ok[i]) s.exch_pack(lft >= 0 ? slab[lft]->inbox[1].p : nullptr, lft_x1, cap_l, rgt >= 0 ? slab[rgt]->inbox[0].p : nullptr, rgt_x0, cap_r);
         else {
-          // no peer mapping between the two devices: pack at home, then a peer copy of exactly the bytes used (one extra host
+          // no peer mapping between the two devices: pack at home, then a peer copy of exactly the tiles used (one extra host
           // synchronisation for the two counts -- what the reference always does)
-          const size_t rec = s.migrate_record_bytes();
-          for (auto &b : s.outbox) b.alloc(EXCH_HDR + s.inbox_cap_rec * rec);
-          s.exch_pack(lft >= 0 ? s.outbox[0].p : nullptr, lft_x1, rgt >= 0 ? s.outbox[1].p : nullptr, rgt_x0);
+          for (auto &b : s.outbox) b.alloc(s.exch_bytes(std::max(cap_l, cap_r)));
+          s.exch_pack(lft >= 0 ? s.outbox[0].p : nullptr, lft_x1, cap_l, rgt >= 0 ? s.outbox[1].p : nullptr, rgt_x0, cap_r);
           uint32_t out[2] = {0, 0};
           s.read_back(out, s.scan_total.p, 2);
-          auto bytes = [&](uint32_t c) { return EXCH_HDR + (c <= s.inbox_cap_rec ? size_t(c) * rec : 0); };
-          if (lft >= 0) HIPCHK(hipMemcpyPeerAsync(slab[lft]->inbox[1].p, dev[lft], s.outbox[0].p, dev[i], bytes(out[0]), s.st));
-          if (rgt >= 0) HIPCHK(hipMemcpyPeerAsync(slab[rgt]->inbox[0].p, dev[rgt], s.outbox[1].p, dev[i], bytes(out[1]), s.st));
+          auto bytes = [&](uint32_t c, size_t capn) { return s.exch_bytes(c <= capn ? c : 0); };      // (an overflowing message is its header only)
+          if (lft >= 0) HIPCHK(hipMemcpyPeerAsync(slab[lft]->inbox[1].p, dev[lft], s.outbox[0].p, dev[i], bytes(out[0], cap_l), s.st));
+          if (rgt >= 0) HIPCHK(hipMemcpyPeerAsync(slab[rgt]->inbox[0].p, dev[rgt], s.outbox[1].p, dev[i], bytes(out[1], cap_r), s.st));
         }
       }
       HIPCHK(hipEventRecord(ev_sent[i], s.st));
@@ -318,7 +330,7 @@ struct MultiParticles : IParticles {
       }
       s.exch_unpack(lft >= 0, rgt >= 0);
       HIPCHK(hipEventRecord(ev_consumed[i], s.st));
-      s.exch_finish(opts);
+      (void)s.exch_finish(opts);
     });
   }
 

@@ -174,11 +174,13 @@ def test_c4_ring_of_8_slabs_vs_oracle():
     assert sum(p.n_part for p in hip.prts) == sum(p.n_part for p in orc.prts)
 
 
-@pytest.mark.parametrize("n,strict_fp", [(8, True), (16, False)])
+@pytest.mark.parametrize("n,strict_fp", [(8, True), (16, True), (16, False)])
 def test_c5_512_sd_per_cell_larger_box_vs_oracle(n, strict_fp):
-    """C5 at sizes where the crowded-cell kernels are the ones compared: 8^3 cells x 512 (strict arithmetic) and 16^3 x 512 = 2.1e6
-    super-droplets (fast arithmetic: >= 4096 cells with >= 192 SDs each select k_cond_cellfinish_wave).  After the first step the
-    occupancies spread around 512, so k_cellsort_wave sees segments on both sides of its 513 ... 576 head + tail merge path"""
+    """C5 at sizes where the crowded-cell kernels are the ones compared: 8^3 cells x 512 and 16^3 x 512 = 2.1e6 super-droplets
+    (fast arithmetic: >= 4096 cells with >= 192 SDs each select k_cond_cellfinish_wave), both arithmetic modes at the larger size.
+    After the first step the occupancies spread around 512, so k_cellsort_wave sees segments on both sides of its 513 ... 576 head +
+    tail merge path.  EVERY droplet inside the substep tolerance: round 2 allowed 1e-5 of them outside it -- those were droplets
+    with the invalid-vt flag of a coalescence in the previous step, see test_cond_step_with_invalid_terminal_velocities"""
     oi = h.box_opts(n, n, n, 512, kernel=lgrngn.kernel_t.hall_pinsky_stratocumulus, strict_fp=strict_fp)
     fields = h.box_fields(oi)
     orc, hip = h.make_pair(oi, fields)
@@ -188,18 +190,45 @@ def test_c5_512_sd_per_cell_larger_box_vs_oracle(n, strict_fp):
         exact(hip.state_u64("n"), orc.state_u64("n"), "n")
         exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
-        # 2e6 droplets: a handful sit at their activation threshold, where the growth-rate function has several roots inside the
-        # root finder's first bracket and the last ulp of one function value decides which of them TOMS748 walks to (seen: 5 of
-        # 2 097 116 off by up to 20 %, in the fast arithmetic) -- everything else within the substep tolerance, half of them to 1e-10
         err = np.abs(hip.get_attr("rw2") / orc.get_attr("rw2") - 1)
-        n_out = int((err > 2e-4).sum())
-        assert n_out < 1e-5 * err.size and np.median(err) < 1e-10, (n_out, np.median(err), err.max())
-        # (the cell of such a droplet carries its latent heat: th and rv agree everywhere else)
-        bad_th, bad_rv = np.abs(thh / tho - 1) > 1e-7, np.abs(rvh / rvo - 1) > 1e-6
-        assert bad_th.sum() <= n_out and bad_rv.sum() <= n_out and np.abs(thh / tho - 1).max() < 1e-4, (n_out, bad_th.sum(), bad_rv.sum())
+        assert err.max() < 1e-4 and np.median(err) < 1e-10, (int((err > 1e-4).sum()), np.median(err), err.max())
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
         h.copy_state(orc, hip)
     cnt = np.diff(hip.state_u64("cell_start").astype(np.int64))
     assert cnt.max() > 512 and cnt.min() < 512 and ((cnt > 512) & (cnt <= 576)).any()
+
+
+@pytest.mark.parametrize("strict_fp", [True, False], ids=["strict_fp", "fast_fp"])
+def test_production_size_paths_vs_oracle(strict_fp):
+    """128 x 128 x 32 cells x 64 = 2^25 super-droplets: the size from which the condensation kernel runs as it does on the headline
+    box with no environment switch -- two passes (iteration budget + dense straggler launch), the workgroup fold, the XCD-aware
+    workgroup order -- two full steps (cond + coal + adve + sedi) with replayed random streams against the oracle's OpenMP build
+    (bit-identical to the serial one, tests/test_oracle_pins.py), both arithmetic modes.  Integers exact, rw2 at the substep
+    tolerance, th / rv at SURVEY 8a's bars.  (Measured: rw2 max 6.8e-5, th 1.7e-11, rv 3.3e-10.)"""
+    import bench
+    nx, ny, nz = 128, 128, 32
+    oi = bench.make_opts_init(nx, ny, nz, 64, 40., 1, 1, 44)
+    oi.strict_fp = strict_fp
+    th, rv, rhod, Cx, Cy, Cz = bench.make_fields(nx, ny, nz, 0, nx, np, np.float64)
+    fields = (th, rv, rhod, {"Cx": Cx, "Cy": Cy, "Cz": Cz})
+    orc, hip = h.make_pair(oi, fields, make_oracle=h.oracle_omp_particles)
+    assert hip.n_part >= (1 << 25) - 64
+    opts = lgrngn.opts_t()
+    for it in range(2):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        err = np.abs(hip.get_attr("rw2") / orc.get_attr("rw2") - 1)
+        assert err.max() < 1e-4 and np.median(err) < 1e-10, (int((err > 1e-4).sum()), np.median(err), err.max())
+        for a_ in ("x", "y"):
+            np.testing.assert_allclose(hip.get_attr(a_), orc.get_attr(a_), rtol=1e-14)
+        # sedimentation moves a droplet by dt * vt(rw2): rw2 to 1e-4 is vt to 1e-4 (measured: 24 of 3.4e7 droplets above 1e-7 m, 4.4e-6 m at most)
+        np.testing.assert_allclose(hip.get_attr("z"), orc.get_attr("z"), rtol=1e-13, atol=2e-5)
+        np.testing.assert_allclose(thh, tho, rtol=1e-7)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        h.copy_state(orc, hip)
 
 
 def test_c5_512_sd_per_cell_vs_oracle():

@@ -152,7 +152,7 @@ def test_vterm(vt):
     orc.stage("hskpng_vterm_all")
     hip.stage("hskpng_vterm_all")
     vo, vh = orc.state_real("vt"), hip.state_real("vt")
-    np.testing.assert_allclose(vh, vo, rtol=1e-11)
+    np.testing.assert_allclose(vh, vo, rtol=1e-12)               # SURVEY 8a's bar (measured: <= 2.3e-13 for every formula, both arithmetic modes)
     if vt == lgrngn.vt_t.beard77fast:
         np.testing.assert_allclose(hip.state_real("vt_0"), orc.state_real("vt_0"), rtol=1e-12)
 
@@ -207,6 +207,35 @@ def test_cond_step_with_drizzle_and_rain_drops(strict_fp):
         big = ro > (8e-6) ** 2
         assert np.median(np.abs(rh[big] / ro[big] - 1)) < 1e-10
         h.copy_state(orc, hip)
+
+
+@pytest.mark.parametrize("strict_fp", [True, False])
+def test_cond_step_with_invalid_terminal_velocities(strict_fp):
+    """A droplet that coalesced in the previous step_async carries the reference's flag vt = -1 through the next condensation (the
+    last coalescence substep is not followed by hskpng_vterm_invalid, particles_step.ipp:386-392): its Reynolds number is negative,
+    the ventilation factors' 1 + Re Sc goes below 1 and, for drops above ~15 um, below zero.  Round 2's fast form sent such
+    droplets through the small-argument series of the cube root (5 of 2.1e6 droplets per step off by up to 20 % on C5): every
+    third droplet is flagged here, wet radii from 1 to 300 um, both arithmetic modes at the bars of test_cond_step"""
+    oi = h.box_opts(4, 4, 6, 64, sstp_cond=1, strict_fp=strict_fp)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    g = orc.state_real
+    rw2 = orc.get_attr("rw2")
+    rw2[::3] = np.geomspace(1e-6, 3e-4, len(rw2[::3])) ** 2
+    vt = g("vt")
+    vt[::3] = -1.
+    args = (orc.state_u64("n"), g("rd3"), rw2, g("kappa"), vt, g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+    (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+    ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
+    assert np.all(np.isfinite(rh))
+    np.testing.assert_allclose(rh, ro, rtol=1e-4)
+    assert np.median(np.abs(rh[::3] / ro[::3] - 1)) < 1e-10
+    np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 1e-6)      # (drops of 0.3 mm at aerosol multiplicities, as in the test above)
+    np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-5)
 
 
 @pytest.mark.parametrize("strict_fp", [True, False])
@@ -288,7 +317,7 @@ def test_coal_replay(kernel, params):
     for st in ("hskpng_Tpr", "hskpng_vterm_all"):
         orc.stage(st)
         hip.stage(st)
-    np.testing.assert_allclose(hip.state_real("vt"), orc.state_real("vt"), rtol=1e-11)
+    np.testing.assert_allclose(hip.state_real("vt"), orc.state_real("vt"), rtol=1e-12)
     hip.set_particles(orc.state_u64("n"), g("rd3"), g("rw2"), g("kappa"), g("vt"), g("x"), g("y"), g("z"))
     h.push_coal_replay(orc, hip)
     orc.stage("coal")
