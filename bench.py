@@ -6,7 +6,8 @@ coalescence, advection, sedimentation, boundary, re-sort) on the BASELINE worklo
     python bench.py --gpus 1 --steps 200 --warmup 5
     python bench.py --gpus N ...                      # ONE process, N devices: the native multi_HIP object (lcx_create_multi)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W        # one process per GPU (SPMD wrapper libcloudphxx_amd/multi.py over RCCL)
+        bench.py --gpus N --steps K --warmup W        # one process per GPU: libcloudphxx_amd/multi.py, migrants over RCCL
+                                                      # (--native: rank 0 drives all N devices with the native object instead)
 
 A "step" is one full pass of the hot path over all super-droplets.  Inputs (th, rv, rhod, Courant numbers) are
 device-resident when the timed region starts (N > 1: every slab's planes on its own device).  Rank 0 prints ONE JSON line.
@@ -166,9 +167,14 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
     ap.add_argument("--oversubscribe", action="store_true", help="--gpus N in one process with all N slabs on device 0")
-    ap.add_argument("--spmd", action="store_true",
-                    help="under torch.distributed.run: one single-device object per rank with the migrants over RCCL "
-                         "(libcloudphxx_amd.multi) instead of the native multi_HIP object driven by rank 0")
+    ap.add_argument("--spmd", action="store_true", help="(the default under torch.distributed.run; kept for older command lines)")
+    ap.add_argument("--native", action="store_true",
+                    help="under torch.distributed.run: rank 0 drives all N devices with the native multi_HIP object (one host thread per "
+                         "device, migrants written into the neighbour's memory), the other ranks only join the barriers; default "
+                         "there: one single-device object per rank with the migrants over RCCL (libcloudphxx_amd.multi)")
+    ap.add_argument("--transport", choices=["rccl", "host"], default=None,
+                    help="one object per rank: how the migrants travel -- device buffers over RCCL (default with one GPU per rank), or "
+                         "staged through the host over gloo (default when the ranks share a GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))          # > 1: launched by torch.distributed.run, one process per GPU
@@ -178,11 +184,11 @@ def main():
         raise SystemExit("--gpus %d does not match the launcher's WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP backend has no CPU fallback)")
-    # --gpus N > 1 runs the library's native multi_HIP object (ONE process, one host thread per device, migrants written straight
-    # into the neighbour's memory over xGMI) -- also under torch.distributed.run, where rank 0 drives all N devices and the other
-    # ranks only join the barriers and the timing reduction (they never touch a GPU).  --spmd, or a launcher that shows each rank
-    # fewer than N devices, selects the one-object-per-rank path over RCCL instead.
-    spmd = world > 1 and (args.spmd or (torch.cuda.device_count() < args.gpus and not args.oversubscribe))
+    # As ONE process, --gpus N > 1 runs the library's native multi_HIP object (one host thread per device, migrants written straight
+    # into the neighbour's memory over xGMI).  Under torch.distributed.run (WORLD_SIZE = N) every rank owns one slab on its own GPU
+    # and the migrants travel over RCCL (libcloudphxx_amd.multi) -- the launcher's N processes are N working ranks; --native lets
+    # rank 0 drive all N devices with the native object instead (the other ranks then only join the barriers).
+    spmd = world > 1 and not args.native
     native_multi = args.gpus > 1 and not spmd
     idle = native_multi and rank > 0
     n_slabs = args.gpus
@@ -251,7 +257,8 @@ def main():
         """a single-device object: the whole domain, or this rank's slab of the one-object-per-rank run"""
         oi.dev_count, oi.dev_id, oi.n_sd_max = 0, dev_index, n_sd_max0
         if world > 1:
-            prt = multi.particles_multi_t(oi, real_t, device=dev)
+            shared_gpu = torch.cuda.device_count() < world           # several ranks on one device: RCCL refuses that, stage through the host
+            prt = multi.particles_multi_t(oi, real_t, device=dev, transport=args.transport or ("host" if shared_gpu else "rccl"))
             nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
         else:
             prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
@@ -431,7 +438,8 @@ def main():
                 "; all slabs on device 0" if args.oversubscribe else "",
                 "; driven by rank 0 of the launcher, ranks 1..%d idle" % (world - 1) if world > 1 else "")
         elif spmd:
-            decomposition_note = " (one single-device object per rank, migrants over RCCL%s)" % (
+            decomposition_note = " (one single-device object per rank, migrants %s, %d second-part exchanges on rank 0%s)" % (
+                "over RCCL" if prt.transport == "rccl" else "staged through the host over gloo (ranks share a GPU)", prt.second_rounds,
                 "; fallback: " + fallback_reason if fallback_reason else "")
         else:
             decomposition_note = ""

@@ -252,6 +252,33 @@ int lcx_migrate_pack(lcx_particles *, int side, double x_rmt, void *dev_buf, siz
 int lcx_migrate_unpack(lcx_particles *, const void *dev_buf, size_t count);
 /* flag emigrants n=0 and run post_copy (post_copy.ipp:18-35) */
 int lcx_migrate_finish(lcx_particles *, const lcx_opts_t *);
+/* ---- the same exchange driven from the DEVICE, for one process per GPU (what particles_t<real_t, multi_CUDA>::step_async does between
+ *      the devices of one process, impl_multi_gpu/..._step_async_and_copy.ipp:28-206; replaces the MPI flavour
+ *      distributed_memory/particles_impl_mpi_exchange.ipp:20-330): the migrant counts never visit the host, one host synchronisation
+ *      per step.  A message = 256-byte header {count, overflow flag, records the sender ships in the first part of its NEXT message}
+ *      + the records in tiles of 256 super-droplets, each tile attribute-major (csrc/lcx_kernels.hpp, k_pack_dev), so that any whole
+ *      number of tiles behind the header is a self-contained prefix: a transport that must fix the size of a message before its count
+ *      is known (RCCL send / recv) ships a first part of agreed size and the rest only in the rare step whose count exceeds it.
+ *   lcx_exch_enable   once, before init: two outboxes + two inboxes of lcx_exch_message_bytes(*cap_rec) bytes each on the object's device
+ *                     (nx_min = x-planes of the thinnest slab of the decomposition: one capacity for all ranks); from then on
+ *                     lcx_step_async() leaves the emigrant lists and their counts on the device
+ *   lcx_exch_buffers  ptrs[4] = {outbox to the left, outbox to the right, inbox from the left, inbox from the right}
+ *   lcx_exch_pack     after lcx_step_async(): emigrants -> outboxes (x re-based to the receiver's frame, pack.ipp:14-26), their
+ *                     multiplicities cleared; queued on the object's stream (lcx_stream), no host synchronisation
+ *   [transport: outbox to the left -> the left neighbour's "inbox from the right", and vice versa -- header + have_* records at least]
+ *   lcx_exch_unpack   immigrants of both inboxes -> storage (left neighbour's first, unpack.ipp:50-143), have_lft / have_rgt = records
+ *                     of each message that have arrived; a message whose count exceeds that is not touched; queued, no host sync
+ *   lcx_exch_finish   the step's ONE host synchronisation: rec[12] = {dead, out_lft, out_rgt, in_lft, in_rgt, flags, crowded cells,
+ *                     largest cell, shift, next_cap_lft, next_cap_rgt, 0}; *complete = 0: a message had not arrived in full, nothing
+ *                     was unpacked -- ship the remaining tiles, call lcx_exch_unpack and lcx_exch_finish again; else post_copy ran
+ *   lcx_stream        the hipStream_t all of the object's work is queued on (for ordering a transport against it without host syncs) */
+int lcx_exch_enable(lcx_particles *, int nx_min, size_t *cap_rec);
+int lcx_exch_buffers(lcx_particles *, void *ptrs[4]);
+size_t lcx_exch_message_bytes(lcx_particles *, size_t n_rec);
+int lcx_exch_pack(lcx_particles *, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_cap_lft, unsigned next_cap_rgt);
+int lcx_exch_unpack(lcx_particles *, int from_lft, int from_rgt, unsigned have_lft, unsigned have_rgt);
+int lcx_exch_finish(lcx_particles *, const lcx_opts_t *, unsigned rec[12], int *complete);
+int lcx_stream(lcx_particles *, void **hip_stream);
 /* Courant halo of pred_corr advection on a decomposed domain (xchng_courants.ipp:15-160).  which: 0 Cx, 1 Cy, 2 Cz;
  * side: 0 left, 1 right.  _count: reals per side (0: nothing to exchange); _pack: the interior planes next to `side`
  * (what that neighbour needs) -> device buffer; _unpack: device buffer received from the neighbour at `side` -> the halo

@@ -122,6 +122,15 @@ struct IParticles {
   virtual void migrate_finish(const lcx_opts_t &) = 0;
   virtual size_t courant_halo_count(int which) = 0;
   virtual void courant_halo_copy(int which, int side, void *buf, bool pack) = 0;
+  // device-driven exchange for one process per GPU (include/lcx.h, lcx_exch_*); a multi-device object does it inside step_async
+  [[noreturn]] static void no_exch() { throw std::runtime_error("libcloudph++: lcx_exch_* drives a single-device object (one process per GPU)"); }
+  virtual size_t x_enable(int) { no_exch(); }
+  virtual void x_buffers(void **) { no_exch(); }
+  virtual size_t x_message_bytes(size_t) { no_exch(); }
+  virtual void x_pack(bool, double, bool, double, unsigned, unsigned) { no_exch(); }
+  virtual void x_unpack(bool, bool, unsigned, unsigned) { no_exch(); }
+  virtual bool x_finish(const lcx_opts_t &, unsigned *) { no_exch(); }
+  virtual void *stream() { return nullptr; }
 };
 
 template <class real_t>
@@ -745,7 +754,10 @@ struct Particles : IParticles {
     // ms per step of all slabs: 64: 20.2, 32: 19.3, 16: 19.4, 8: 19.6; a single device: 64 and 32 alike)
     const int every_ = o.reorder_every > 0 ? o.reorder_every : (distmem() ? 32 : 64);
     const bool reorder_due = compact_now || (!strict_order && steps_since_reorder + 1 >= every_);     // (the re-ordering wants the plain order)
-    const bool preshuffle = !strict_order && last_async_coal && o.coal_switch && !reorder_due && npart >= 2;
+    // (strict arithmetic sums a cell's droplets in the reference's order, ascending id: k_cond_cellfinish<T, 1> walks the sorted order
+    // as it finds it, so the cells must not be left in the shuffled order there -- the in-cell ranking by id stays, coalescence
+    // shuffles for itself)
+    const bool preshuffle = !strict_order && !o.strict_fp && last_async_coal && o.coal_switch && !reorder_due && npart >= 2;
     sort_from_hist(preshuffle, meta_p);
     shuffle_fresh = preshuffle;
     // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
@@ -1878,6 +1890,34 @@ struct Particles : IParticles {
     return true;
   }
 
+  // ---- lcx_exch_*: the device-driven exchange with a copying transport between processes (RCCL / host-staged, libcloudphxx_amd/multi.py)
+  size_t x_enable(int nx_min) override
+  {
+    if (init_called) throw lcx_error("libcloudph++: lcx_exch_enable must be called before init()");
+    if (!distmem()) throw lcx_error("libcloudph++: lcx_exch_enable needs a slab with a neighbour (bcond_lft / bcond_rgt = distmem)");
+    exch_alloc(exch_capacity(cap, nx_min), true);
+    return inbox_cap_rec;
+  }
+  void need_exch() const { if (!dev_exchange) throw lcx_error("libcloudph++: call lcx_exch_enable first"); }
+  void x_buffers(void **p4) override { need_exch(); p4[0] = outbox[0].p; p4[1] = outbox[1].p; p4[2] = inbox[0].p; p4[3] = inbox[1].p; }
+  size_t x_message_bytes(size_t n_rec) override { return exch_bytes(n_rec); }
+  void x_pack(bool has_l, double lft_x1, bool has_r, double rgt_x0, unsigned next_l, unsigned next_r) override
+  {
+    need_exch();
+    { Range r(this, "exchange_pack");
+      exch_pack(has_l ? outbox[0].p : nullptr, lft_x1, inbox_cap_rec, has_r ? outbox[1].p : nullptr, rgt_x0, inbox_cap_rec, next_l, next_r); }
+    puddle_reduce_deferred();
+  }
+  void x_unpack(bool from_l, bool from_r, unsigned have_l, unsigned have_r) override { need_exch(); exch_unpack(from_l, from_r, have_l, have_r); }
+  bool x_finish(const lcx_opts_t &opts, unsigned *rec) override
+  {
+    need_exch();
+    const bool done = exch_finish(opts);
+    for (int k = 0; k < 12; ++k) rec[k] = exch_rec_h[k];
+    return done;
+  }
+  void *stream() override { return (void *)st; }
+
   void migrate_finish(const lcx_opts_t &opts) override
   {
     flag_emigrants();
@@ -1906,8 +1946,16 @@ struct lcx_particles {
   ~lcx_particles() { slabs.clear(); if (own) delete p; }
 };
 static inline IParticles *bound(lcx_particles *h) { h->p->bind(); return h->p; }
+// An entry point makes the object's device current on the CALLER's thread (bind) and a multi-device object walks over its devices:
+// the caller's own current device is put back when the call returns, so that a host model that allocates or launches on "its" GPU
+// next to this library keeps doing so
+struct DevGuard {
+  int prev = -1;
+  DevGuard() { if (hipGetDevice(&prev) != hipSuccess) { prev = -1; (void)hipGetLastError(); } }
+  ~DevGuard() { int now = -1; if (prev >= 0 && hipGetDevice(&now) == hipSuccess && now != prev) (void)hipSetDevice(prev); }
+};
 
-#define LCX_TRY(body) try { body; return 0; } catch (const std::exception &e) { g_err = e.what(); return 1; } catch (...) { g_err = "libcloudph++: unknown error"; return 1; }
+#define LCX_TRY(body) try { DevGuard dev_guard_; body; return 0; } catch (const std::exception &e) { g_err = e.what(); return 1; } catch (...) { g_err = "libcloudph++: unknown error"; return 1; }
 #define H (bound(h))
 
 template <class T> static bool multi_slabs(lcx_particles *h, int *n, int i, lcx_particles **out)
@@ -1979,7 +2027,7 @@ int lcx_multi_slab(lcx_particles *h, int i, lcx_particles **slab)
       throw std::runtime_error("libcloudph++: not a multi-device object");
   })
 }
-void lcx_destroy(lcx_particles *h) { if (h && h->own) delete h; }
+void lcx_destroy(lcx_particles *h) { if (h && h->own) { DevGuard dev_guard_; delete h; } }
 int lcx_init(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *p,
              const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz) { LCX_TRY(H->init(th, rv, rhod, p, cx, cy, cz)) }
 int lcx_sync_in(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,
@@ -2031,11 +2079,19 @@ int lcx_stage(lcx_particles *h, const char *stage, const lcx_opts_t *o) { LCX_TR
 int lcx_timings(lcx_particles *h, const char **names, double *ms, size_t cap, size_t *n) { LCX_TRY(H->timings(names, ms, cap, n)) }
 int lcx_set_profiling(lcx_particles *h, int on) { LCX_TRY(H->set_profiling(on)) }
 int lcx_migrate_counts(lcx_particles *h, size_t *l, size_t *r) { LCX_TRY(H->migrate_counts(l, r)) }
-size_t lcx_migrate_record_bytes(lcx_particles *h) { return H->migrate_record_bytes(); }
+size_t lcx_migrate_record_bytes(lcx_particles *h) { DevGuard dev_guard_; return H->migrate_record_bytes(); }
 int lcx_migrate_pack(lcx_particles *h, int side, double x_rmt, void *buf, size_t cap) { LCX_TRY(H->migrate_pack(side, x_rmt, buf, cap)) }
 int lcx_migrate_unpack(lcx_particles *h, const void *buf, size_t count) { LCX_TRY(H->migrate_unpack(buf, count)) }
 int lcx_migrate_finish(lcx_particles *h, const lcx_opts_t *o) { LCX_TRY(H->migrate_finish(*o)) }
-size_t lcx_courant_halo_count(lcx_particles *h, int which) { return H->courant_halo_count(which); }
+int lcx_exch_enable(lcx_particles *h, int nx_min, size_t *cap_rec) { LCX_TRY(*cap_rec = H->x_enable(nx_min)) }
+int lcx_exch_buffers(lcx_particles *h, void *ptrs[4]) { LCX_TRY(H->x_buffers(ptrs)) }
+size_t lcx_exch_message_bytes(lcx_particles *h, size_t n_rec) { try { DevGuard dev_guard_; return H->x_message_bytes(n_rec); } catch (const std::exception &e) { g_err = e.what(); return 0; } }
+int lcx_exch_pack(lcx_particles *h, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_cap_lft, unsigned next_cap_rgt)
+{ LCX_TRY(H->x_pack(has_lft != 0, lft_x1, has_rgt != 0, rgt_x0, next_cap_lft, next_cap_rgt)) }
+int lcx_exch_unpack(lcx_particles *h, int from_lft, int from_rgt, unsigned have_lft, unsigned have_rgt) { LCX_TRY(H->x_unpack(from_lft != 0, from_rgt != 0, have_lft, have_rgt)) }
+int lcx_exch_finish(lcx_particles *h, const lcx_opts_t *o, unsigned rec[12], int *complete) { LCX_TRY(*complete = H->x_finish(*o, rec) ? 1 : 0) }
+int lcx_stream(lcx_particles *h, void **hip_stream) { LCX_TRY(*hip_stream = H->stream()) }
+size_t lcx_courant_halo_count(lcx_particles *h, int which) { DevGuard dev_guard_; return H->courant_halo_count(which); }
 int lcx_courant_halo_pack(lcx_particles *h, int which, int side, void *buf) { LCX_TRY(H->courant_halo_copy(which, side, buf, true)) }
 int lcx_courant_halo_unpack(lcx_particles *h, int which, int side, const void *buf) { LCX_TRY(H->courant_halo_copy(which, side, const_cast<void *>(buf), false)) }
 int lcx_dev_alloc(void **ptr, size_t bytes) { LCX_TRY({ if (hipMalloc(ptr, bytes ? bytes : 1) != hipSuccess) throw std::runtime_error("libcloudph++ (HIP): hipMalloc failed"); }) }

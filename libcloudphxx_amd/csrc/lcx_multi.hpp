@@ -162,6 +162,7 @@ struct MultiParticles : IParticles {
     const size_t exch_cap = Particles<T>::exch_capacity(size_t(oi.n_sd_max / D + 1), get_dev_nx(oi.nx, 0, D));
     slab.resize(D); n_rendezvous.assign(D, 0); n_rendezvous_hidden.assign(D, 0);
     ev_sent.assign(D, nullptr); ev_consumed.assign(D, nullptr);
+    try {
     for (int i = 0; i < D; ++i) {
       lcx_opts_init_t o = oi;                                                      // distmem_opts.hpp:20-52
       const int bfr = D > 1 ? i * get_dev_nx(oi.nx, 0, D) : 0;
@@ -189,6 +190,7 @@ struct MultiParticles : IParticles {
         HIPCHK(hipEventRecord(ev_consumed[i], slab[i]->st));
       }
     }
+    } catch (...) { release_devices(); throw; }     // (a slab that could not be built: the ones before it go, each under its own device)
     // an inbox that could not be had as fine-grained memory must not be written by a neighbour's kernel from another device (its
     // receiver could read stale cache lines): those senders pack at home and copy
     if (D > 1)
@@ -200,14 +202,20 @@ struct MultiParticles : IParticles {
     if (serialize) fprintf(stderr, "libcloudph++ (multi_HIP): LCX_MULTI_SERIALIZE is set -- the %d slabs take turns (measurement mode)\n", D);
     pool->run([this](int i) { HIPCHK(hipSetDevice(dev[i])); });                    // each worker stays on its device
   }
+  // slabs and events are freed with their own device current (the caller's device is put back by the C ABI's guard)
+  void release_devices()
+  {
+    for (int i = 0; i < D; ++i) {
+      (void)hipSetDevice(dev[i]);
+      if (slab[i]) slab[i].reset();
+      if (ev_sent[i]) { (void)hipEventDestroy(ev_sent[i]); ev_sent[i] = nullptr; }
+      if (ev_consumed[i]) { (void)hipEventDestroy(ev_consumed[i]); ev_consumed[i] = nullptr; }
+    }
+  }
   ~MultiParticles() override
   {
     pool.reset();
-    for (int i = 0; i < D; ++i) {
-      if (slab[i]) { (void)hipSetDevice(dev[i]); slab[i].reset(); }
-      if (ev_sent[i]) (void)hipEventDestroy(ev_sent[i]);
-      if (ev_consumed[i]) (void)hipEventDestroy(ev_consumed[i]);
-    }
+    release_devices();
   }
   int real_kind() const override { return int(sizeof(T)); }
 

@@ -602,6 +602,45 @@ class particles_t:
         oc = opts._to_c()
         self._chk(self._f("migrate_finish")(self._h, C.byref(oc)))
 
+    # -- the device-driven exchange for one process per GPU (include/lcx.h lcx_exch_*; driven by libcloudphxx_amd.multi)
+    def exch_enable(self, nx_min):
+        cap = C.c_size_t()
+        self._chk(self._f("exch_enable")(self._h, C.c_int(nx_min), C.byref(cap)))
+        return cap.value
+
+    def exch_buffers(self):
+        """addresses of (outbox to the left, outbox to the right, inbox from the left, inbox from the right)"""
+        p4 = (C.c_void_p * 4)()
+        self._chk(self._f("exch_buffers")(self._h, p4))
+        return [int(v or 0) for v in p4]
+
+    def exch_message_bytes(self, n_rec):
+        f = self._f("exch_message_bytes")
+        f.restype = C.c_size_t
+        return f(self._h, C.c_size_t(n_rec))
+
+    def exch_pack(self, has_lft, lft_x1, has_rgt, rgt_x0, next_cap_lft=0, next_cap_rgt=0):
+        self._chk(self._f("exch_pack")(self._h, C.c_int(bool(has_lft)), C.c_double(lft_x1), C.c_int(bool(has_rgt)), C.c_double(rgt_x0),
+                                       C.c_uint(next_cap_lft), C.c_uint(next_cap_rgt)))
+
+    def exch_unpack(self, from_lft, from_rgt, have_lft=0xFFFFFFFF, have_rgt=0xFFFFFFFF):
+        self._chk(self._f("exch_unpack")(self._h, C.c_int(bool(from_lft)), C.c_int(bool(from_rgt)), C.c_uint(have_lft), C.c_uint(have_rgt)))
+
+    def exch_finish(self, opts):
+        """the step's one host synchronisation: (complete, record) -- record = [dead, out_lft, out_rgt, in_lft, in_rgt, flags, crowded
+        cells, largest cell, shift, next_cap_lft, next_cap_rgt, 0]"""
+        oc = opts._to_c()
+        rec = (C.c_uint * 12)()
+        done = C.c_int()
+        self._chk(self._f("exch_finish")(self._h, C.byref(oc), rec, C.byref(done)))
+        return bool(done.value), list(rec)
+
+    def stream(self):
+        """the hipStream_t (as an integer) every launch of this object is queued on; 0 for an engine without one"""
+        p = C.c_void_p()
+        self._chk(self._f("stream")(self._h, C.byref(p)))
+        return int(p.value or 0)
+
 
 def factory(backend, opts_init, real_t=np.float64):
     """factory<real_t>(backend, opts_init)  (factory.hpp:12-15, src/lib.cpp:13-40).

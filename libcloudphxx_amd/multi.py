@@ -1,16 +1,25 @@
-"""1-D domain decomposition across the GPUs of one node: one process per GPU, neighbour exchange of
-migrating super-droplets with torch.distributed point-to-point operations (backend "nccl" == RCCL over
-xGMI on ROCm; "gloo" in the CPU tests).
+"""1-D domain decomposition across the GPUs of one node, ONE PROCESS PER GPU: neighbour exchange of migrating super-droplets with
+torch.distributed point-to-point operations (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests and for several
+ranks on one GPU).
 
-This is the SPMD flavour (one PROCESS per GPU, e.g. under torch.distributed.run or next to an MPI host model); the reference's
-multi_CUDA object -- ONE process, all GPUs of the node -- is native in the C library (lcx_create_multi, csrc/lcx_multi.hpp) and is
-what factory(multi_CUDA | multi_HIP) returns.  It replaces the reference's multi_CUDA backend (src/particles_multi_gpu_*.ipp,
-src/impl_multi_gpu/particles_multi_gpu_impl_step_async_and_copy.ipp:28-206: one std::thread per GPU,
-cudaMemcpyPeerAsync of two packed buffers, five thread barriers per step) and its MPI twin
-(src/impl/distributed_memory/particles_impl_mpi_exchange.ipp:20-330).  There is no collective on the data
-path: each rank talks to its left and right neighbour only (periodic ring, or open ends with
-open_side_walls), one message pair per direction per step:  counts first, then the attribute-major packed
-records produced on the device by lcx_migrate_pack (include/lcx.h).
+The reference's multi_CUDA object -- ONE process, all GPUs of the node -- is native in the C library (lcx_create_multi,
+csrc/lcx_multi.hpp) and is what factory(multi_CUDA | multi_HIP) returns.  This module is its SPMD twin (e.g. under
+torch.distributed.run, or next to an MPI host model) and replaces the reference's MPI flavour
+(src/impl/distributed_memory/particles_impl_mpi_exchange.ipp:20-330) as well as the per-step choreography of
+src/impl_multi_gpu/particles_multi_gpu_impl_step_async_and_copy.ipp:28-206 (one std::thread per GPU, cudaMemcpyPeerAsync of two
+packed buffers, five thread barriers).  There is no collective on the data path: each rank talks to its left and right neighbour
+only (periodic ring, or open ends with open_side_walls).
+
+Protocol of a step (include/lcx.h, lcx_exch_*; the engine keeps the emigrant lists and their counts on the device):
+
+  step_async                      coalescence ... advection, boundary, re-index of those that stay           (queued)
+  exch_pack                       emigrants -> two outboxes, header = {count, overflow, first-part size of the NEXT message}  (queued)
+  ONE batch of isend / irecv      the header and the first `cap` records of each message, `cap` agreed one step ahead through the
+                                  header (the sender sizes it from its previous counts), so that no count travels ahead of the
+                                  payload and the host never waits for one; ordered against the engine's stream, not the host
+  exch_unpack                     both inboxes -> storage, histogram                                                     (queued)
+  exch_finish                     the step's ONE host synchronisation (32 bytes of counts), then scan / scatter / rank
+  (rarely) a second batch         only when a message held more records than its first part: the remaining tiles, unpack, finish
 
 Slab sizes follow detail::get_dev_nx / distmem_opts (src/detail/distmem_opts.hpp:10-52).
 """
@@ -21,6 +30,7 @@ import numpy as np
 from . import lgrngn
 
 BCOND_SHAREDMEM, BCOND_DISTMEM, BCOND_OPEN = 0, 1, 3      # src/detail/bcond.hpp
+EXCH_HDR, EXCH_TILE = 256, 256                            # csrc/lcx_kernels.hpp
 
 
 def get_dev_nx(nx, rank, size):
@@ -58,17 +68,31 @@ def distmem_opts(opts_init, rank, size):
     return oi, n_x_bfr
 
 
+class _DevMem:
+    """a device allocation owned by the engine, seen by torch through the CUDA array interface"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def _tiles(n_rec):
+    return (int(n_rec) + EXCH_TILE - 1) // EXCH_TILE
+
+
 class particles_multi_t:
     """SPMD flavour of particles_t<real_t, multi_CUDA>: every rank constructs it with the GLOBAL opts_init;
     arrays passed to init/step_sync are the rank's LOCAL slabs (x-planes [n_x_bfr, n_x_bfr + nx_local)) unless
     global_arrays=True, in which case the library indexes the global arrays with the n_x_bfr offset exactly like
     the reference does (initialization/particles_impl_init_e2l.ipp:44-46).
 
-    make_particles(opts_init_local) -> particles object (defaults to the HIP backend); make_buffer(nbytes) ->
-    (object keeping the buffer alive, address, torch tensor view) lets the CPU tests run the same protocol on gloo.
+    make_particles(opts_init_local) -> particles object (defaults to the HIP backend).
+    transport: "rccl"  -- device buffers handed to torch.distributed as they are (backend nccl = RCCL over xGMI), ordered against the
+                          engine's stream: no host synchronisation of its own; needs one GPU per rank;
+               "host"  -- the used part of each message staged through host memory (gloo): several ranks on one GPU, CPU engines;
+               None    -- "rccl" when the engine runs on a GPU and the process group has a device backend, else "host".
     """
 
-    def __init__(self, opts_init, real_t=np.float64, make_particles=None, device=None, global_arrays=False):
+    def __init__(self, opts_init, real_t=np.float64, make_particles=None, device=None, global_arrays=False, transport=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -87,8 +111,7 @@ class particles_multi_t:
             oi.n_x_tot = oi.nx        # slab-local arrays: a Courant halo wraps inside the slab, the exchange below overwrites it
         self.opts_init = oi
         if device is None and make_particles is None:
-            # the HIP engine works on device buffers: with the default engine the rank's current GPU is the device (a host tensor's
-            # address handed to the pack / unpack kernels would fault)
+            # the HIP engine works on device buffers: with the default engine the rank's current GPU is the device
             if not torch.cuda.is_available():
                 raise RuntimeError("libcloudph++: multi_HIP needs a GPU per process (pass make_particles / device for another engine)")
             device = torch.device("cuda", torch.cuda.current_device())
@@ -109,6 +132,54 @@ class particles_multi_t:
             self.lft_x1 = opts_init.x1 - self.lft * get_dev_nx(opts_init.nx, 0, self.size) * opts_init.dx
         self.rgt_x0 = (opts_init.x0 if self.rgt == 0 else 0.) if self.rgt is not None else -1.
         self.bytes_moved = 0
+        self.second_rounds = 0
+        self.host_syncs = 0            # host synchronisations this object caused beyond the engine's one per step
+        if transport is None:
+            has_dev_backend = False
+            try:
+                has_dev_backend = "nccl" in str(dist.get_backend()).lower()
+            except Exception:
+                pass
+            transport = "rccl" if (self.on_gpu and has_dev_backend) else "host"
+        if transport not in ("rccl", "host"):
+            raise RuntimeError("libcloudph++: transport must be 'rccl' or 'host'")
+        if transport == "rccl" and not self.on_gpu:
+            raise RuntimeError("libcloudph++: the rccl transport needs the engine's buffers on a GPU")
+        self.transport = transport
+        self._halo_bufs = {}
+        if self.size > 1:
+            self._setup_exchange()
+
+    # ---- message buffers: owned by the engine, wrapped once
+    def _setup_exchange(self):
+        torch = self.torch
+        p = self.prt
+        self.cap_rec = p.exch_enable(get_dev_nx(self.glob_opts_init.nx, 0, self.size))       # one capacity for all ranks
+        self.tile_bytes = (p.exch_message_bytes(EXCH_TILE) - EXCH_HDR)
+        nbytes = p.exch_message_bytes(self.cap_rec)
+        ptrs = p.exch_buffers()
+        if self.on_gpu:
+            self.box = [torch.as_tensor(_DevMem(q, nbytes), device=self.device) for q in ptrs]
+            if self.transport == "host":
+                self.stage = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(4)]
+            s = p.stream()
+            self.ext_stream = torch.cuda.ExternalStream(s, device=self.device) if s else None
+        else:
+            import ctypes
+            self.box = [torch.from_numpy(np.ctypeslib.as_array((ctypes.c_ubyte * nbytes).from_address(q))) for q in ptrs]
+            self.stage = self.box
+            self.ext_stream = None
+        # first-part capacities in records (multiples of a tile): [to/from the left, to/from the right].  The start value is the same
+        # on every rank by construction; from then on the sender announces the next one in its header
+        cap0 = min(self.cap_rec, max(EXCH_TILE, _tiles(self.cap_rec // 8) * EXCH_TILE))
+        self.send_cap = [cap0, cap0]
+        self.recv_cap = [cap0, cap0]
+        self.last_out = [0, 0]
+
+    def _next_cap(self, side):
+        """first-part size of the NEXT message to `side`: a quarter above the last count, at least one tile, at most the inbox"""
+        want = _tiles(self.last_out[side] * 5 // 4 + 1) * EXCH_TILE
+        return int(min(self.cap_rec, max(EXCH_TILE, want)))
 
     # ---- fan-outs (particles_multi_gpu_step.ipp:16-56, particles_multi_gpu_diag.ipp)
     def __getattr__(self, name):
@@ -125,103 +196,140 @@ class particles_multi_t:
         self.prt.step_sync(*a, **kw)
         self._exchange_courant_halo()
 
+    # ---- transports: one batch of point-to-point operations; segs = [(tensor view to send | None, peer), ...] in the fixed order
+    #      send left, send right, receive from right, receive from left (with two ranks both messages travel between the same pair and
+    #      are matched in posting order)
+    def _p2p(self, send_l, send_r, recv_r, recv_l):
+        dist = self.dist
+        ops = []
+        if send_l is not None:
+            ops.append(dist.P2POp(dist.isend, send_l, self.lft))
+        if send_r is not None:
+            ops.append(dist.P2POp(dist.isend, send_r, self.rgt))
+        if recv_r is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_r, self.rgt))
+        if recv_l is not None:
+            ops.append(dist.P2POp(dist.irecv, recv_l, self.lft))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()                   # (device tensors: the CURRENT STREAM waits, not the host)
+
+    def _ship(self, ranges):
+        """ranges: [(lo, hi) bytes of outbox-left to send | None, outbox-right | None, inbox-from-right to fill | None, inbox-from-left | None]"""
+        torch = self.torch
+        out_l, out_r, in_l, in_r = self.box
+        views = lambda t, r: None if r is None else t[r[0]:r[1]]
+        if self.transport == "rccl":
+            if self.ext_stream is not None:
+                with torch.cuda.stream(self.ext_stream):       # torch's "current stream" = the engine's: RCCL orders itself against it
+                    self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]))
+            else:
+                self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]))
+            return
+        # host-staged: the engine's queue drains, the used bytes cross the host
+        st = self.stage
+        if self.on_gpu:
+            if self.ext_stream is not None:
+                self.ext_stream.synchronize()
+            self.host_syncs += 1
+            for k in (0, 1):
+                if ranges[k] is not None:
+                    st[k][ranges[k][0]:ranges[k][1]].copy_(self.box[k][ranges[k][0]:ranges[k][1]])
+            torch.cuda.synchronize(self.device)
+        self._p2p(views(st[0], ranges[0]), views(st[1], ranges[1]), views(st[3], ranges[2]), views(st[2], ranges[3]))
+        if self.on_gpu:
+            for k, r in ((3, ranges[2]), (2, ranges[3])):
+                if r is not None:
+                    self.box[k][r[0]:r[1]].copy_(st[k][r[0]:r[1]])
+            torch.cuda.synchronize(self.device)
+
+    def _msg_range(self, rec_lo, rec_hi, with_header):
+        """bytes of a message that hold the tiles of records [rec_lo, rec_hi) (rec_lo a multiple of the tile), optionally from the header on"""
+        lo = 0 if with_header else EXCH_HDR + (rec_lo // EXCH_TILE) * self.tile_bytes
+        return (lo, EXCH_HDR + _tiles(rec_hi) * self.tile_bytes)
+
+    def step_async(self, opts):
+        """local step_async, then the neighbour exchange and post_copy
+        (impl_multi_gpu/..._step_async_and_copy.ipp:28-206 without the thread barriers)"""
+        p = self.prt
+        p.step_async(opts)
+        if self.size == 1:
+            return
+        hl, hr = self.lft is not None, self.rgt is not None
+        nxt = [self._next_cap(0), self._next_cap(1)]
+        p.exch_pack(hl, self.lft_x1, hr, self.rgt_x0, nxt[0], nxt[1])
+        sc, rc = self.send_cap, self.recv_cap
+        self._ship([self._msg_range(0, sc[0], True) if hl else None, self._msg_range(0, sc[1], True) if hr else None,
+                    self._msg_range(0, rc[1], True) if hr else None, self._msg_range(0, rc[0], True) if hl else None])
+        p.exch_unpack(hl, hr, rc[0], rc[1])
+        done, rec = p.exch_finish(opts)
+        out, inc = [rec[1], rec[2]], [rec[3], rec[4]]
+        # the rare second part: a message that held more than its agreed first part (both ends see it in their own record)
+        more_out = [hl and out[0] > sc[0], hr and out[1] > sc[1]]
+        more_in = [hl and inc[0] > rc[0], hr and inc[1] > rc[1]]
+        if any(more_out) or any(more_in):
+            self.second_rounds += 1
+            self._ship([self._msg_range(sc[0], out[0], False) if more_out[0] else None, self._msg_range(sc[1], out[1], False) if more_out[1] else None,
+                        self._msg_range(rc[1], inc[1], False) if more_in[1] else None, self._msg_range(rc[0], inc[0], False) if more_in[0] else None])
+        if not done:
+            p.exch_unpack(hl, hr)
+            done, rec = p.exch_finish(opts)
+            if not done:
+                raise RuntimeError("libcloudph++: neighbour exchange incomplete after its second part")
+        rec_bytes = self.tile_bytes // EXCH_TILE
+        self.bytes_moved += (out[0] + out[1]) * rec_bytes
+        self.last_out = out
+        self.send_cap = nxt
+        self.recv_cap = [rec[9] if hl else rc[0], rec[10] if hr else rc[1]]
+
+    # ---- Courant halo of pred_corr
+    def _halo_buf(self, key, nbytes, where):
+        t = self._halo_bufs.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self.torch.empty(max(int(nbytes), 8), dtype=self.torch.uint8, device=where)
+            self._halo_bufs[key] = t
+        return t
+
     def _exchange_courant_halo(self):
         """pred_corr advection reads Courant numbers up to two x-planes outside the slab: every rank sends the planes next
         to its edges to the neighbours (particles_impl_xchng_courants.ipp:15-160), three small messages per side"""
         if self.size == 1:
             return
-        torch, dist = self.torch, self.dist
+        torch = self.torch
         isz = self.real_t.itemsize
+        staged = self.on_gpu and self.transport == "host"
+        hl, hr = self.lft is not None, self.rgt is not None
         for which in (0, 1, 2):
             cnt = self.prt.courant_halo_count(which)
             if not cnt:
                 continue
-            out_l, out_r, in_l, in_r = (self._buf(cnt * isz) for _ in range(4))
-            ops = []
-            if self.lft is not None:
-                self.prt.courant_halo_pack(which, 0, out_l.data_ptr())
-                ops.append(dist.P2POp(dist.isend, out_l, self.lft))
-            if self.rgt is not None:
-                self.prt.courant_halo_pack(which, 1, out_r.data_ptr())
-                ops.append(dist.P2POp(dist.isend, out_r, self.rgt))
-            if self.rgt is not None:
-                ops.append(dist.P2POp(dist.irecv, in_r, self.rgt))
-            if self.lft is not None:
-                ops.append(dist.P2POp(dist.irecv, in_l, self.lft))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if self.on_gpu:
-                torch.cuda.current_stream().synchronize()
-            if self.lft is not None:
-                self.prt.courant_halo_unpack(which, 0, in_l.data_ptr())
-            if self.rgt is not None:
-                self.prt.courant_halo_unpack(which, 1, in_r.data_ptr())
-
-    def _buf(self, nbytes):
-        t = self.torch.empty(max(int(nbytes), 8), dtype=self.torch.uint8, device=self.device if self.on_gpu else "cpu")
-        return t
-
-    def step_async(self, opts):
-        """local step_async, then the neighbour exchange and post_copy
-        (impl_multi_gpu/..._step_async_and_copy.ipp:28-206 without the thread barriers)"""
-        torch, dist = self.torch, self.dist
-        self.prt.step_async(opts)
-        if self.size == 1:
-            return
-        n_lft, n_rgt = self.prt.migrate_counts()
-        rec = self.prt.migrate_record_bytes()
-        dev = self.device if self.on_gpu else "cpu"
-        # 0) pack on the device (x re-based to the receiver's frame): needs only this rank's own counts, so it is issued
-        #    before the count exchange
-        out_l, out_r = self._buf(n_lft * rec), self._buf(n_rgt * rec)
-        if self.lft is not None and n_lft:
-            self.prt.migrate_pack(0, self.lft_x1, out_l.data_ptr(), out_l.numel())
-        if self.rgt is not None and n_rgt:
-            self.prt.migrate_pack(1, self.rgt_x0, out_r.data_ptr(), out_r.numel())
-        # 1) counts.  send order (left, right); receive order (from right, from left): with two ranks both
-        #    messages travel between the same pair and are matched in posting order.
-        cnt_out = [torch.tensor([n_lft], dtype=torch.int64, device=dev), torch.tensor([n_rgt], dtype=torch.int64, device=dev)]
-        cnt_in = [torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)]   # [from right, from left]
-        ops = []
-        if self.lft is not None:
-            ops.append(dist.P2POp(dist.isend, cnt_out[0], self.lft))
-        if self.rgt is not None:
-            ops.append(dist.P2POp(dist.isend, cnt_out[1], self.rgt))
-        if self.rgt is not None:
-            ops.append(dist.P2POp(dist.irecv, cnt_in[0], self.rgt))
-        if self.lft is not None:
-            ops.append(dist.P2POp(dist.irecv, cnt_in[1], self.lft))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        in_rgt, in_lft = int(cnt_in[0].item()), int(cnt_in[1].item())
-        # 2) exchange the payloads
-        buf_r, buf_l = self._buf(in_rgt * rec), self._buf(in_lft * rec)
-        ops = []
-        if self.lft is not None and n_lft:
-            ops.append(dist.P2POp(dist.isend, out_l[:n_lft * rec], self.lft))
-        if self.rgt is not None and n_rgt:
-            ops.append(dist.P2POp(dist.isend, out_r[:n_rgt * rec], self.rgt))
-        if self.rgt is not None and in_rgt:
-            ops.append(dist.P2POp(dist.irecv, buf_r[:in_rgt * rec], self.rgt))
-        if self.lft is not None and in_lft:
-            ops.append(dist.P2POp(dist.irecv, buf_l[:in_lft * rec], self.lft))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if self.on_gpu:
-                torch.cuda.current_stream().synchronize()
-        self.bytes_moved += (n_lft + n_rgt) * rec
-        # 3) append immigrants (left neighbour's first, as the reference unpacks lft then rgt), drop emigrants, re-index
-        if in_lft:
-            self.prt.migrate_unpack(buf_l.data_ptr(), in_lft)
-        if in_rgt:
-            self.prt.migrate_unpack(buf_r.data_ptr(), in_rgt)
-        self.prt.migrate_finish(opts)
+            nb = cnt * isz
+            # what the engine packs into / unpacks from (its own memory space), and what torch.distributed ships: out_l, out_r, in_l, in_r
+            eng = [self._halo_buf((which, "e", k), nb, self.device if self.on_gpu else "cpu") for k in range(4)]
+            wire = eng if not staged else [self._halo_buf((which, "w", k), nb, "cpu") for k in range(4)]
+            if hl:
+                self.prt.courant_halo_pack(which, 0, eng[0].data_ptr())        # (synchronous: the planes are in the buffer on return)
+            if hr:
+                self.prt.courant_halo_pack(which, 1, eng[1].data_ptr())
+            if staged:
+                wire[0].copy_(eng[0]); wire[1].copy_(eng[1])
+                torch.cuda.synchronize(self.device)
+            self._p2p(wire[0][:nb] if hl else None, wire[1][:nb] if hr else None, wire[3][:nb] if hr else None, wire[2][:nb] if hl else None)
+            if self.on_gpu and not staged:
+                torch.cuda.current_stream().synchronize()                      # the engine unpacks on its own stream
+            if staged:
+                eng[2].copy_(wire[2]); eng[3].copy_(wire[3])
+                torch.cuda.synchronize(self.device)
+            if hl:
+                self.prt.courant_halo_unpack(which, 0, eng[2].data_ptr())
+            if hr:
+                self.prt.courant_halo_unpack(which, 1, eng[3].data_ptr())
 
     def diag_puddle(self):
         """sum over ranks (particles_multi_gpu_diag.ipp:246-268)"""
         torch, dist = self.torch, self.dist
         loc = self.prt.diag_puddle()
-        t = torch.tensor([loc[k] for k in lgrngn.output_names], dtype=torch.float64, device=self.device if self.on_gpu else "cpu")
+        dev_ = self.device if (self.on_gpu and self.transport == "rccl") else "cpu"
+        t = torch.tensor([loc[k] for k in lgrngn.output_names], dtype=torch.float64, device=dev_)
         dist.all_reduce(t)
         return {k: float(v) for k, v in zip(lgrngn.output_names, t.cpu())}

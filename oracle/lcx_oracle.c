@@ -124,6 +124,8 @@ struct orc_particles {
   double eps_tol;
   /* distmem */
   sz *lft_id, *rgt_id; sz lft_count, rgt_count;
+  /* message buffers of the device-driven exchange protocol (orc_exch_*, the CPU twin of include/lcx.h lcx_exch_*) */
+  unsigned char *xbox[4]; sz xcap; unsigned xflags;
 };
 typedef struct orc_particles orc_particles;
 
@@ -240,7 +242,7 @@ void orc_destroy(orc_particles *s)
     s->pp_rv, s->pp_th, s->pp_rh, s->pp_p, s->rc2, s->dlt_rv, s->dlt_th, s->dlt_rh, s->dlt_p, s->rwX, s->drwX, s->Tp, s->pp_sstp,
     s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
     s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
-    s->count_num, s->count_mom, s->outbuf, s->courant_x, s->courant_y, s->courant_z};
+    s->count_num, s->count_mom, s->outbuf, s->courant_x, s->courant_y, s->courant_z, s->xbox[0], s->xbox[1], s->xbox[2], s->xbox[3]};
   for (sz i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) free(ptrs[i]);
   free(s);
 }
@@ -2036,6 +2038,90 @@ int orc_migrate_finish(orc_particles *s, const lcx_opts_t *opts)
   s->lft_count = s->rgt_count = 0;
   return post_copy(s, opts);
 }
+
+/* ---------------- the same three steps behind the message interface of include/lcx.h lcx_exch_* ----------------
+ * CPU twin of the product's device-driven exchange so that libcloudphxx_amd/multi.py runs ONE protocol with either engine (the gloo
+ * tests drive it with this oracle).  Message = 256-byte header {count, overflow, next capacity} + tiles of 256 records, each tile
+ * n[256] | attr_0[256] | attr_1[256] ... (csrc/lcx_kernels.hpp k_pack_dev states the layout; pack.ipp:30-133 / unpack.ipp:50-143 the
+ * reference's attribute-major buffers it replaces). */
+#define XHDR 256
+#define XTILE 256
+static size_t x_rec_bytes(orc_particles *s) { double *a[24]; return 8 + 8 * (size_t)mig_attrs(s, a); }
+static size_t x_msg_bytes(orc_particles *s, size_t n_rec) { return XHDR + ((n_rec + XTILE - 1) / XTILE) * XTILE * x_rec_bytes(s); }
+int orc_exch_enable(orc_particles *s, int nx_min, size_t *cap_rec)
+{
+  sz c = 2 * s->cap / (sz)(nx_min > 0 ? nx_min : 1) + 1024;
+  if (c > s->cap) c = s->cap;
+  s->xcap = (c + XTILE - 1) / XTILE * XTILE;
+  for (int k = 0; k < 4; ++k) s->xbox[k] = (unsigned char *)calloc(x_msg_bytes(s, s->xcap), 1);
+  *cap_rec = s->xcap;
+  return 0;
+}
+int orc_exch_buffers(orc_particles *s, void *ptrs[4]) { for (int k = 0; k < 4; ++k) ptrs[k] = s->xbox[k]; return 0; }
+size_t orc_exch_message_bytes(orc_particles *s, size_t n_rec) { return x_msg_bytes(s, n_rec); }
+static void x_pack_side(orc_particles *s, unsigned char *msg, const sz *id, sz cnt, double x_rmt, double x_lcl, unsigned next_cap)
+{
+  unsigned *h = (unsigned *)msg;
+  h[0] = (unsigned)cnt; h[1] = cnt > s->xcap; h[2] = next_cap;
+  if (cnt > s->xcap) return;
+  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  const size_t tile_bytes = XTILE * x_rec_bytes(s);
+  for (sz i = 0; i < cnt; ++i) {
+    s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;                       /* detail::remote, pack.ipp:14-26 */
+    unsigned char *t = msg + XHDR + (i / XTILE) * tile_bytes;
+    const sz j = i % XTILE;
+    ((n_t *)t)[j] = s->n[id[i]];
+    for (int a = 0; a < na; ++a) ((double *)(t + XTILE * 8))[(sz)a * XTILE + j] = attrs[a][id[i]];
+    s->n[id[i]] = 0;                                                   /* flag_lft / flag_rgt, unpack.ipp:118-141 */
+  }
+}
+int orc_exch_pack(orc_particles *s, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_lft, unsigned next_rgt)
+{
+  if (has_lft) x_pack_side(s, s->xbox[0], s->lft_id, s->lft_count, lft_x1, s->o.x0, next_lft);
+  if (has_rgt) x_pack_side(s, s->xbox[1], s->rgt_id, s->rgt_count, rgt_x0, s->o.x1, next_rgt);
+  return 0;
+}
+static int x_unpack_side(orc_particles *s, const unsigned char *msg)
+{
+  const unsigned *h = (const unsigned *)msg;
+  const sz cnt = h[1] ? 0 : h[0], old = s->n_part;
+  if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
+  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  const size_t tile_bytes = XTILE * x_rec_bytes(s);
+  const double tol = 5e-4;                                             /* config.hpp:31, tolerance_away_from_bcond */
+  for (sz i = 0; i < cnt; ++i) {
+    const unsigned char *t = msg + XHDR + (i / XTILE) * tile_bytes;
+    const sz j = i % XTILE;
+    s->n[old + i] = ((const n_t *)t)[j];
+    for (int a = 0; a < na; ++a) attrs[a][old + i] = ((const double *)(t + XTILE * 8))[(sz)a * XTILE + j];
+    const double x = s->x[old + i];
+    s->x[old + i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x;
+  }
+  s->n_part = old + cnt;
+  return 0;
+}
+int orc_exch_unpack(orc_particles *s, int from_lft, int from_rgt, unsigned have_lft, unsigned have_rgt)
+{
+  const unsigned *hl = (const unsigned *)s->xbox[2], *hr = (const unsigned *)s->xbox[3];
+  s->xflags = 0;
+  if ((from_lft && !hl[1] && hl[0] > have_lft) || (from_rgt && !hr[1] && hr[0] > have_rgt)) { s->xflags = 4; return 0; }
+  if ((from_lft && hl[1]) || (from_rgt && hr[1])) s->xflags |= 1;
+  if (from_lft && x_unpack_side(s, s->xbox[2])) return 1;             /* the left neighbour's first (unpack.ipp: lft, then rgt) */
+  if (from_rgt && x_unpack_side(s, s->xbox[3])) return 1;
+  return 0;
+}
+int orc_exch_finish(orc_particles *s, const lcx_opts_t *opts, unsigned rec[12], int *complete)
+{
+  const unsigned *hl = (const unsigned *)s->xbox[2], *hr = (const unsigned *)s->xbox[3];
+  memset(rec, 0, 12 * sizeof *rec);
+  rec[1] = (unsigned)s->lft_count; rec[2] = (unsigned)s->rgt_count; rec[3] = hl[0]; rec[4] = hr[0]; rec[5] = s->xflags; rec[9] = hl[2]; rec[10] = hr[2];
+  *complete = !(s->xflags & 4);
+  if (!*complete) return 0;
+  if (s->xflags & 1) FAIL("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (%zu records); raise opts_init.n_sd_max", s->xcap);
+  s->lft_count = s->rgt_count = 0;
+  return post_copy(s, opts);
+}
+int orc_stream(orc_particles *s, void **stream) { (void)s; *stream = NULL; return 0; }
 
 /* ---------------- Courant halo exchange of pred_corr (xchng_courants.ipp:15-160) ---------------- */
 /* element ranges inside the halo-extended arrays: [send to left, send to right, recv from left, recv from right] */

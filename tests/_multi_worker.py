@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
-def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler"):
+def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler", sd_conc=8):
     import torch.distributed as dist
     import _harness as h
     from libcloudphxx_amd import lgrngn, multi
@@ -24,8 +24,8 @@ def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler"):
         oi.dt = 1
         oi.nx, oi.nz, oi.dx, oi.dz = nx, nz, 1, 1
         oi.x1, oi.z1 = nx * oi.dx, nz * oi.dz
-        oi.sd_conc = 8
-        oi.n_sd_max = 8 * nx * nz * 2
+        oi.sd_conc = sd_conc
+        oi.n_sd_max = sd_conc * nx * nz * 2
         oi.adve_scheme = lgrngn.as_t[scheme]         # pred_corr: the Courant halo is exchanged between the ranks as well
         oi.rng_seed = 44 + rank                      # mpi_adve_test.cpp:95 seeds every rank differently
         prt = multi.particles_multi_t(oi, np.float64, make_particles=h.oracle_particles)
@@ -52,6 +52,12 @@ def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler"):
         after = diags()
         np.save(result_path % rank, np.stack([before, after]))
         ok = np.array_equal(before, after) and prt.n_part == n_before and prt.bytes_moved > 0
+        # a whole x-plane crosses each face per step: with more than a tile (256) of super-droplets per plane the first message exceeds
+        # its agreed first part and the protocol's second batch must have run (once: the sender then announces a larger first part)
+        if sd_conc * nz > 256:
+            ok = ok and prt.second_rounds >= 1 and prt.second_rounds <= 2
+        else:
+            ok = ok and prt.second_rounds == 0
         sys.exit(0 if ok else 3)
     finally:
         dist.destroy_process_group()
@@ -59,4 +65,4 @@ def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler"):
 
 if __name__ == "__main__":
     a = sys.argv
-    run(int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), a[7], a[8] if len(a) > 8 else "euler")
+    run(int(a[1]), int(a[2]), int(a[3]), int(a[4]), int(a[5]), float(a[6]), a[7], a[8] if len(a) > 8 else "euler", int(a[9]) if len(a) > 9 else 8)

@@ -79,6 +79,28 @@ def test_multi_device_object_matches_oracle_ring(dims, size, monkeypatch):
     assert np.array_equal(got, orc.gather(one))
 
 
+@pytest.mark.parametrize("dims,size,cx", [((7, 0, 5), 3, 0.95), ((15, 0, 4), 8, 0.95), ((11, 2, 3), 4, -0.9)])
+def test_multi_device_uneven_slabs_at_courant_one(dims, size, cx, monkeypatch):
+    """nx not divisible by the number of slabs: the last slab takes the remainder (distmem_opts.hpp:10-16: 15 planes over 8 slabs =
+    seven of 1 plane and one of 8) and the thin slabs send nearly a whole plane per step into its inbox.  Round 2 sized every inbox
+    from the slab's OWN plane count while the senders checked against theirs: the thick slab's inbox was the smallest.  One
+    capacity for all slabs now (Particles::exch_capacity); against the oracle ring, six steps"""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False)
+    oi.n_sd_max = 24 * nx * max(ny, 1) * nz * 3
+    th, rv, rhod, C = h.box_fields(oi)
+    C["Cx"] = cx * np.ones_like(C["Cx"])
+    orc, mul, slabs = multi_pair(oi, size, (th, rv, rhod, C), monkeypatch)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    for it in range(6):
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_async(opts)
+        compare_slabs(orc, slabs, oi, it, attrs=("x", "y", "z"))
+    assert mul.n_part == sum(p.n_part for p in orc.prts)
+
+
 @pytest.mark.parametrize("dims,size", [((8, 0, 5), 2), ((9, 3, 4), 3)])
 def test_multi_device_pred_corr_and_open_walls(dims, size, monkeypatch):
     """pred_corr (Courant halo of two planes per side) and open side walls through the multi-device object"""

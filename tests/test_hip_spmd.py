@@ -1,0 +1,83 @@
+"""The one-process-per-GPU path with the HIP ENGINE: libcloudphxx_amd.multi.particles_multi_t (lcx_exch_* of the C ABI: emigrant
+counts stay on the device, one message per direction whose size is agreed one step ahead, one host synchronisation per step) run by
+two and three ranks under torch.distributed.  The test box has one GPU, so the ranks share device 0 and the messages are staged
+through the host (gloo); on a node with one GPU per rank the same calls hand the device buffers to RCCL.
+
+Checkers: the ring round trip of the reference's MPI test (tests/mpi/mpi_adve_test.cpp:196-255) bit-identical; the slabs of the
+native multi-device object (factory(multi_CUDA), itself held to the oracle ring in tests/test_hip_multi.py) bit-identical."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(mode, world, res):
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_spmd_worker.py"), mode, str(r), str(world), str(port), res, "host"])
+             for r in range(world)]
+    codes = [p.wait(timeout=600) for p in procs]
+    assert codes == [0] * world, codes
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spmd_hip_engine_ring_round_trip_bit_identical(world, tmp_path):
+    res = str(tmp_path / "r%d.npy")
+    launch("ring", world, res)
+    for r in range(world):
+        d = np.load(res % r)
+        assert np.array_equal(d[0], d[1]) and d[0][0].sum() > 0
+
+
+@pytest.mark.parametrize("mode,world", [("steps", 2), ("steps", 4), ("uneven", 3)])
+def test_spmd_hip_engine_equals_the_native_multi_device_object(mode, world, tmp_path, monkeypatch):
+    """three full steps (cond + coal + adve + sedi, Philox streams, production storage order) by `world` ranks = the slabs of ONE
+    multi-device object over `world` slabs on the same device, bit for bit: same kernels, same message layout, same unpack order --
+    only the transport differs.  "uneven": nx = 7 over 3 ranks (2 + 2 + 3 planes) at Courant number 0.95: the thin slabs send nearly a
+    whole plane each step into the inbox of the thick one (one capacity for all slabs; the native object at these sizes is held to the
+    oracle ring by tests/test_hip_multi.py::test_multi_device_uneven_slabs_at_courant_one)"""
+    import _spmd_worker as w
+    res = str(tmp_path / "s%d.npz")
+    launch(mode, world, res)
+    nx, ny, nz = (8, 3, 4) if mode == "steps" else (7, 0, 5)
+    oi = w.box(nx, ny, nz, 24, 44, coal_switch=(mode == "steps"))
+    th, rv, rhod, C = h.box_fields(oi)
+    if mode == "uneven":
+        C["Cx"] = 0.95 * np.ones_like(C["Cx"])
+    monkeypatch.setenv("LCX_MULTI_DEVICE_MAP", ",".join(["0"] * world))
+    oi.dev_count = world
+    mul = lgrngn.factory(lgrngn.backend_t.multi_CUDA, oi)
+    mul.init(th, rv, rhod, **C)
+    opts = lgrngn.opts_t()
+    opts.coal = mode == "steps"
+    n0 = mul.n_part
+    for it in range(3 if mode == "steps" else 5):
+        mul.step_sync(opts, th, rv, rhod, **C)
+        mul.step_async(opts)
+    per = nx // world
+    tot = 0
+    for r in range(world):
+        d = np.load(res % r)
+        s = w.slab_state(mul.slab(r))
+        tot += int(d["n_part"][0])
+        for k in s:
+            assert np.array_equal(d[k], s[k]), (r, k)
+        b, n = r * per, (per if r < world - 1 else nx - r * per)
+        assert np.array_equal(d["th"], th[b:b + n]) and np.array_equal(d["rv"], rv[b:b + n]), r
+    assert tot == mul.n_part and n0 - 4 <= tot <= n0      # (no coalescence in "uneven": at most a droplet or two through the floor)

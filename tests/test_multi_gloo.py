@@ -38,12 +38,14 @@ def test_distmem_opts_follow_reference_split():
     assert (o0.bcond_lft, o0.bcond_rgt) == (multi.BCOND_OPEN, multi.BCOND_DISTMEM)
 
 
-@pytest.mark.parametrize("world,nx,Cx,scheme", [(2, 6, 1., "euler"), (2, 5, -1., "euler"), (3, 7, 1., "euler"), (2, 8, 1., "pred_corr"),
-                                                (3, 10, -1., "pred_corr")])
-def test_ring_round_trip_is_bit_identical(world, nx, Cx, scheme, tmp_path):
+@pytest.mark.parametrize("world,nx,Cx,scheme,sd_conc", [(2, 6, 1., "euler", 8), (2, 5, -1., "euler", 8), (3, 7, 1., "euler", 8), (2, 8, 1., "pred_corr", 8),
+                                                        (3, 10, -1., "pred_corr", 8), (2, 6, 1., "euler", 80), (3, 7, -1., "euler", 80)])
+def test_ring_round_trip_is_bit_identical(world, nx, Cx, scheme, sd_conc, tmp_path):
+    """sd_conc = 80: 320 super-droplets cross each face per step, more than the one-tile first part the ranks start with -- the
+    protocol's second batch (libcloudphxx_amd/multi.py) runs in the first step and the announced capacity covers the later ones"""
     port = free_port()
     res = str(tmp_path / "r%d.npy")
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_multi_worker.py"), str(r), str(world), str(port), str(nx), "4", str(Cx), res, scheme])
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_multi_worker.py"), str(r), str(world), str(port), str(nx), "4", str(Cx), res, scheme, str(sd_conc)])
              for r in range(world)]
     codes = [p.wait(timeout=300) for p in procs]
     assert codes == [0] * world, codes
