@@ -265,6 +265,8 @@ int lcx_migrate_finish(lcx_particles *, const lcx_opts_t *);
  *   lcx_exch_buffers  ptrs[4] = {outbox to the left, outbox to the right, inbox from the left, inbox from the right}
  *   lcx_exch_pack     after lcx_step_async(): emigrants -> outboxes (x re-based to the receiver's frame, pack.ipp:14-26), their
  *                     multiplicities cleared; queued on the object's stream (lcx_stream), no host synchronisation
+ *   lcx_exch_sort_interior  (optional, right after the transport has been STARTED) queues what does not depend on the neighbours --
+ *                     scan, scatter and in-cell ranking of the slab's interior cells -- so that it runs while the messages travel
  *   [transport: outbox to the left -> the left neighbour's "inbox from the right", and vice versa -- header + have_* records at least]
  *   lcx_exch_unpack   immigrants of both inboxes -> storage (left neighbour's first, unpack.ipp:50-143), have_lft / have_rgt = records
  *                     of each message that have arrived; a message whose count exceeds that is not touched; queued, no host sync
@@ -276,6 +278,7 @@ int lcx_exch_enable(lcx_particles *, int nx_min, size_t *cap_rec);
 int lcx_exch_buffers(lcx_particles *, void *ptrs[4]);
 size_t lcx_exch_message_bytes(lcx_particles *, size_t n_rec);
 int lcx_exch_pack(lcx_particles *, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_cap_lft, unsigned next_cap_rgt);
+int lcx_exch_sort_interior(lcx_particles *);
 int lcx_exch_unpack(lcx_particles *, int from_lft, int from_rgt, unsigned have_lft, unsigned have_rgt);
 int lcx_exch_finish(lcx_particles *, const lcx_opts_t *, unsigned rec[12], int *complete);
 int lcx_stream(lcx_particles *, void **hip_stream);

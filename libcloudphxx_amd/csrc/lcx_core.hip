@@ -129,6 +129,7 @@ struct IParticles {
   virtual size_t x_message_bytes(size_t) { no_exch(); }
   virtual void x_pack(bool, double, bool, double, unsigned, unsigned) { no_exch(); }
   virtual void x_unpack(bool, bool, unsigned, unsigned) { no_exch(); }
+  virtual void x_sort_interior() { no_exch(); }
   virtual bool x_finish(const lcx_opts_t &, unsigned *) { no_exch(); }
   virtual void *stream() { return nullptr; }
 };
@@ -178,6 +179,13 @@ struct Particles : IParticles {
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
   bool turb_any() const { return turb() || o.turb_coal_switch; }     // diss_rate is synced in for any of the three (particles_step.ipp:74-78,121)
   DevBuf<uint32_t> ijk, sorted_id, sorted_ijk, rank, cell_cnt, cell_start, tile_sums, scan_total, big_list, step_cnt, mig_ids[2];
+  // The cell-sorted order begins at sorted_id.p + sort_base.  0 for an object without neighbours.  A slab with neighbours sorts its
+  // interior while their messages travel (exch_sort_interior) and lets the order begin `shift` = (immigrants of the left boundary
+  // planes) below a fixed headroom, instead of moving the interior's entries once that number is known: sort_base = headroom - shift.
+  size_t sort_base = 0, sort_headroom = 0;
+  DevBuf<uint32_t> sorted_alt;          // (exchange only) the in-cell ranking's output while `rank` still holds the boundary SDs' arrival ranks
+  uint32_t *sid() const { return sorted_id.p + sort_base; }
+  uint32_t *sijk() const { return sorted_ijk.p + sort_base; }
   DevBuf<uint8_t> mig, cond_pre; DevBuf<uint32_t> defer_cnt;
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
@@ -345,14 +353,17 @@ struct Particles : IParticles {
   }
 
   // ---- device exclusive scan: out[0..m) = exclusive scan of in, out[m] (if out_last) = total; returns nothing (async) ----
+  // total_slot: where the grand total is kept (default scan_total[0]; the emigrant counts of a slab with neighbours live in
+  // scan_total[0..1] from the move to the end of the exchange, so a scan in between names another slot)
   void exclusive_scan(const uint32_t *in, uint32_t *out, size_t m, uint32_t *out_last, uint32_t *zero_in = nullptr, uint32_t *zero_words = nullptr,
-                      int n_zero_words = 0)
+                      int n_zero_words = 0, uint32_t *total_slot = nullptr)
   {
+    uint32_t *total = total_slot ? total_slot : scan_total.p;
     const size_t tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
-    if (tiles == 0) { if (out_last) HIPCHK(hipMemsetAsync(out_last, 0, sizeof(uint32_t), st)); HIPCHK(hipMemsetAsync(scan_total.p, 0, sizeof(uint32_t), st)); return; }
+    if (tiles == 0) { if (out_last) HIPCHK(hipMemsetAsync(out_last, 0, sizeof(uint32_t), st)); HIPCHK(hipMemsetAsync(total, 0, sizeof(uint32_t), st)); return; }
     hipLaunchKernelGGL(k_scan_tiles, dim3(unsigned(tiles)), dim3(BS), 0, st, in, out, tile_sums.p, m);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblk(m)), dim3(BS), 0, st, out, tile_sums.p, m, scan_total.p, out_last, zero_in, zero_words, n_zero_words);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, tile_sums.p, tiles, total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblk(m)), dim3(BS), 0, st, out, tile_sums.p, m, total, out_last, zero_in, zero_words, n_zero_words);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -524,7 +535,7 @@ struct Particles : IParticles {
     ++cells_version;
     if (meta_known) { big_n = meta_known[0]; big_mx = meta_known[1]; meta_version = cells_version; }
     if (nphys)
-      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sorted_id.p, sorted_ijk.p);
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid(), sijk());
     order_cells(shuffle);
   }
   // puts every cell segment of sorted_id into the reference's order: ascending id, or ascending (un[id], id)
@@ -533,7 +544,7 @@ struct Particles : IParticles {
     if (npart) {
       rng_src rs{nullptr, 0, 0};
       if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
-      if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
+      if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
       else {
         // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
         // the in-cell shuffle of coalescence re-orders the SAME segments as the sort before it, so the list is kept until cell_start changes
@@ -543,36 +554,39 @@ struct Particles : IParticles {
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
-        if (shuffle && !rs.un && !crowded) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
-        else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
-        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_ijk.p, cell_start.p, sorted_id.p, rank.p, rs, crowded);
+        if (shuffle && !rs.un && !crowded) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
           uint32_t m2[2];
           read_back(m2, big_meta_own_p(), 2);
           big_n = m2[0]; big_mx = m2[1]; meta_version = cells_version;
         }
-        const uint32_t meta[2] = {big_n, big_mx};
-        if (meta[0]) {
-          const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
-          if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
-          else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
-        }
-        if (meta[0] && meta[1] > uint32_t(CELLSORT_WAVE_MAX)) {
-          const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
-          if (shuffle) hipLaunchKernelGGL(k_cellsort_lds<uint64_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
-          else         hipLaunchKernelGGL(k_cellsort_lds<uint32_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, rs);
-        }
-        if (meta[0] && meta[1] > uint32_t(CELLSORT_LDS_MAX)) {
-          size_t P = 1; while (P < meta[1]) P <<= 1;
-          const unsigned nb = std::min<unsigned>(meta[0], 64u);
-          sort_scratch.alloc(P * nb);
-          hipLaunchKernelGGL(k_cellsort_big, dim3(nb), dim3(1024), 0, st, big_list.p, meta[0], cell_start.p, sorted_id.p, int(shuffle), rs,
-                             sort_scratch.p, P);
-        }
+        if (big_n) sort_listed_cells(shuffle, rs);
       }
     }
     sorted = true; sorted_shuffled = shuffle; shuffle_fresh = false;
+  }
+  // the cells too crowded for k_cellrank (big_list, big_n of them, the largest holds big_mx): one wave, one workgroup or global scratch each
+  void sort_listed_cells(bool shuffle, const rng_src &rs)
+  {
+    const uint32_t meta[2] = {big_n, big_mx};
+    const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
+    if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    if (meta[1] > uint32_t(CELLSORT_WAVE_MAX)) {
+      const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
+      if (shuffle) hipLaunchKernelGGL(k_cellsort_lds<uint64_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+      else         hipLaunchKernelGGL(k_cellsort_lds<uint32_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    }
+    if (meta[1] > uint32_t(CELLSORT_LDS_MAX)) {
+      size_t P = 1; while (P < meta[1]) P <<= 1;
+      const unsigned nb = std::min<unsigned>(meta[0], 64u);
+      sort_scratch.alloc(P * nb);
+      hipLaunchKernelGGL(k_cellsort_big, dim3(nb), dim3(1024), 0, st, big_list.p, meta[0], cell_start.p, sid(), int(shuffle), rs,
+                         sort_scratch.p, P);
+    }
   }
   void hskpng_sort_helper(bool shuffle)
   {
@@ -770,10 +784,10 @@ struct Particles : IParticles {
     if (!npart) return;
     Range r(this, "reorder_storage");
     if (!B.n.p) alloc_attrs(B);
-    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, aset(A), aset(B), g, rank.p);
+    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p);
     swap_attr_sets();
     ijk.swap(rank);
-    hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sorted_id.p, npart);
+    hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
     nphys = npart;
   }
   void swap_attr_sets()
@@ -834,7 +848,7 @@ struct Particles : IParticles {
     }
     if (npart) {
       Range r(this, "cond");
-      cond_args<T> a{sorted_id.p, sorted_ijk.p, A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
+      cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
@@ -893,7 +907,7 @@ struct Particles : IParticles {
   {
     if (!npart) return;
     pp_args<T> a{};
-    a.sorted_id = sorted_id.p; a.sorted_ijk = sorted_ijk.p;
+    a.sorted_id = sid(); a.sorted_ijk = sijk();
     a.n = A.n.p; a.rd3 = A.rd3.p; a.kpa = A.kpa.p; a.vt = A.vt.p; a.rw2 = A.rw2.p;
     a.pp_rv = A.ext[ix_rv].p; a.pp_th = A.ext[ix_th].p; a.pp_rh = A.ext[ix_rh].p; a.pp_p = o.const_p ? A.ext[ix_p].p : nullptr;
     a.rv = rv.p; a.th = th.p; a.rhod = rhod.p; a.p = p.p;
@@ -933,7 +947,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, dv.p, rhod.p, 0, pp_dst_rv.p);
       hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p, 0, pp_dst_th.p);
     }
-    hipLaunchKernelGGL(k_pp_mix_finish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, A.ext[ix_rv].p, A.ext[ix_th].p,
+    hipLaunchKernelGGL(k_pp_mix_finish<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sid(), A.ext[ix_rv].p, A.ext[ix_th].p,
                        pp_dst_rv.p, pp_dst_th.p, rv.p, th.p);
   }
   bool turb_adve_now = false;
@@ -994,7 +1008,7 @@ struct Particles : IParticles {
     // diss == nullptr stands for the reference's constant-zero dissipation rate when opts.turb_coal is off (coal.ipp:392-403,439-451)
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p, eta.p, rhod.p, turb_coal ? diss_rate.p : nullptr};
     auto launch = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, A.n.p, A.rw2.p, A.vt.p,
+      hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sid(), sijk(), cell_start.p, A.n.p, A.rw2.p, A.vt.p,
                          A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
                          ix_ict >= 0 ? A.ext[ix_ict].p : nullptr, coal_marks_dead ? ijk.p : nullptr);
     };
@@ -1003,7 +1017,7 @@ struct Particles : IParticles {
     else if (tabulated && !pure_const_multi && !rs.arr && !use_rc2 && ix_ict < 0 && coal_marks_dead) launch(k_coal<T, false, true>);
     else launch(k_coal<T, false>);
     if (o.n_dry_distros + n_size_keys > 1)
-      hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, col.p, A.kpa.p, A.rd3.p);
+      hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), col.p, A.kpa.p, A.rd3.p);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1571,7 +1585,7 @@ struct Particles : IParticles {
     if (!selected_before_counting) throw lcx_error("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
     hskpng_sort();
     if (npart)
-      hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, n_filtered.p, vec, vec2, power, kind, m3_after.p);
+      hipLaunchKernelGGL(k_mom_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), n_filtered.p, vec, vec2, power, kind, m3_after.p);
     hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p,
                        int(specific && n_dims > 0), count_mom.p);
     sync();
@@ -1590,7 +1604,7 @@ struct Particles : IParticles {
     if (!selected_before_counting) throw lcx_error("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
     hskpng_sort();
     if (npart)
-      hipLaunchKernelGGL(k_massdens_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sorted_id.p, sorted_ijk.p, cell_start.p, n_filtered.p, A.rw2.p,
+      hipLaunchKernelGGL(k_massdens_vals<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), cell_start.p, n_filtered.p, A.rw2.p,
                          T(rad), T(sig0), m3_after.p);
     hipLaunchKernelGGL(k_cell_seqsum<T>, dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_after.p, dv.p, rhod.p, 0, count_mom.p);
     hipLaunchKernelGGL(k_massdens_scale<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, dv.p,
@@ -1607,7 +1621,7 @@ struct Particles : IParticles {
   void diag_max_rw() override
   {
     hskpng_sort();
-    hipLaunchKernelGGL(k_cell_max<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sorted_id.p, A.rw2.p, count_mom.p);
+    hipLaunchKernelGGL(k_cell_max<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, sid(), A.rw2.p, count_mom.p);
     sync();
   }
   void outbuf(const void **data, size_t *n) override
@@ -1654,9 +1668,9 @@ struct Particles : IParticles {
       hskpng_sort();
       if (sorted_shuffled && shuffle_fresh) order_cells(false);   // (production order: post_copy has pre-shuffled for the next coalescence;
                                                                   //  the getter shows the reference's state at this point, ids ascending inside a cell)
-      auto h = d2h(sorted_id.p, npart); v.assign(h.begin(), h.end());
+      auto h = d2h(sid(), npart); v.assign(h.begin(), h.end());
     }
-    else if (s == "sorted_ijk") { hskpng_sort(); auto h = d2h(sorted_ijk.p, npart); v.assign(h.begin(), h.end()); }
+    else if (s == "sorted_ijk") { hskpng_sort(); auto h = d2h(sijk(), npart); v.assign(h.begin(), h.end()); }
     else if (s == "cell_start") { hskpng_sort(); auto h = d2h(cell_start.p, ncell + 1); v.assign(h.begin(), h.end()); }
     else if (s == "count_ijk" || s == "count_num") {
       hskpng_sort();
@@ -1843,29 +1857,115 @@ struct Particles : IParticles {
     if (with_outbox) for (auto &b : outbox) { b.alloc(exch_bytes(inbox_cap_rec)); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
     xcnt.alloc_zero(24, st);
     if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
+    // headroom in front of the sorted order (see sort_base): as many entries as a message can bring.  `rank` and `ijk` trade places
+    // with the sorted arrays now and then (order_cells, reorder_storage), so all of them get it; nothing is stored in them yet
+    sort_headroom = inbox_cap_rec;
+    for (DevBuf<uint32_t> *b : {&ijk, &sorted_id, &sorted_ijk, &rank, &sorted_alt}) { b->release(); b->alloc(cap + sort_headroom); }
     sync();
+  }
+  // x-planes at either end of the slab that an immigrant can reach (a Courant number of 1; pred_corr: 2)
+  int bnd_planes() const { return halo ? halo : 1; }
+  size_t plane_cells() const { return ncell / size_t(std::max(o.nx, 1)); }
+  const bool no_overlap = getenv("LCX_NO_OVERLAP") != nullptr;      // measurement / test switch: the exchange without the overlapped re-sort
+  // the overlapped re-sort needs the fused move's histogram, an interior, and the production rules for the storage order are not in
+  // its way: a slab so thin that every plane is a boundary plane, rcyc and the unfused paths take the plain sequence
+  bool overlap_possible() const
+  { return dev_exchange && !no_overlap && fused_pending && n_dims > 0 && o.nx > 2 * bnd_planes() && sort_headroom > 0 && nphys > 0; }
+  // ---- phase A of the overlapped re-sort: everything that does not depend on the neighbours, queued behind the pack kernel while
+  // their messages travel: the stayers' scan, scatter and in-cell ranking of the interior cells [c_lo, c_hi).
+  bool overlap_active = false, overlap_preshuffle = false; rng_src overlap_rs{nullptr, 0, 0}; uint32_t ov_c_lo = 0, ov_c_hi = 0;
+  void exch_sort_interior()
+  {
+    overlap_active = false;
+    if (!overlap_possible()) return;
+    Range r(this, "exchange_sort_interior");
+    overlap_active = true;
+    ov_c_lo = uint32_t(size_t(bnd_planes()) * plane_cells()); ov_c_hi = uint32_t(ncell - size_t(bnd_planes()) * plane_cells());
+    // (the storage re-ordering wants the plain order: its period is known ahead; a compaction that turns out to be due is not -- rare,
+    // exch_finish re-ranks then)
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    const bool reorder_sched = !strict_order() && steps_since_reorder + 1 >= every_;
+    overlap_preshuffle = !strict_order() && !o.strict_fp && last_async_coal && o.coal_switch && !reorder_sched;
+    // crowded interior cells from the stayers' histogram, which is final there (big_meta was cleared behind the previous sort)
+    hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ov_c_hi - ov_c_lo)), dim3(BS), 0, st, size_t(ov_c_hi), (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p,
+                       big_meta_p(), big_meta_p() + 1, (const uint32_t *)cell_cnt.p, ov_c_lo);
+    listed_from_hist = true;
+    // stayers' CSR offsets; the histogram stays (the immigrants are added to it, their ranks continue behind the stayers), and so do the
+    // step's counters
+    exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, nullptr, nullptr, 0, scan_total.p + 3);      // (scan_total[0..1]: the emigrant counts)
+    ++cells_version;
+    uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
+    hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
+                       sort_part{ov_c_lo, ov_c_hi, 1, nullptr, nullptr});
+    overlap_rs = rng_src{nullptr, 0, 0};
+    if (overlap_preshuffle) overlap_rs = rand_un(nphys);
+    launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{cell_start.p + ov_c_lo, cell_start.p + ov_c_hi, nullptr}, nblk(nphys));
+  }
+  size_t bnd_pop_hint = 0;
+  void rank_boundary(unsigned blocks)
+  {
+    uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
+    const uint32_t *shift = xcnt.p + 17;
+    launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{xcnt.p + 19 /* = 0 */, cell_start.p + ov_c_lo, shift}, blocks);
+    launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{cell_start.p + ov_c_hi, cell_start.p + ncell, shift}, blocks);
+  }
+  void launch_cellrank_range(bool shuffle, const rng_src &rs, const uint32_t *sijk_p, const uint32_t *in, uint32_t *out, const rank_range &rg, unsigned blocks)
+  {
+    const int crowded = 0;       // (cells above CELLRANK_MAX keep their arrival order here and are sorted from the list, as everywhere)
+    if (shuffle && !rs.un) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
+    else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
+    else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
   }
   // emigrants of both faces -> the neighbours' inboxes (pointers this device can write: peer-mapped, inboxes on this very device, or
   // this slab's own outboxes; nullptr: no neighbour behind that face), their multiplicities cleared in the same launch.
   // cap_l / cap_r: the capacity of the inbox behind each pointer; next_l / next_r: header word 2 (see k_pack_dev)
+  const unsigned test_pack_delay_us = getenv("LCX_TEST_PACK_DELAY_US") ? unsigned(atoi(getenv("LCX_TEST_PACK_DELAY_US"))) : 0u;
   void exch_pack(uint8_t *dst_l, double lft_x1, size_t cap_l, uint8_t *dst_r, double rgt_x0, size_t cap_r, uint32_t next_l = 0, uint32_t next_r = 0)
   {
+    // test / measurement: the slabs with an odd first plane are late with their messages by so many microseconds
+    if (test_pack_delay_us && ((o.n_x_bfr / std::max(o.nx, 1)) & 1)) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, st, test_pack_delay_us);
     const unsigned half = nblk(std::max(cap_l, cap_r));
     hipLaunchKernelGGL(k_pack_dev<T>, dim3(2 * half), dim3(BS), 0, st, scan_total.p, half,
                        pack_side<T>{mig_ids[0].p, dst_l, T(lft_x1), T(o.x0), uint32_t(cap_l), next_l},
                        pack_side<T>{mig_ids[1].p, dst_r, T(rgt_x0), T(o.x1), uint32_t(cap_r), next_r}, aset(A), g);
   }
   // have_l / have_r: records of each message that have arrived (all of it unless the transport ships in two parts)
-  void exch_unpack(bool from_l, bool from_r, uint32_t have_l = ~0u, uint32_t have_r = ~0u)
+  // With the overlapped re-sort (phase B): the immigrants' ranks continue behind the stayers of their cells, the boundary planes'
+  // offsets are redone, the interior's shifted, boundary SDs scattered and ranked -- all queued, nothing known to the host yet.
+  void exch_unpack(bool from_l, bool from_r, uint32_t have_l = ~0u, uint32_t have_r = ~0u, bool retry = false)
   {
     Range r(this, "exchange_unpack");
-    HIPCHK(hipMemsetAsync(xcnt.p + 16, 0, 2 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr, have_l, have_r,
-                       nphys, cap, aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, strict_order() ? (const uint32_t *)nullptr : scan_total.p,
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, (const uint32_t *)nullptr, 0u, 0u);
-    if (fused_pending) list_big_from_hist();            // the histogram is complete now: crowded cells for order_cells, same read-back
-    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, step_cnt.p, scan_total.p, from_l ? inbox[0].p : nullptr, from_r ? inbox[1].p : nullptr,
-                       xcnt.p + 16, (const uint32_t *)nullptr, xcnt.p);
+    HIPCHK(hipMemsetAsync(xcnt.p + 16, 0, 6 * sizeof(uint32_t), st));      // flags, shift, extent, the constant 0, -, boundary population
+    const bool ov = overlap_active;
+    if (retry && fused_pending && !ov) HIPCHK(hipMemsetAsync(big_meta_p(), 0, 2 * sizeof(uint32_t), st));   // (the first attempt listed the crowded cells already)
+    const uint8_t *in_l = from_l ? inbox[0].p : nullptr, *in_r = from_r ? inbox[1].p : nullptr;
+    const uint32_t *n_free = strict_order() ? (const uint32_t *)nullptr : scan_total.p;
+    // the boundary ranking's grid: sized from the last step's boundary populations (twice that and half a message), the whole extent
+    // when there is no history; a step that outgrows it says so (flag 16) and the host ranks the boundary again
+    const size_t ext_max = std::min(cap, nphys + 2 * inbox_cap_rec);
+    const unsigned bnd_blocks = ov ? nblk(bnd_pop_hint ? std::min(ext_max, 2 * bnd_pop_hint + inbox_cap_rec / 2) : ext_max) : 0u;
+    // (second call of the step: the first one's scan has cleared the histogram -- the stayers' counts come back from its offsets)
+    if (ov && retry) hipLaunchKernelGGL(k_csr_to_counts, dim3(nblk(ncell)), dim3(BS), 0, st, cell_start.p, cell_cnt.p, ncell);
+    hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, in_l, in_r, have_l, have_r,
+                       nphys, cap, aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, n_free,
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, int(ov), ov_c_lo, ov_c_hi, big_meta_p(), xcnt.p + 22, int(retry));
+    if (ov) {
+      const uint32_t *shift = xcnt.p + 17, *extent = xcnt.p + 18;
+      // crowded boundary cells from the completed histogram, then the final offsets of every cell (the histogram is cleared behind them)
+      hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ov_c_lo)), dim3(BS), 0, st, size_t(ov_c_lo), (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p,
+                         big_meta_p(), big_meta_p() + 1, (const uint32_t *)cell_cnt.p, 0u);
+      hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell - ov_c_hi)), dim3(BS), 0, st, ncell, (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p,
+                         big_meta_p(), big_meta_p() + 1, (const uint32_t *)cell_cnt.p, ov_c_hi);
+      exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, cell_cnt.p, nullptr, 0, scan_total.p + 3);
+      uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom;
+      hipLaunchKernelGGL(k_scatter_outside4, dim3(nblk((ext_max + 3) / 4)), dim3(BS), 0, st, ext_max, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
+                         sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
+      rank_boundary(bnd_blocks);
+    }
+    else if (fused_pending) list_big_from_hist();       // the histogram is complete now: crowded cells for order_cells, same read-back
+    hipLaunchKernelGGL(k_collect_counts, dim3(1), dim3(64), 0, st, step_cnt.p, scan_total.p, in_l, in_r,
+                       xcnt.p + 16, ov ? (const uint32_t *)(xcnt.p + 17) : (const uint32_t *)nullptr, xcnt.p, ov ? step_cnt.p : (uint32_t *)nullptr,
+                       ov ? (const uint32_t *)(cell_start.p + ov_c_lo) : (const uint32_t *)nullptr, cell_start.p + ov_c_hi, cell_start.p + ncell, bnd_blocks * unsigned(BS));
   }
   size_t exch_moved = 0;       // super-droplets this slab has sent so far (bench / diagnostics)
   // returns false when a message had not arrived in full (nothing was unpacked: ship the rest, call exch_unpack and this again)
@@ -1873,21 +1973,52 @@ struct Particles : IParticles {
   {
     uint32_t *h = exch_rec_h;
     read_back(h, xcnt.p, 12);                           // the step's one host synchronisation
+    // (overlapped re-sort: the boundary pass has run without the immigrants of the incomplete message -- offsets with a shift of zero,
+    // boundary SDs scattered and ranked among themselves; the second call redoes exactly that pass with them, nothing else is lost)
     if (h[5] & 4u) return false;
     if (h[5] & 1u) throw lcx_error("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (" +
                                     std::to_string(inbox_cap_rec) + " records); raise opts_init.n_sd_max");
     if (h[5] & 2u) throw lcx_error("n_sd_max (" + std::to_string(o.n_sd_max) + ") < n_part after the neighbour exchange");
+    if (h[5] & 8u) throw lcx_error("libcloudph++: an immigrant landed beyond the boundary planes of its slab (Courant number above the scheme's limit?)");
     const size_t n_in = size_t(h[3]) + h[4], n_free = strict_order() ? 0 : size_t(h[1]) + h[2], reuse = std::min(n_in, n_free);
     exch_moved += size_t(h[1]) + h[2];
     nphys += n_in - reuse;
     lft_count = rgt_count = 0; free_n[0] = free_n[1] = 0; free_used = 0; reused_total = 0;
-    if (fused_pending) {
+    if (fused_pending && overlap_active) {
+      if (h[5] & 16u) rank_boundary(nblk(std::min(cap, nphys + 2 * inbox_cap_rec)));      // (this step's boundary planes outgrew the planned grid)
+      bnd_pop_hint = h[11];
+      fused_pending = false; overlap_active = false;
+      finish_overlapped(opts, long(h[0]) - long(reuse), h[8], h[6], h[7]);
+    }
+    else if (fused_pending) {
       fused_pending = false;
       meta_known_valid = listed_from_hist; meta_known_v[0] = h[6]; meta_known_v[1] = h[7];
       post_copy_after_fused_move(opts, long(h[0]) - long(reuse));
     }
     else post_copy(opts);
     return true;
+  }
+  // phase C of the overlapped re-sort: the order is in place (interior ranked before the messages arrived, boundary planes behind
+  // them); the host learns the counts, sorts the crowded cells from their list and applies the storage rules of post_copy_after_fused_move
+  void finish_overlapped(const lcx_opts_t &opts, long dead_l, uint32_t shift, uint32_t n_big, uint32_t max_big)
+  {
+    const size_t dead = size_t(std::max(0l, dead_l));
+    listed_from_hist = meta_known_valid = false;
+    sorted_id.swap(sorted_alt);
+    sort_base = sort_headroom - shift;
+    npart = nphys - dead;
+    big_n = n_big; big_mx = max_big; meta_version = cells_version;
+    sorted = true; sorted_shuffled = overlap_preshuffle; shuffle_fresh = overlap_preshuffle;
+    const bool strict = strict_order();
+    const bool compact_now = dead && (eager_compact || dead * 32 > nphys);
+    if (compact_now && strict) { post_copy(opts, true); return; }
+    Range r(this, "post_copy");
+    if (big_n) sort_listed_cells(overlap_preshuffle, overlap_rs);
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    if (compact_now || (!strict && ++steps_since_reorder >= every_)) {
+      if (sorted_shuffled) { order_cells(false); shuffle_fresh = false; }      // (a compaction that was not foreseen: the re-ordering wants ascending ids)
+      reorder_storage();
+    }
   }
 
   // ---- lcx_exch_*: the device-driven exchange with a copying transport between processes (RCCL / host-staged, libcloudphxx_amd/multi.py)
@@ -1908,11 +2039,14 @@ struct Particles : IParticles {
       exch_pack(has_l ? outbox[0].p : nullptr, lft_x1, inbox_cap_rec, has_r ? outbox[1].p : nullptr, rgt_x0, inbox_cap_rec, next_l, next_r); }
     puddle_reduce_deferred();
   }
-  void x_unpack(bool from_l, bool from_r, unsigned have_l, unsigned have_r) override { need_exch(); exch_unpack(from_l, from_r, have_l, have_r); }
+  int x_unpack_calls = 0;             // within the current step (the second call is the retry with the whole messages)
+  void x_unpack(bool from_l, bool from_r, unsigned have_l, unsigned have_r) override { need_exch(); exch_unpack(from_l, from_r, have_l, have_r, x_unpack_calls++ > 0); }
+  void x_sort_interior() override { need_exch(); exch_sort_interior(); }
   bool x_finish(const lcx_opts_t &opts, unsigned *rec) override
   {
     need_exch();
     const bool done = exch_finish(opts);
+    if (done) x_unpack_calls = 0;
     for (int k = 0; k < 12; ++k) rec[k] = exch_rec_h[k];
     return done;
   }
@@ -2088,6 +2222,7 @@ int lcx_exch_buffers(lcx_particles *h, void *ptrs[4]) { LCX_TRY(H->x_buffers(ptr
 size_t lcx_exch_message_bytes(lcx_particles *h, size_t n_rec) { try { DevGuard dev_guard_; return H->x_message_bytes(n_rec); } catch (const std::exception &e) { g_err = e.what(); return 0; } }
 int lcx_exch_pack(lcx_particles *h, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_cap_lft, unsigned next_cap_rgt)
 { LCX_TRY(H->x_pack(has_lft != 0, lft_x1, has_rgt != 0, rgt_x0, next_cap_lft, next_cap_rgt)) }
+int lcx_exch_sort_interior(lcx_particles *h) { LCX_TRY(H->x_sort_interior()) }
 int lcx_exch_unpack(lcx_particles *h, int from_lft, int from_rgt, unsigned have_lft, unsigned have_rgt) { LCX_TRY(H->x_unpack(from_lft != 0, from_rgt != 0, have_lft, have_rgt)) }
 int lcx_exch_finish(lcx_particles *h, const lcx_opts_t *o, unsigned rec[12], int *complete) { LCX_TRY(*complete = H->x_finish(*o, rec) ? 1 : 0) }
 int lcx_stream(lcx_particles *h, void **hip_stream) { LCX_TRY(*hip_stream = H->stream()) }

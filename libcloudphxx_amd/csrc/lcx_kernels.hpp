@@ -317,15 +317,45 @@ k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const 
 }
 // (measured: several super-droplets per lane -- four consecutive ids, or one from each of four chunks -- do not help here, 2.13-2.43
 // against 2.07 ms for the whole re-sort: the pass is bound by its scattered 4-byte stores, not by the latency of its loads)
+// Which part of the order a pass serves.  The overlapped re-sort of a slab with neighbours (lcx_core.hip, exch_*) puts its INTERIOR
+// cells [c_lo, c_hi) in order while the neighbours' messages are still travelling and the boundary planes afterwards; the sorted
+// arrays of such a slab begin `shift` entries BELOW the address the host knows (the left boundary planes' immigrants go in front).
+//   mode 0: every cell;  1: cells in [c_lo, c_hi) only;  2: the others only.
+//   n_dev / shift != nullptr: the extent of the storage / the shift are read from device memory (not known to the host yet)
+struct sort_part { uint32_t c_lo, c_hi; int mode; const uint32_t *n_dev, *shift; };
+__device__ __forceinline__ bool part_has(const sort_part &sp, uint32_t c)
+{ return sp.mode == 0 || ((c >= sp.c_lo && c < sp.c_hi) == (sp.mode == 1)); }
 __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
-                                 uint32_t *sorted_id, uint32_t *sorted_ijk)
+                                 uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp = sort_part{0u, 0u, 0, nullptr, nullptr})
 {
+  if (sp.n_dev) n = *sp.n_dev;
   const size_t i = gid(); if (i >= n) return;
   const uint32_t c = ijk[i];
-  if (c == DEAD_CELL) return;
-  const uint32_t pos = cell_start[c] + rank[i];
-  sorted_id[pos] = uint32_t(i);
-  sorted_ijk[pos] = c;
+  if (c == DEAD_CELL || !part_has(sp, c)) return;
+  const size_t pos = size_t(cell_start[c]) + rank[i] - (sp.shift ? *sp.shift : 0u);      // (shift <= the headroom in front of the arrays)
+  (sorted_id + pos)[0] = uint32_t(i);
+  (sorted_ijk + pos)[0] = c;
+}
+
+// the boundary pass of the overlapped re-sort: only one SD in eight or sixteen has anything to store, the pass is the read of ijk -- four
+// ids per lane with one 16-byte load (37 -> see DESIGN.md us on a 16.7e6-SD slab)
+__global__ void __launch_bounds__(BS)
+k_scatter_outside4(size_t n_max, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start, uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp)
+{
+  const size_t n = sp.n_dev ? size_t(*sp.n_dev) : n_max;
+  const size_t i0 = gid() * 4;
+  if (i0 >= n) return;
+  const uint32_t shift = sp.shift ? *sp.shift : 0u;
+  uint32_t c[4];
+  if (i0 + 4 <= n) { const uint4 v = *reinterpret_cast<const uint4 *>(ijk + i0); c[0] = v.x; c[1] = v.y; c[2] = v.z; c[3] = v.w; }
+  else for (int k = 0; k < 4; ++k) c[k] = i0 + k < n ? ijk[i0 + k] : DEAD_CELL;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (c[k] == DEAD_CELL || (c[k] >= sp.c_lo && c[k] < sp.c_hi)) continue;
+    const size_t pos = size_t(cell_start[c[k]]) + rank[i0 + k] - shift;
+    sorted_id[pos] = uint32_t(i0 + k);
+    sorted_ijk[pos] = c[k];
+  }
 }
 
 // Per-cell ordering.  Reference semantics (hskpng_sort.ipp:15-57): sorted_id = stable_sort_by_key(ijk) of the
@@ -358,15 +388,23 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // Also tried: ranking by buckets as k_cellsort_wave does for crowded cells (bucket = the key's expected rank in its cell, LDS histogram +
 // workgroup scan + in-bucket compares instead of 64 compares per key) -- a third of the instructions but five barriers instead of
 // two: post_copy 2.03 against 2.09 ms on C3, not worth a second kernel.
+// rank_range: the positions [*lo, *hi) of the order this launch serves (both CSR offsets in device memory, i.e. cell boundaries; nullptr:
+// [0, n)), workgroup b taking the 256 positions from *lo + 256 b; shift: see sort_part
+struct rank_range { const uint32_t *lo, *hi, *shift; };
 template <class KEY, bool PROD = false>      // PROD: keys from Philox (no replayed array), no crowded cells expected -- the uniform tests folded away
 __global__ void __launch_bounds__(BS)
-k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded)
+k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded,
+           rank_range rg = rank_range{nullptr, nullptr, nullptr})
 {
   constexpr int shuffle = sizeof(KEY) == 8;
   if (PROD) { r.un = nullptr; crowded = 0; }
   __shared__ KEY lds[cr_cap<KEY>];
   __shared__ uint32_t bounds[2];
-  const size_t p0 = size_t(blockIdx.x) * BS;
+  size_t r_lo = 0;
+  if (rg.lo) { r_lo = *rg.lo; n = *rg.hi; }
+  if (rg.shift) { const uint32_t sh = *rg.shift; in -= sh; out -= sh; sorted_ijk -= sh; }
+  const size_t p0 = r_lo + size_t(blockIdx.x) * BS;
+  if (p0 >= n) return;                                     // (uniform: the grid covers an upper bound of the range)
   const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
   const size_t p = p0 + threadIdx.x;
   const bool active = p < n;
@@ -375,7 +413,7 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   // overhang of the first and last cell (half a cell on average) is then staged without a third dependent load level
   constexpr int SPEC = BS / 2;
   const size_t pe = threadIdx.x < SPEC ? p0 - SPEC + threadIdx.x : p0 + BS + (threadIdx.x - SPEC);      // (wraps below zero: caught by pe < n)
-  const bool have_e = (threadIdx.x < SPEC ? p0 >= size_t(SPEC) - threadIdx.x : true) && pe < n;
+  const bool have_e = (threadIdx.x < SPEC ? p0 >= r_lo + (size_t(SPEC) - threadIdx.x) : true) && pe < n;
   uint32_t id_e = 0;
   if (have_e) id_e = in[pe];
   if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
@@ -393,7 +431,7 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
     if (active) lds[p - lo] = mine;
     if (have_e && pe >= lo && pe < hi) lds[pe - lo] = key_e;
     // what the speculative window does not cover (cells above SPEC super-droplets)
-    if (p0 >= size_t(SPEC))
+    if (p0 >= r_lo + size_t(SPEC))
       for (size_t q = size_t(lo) + threadIdx.x; q < p0 - SPEC; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));  // the first cell's part before the block
     for (size_t q = p0 + BS + SPEC + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));         // the last cell's part behind it
   }
@@ -413,10 +451,11 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
 // the cells with more than `thr` SDs: wave-aggregated append (one atomic per wave of 64 cells, not one per cell -- with
 // 512 SDs in every cell a per-cell atomicAdd on one counter cost more than the sort itself)
 // counts != nullptr: straight from the cell histogram (before the scan: the fused move has just produced it), else from the CSR offsets
+// c_first: the launch covers the cells [c_first, n_cell)
 __global__ void k_list_big_cells(size_t n_cell, const uint32_t *cell_start, uint32_t thr, uint32_t *big_list, uint32_t *big_count, uint32_t *big_max,
-                                 const uint32_t *counts = nullptr)
+                                 const uint32_t *counts = nullptr, uint32_t c_first = 0u)
 {
-  const size_t c = gid();
+  const size_t c = size_t(c_first) + gid();
   uint32_t cnt = 0;
   if (c < n_cell) cnt = counts ? counts[c] : cell_start[c + 1] - cell_start[c];
   const bool big = cnt > thr;
@@ -2246,18 +2285,26 @@ k_pack_dev(const uint32_t *counts, unsigned half, pack_side<T> L, pack_side<T> R
 // immigrants of both inboxes in one launch, the left neighbour's first (the reference unpacks lft, then rgt); slots as in k_unpack.
 // have_l / have_r: how many records of each message have ARRIVED (a transport that ships a message in two parts, see above): a message
 // that is not complete is not touched at all -- flag bit 2 asks the host for the rest and a second call.
-// stay_start != nullptr (the overlapped re-sort, lcx_core.hip exch_*): the immigrant's rank in its cell continues behind the SDs that
-// stayed there, whose number the CSR offsets of the stayers' scan still hold; cells [c_lo, c_hi) are the slab's interior, where no
-// immigrant may land (flag bit 4).
+// ov (the overlapped re-sort, lcx_core.hip exch_*): cells [c_lo, c_hi) are the slab's interior, where no immigrant may land (flag
+// bit 8); flags[1] counts the living immigrants of the left message (the shift of the sorted order), flags[2] = the storage extent
+// behind the unpack, big_count / big_mark: the list of crowded cells is marked (first call) or wound back to the mark (second call).
 template <class T>
 __global__ void __launch_bounds__(BS)
 k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, uint32_t have_l, uint32_t have_r, size_t n_old, size_t cap, attr_set<T> s, grid_t g, T x0, T x1, T tol,
              const uint32_t *free_l, const uint32_t *free_r, const uint32_t *n_free /* [2] on the device, nullptr: no slot re-use */,
-             uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *flags, const uint32_t *stay_start, uint32_t c_lo, uint32_t c_hi)
+             uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *flags, int ov, uint32_t c_lo, uint32_t c_hi,
+             uint32_t *big_count, uint32_t *big_mark, int retry)
 {
   auto hdr_count = [](const uint8_t *b) { const uint32_t *h = reinterpret_cast<const uint32_t *>(b); return b && !h[1] ? h[0] : 0u; };
   const uint32_t cl = hdr_count(inbox_l), cr = hdr_count(inbox_r);
-  if (cl > have_l || cr > have_r) { if (gid() == 0) atomicOr(flags, 4u); return; }      // (uniform over the launch)
+  const bool incomplete = cl > have_l || cr > have_r;
+  if (gid() == 0) {
+    const uint32_t nf = n_free ? n_free[0] + n_free[1] : 0u, n_in = incomplete ? 0u : cl + cr;
+    flags[2] = uint32_t(n_old) + (n_in > nf ? n_in - nf : 0u);
+    if (ov) { if (retry) *big_count = *big_mark; else *big_mark = *big_count; }
+    if (incomplete) atomicOr(flags, 4u);
+  }
+  if (incomplete) return;                              // (uniform over the launch)
   const size_t i = gid();
   bool in = i < size_t(cl) + cr;
   uint32_t c = DEAD_CELL;
@@ -2285,28 +2332,54 @@ k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, uint32_t have_l, ui
   }
   if (cnt) {                                           // every lane of the wave takes part (ballots inside)
     const bool active = in && c != DEAD_CELL;
-    uint32_t r = wave_hist_rank(cnt, c, active);
+    const uint32_t r = wave_hist_rank(cnt, c, active);
     if (active) {
-      if (stay_start) { r += stay_start[c + 1] - stay_start[c]; if (c >= c_lo && c < c_hi) atomicOr(flags, 8u); }
+      if (ov && c >= c_lo && c < c_hi) atomicOr(flags, 8u);
       rank[d] = r;
+    }
+    if (ov) {
+      const unsigned long long bl = __ballot(active && i < cl);
+      if (bl && lane_id() == 0) atomicAdd(flags + 1, uint32_t(__popcll(bl)));
     }
   }
 }
+// ---- the overlapped re-sort's boundary pass (lcx_core.hip, exch_unpack).  The stayers' scan leaves the histogram in place, the unpack adds
+// the immigrants to it (their ranks continue behind the stayers of their cells by themselves) and counts those of the left message: they
+// can only land in the left boundary planes, so their number is by how much every later entry of the sorted order moves -- the host's
+// arrays begin that far below their nominal start instead of anything being moved.  A second scan of the whole histogram (a few
+// microseconds: cells, not super-droplets) then gives the final offsets; boundary SDs are scattered and ranked behind it.
+// (A first version redid the two boundary regions' offsets in ONE workgroup: 59 us of latency for 32k cells against 18 for the whole scan.)
+// rebuilds the histogram from CSR offsets (the second call of a step whose message arrived in two parts: the first one's scan has cleared it)
+__global__ void k_csr_to_counts(const uint32_t *cell_start, uint32_t *cnt, size_t n_cell) { const size_t c = gid(); if (c < n_cell) cnt[c] = cell_start[c + 1] - cell_start[c]; }
+// test / measurement only (LCX_TEST_PACK_DELAY_US): holds a stream for so many microseconds -- a neighbour that is late with its message
+__global__ void k_spin_us(unsigned us) { const unsigned long long t0 = wall_clock64(); while (wall_clock64() - t0 < 100ull * us) __builtin_amdgcn_s_sleep(32); }
+
 // the step's counts in one small record for ONE host read-back: dead, out_l, out_r, in_l, in_r, flags (1 my inbox overflowed at a
 // sender, 2 storage full, 4 a message has not arrived in full yet, 8 an immigrant landed beyond the boundary planes), number of crowded
 // cells and the largest occupancy (order_cells), [8] immigrants that joined the left boundary planes (the overlapped re-sort's shift of
-// the sorted order, exch_*), [9] / [10] the capacity each neighbour will use for its NEXT message (header word 2; RCCL transport)
+// the sorted order, exch_*), [9] / [10] the capacity each neighbour will use for its NEXT message (header word 2; RCCL transport), [11] the
+// population of the fuller pair of boundary planes; flag 16: the boundary ranking's grid was too small for it
 __global__ void k_collect_counts(const uint32_t *step_cnt /* dead, n_big, max_big */, const uint32_t *out_cnt, const uint8_t *inbox_l, const uint8_t *inbox_r,
-                                 const uint32_t *flags, const uint32_t *shift, uint32_t *rec)
+                                 const uint32_t *flags, const uint32_t *shift, uint32_t *rec, uint32_t *clear_step_cnt = nullptr,
+                                 const uint32_t *cs_lo = nullptr, const uint32_t *cs_hi = nullptr, const uint32_t *cs_end = nullptr, uint32_t planned_pos = 0u)
 {
   if (threadIdx.x != 0) return;
   const uint32_t *hl = reinterpret_cast<const uint32_t *>(inbox_l), *hr = reinterpret_cast<const uint32_t *>(inbox_r);
   rec[0] = step_cnt[0]; rec[1] = out_cnt[0]; rec[2] = out_cnt[1]; rec[6] = step_cnt[1]; rec[7] = step_cnt[2];
   rec[3] = hl ? hl[0] : 0u; rec[4] = hr ? hr[0] : 0u;
-  const uint32_t f = *flags;
-  rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | ((f & 1u) ? 2u : 0u) | (f & 4u) | (f & 8u);
+  uint32_t f = *flags;
+  rec[11] = 0u;
+  if (cs_lo) {                                       // the larger boundary population; was the boundary ranking's grid large enough for it?
+    const uint32_t pop_l = *cs_lo, pop_r = *cs_end - *cs_hi, pop = pop_l > pop_r ? pop_l : pop_r;
+    rec[11] = pop;
+    if (pop > planned_pos) f |= 16u;
+  }
+  rec[5] = ((hl && hl[1]) || (hr && hr[1]) ? 1u : 0u) | ((f & 1u) ? 2u : 0u) | (f & 4u) | (f & 8u) | (f & 16u);
   rec[8] = shift ? *shift : 0u;
   rec[9] = hl ? hl[2] : 0u; rec[10] = hr ? hr[2] : 0u;
+  // (the overlapped re-sort's scans leave the step's counters alone -- they are read here -- and have them cleared now, unless a
+  // message is still incomplete and the boundary pass will run again)
+  if (clear_step_cnt && !(f & 4u)) { clear_step_cnt[0] = 0u; clear_step_cnt[1] = 0u; clear_step_cnt[2] = 0u; }
 }
 
 

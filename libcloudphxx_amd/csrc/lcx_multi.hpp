@@ -324,7 +324,10 @@ struct MultiParticles : IParticles {
         }
       }
       HIPCHK(hipEventRecord(ev_sent[i], s.st));
-      s.puddle_reduce_deferred();                 // work that does not depend on the neighbours runs while the messages travel
+      // work that does not depend on the neighbours runs while the messages travel: the precipitation sums, and the re-sort of the
+      // slab's interior (scan, scatter, in-cell ranking of every cell that no immigrant can reach)
+      s.puddle_reduce_deferred();
+      s.exch_sort_interior();
       rendezvous(i);                              // every slab's `sent` event is recorded
       // The host runs ahead of its device (nothing above waits for the GPU): normally the pack kernel has not even started when
       // the threads meet here, i.e. the rendezvous costs the device nothing.  Counted for the record (lcx_timings).

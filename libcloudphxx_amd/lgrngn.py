@@ -623,6 +623,9 @@ class particles_t:
         self._chk(self._f("exch_pack")(self._h, C.c_int(bool(has_lft)), C.c_double(lft_x1), C.c_int(bool(has_rgt)), C.c_double(rgt_x0),
                                        C.c_uint(next_cap_lft), C.c_uint(next_cap_rgt)))
 
+    def exch_sort_interior(self):
+        self._chk(self._f("exch_sort_interior")(self._h))
+
     def exch_unpack(self, from_lft, from_rgt, have_lft=0xFFFFFFFF, have_rgt=0xFFFFFFFF):
         self._chk(self._f("exch_unpack")(self._h, C.c_int(bool(from_lft)), C.c_int(bool(from_rgt)), C.c_uint(have_lft), C.c_uint(have_rgt)))
 

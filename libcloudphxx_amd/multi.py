@@ -14,6 +14,7 @@ Protocol of a step (include/lcx.h, lcx_exch_*; the engine keeps the emigrant lis
 
   step_async                      coalescence ... advection, boundary, re-index of those that stay           (queued)
   exch_pack                       emigrants -> two outboxes, header = {count, overflow, first-part size of the NEXT message}  (queued)
+  exch_sort_interior              (queued once the batch below is under way) scan / scatter / rank of the cells no immigrant can reach
   ONE batch of isend / irecv      the header and the first `cap` records of each message, `cap` agreed one step ahead through the
                                   header (the sender sizes it from its previous counts), so that no count travels ahead of the
                                   payload and the host never waits for one; ordered against the engine's stream, not the host
@@ -199,7 +200,8 @@ class particles_multi_t:
     # ---- transports: one batch of point-to-point operations; segs = [(tensor view to send | None, peer), ...] in the fixed order
     #      send left, send right, receive from right, receive from left (with two ranks both messages travel between the same pair and
     #      are matched in posting order)
-    def _p2p(self, send_l, send_r, recv_r, recv_l):
+    def _p2p(self, send_l, send_r, recv_r, recv_l, between=None):
+        """between: called after the operations have been STARTED and before they are waited for (work that overlaps the transfer)"""
         dist = self.dist
         ops = []
         if send_l is not None:
@@ -210,22 +212,27 @@ class particles_multi_t:
             ops.append(dist.P2POp(dist.irecv, recv_r, self.rgt))
         if recv_l is not None:
             ops.append(dist.P2POp(dist.irecv, recv_l, self.lft))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()                   # (device tensors: the CURRENT STREAM waits, not the host)
+        works = dist.batch_isend_irecv(ops) if ops else []
+        if between is not None:
+            between()
+        for w in works:
+            w.wait()                       # (device tensors: the CURRENT STREAM waits, not the host)
 
-    def _ship(self, ranges):
-        """ranges: [(lo, hi) bytes of outbox-left to send | None, outbox-right | None, inbox-from-right to fill | None, inbox-from-left | None]"""
+    def _ship(self, ranges, between=None):
+        """ranges: [(lo, hi) bytes of outbox-left to send | None, outbox-right | None, inbox-from-right to fill | None, inbox-from-left | None]
+        between: engine work that does not depend on the messages, queued once they are under way"""
         torch = self.torch
         out_l, out_r, in_l, in_r = self.box
         views = lambda t, r: None if r is None else t[r[0]:r[1]]
         if self.transport == "rccl":
             if self.ext_stream is not None:
                 with torch.cuda.stream(self.ext_stream):       # torch's "current stream" = the engine's: RCCL orders itself against it
-                    self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]))
+                    self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]), between)
             else:
-                self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]))
+                self._p2p(views(out_l, ranges[0]), views(out_r, ranges[1]), views(in_r, ranges[2]), views(in_l, ranges[3]), between)
             return
+        if between is not None:
+            between()                      # (host-staged: nothing overlaps, the work is simply done first)
         # host-staged: the engine's queue drains, the used bytes cross the host
         st = self.stage
         if self.on_gpu:
@@ -259,8 +266,9 @@ class particles_multi_t:
         nxt = [self._next_cap(0), self._next_cap(1)]
         p.exch_pack(hl, self.lft_x1, hr, self.rgt_x0, nxt[0], nxt[1])
         sc, rc = self.send_cap, self.recv_cap
+        # the re-sort of the slab's interior needs nothing from the neighbours: queued while the messages travel
         self._ship([self._msg_range(0, sc[0], True) if hl else None, self._msg_range(0, sc[1], True) if hr else None,
-                    self._msg_range(0, rc[1], True) if hr else None, self._msg_range(0, rc[0], True) if hl else None])
+                    self._msg_range(0, rc[1], True) if hr else None, self._msg_range(0, rc[0], True) if hl else None], between=p.exch_sort_interior)
         p.exch_unpack(hl, hr, rc[0], rc[1])
         done, rec = p.exch_finish(opts)
         out, inc = [rec[1], rec[2]], [rec[3], rec[4]]

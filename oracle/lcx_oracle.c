@@ -2121,6 +2121,7 @@ int orc_exch_finish(orc_particles *s, const lcx_opts_t *opts, unsigned rec[12], 
   s->lft_count = s->rgt_count = 0;
   return post_copy(s, opts);
 }
+int orc_exch_sort_interior(orc_particles *s) { (void)s; return 0; }      /* (the product's overlap of the re-sort with the transport: nothing to do here) */
 int orc_stream(orc_particles *s, void **stream) { (void)s; *stream = NULL; return 0; }
 
 /* ---------------- Courant halo exchange of pred_corr (xchng_courants.ipp:15-160) ---------------- */

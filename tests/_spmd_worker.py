@@ -36,6 +36,9 @@ def slab_state(p):
 
 
 def run(mode, rank, world, port, res, transport):
+    if os.environ.get("LCX_SPMD_TRACE"):
+        import faulthandler
+        faulthandler.dump_traceback_later(40, exit=True)
     import torch
     import torch.distributed as dist
     import _harness as h
@@ -75,6 +78,8 @@ def run(mode, rank, world, port, res, transport):
             for step in range(nx):
                 prt.step_sync(opts, th, rv, rhod, Cx, None, Cz)
                 prt.step_async(opts)
+                if os.environ.get("LCX_SPMD_TRACE"):
+                    print("rank", rank, "step", step, "n_part", prt.n_part, "second_rounds", prt.second_rounds, flush=True)
             after = diags()
             np.save(res % rank, np.stack([before, after]))
             ok = np.array_equal(before, after) and prt.n_part == n_before and prt.bytes_moved > 0 and 1 <= prt.second_rounds <= 2

@@ -87,7 +87,7 @@ def test_multi_device_uneven_slabs_at_courant_one(dims, size, cx, monkeypatch):
     capacity for all slabs now (Particles::exch_capacity); against the oracle ring, six steps"""
     nx, ny, nz = dims
     oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False)
-    oi.n_sd_max = 24 * nx * max(ny, 1) * nz * 3
+    oi.n_sd_max = 24 * nx * max(ny, 1) * nz * size          # (every slab gets n_sd_max / size + 1: room for the thick one)
     th, rv, rhod, C = h.box_fields(oi)
     C["Cx"] = cx * np.ones_like(C["Cx"])
     orc, mul, slabs = multi_pair(oi, size, (th, rv, rhod, C), monkeypatch)
@@ -322,3 +322,45 @@ def test_multi_device_without_peer_mapping(monkeypatch):
         mul.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
         mul.step_async(opts)
         compare_slabs(orc, slabs, oi, it, attrs=("x", "y", "z", "rw2"))
+
+
+def _run_skewed(monkeypatch, overlap, delay_us, steps=12):
+    import bench
+    if overlap:
+        monkeypatch.delenv("LCX_NO_OVERLAP", raising=False)
+    else:
+        monkeypatch.setenv("LCX_NO_OVERLAP", "1")
+    monkeypatch.setenv("LCX_TEST_PACK_DELAY_US", str(delay_us))
+    nx, ny, nz, size = 64, 128, 128, 4
+    oi = bench.make_opts_init(nx, ny, nz, 64, 40., 1, 1, 44)
+    oi.n_sd_max = int(oi.n_sd_max * 1.1)
+    th, rv, rhod, Cx, Cy, Cz = bench.make_fields(nx, ny, nz, 0, nx, np, np.float64)
+    mul = make_multi(oi, size, monkeypatch)
+    mul.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
+    opts = lgrngn.opts_t()
+    for _ in range(3):
+        mul.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        mul.step_async(opts)
+    mul.set_profiling(True)
+    for _ in range(steps):
+        mul.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        mul.step_async(opts)
+    t = mul.timings()
+    state = [(s.n_part, s.state_u64("n"), s.get_attr("rw2"), s.get_attr("x")) for s in (mul.slab(r) for r in range(size))]
+    return {k: v / steps for k, v in t.items() if k != "rendezvous_hidden_share"}, state
+
+
+def test_overlapped_resort_hides_a_late_neighbour(monkeypatch):
+    """north_star: the neighbour exchange overlapped with interior work.  Four slabs of 16 x 128 x 128 cells x 64 super-droplets on
+    the one device; every second slab is 300 us late with its messages (a spin kernel ahead of its pack kernel).  Without the overlap a
+    slab's stream sits in `exchange_wait` until the late neighbour's message is there and only then scans, scatters and ranks; with
+    it the interior's re-sort is queued ahead of the wait and fills the gap.  Same droplets either way, bit for bit."""
+    t_ov, s_ov = _run_skewed(monkeypatch, True, 300)
+    t_no, s_no = _run_skewed(monkeypatch, False, 300)
+    for (na, ma, ra, xa), (nb, mb, rb, xb) in zip(s_ov, s_no):
+        assert na == nb and np.array_equal(ma, mb) and np.array_equal(ra, rb) and np.array_equal(xa, xb)
+    print("per step, slowest slab: overlap", {k: round(v, 3) for k, v in t_ov.items() if k.startswith(("exchange", "post_copy"))},
+          "no overlap", {k: round(v, 3) for k, v in t_no.items() if k.startswith(("exchange", "post_copy"))})
+    assert "exchange_sort_interior" in t_ov and "exchange_sort_interior" not in t_no
+    # the time a stream spends blocked on its neighbours shrinks by (most of) the interior work that now runs ahead of the wait
+    assert t_ov["exchange_wait"] < t_no["exchange_wait"] - 0.5 * min(t_ov["exchange_sort_interior"], 0.3)

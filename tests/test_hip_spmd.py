@@ -28,11 +28,27 @@ def free_port():
     return p
 
 
+def wait_all(procs, limit_s):
+    """exit codes of the ranks; a rank that fails (or the time limit) ends the others at once -- they would wait for its messages for ever"""
+    import time
+    t0 = time.time()
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            return codes
+        if any(c not in (None, 0) for c in codes) or time.time() - t0 > limit_s:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            return [p.wait() for p in procs]
+        time.sleep(0.05)
+
+
 def launch(mode, world, res):
     port = free_port()
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_spmd_worker.py"), mode, str(r), str(world), str(port), res, "host"])
              for r in range(world)]
-    codes = [p.wait(timeout=600) for p in procs]
+    codes = wait_all(procs, 240)
     assert codes == [0] * world, codes
 
 

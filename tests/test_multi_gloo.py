@@ -47,7 +47,8 @@ def test_ring_round_trip_is_bit_identical(world, nx, Cx, scheme, sd_conc, tmp_pa
     res = str(tmp_path / "r%d.npy")
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_multi_worker.py"), str(r), str(world), str(port), str(nx), "4", str(Cx), res, scheme, str(sd_conc)])
              for r in range(world)]
-    codes = [p.wait(timeout=300) for p in procs]
+    from test_hip_spmd import wait_all
+    codes = wait_all(procs, 240)
     assert codes == [0] * world, codes
     for r in range(world):
         d = np.load(res % r)
