@@ -1013,6 +1013,12 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 }
 
+// Measured and dropped (round 3): the fold REPEATED between the bracket updates.  Of the droplets that enter the loop 70 % end after one
+// more update, 19 % after two, 10 % after three, so the folded waves run their second and third update at a lane use of 30 and 10 %.  With
+// the loop advanced one update at a time (a state machine with ONE evaluation site, the same operations as toms748_tail: bit-identical
+// results) and the workgroup dealt again whenever that frees a wave (95 droplets -> 2 waves, 28 -> 1): 128 VGPRs + 28 B of scratch, cond on
+// C3 7.6 ms against 6.3 -- the selects that pick the step's abscissa, the run-time trip count of the quadratic step and the spills cost
+// more than the emptier waves did.
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
 // sums each 8th value of the staged segment and a fixed 3-step shuffle tree joins them (deterministic, different rounding)
 template <class T, int G>
