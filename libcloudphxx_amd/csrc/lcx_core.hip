@@ -463,6 +463,7 @@ struct Particles : IParticles {
     }
     return u01_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
   }
+  const bool shuffle_philox = getenv("LCX_SHUFFLE_PHILOX") != nullptr;      // measurement switch: round 2's shuffle keys (Philox, 64-bit ranking)
   rng_src rand_un(size_t n)
   {
     if (!replay.empty()) {
@@ -470,9 +471,15 @@ struct Particles : IParticles {
       if (r.kind != 1 || r.n < n) throw lcx_error("libcloudph++: rng replay queue does not match the requested rand_un call");
       const uint32_t *ptr = r.un->p;
       replay_keep_u.push_back(std::move(r.un));
-      return rng_src{ptr, 0, 0};
+      return rng_src{ptr, 0, 0, 0u, 0u};
     }
-    return rng_src{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
+    // the device generator's shuffle keys: a salted bijection of the ids (lcx_kernels.hpp, rng_src); the two salt words of this call
+    rng_src rs{nullptr, ++rng_call, uint64_t(uint32_t(seed_now())), 0u, 0u};
+    uint32_t w[4];
+    philox::gen(0x756e73616c74ull /* "unsalt" */, rs.call, rs.seed, w);
+    rs.s1 = w[0]; rs.s2 = w[1] | 1u;                 // (never both zero: that selects the switch below)
+    if (shuffle_philox) rs.s1 = rs.s2 = 0u;
+    return rs;
   }
   void release_replay_keep() { if (replay_keep_T.empty() && replay_keep_u.empty()) return; sync(); replay_keep_T.clear(); replay_keep_u.clear(); }
   void rng_replay_push(int kind, const double *data, size_t n) override
@@ -542,7 +549,7 @@ struct Particles : IParticles {
   void order_cells(bool shuffle)
   {
     if (npart) {
-      rng_src rs{nullptr, 0, 0};
+      rng_src rs{nullptr, 0, 0, 0u, 0u};
       if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
       else {
@@ -554,7 +561,7 @@ struct Particles : IParticles {
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
-        if (shuffle && !rs.un && !crowded) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        if (shuffle && !rs.un && !crowded && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
@@ -1873,7 +1880,7 @@ struct Particles : IParticles {
   { return dev_exchange && !no_overlap && fused_pending && n_dims > 0 && o.nx > 2 * bnd_planes() && sort_headroom > 0 && nphys > 0; }
   // ---- phase A of the overlapped re-sort: everything that does not depend on the neighbours, queued behind the pack kernel while
   // their messages travel: the stayers' scan, scatter and in-cell ranking of the interior cells [c_lo, c_hi).
-  bool overlap_active = false, overlap_preshuffle = false; rng_src overlap_rs{nullptr, 0, 0}; uint32_t ov_c_lo = 0, ov_c_hi = 0;
+  bool overlap_active = false, overlap_preshuffle = false; rng_src overlap_rs{nullptr, 0, 0, 0u, 0u}; uint32_t ov_c_lo = 0, ov_c_hi = 0;
   void exch_sort_interior()
   {
     overlap_active = false;
@@ -1897,7 +1904,7 @@ struct Particles : IParticles {
     uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
     hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
                        sort_part{ov_c_lo, ov_c_hi, 1, nullptr, nullptr});
-    overlap_rs = rng_src{nullptr, 0, 0};
+    overlap_rs = rng_src{nullptr, 0, 0, 0u, 0u};
     if (overlap_preshuffle) overlap_rs = rand_un(nphys);
     launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{cell_start.p + ov_c_lo, cell_start.p + ov_c_hi, nullptr}, nblk(nphys));
   }
@@ -1912,7 +1919,7 @@ struct Particles : IParticles {
   void launch_cellrank_range(bool shuffle, const rng_src &rs, const uint32_t *sijk_p, const uint32_t *in, uint32_t *out, const rank_range &rg, unsigned blocks)
   {
     const int crowded = 0;       // (cells above CELLRANK_MAX keep their arrival order here and are sorted from the list, as everywhere)
-    if (shuffle && !rs.un) hipLaunchKernelGGL((k_cellrank<uint64_t, true>), dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
+    if (shuffle && !rs.un && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
     else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
     else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
   }

@@ -370,13 +370,29 @@ constexpr int CELLRANK_MAX = 256;
 template <class KEY> constexpr int cellrank_max = CELLRANK_MAX;
 constexpr int CELLSORT_LDS_MAX = 2048;  // ... in LDS up to this size (k_cellsort_lds), in global scratch beyond (k_cellsort_big)
 template <class KEY> constexpr int cr_cap = 1024;                               // keys staged per workgroup (4 / 8 KiB)
-struct rng_src { const uint32_t *un; uint64_t call, seed; };
+// un == nullptr: the device generator.  The random key of the in-cell shuffle is then un(id) = mix(mix(id ^ s1) + s2) with the 32-bit
+// finaliser of MurmurHash3 for mix -- a BIJECTION of the 32-bit ids, salted per call with two words of Philox(call, seed) that the host
+// draws (rand_un): the keys of a call are all different, so 32 bits order a cell without a tie-break (half the LDS traffic of the
+// ranking, and a dozen integer operations per key instead of Philox's ten rounds: re-sort on C3 2.0 -> see DESIGN.md).  Any function
+// of (id, call, seed) alone is as deterministic as any other; the reference draws un from its generator's stream the same way
+// (hskpng_sort.ipp:38-46, urand.hpp:57-86).
+struct rng_src { const uint32_t *un; uint64_t call, seed; uint32_t s1, s2; };
+LCX_HD uint32_t mix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+LCX_HD uint32_t shuffle_un(uint32_t id, uint32_t s1, uint32_t s2) { return mix32(mix32(id ^ s1) + s2); }
 
 __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng_src &r)
 {
   if (!shuffle) return id;
-  const uint32_t u = r.un ? r.un[id] : philox::un(id, r.call, r.seed);
+  // (s1 == s2 == 0: the measurement switch LCX_SHUFFLE_PHILOX -- keys drawn from Philox as in round 2, 64-bit ranking)
+  const uint32_t u = r.un ? r.un[id] : (r.s1 | r.s2) ? shuffle_un(id, r.s1, r.s2) : philox::un(id, r.call, r.seed);
   return (uint64_t(u) << 32) | id;
+}
+// KEY = uint32_t with shuffle: the device generator's keys alone (unique, see above)
+template <class KEY, bool SHUFFLE> __device__ __forceinline__ KEY rank_key(uint32_t id, const rng_src &r)
+{
+  if constexpr (!SHUFFLE) return KEY(id);
+  else if constexpr (sizeof(KEY) == 4) return KEY(shuffle_un(id, r.s1, r.s2));
+  else return KEY(sort_key(id, 1, r));
 }
 // KEY = uint32_t for the plain order (key == id), uint64_t for the shuffled order ((un << 32) | id).
 // The kernel is bound by the latency of its dependent loads (three quarters of its wave-cycles are waits), so every lane
@@ -391,12 +407,14 @@ __device__ __forceinline__ uint64_t sort_key(uint32_t id, int shuffle, const rng
 // rank_range: the positions [*lo, *hi) of the order this launch serves (both CSR offsets in device memory, i.e. cell boundaries; nullptr:
 // [0, n)), workgroup b taking the 256 positions from *lo + 256 b; shift: see sort_part
 struct rank_range { const uint32_t *lo, *hi, *shift; };
-template <class KEY, bool PROD = false>      // PROD: keys from Philox (no replayed array), no crowded cells expected -- the uniform tests folded away
+// PROD: keys from the device generator (no replayed array), no crowded cells expected -- the uniform tests folded away; with KEY =
+// uint32_t it is the SHUFFLED order on 32-bit keys (rank_key)
+template <class KEY, bool PROD = false>
 __global__ void __launch_bounds__(BS)
 k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r, int crowded,
            rank_range rg = rank_range{nullptr, nullptr, nullptr})
 {
-  constexpr int shuffle = sizeof(KEY) == 8;
+  constexpr bool shuffle = sizeof(KEY) == 8 || PROD;
   if (PROD) { r.un = nullptr; crowded = 0; }
   __shared__ KEY lds[cr_cap<KEY>];
   __shared__ uint32_t bounds[2];
@@ -420,8 +438,8 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   // a workgroup that sees only crowded cells (every cell of C5) has nothing to rank: the listed-cell sorts take the ids as they are.
   // `crowded`: the host's guess from the mean SDs per cell -- the vote is a barrier behind the loads, 0.15 ms on C3 where it never hits
   if (crowded && __syncthreads_and(!active || (e - s) > uint32_t(cellrank_max<KEY>))) { if (active) out[p] = id; return; }
-  const KEY mine = active ? KEY(sort_key(id, shuffle, r)) : KEY(0);
-  const KEY key_e = have_e ? KEY(sort_key(id_e, shuffle, r)) : KEY(0);
+  const KEY mine = active ? rank_key<KEY, shuffle>(id, r) : KEY(0);
+  const KEY key_e = have_e ? rank_key<KEY, shuffle>(id_e, r) : KEY(0);
   if (threadIdx.x == 0) bounds[0] = s;
   if (p == plast) bounds[1] = e;
   __syncthreads();
@@ -432,8 +450,8 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
     if (have_e && pe >= lo && pe < hi) lds[pe - lo] = key_e;
     // what the speculative window does not cover (cells above SPEC super-droplets)
     if (p0 >= r_lo + size_t(SPEC))
-      for (size_t q = size_t(lo) + threadIdx.x; q < p0 - SPEC; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));  // the first cell's part before the block
-    for (size_t q = p0 + BS + SPEC + threadIdx.x; q < hi; q += BS) lds[q - lo] = KEY(sort_key(in[q], shuffle, r));         // the last cell's part behind it
+      for (size_t q = size_t(lo) + threadIdx.x; q < p0 - SPEC; q += BS) lds[q - lo] = rank_key<KEY, shuffle>(in[q], r);  // the first cell's part before the block
+    for (size_t q = p0 + BS + SPEC + threadIdx.x; q < hi; q += BS) lds[q - lo] = rank_key<KEY, shuffle>(in[q], r);         // the last cell's part behind it
   }
   __syncthreads();
   if (!active) return;
@@ -444,7 +462,7 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
     const KEY *seg = lds + (s - lo);
     for (uint32_t q = 0; q < cnt; ++q) rank += seg[q] < mine;
   } else {
-    for (uint32_t q = s; q < e; ++q) rank += KEY(sort_key(in[q], shuffle, r)) < mine;
+    for (uint32_t q = s; q < e; ++q) rank += rank_key<KEY, shuffle>(in[q], r) < mine;
   }
   out[s + rank] = id;
 }
