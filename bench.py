@@ -393,6 +393,11 @@ def main():
                         src = "profiles/" + os.path.basename(tf)
                         roof["traffic"] = t["hbm_bytes"]
                         roof["traffic_source"] = src
+                        if "hbm_bytes_low" in t:
+                            # FETCH_SIZE counts requests, not bytes: 128-B requests (coalesced reads) and 64-B ones (sparse gathers) look
+                            # alike.  `traffic` prices every read request at 128 B (an upper bound), `traffic_low` at 64 B (a lower one);
+                            # calibration: profiles/r03_traffic_calibration.json
+                            roof["traffic_low"] = t["hbm_bytes_low"]
                         if "valu_insts" in t:
                             # the second roof: fp64 vector arithmetic.  78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 x 2.4 GHz.
                             # A wave64 fp64 instruction occupies its SIMD for 4 cycles, any other VALU instruction for 2

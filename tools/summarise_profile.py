@@ -41,11 +41,16 @@ for k, v in sorted(agg.items()):
     line = {c: "%.4g" % (sum(x[-2:]) / len(x[-2:])) for c, x in sorted(v.items())}      # last two launches = timed steps
     print("%-48s n=%-4d %s" % (k, n, line))
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        # MI355X_MICROARCH.md: counters are in KiB; FETCH_SIZE under-reports by 2x on gfx950 (calibrated with the
-        # streaming k_move kernel whose reads are known exactly); WRITE_SIZE needs no correction
-        rd = sum(v["FETCH_SIZE"][-2:]) / len(v["FETCH_SIZE"][-2:]) * 1024 * 2
+        # MI355X_MICROARCH.md: counters are in KiB.  FETCH_SIZE tallies every read request of the L2 at 64 B.  Calibration on known-byte
+        # patterns (tools/traffic_calib.hip, profiles/r03_traffic_calibration.json): coalesced reads of 4, 8 and 16 B per lane go out as
+        # 128-B requests (the counter shows exactly half the bytes); a sparse 8-byte gather goes out as one request per element whose
+        # size the counters do not tell (64-B sectors by the time it takes: 128 B each would be 6.9 TB/s of random reads).  A kernel
+        # that mixes both -- k_cond's index stream + attribute gathers -- lies between: read_bytes_low = every request a 64-B one,
+        # read_bytes = every request a 128-B one (what rounds 1-2 reported).  WRITE_SIZE needs no correction.
+        raw = sum(v["FETCH_SIZE"][-2:]) / len(v["FETCH_SIZE"][-2:]) * 1024
+        rd = raw * 2
         wr = sum(v["WRITE_SIZE"][-2:]) / len(v["WRITE_SIZE"][-2:]) * 1024
-        traffic[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr}
+        traffic[k] = {"read_bytes": rd, "read_bytes_low": raw, "write_bytes": wr, "hbm_bytes": rd + wr, "hbm_bytes_low": raw + wr}
         if "SQ_INSTS_VALU" in v:      # wave-level vector instructions per launch (fp64 vector utilisation of the cond kernel)
             traffic[k]["valu_insts"] = sum(v["SQ_INSTS_VALU"][-2:]) / len(v["SQ_INSTS_VALU"][-2:])
             traffic[k]["valu_f64_insts"] = sum(sum(v[c][-2:]) / len(v[c][-2:]) for c in
