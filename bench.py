@@ -163,6 +163,10 @@ def main():
                          "many steps (0 = the library default, every 64 steps -- 32 for slabs with neighbours -- and with every compaction; -1 = never, the reference's "
                          "storage order)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strict-leg", action="store_true",
+                    help="skip the second, short measurement with opts_init.strict_fp = 1 (the API's default arithmetic: IEEE operation "
+                         "order, what a caller who changes nothing gets), reported as `strict_fp` next to the headline figure")
+    ap.add_argument("--strict-leg-steps", type=int, default=20)
     ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--cpu-sample-steps", type=int, default=6)
     ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
@@ -468,6 +472,37 @@ def main():
             "stage_ms_per_step": {k: (v / args.steps if k != "rendezvous_hidden_share" else v) for k, v in stage_ms.items()},
             "stage_roofline": stage_roof,
         }
+        if world_out == 1 and not args.strict_fp and not args.no_strict_leg and args.cond_mode == "percell":
+            # the API default (opts_init.strict_fp = 1; both host mirrors): the same box, the same steps, IEEE operation order in the
+            # condensation kernel and the reference's ordered per-cell sums -- what a driver that changes nothing gets
+            del prt
+            torch.cuda.synchronize()
+            oi.strict_fp = True
+            prt_s = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
+            prt_s.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
+            for _ in range(3):
+                prt_s.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+                prt_s.step_async(opts)
+            prt_s.set_profiling(True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done_s = 0
+            for _ in range(args.strict_leg_steps):
+                prt_s.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+                prt_s.step_async(opts)
+                done_s += prt_s.n_part
+            torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t0
+            st_s = prt_s.timings()
+            cond_ms = st_s.get("cond", 0.) / max(args.strict_leg_steps * args.sstp_cond, 1)
+            ach_s = cond_bytes_per_sd * (done_s / args.strict_leg_steps) / (cond_ms * 1e-3) / 1e9 if cond_ms else None
+            out["strict_fp"] = {"value": done_s / dt_s, "unit": "super-droplets/s", "ms_per_step": dt_s / args.strict_leg_steps * 1e3, "steps": args.strict_leg_steps,
+                                "fp_mode": "strict IEEE order (opts_init.strict_fp = 1, the API default)",
+                                "roofline": {"bound": "hbm", "kernel": "k_cond", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": ach_s / HBM_PEAK_GBS if ach_s else None, "avg_launch_ms": cond_ms,
+                                             "algorithmic_bytes_per_sd": cond_bytes_per_sd},
+                                "stage_ms_per_step": {k: v / args.strict_leg_steps for k, v in st_s.items()}}
+            del prt_s
         if world_out == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -860,7 +860,14 @@ struct Particles : IParticles {
                      xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
-      if (fast) {
+      // fast arithmetic: the lean bracketed secant (k_cond_lean); LCX_COND_TOMS=1 keeps round 2's kernels -- TOMS748 iterates in fast
+      // arithmetic, iteration budget + straggler launch, fold -- for measurements and for the tests of that machinery
+      const bool cond_toms = getenv("LCX_COND_TOMS") != nullptr;
+      if (fast && !cond_toms) {
+        a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
+        hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);
+      }
+      else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         // two passes: a short iteration budget first, the droplets that need more in a dense second launch (k_cond_fast)
         // The second launch costs what its slowest wave costs (~60 us) however few droplets it holds, and the first pass saves ~2.3 us

@@ -949,6 +949,28 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
   }
 }
 
+// Fast arithmetic's production kernel since round 3: the growth rate of k_cond_fast under the lean bracketed secant of lcx_math.hpp
+// (advance_rw2_lean_with) instead of TOMS748 -- no iteration budget, no second launch, no fold: the iteration counts are short and even.
+template <class T, int OPT = 3>
+__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
+{
+  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
+  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  T rw2_old = a.rw2[id], rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
+  T nn = T(a.n[id]);
+  cond_cell_fast<T> cc = a.pre[c];
+  asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+  T r = rw2_old;
+  if (rw2_old > 0) {
+    cond_fun_fast<T, OPT> ff;
+    ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+    r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    a.rw2[id] = r;
+  }
+  a.m3_after[pos] = nn * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+}
+
 // The first pass with the workgroup FOLDED at the root finder's loop entry: every lane runs the head (the two end evaluations, the secant
 // and the first quadratic step: uniform work); the ~37 % of the droplets that enter the loop hand their state (bracket, function values,
 // the droplet's own constants: 13 reals + 4 words) through LDS to the lowest lanes of the workgroup, the emptied waves leave, and the

@@ -745,6 +745,60 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
   if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) { if (iters_left) *iters_left = k.count; return r; }
   return advance_rw2_tail_with(f, rd3, eps, k, iters_left);
 }
+// ---- Fast arithmetic's own root finder (opts_init.strict_fp == 0).  TOMS748 was written to spend few FUNCTION EVALUATIONS; here an
+// evaluation is ~75 fp64 operations and the algorithm's own interpolation (a cubic through four points: six reciprocals and thirty
+// products per update), its six-value bracket state and its branches were MORE than half of the condensation kernel's instructions (profiles/
+// r02h_k_cond_fast_instruction_mix.txt: 360 of 759 fp64 instructions per wave in the growth rate, the rest in the root finder, next to 574
+// moves / selects / compares).  It also has to pull BOTH ends of its bracket inside the tolerance, although the tolerance is relative
+// to rw2 and the function is all but linear over the bracket for every droplet whose radius changes by less than a per cent in a step
+// (cloud droplets): the secant through the two ends is then already the answer.
+// This solver keeps the reference's bracket and its early outs (cond_common.ipp:197-305), then iterates the secant on a bracket that always
+// holds a sign change (regula falsi with the Anderson-Bjorck scaling of the retained end, order ~1.7) and stops when the ITERATE has
+// converged: |c_new - c| <= eps c, or the bracket is inside the tolerance.  The root it returns solves the same backward-Euler equation
+// to the same tolerance, eps = 2^-15 (config.hpp:39): it lies within that of the reference's answer (the midpoint of TOMS748's last
+// bracket), which is SURVEY 8a's bar for rw2 (rtol 1e-4), not bit for bit.  The strict arithmetic (the API default) keeps TOMS748.
+template <class T, class F>
+LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+{
+  constexpr int FD = fastdiv<F>::value;
+  const T drw2 = dt * f.drw2_dt(rw2_old);
+  if (drw2 == 0) return rw2_old;
+  T rd;
+  if constexpr (FD != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);
+  const T rd2 = rd * rd;
+  const T a_un = rw2_old + mn(T(0), cond_mlt * drw2);
+  T a = mx(rd2, a_un), b = rw2_old + mx(T(0), cond_mlt * drw2);
+  if (a == b) return rw2_old;
+  if (a == a_un && tol_reached(eps, a, b)) return (a + b) / 2;
+  const bool grows = drw2 > 0;
+  const T f_far = f(grows ? b : a);
+  T fa = grows ? drw2 : f_far, fb = grows ? f_far : drw2;          // f(rw2_old) == drw2 (cond_common.ipp:296-305)
+  T r;
+  if (fa * fb > 0) r = rw2_old + drw2;
+  else if (fa == 0) r = a;
+  else if (fb == 0) r = b;
+  else {
+    // (x1, f1): the latest point, (x0, f0): the retained end of the bracket (opposite sign)
+    T x0 = a, f0 = fa, x1 = b, f1 = fb;
+    T c = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
+    r = c;
+    for (unsigned it = 0; it < n_iter; ++it) {
+      if (!(c > mn(x0, x1) && c < mx(x0, x1))) c = x0 + (x1 - x0) / 2;          // (rounding at the very end of a search)
+      const T fc = f(c);
+      if (fc == 0) { r = c; break; }
+      if ((fc < 0) != (f1 < 0)) { x0 = x1; f0 = f1; }                            // the root is between the last two points
+      else { T m = T(1) - dvd<FD>(fc, f1); if (!(m > 0)) m = T(0.5); f0 = f0 * m; }     // same side twice: Anderson-Bjorck
+      x1 = c; f1 = fc;
+      const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
+      r = c_new;
+      if (fabs(c_new - c) <= eps * mn(fabs(c_new), fabs(c)) || tol_reached(eps, x0, x1)) break;
+      c = c_new;
+    }
+    if (!(r > mn(a, b) && r < mx(a, b))) r = x1;                                  // (never leave the reference's bracket)
+  }
+  if (r < rd2) r = rd2;
+  return r;
+}
 // per-cell part of with_cond_fun + cond_fun_fast::setup (same expressions, same order)
 template <class T>
 LCX_HD cond_cell_fast<T> make_cond_cell_fast(T rhod, T rv, T Tk, T eta, T lambda_D, T lambda_K, T RH, T RH_max)
