@@ -156,8 +156,11 @@ def main():
     ap.add_argument("--real", choices=["f64", "f32"], default="f64")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--strict-fp", action="store_true",
-                    help="IEEE operation order in the condensation kernel (bit-faithful to the reference's formulas); default: "
-                         "the collected one-division form with FMA contraction, parity-tested at the same tolerances")
+                    help="IEEE operation order in the condensation kernel and the reference's TOMS748 iterates (the API default); default "
+                         "here: fast arithmetic -- the collected one-division growth rate with FMA under the lean bracketed secant")
+    ap.add_argument("--cond-solver", choices=["lean", "toms748"], default="lean",
+                    help="fast arithmetic only (opts_init.cond_solver): the lean bracketed secant, or the reference's TOMS748 iterates in "
+                         "fast arithmetic (round 2's kernels)")
     ap.add_argument("--reorder-every", type=int, default=0,
                     help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
                          "many steps (0 = the library default, every 64 steps -- 32 for slabs with neighbours -- and with every compaction; -1 = never, the reference's "
@@ -227,6 +230,7 @@ def main():
     oi = make_opts_init(nx_tot, ny, nz, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
     oi.dev_id = -1 if native_multi else dev_index
     oi.strict_fp = args.strict_fp
+    oi.cond_solver = 1 if args.cond_solver == "toms748" else 0
     oi.reorder_every = args.reorder_every
     if args.cond_mode != "percell":
         oi.exact_sstp_cond = True
@@ -378,20 +382,19 @@ def main():
             launches = args.steps * args.sstp_cond
             avg_ms = stage_ms["cond"] / launches
             ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_cond_fast_fold + k_cond_fast (first pass + straggler pass)" if not args.strict_fp else "k_cond", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            kname = "k_cond" if args.strict_fp else "k_cond_lean" if args.cond_solver == "lean" else "k_cond_fast_fold + k_cond_fast (first pass + straggler pass)"
+            roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
             # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
             default_cfg = (world_out == 1 and n == 128 and not (args.nx or args.ny or args.nz) and args.sd_conc == 64 and args.real == "f64"
-                           and not args.strict_fp and args.sstp_cond == 1)
+                           and not args.strict_fp and args.sstp_cond == 1 and args.cond_solver == "lean")
             if default_cfg:
                 import glob
                 for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1:]:
                     tj = json.load(open(tf))
-                    # the condensation kernel runs as two launches per substep (first pass + deferred stragglers): the stage timer and the
-                    # counters below cover the pair
-                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_fast") and "<double" in k_]     # k_cond_fast_fold + k_cond_fast<.., true>
+                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_lean") and "<double" in k_]
                     t = {k_: sum(v.get(k_, 0) for v in both) for k_ in set().union(*both) if isinstance(both[0].get(k_, 0), (int, float))} if both else None
                     if t:
                         src = "profiles/" + os.path.basename(tf)
@@ -466,7 +469,9 @@ def main():
             "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
                                    % (nx_tot, ny, nz, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
                        "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, decomposition_note), "cond_mode": args.cond_mode,
-                       "fp_mode": "strict IEEE order" if args.strict_fp else "fp64, growth rate as one rational expression + FMA (parity-tested)",
+                       "fp_mode": "strict IEEE order, TOMS748 iterates" if args.strict_fp else
+                                  "fp64, growth rate as one rational expression + FMA; " + ("lean bracketed secant to the reference's tolerance 2^-15" if args.cond_solver == "lean"
+                                                                                             else "the reference's TOMS748 iterates"),
                        "init_s": t_init},
             "roofline": roof,
             "stage_ms_per_step": {k: (v / args.steps if k != "rendezvous_hidden_share" else v) for k, v in stage_ms.items()},

@@ -102,7 +102,15 @@ typedef struct {
   int n_x_tot;          /* total nx of the decomposed domain (ctor arg n_x_tot, particles.hpp:233) */
   int n_x_bfr;          /* x-planes owned by ranks to the left (distmem_opts.hpp:27) */
   int bcond_lft, bcond_rgt; /* 0 sharedmem, 1 distmem, 3 open  (src/detail/bcond.hpp) */
-  int strict_fp;        /* 1: IEEE order-preserving arithmetic (parity mode, default); 0: allow contraction */
+  int strict_fp;        /* 1: IEEE order-preserving arithmetic, the reference's TOMS748 iterates (parity mode, default);
+                         * 0: fast arithmetic -- growth rate collected into one rational expression + FMA, refined reciprocals, and the
+                         *    condensation equation solved by cond_solver below */
+  int cond_solver;      /* fast arithmetic only.  0 (default): a lean bracketed secant on the reference's bracket, to the reference's
+                         *    tolerance 2^-15 (csrc/lcx_math.hpp advance_rw2_lean_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within
+                         *    that tolerance of the reference's answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5
+                         *    from the root it brackets;
+                         * 1: the reference's TOMS748 iterates in the fast arithmetic (round 2's kernels: 1.6x the time of 0), for runs
+                         *    that are to follow the reference's answers as closely as its own builds follow each other */
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers
                          * line-coalesced in long runs: 18.1 instead of 21.5 ms per step after 400 steps of the 128^3 box).
                          * N > 0: every N steps, and whenever dead super-droplets are compacted away anyway (the same one pass over

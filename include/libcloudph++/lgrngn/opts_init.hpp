@@ -61,6 +61,7 @@ namespace libcloudphxx { namespace lgrngn {
     int supstp_rlx = 1;
     // --- extensions of this backend (no reference counterpart, see include/lcx.h) ---
     bool strict_fp = true;     // false: contracted one-division form of the condensational growth rate
+    int cond_solver = 0;       // fast arithmetic only: 0 lean bracketed secant (default), 1 the reference's TOMS748 iterates (lcx.h)
     // a slab of a 1-D decomposed domain (what detail::distmem_opts derives from the MPI rank inside the reference, distmem_opts.hpp:20-52):
     // x-planes owned by the ranks to the left, and the kind of the two x-faces (0 this process owns the whole domain, 1 neighbour
     // slab: leaving SDs are listed for lcx_migrate_pack, 3 open wall)

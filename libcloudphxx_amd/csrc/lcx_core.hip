@@ -860,9 +860,9 @@ struct Particles : IParticles {
                      xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
-      // fast arithmetic: the lean bracketed secant (k_cond_lean); LCX_COND_TOMS=1 keeps round 2's kernels -- TOMS748 iterates in fast
-      // arithmetic, iteration budget + straggler launch, fold -- for measurements and for the tests of that machinery
-      const bool cond_toms = getenv("LCX_COND_TOMS") != nullptr;
+      // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 (or LCX_COND_TOMS=1) keeps round 2's kernels
+      // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
+      const bool cond_toms = o.cond_solver == 1 || getenv("LCX_COND_TOMS") != nullptr;
       if (fast && !cond_toms) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);

@@ -141,7 +141,7 @@ class _opts_init_c(C.Structure):
         ("dry_distros", C.POINTER(_distro_c)), ("n_dry_distros", C.c_int),
         ("dry_sizes", C.POINTER(_dry_size_c)), ("n_dry_sizes", C.c_int),
         ("n_x_tot", C.c_int), ("n_x_bfr", C.c_int), ("bcond_lft", C.c_int), ("bcond_rgt", C.c_int),
-        ("strict_fp", C.c_int), ("reorder_every", C.c_int),
+        ("strict_fp", C.c_int), ("cond_solver", C.c_int), ("reorder_every", C.c_int),
     ]
 
 
@@ -234,6 +234,7 @@ class opts_init_t:
         self.n_x_bfr = 0
         self.bcond_lft = self.bcond_rgt = 0
         self.strict_fp = True
+        self.cond_solver = 0          # fast arithmetic only: 0 lean bracketed secant, 1 the reference's TOMS748 iterates (include/lcx.h)
         self.reorder_every = 0
 
     def _to_c(self, keep):

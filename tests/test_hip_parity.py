@@ -172,10 +172,12 @@ def test_cond_step(sstp, strict_fp):
         (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
         ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
         np.testing.assert_allclose(rh, ro, rtol=1e-4)
-        np.testing.assert_allclose(thh, tho, rtol=1e-7)
-        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        # (this box is a stress case -- fresh aerosol activating at RH 1.01, a step moves th by 0.8 K: see _harness.cond_bars)
+        th_tol, rv_tol, med_tol = h.cond_bars(strict_fp)
+        np.testing.assert_allclose(thh, tho, rtol=th_tol)
+        np.testing.assert_allclose(rvh, rvo, rtol=rv_tol)
         h.copy_state(orc, hip)      # keep later iterations comparable one step at a time
-    assert np.median(np.abs(rh / ro - 1)) < 1e-10     # ulp-level differences of the moment sums feed back through th/rv
+    assert np.median(np.abs(rh / ro - 1)) < (med_tol if strict_fp else med_tol * sstp)    # (strict: ulp-level differences of the moment sums feed back through th / rv)
 
 
 @pytest.mark.parametrize("strict_fp", [True, False])
@@ -200,12 +202,13 @@ def test_cond_step_with_drizzle_and_rain_drops(strict_fp):
         ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
         assert (orc.state_real("vt") > 0.3).sum() > 100           # drops with Re > 1 are there
         np.testing.assert_allclose(rh, ro, rtol=1e-4)
-        # millimetre drops at the multiplicities of aerosol particles hold far more water than the vapour: where the fast form's
-        # last-ulp differences end the root search on a neighbouring bracket (2^-15 wide), one cell's rv shows it at 1e-6
-        np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 1e-6)
-        np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-5)
+        # millimetre drops at the multiplicities of aerosol particles hold far more water than the vapour (10 kg per kg of air in a
+        # cell): the fast arithmetic's root and the reference's bracket midpoint (_harness.cond_bars), 1e-5 apart in rw2, show in a
+        # cell's rv at 1e-4
+        np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 2e-6)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-4)
         big = ro > (8e-6) ** 2
-        assert np.median(np.abs(rh[big] / ro[big] - 1)) < 1e-10
+        assert np.median(np.abs(rh[big] / ro[big] - 1)) < h.cond_bars(strict_fp)[2]
         h.copy_state(orc, hip)
 
 
@@ -233,9 +236,9 @@ def test_cond_step_with_invalid_terminal_velocities(strict_fp):
     ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
     assert np.all(np.isfinite(rh))
     np.testing.assert_allclose(rh, ro, rtol=1e-4)
-    assert np.median(np.abs(rh[::3] / ro[::3] - 1)) < 1e-10
-    np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 1e-6)      # (drops of 0.3 mm at aerosol multiplicities, as in the test above)
-    np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-5)
+    assert np.median(np.abs(rh[::3] / ro[::3] - 1)) < h.cond_bars(strict_fp)[2]
+    np.testing.assert_allclose(thh, tho, rtol=1e-7 if strict_fp else 2e-6)      # (drops of 0.3 mm at aerosol multiplicities, as in the test above)
+    np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if strict_fp else 2e-4)
 
 
 @pytest.mark.parametrize("strict_fp", [True, False])
@@ -536,9 +539,9 @@ def test_full_steps_replay(dims, sstp, strict_fp):
         (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
         assert hip.n_part == orc.n_part
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
-        np.testing.assert_allclose(thh, tho, rtol=1e-7)
-        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
-        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4)
+        np.testing.assert_allclose(thh, tho, rtol=h.cond_bars(strict_fp)[0])
+        np.testing.assert_allclose(rvh, rvo, rtol=h.cond_bars(strict_fp)[1])
+        np.testing.assert_allclose(hip.get_attr("rw2"), orc.get_attr("rw2"), rtol=1e-4 if strict_fp else 1e-4 * sstp[0])
         h.copy_state(orc, hip)
 
 
@@ -732,6 +735,7 @@ def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
     against the plain fast form that evaluates everything per droplet (LCX_NO_COND_PRE=1 selects it)"""
     oi = h.box_opts(4, 3, 5, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
+    oi.cond_solver = 1                                 # (round 2's fast kernels: TOMS748 iterates in fast arithmetic)
     res = []
     for off in (False, True):
         if off:
@@ -752,6 +756,31 @@ def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-8)
 
 
+def test_lean_solver_against_toms748_in_fast_arithmetic(monkeypatch):
+    """The fast arithmetic's bracketed secant (k_cond_lean) against TOMS748 on the SAME growth-rate arithmetic (LCX_COND_TOMS=1: round 2's
+    kernels), 2^20 droplets, two steps: both solve rw2_new = rw2_old + dt f(rw2_new) on the reference's bracket to 2^-15 -- every
+    droplet's answers within that tolerance of each other (no droplet on another root), th and rv to 1e-9"""
+    oi = h.box_opts(32, 16, 32, 64, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for toms in (False, True):
+        oi.cond_solver = int(toms)
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        opts.coal = opts.adve = opts.sedi = False
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(2):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh))
+    err = np.abs(res[0][0] / res[1][0] - 1)
+    assert err.max() < 1e-4 and np.median(err) < 3e-6, (err.max(), np.median(err), int((err > 3e-5).sum()))
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-8)      # (measured 4.4e-9: the spin-up steps of fresh aerosol, see _harness.cond_bars)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=2e-7)
+
+
 @pytest.mark.parametrize("budget", ["6", "3", "1"])
 def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget):
     """k_cond_fast with a short iteration budget + the dense second launch over the droplets that ran out of it (the production
@@ -759,6 +788,7 @@ def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget)
     identical bits in rw2, th and rv.  Budget 6 defers the far tail, 3 and 1 defer most of the droplets that iterate at all."""
     oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
+    oi.cond_solver = 1
     res = []
     for b in ("0", budget):
         monkeypatch.setenv("LCX_COND_BUDGET", b)
@@ -784,6 +814,7 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
     oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
     monkeypatch.setenv("LCX_COND_BUDGET", budget)
+    oi.cond_solver = 1
     res = []
     for plain in (False, True):
         if plain:
