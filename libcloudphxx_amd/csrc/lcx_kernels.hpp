@@ -971,6 +971,10 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
   a.m3_after[pos] = nn * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
 }
 
+// (Measured and dropped: two droplets per lane with all index loads and attribute gathers of both issued up front, so that the second
+// droplet's memory latency passes behind the first one's root search -- 126 VGPRs, no scratch, 3.96 against 3.89 ms: the 42 % of
+// wave-cycles that the counters show as waiting are not the gathers at the head of the kernel.)
+
 // The first pass with the workgroup FOLDED at the root finder's loop entry: every lane runs the head (the two end evaluations, the secant
 // and the first quadratic step: uniform work); the ~37 % of the droplets that enter the loop hand their state (bracket, function values,
 // the droplet's own constants: 13 reals + 4 words) through LDS to the lowest lanes of the workgroup, the emptied waves leave, and the
