@@ -121,6 +121,58 @@ def test_c2_icicle_2d_full_size_double_vs_oracle(strict_fp):
         h.copy_state(orc, hip)
 
 
+@pytest.mark.parametrize("strict_fp", [True, False])
+def test_c2_icicle_2d_float_against_the_double_oracle(strict_fp):
+    """C2 in the arithmetic icicle runs it in, real_t = float (fig_a/calc.cpp:36-39; root-finder tolerance 2^-7, config.hpp:39), at its
+    full size against the DOUBLE oracle, step by step from the same state (replayed random streams, state copied back each step):
+    what float changes is bounded by what float is.
+      * cell index and sort: a position differs by 1e-7 of the domain, so a droplet within that of a cell face lands next door:
+        at most 1e-4 of the droplets, and everywhere else the permutation inside a cell is the oracle's;
+      * multiplicities under the replayed stream: equal except around those droplets (a different partner) and where a collision
+        probability sits within float's resolution of the random number: at most 1e-3;
+      * wet radii: every substep ends on the midpoint of a bracket 2^-7 wide instead of 2^-15: 99.9 % of the droplets within 3e-2
+        of the double answer after ten substeps, the median within 2e-3;
+      * th, rv: sums of the same changes in 24-bit arithmetic, ten substeps: 2e-6 and 2e-4.
+    (No float build of the oracle exists: it would have to restate every literal's type of the reference's templates a second time;
+    this holds the float product to the pinned double oracle instead of to a conservation bound.)"""
+    nx = nz = 76
+    oi = icicle_opts(nx, nz, 64, sstp=10)
+    oi.strict_fp = strict_fp
+    th, rv, rhod, C = icicle_fields(nx, nz, np.float32)
+    f64 = (th.astype(np.float64), rv.astype(np.float64), rhod.astype(np.float64), {k: v.astype(np.float64) for k, v in C.items()})
+    orc = h.oracle_particles(oi)
+    hip = h.hip_particles(oi, np.float32)
+    for arr in h.oracle_rng_preview(orc, h.init_replay_calls(oi)):
+        hip.rng_replay_push(0, arr)
+    orc.init(f64[0].copy(), f64[1].copy(), f64[2].copy(), **f64[3])
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    assert hip.n_part == orc.n_part == nx * nz * 64
+    h.copy_state(orc, hip)
+    opts = lgrngn.opts_t()
+    n_sd = orc.n_part
+    for it in range(2):
+        tho, rvo, thh, rvh = f64[0].copy(), f64[1].copy(), th.copy(), rv.copy()
+        orc.step_sync(opts, tho, rvo, f64[2], **f64[3])
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        h.push_coal_replay(orc, hip, oi.sstp_coal)
+        orc.step_async(opts)
+        hip.step_async(opts)
+        np.testing.assert_allclose(thh, tho, rtol=2e-6)
+        np.testing.assert_allclose(rvh, rvo, rtol=2e-4)
+        assert abs(hip.n_part - orc.n_part) <= 1e-4 * n_sd
+        if hip.n_part == orc.n_part:
+            ijk_h, ijk_o = hip.state_u64("ijk"), orc.state_u64("ijk")
+            moved = ijk_h != ijk_o
+            assert moved.mean() < 1e-4, moved.mean()
+            n_h, n_o = hip.state_u64("n"), orc.state_u64("n")
+            assert (n_h != n_o).mean() < 1e-3, (n_h != n_o).mean()
+            same = ~moved & (n_h == n_o)
+            err = np.abs(hip.get_attr("rw2").astype(np.float64)[same] / orc.get_attr("rw2")[same] - 1)
+            assert np.quantile(err, .999) < 3e-2 and np.median(err) < 2e-3, (np.quantile(err, .999), np.median(err), err.max())
+            np.testing.assert_allclose(hip.get_attr("x").astype(np.float64)[same], orc.get_attr("x")[same], rtol=2e-6, atol=2e-4)
+        h.copy_state(orc, hip)
+
+
 def test_c2_icicle_2d_full_size_float():
     """76 x 76 x 64 = 369 664 super-droplets in real_t = float as icicle runs it: 20 steps; water is conserved between
     vapour and droplets up to precipitation, the SD count only decreases, the cell-sorted order stays a stable argsort"""

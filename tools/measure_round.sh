@@ -6,7 +6,7 @@ tag=${1:-r02}
 ulimit -c 0
 out=gpurun_out/meas_$tag
 mkdir -p $out
-B="python3 bench.py --no-cpu-baseline"
+B="python3 bench.py --no-cpu-baseline --no-strict-leg"
 # one slab of the strong-scaling split of C3 on a device of its own (what each GPU of an N-GPU run computes, without exchange)
 for nx in 64 32 16; do $B --nx $nx --steps 100 > $out/slab_nx$nx.json 2> $out/slab_nx$nx.err; done
 # the native multi_HIP object with all slabs on this one device: concurrent (exchange overlapped) and one slab at a time
