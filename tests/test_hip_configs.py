@@ -132,7 +132,7 @@ def test_c2_icicle_2d_float_against_the_double_oracle(strict_fp):
         probability sits within float's resolution of the random number: at most 1e-3;
       * wet radii: every substep ends on the midpoint of a bracket 2^-7 wide instead of 2^-15: 99.9 % of the droplets within 3e-2
         of the double answer after ten substeps, the median within 2e-3;
-      * th, rv: sums of the same changes in 24-bit arithmetic, ten substeps: 2e-6 and 2e-4.
+      * th, rv: sums of the same changes in 24-bit arithmetic, ten substeps: 2e-6 and 2e-4; positions: 1e-2 m of 1500 (5e-4 of a cell).
     (No float build of the oracle exists: it would have to restate every literal's type of the reference's templates a second time;
     this holds the float product to the pinned double oracle instead of to a conservation bound.)"""
     nx = nz = 76
@@ -169,7 +169,9 @@ def test_c2_icicle_2d_float_against_the_double_oracle(strict_fp):
             same = ~moved & (n_h == n_o)
             err = np.abs(hip.get_attr("rw2").astype(np.float64)[same] / orc.get_attr("rw2")[same] - 1)
             assert np.quantile(err, .999) < 3e-2 and np.median(err) < 2e-3, (np.quantile(err, .999), np.median(err), err.max())
-            np.testing.assert_allclose(hip.get_attr("x").astype(np.float64)[same], orc.get_attr("x")[same], rtol=2e-6, atol=2e-4)
+            # (positions: the implicit scheme's x + dx (C_l - i (C_r - C_l)) cancels at i ~ 75: a few dozen ulps of the 1500 m domain;
+            # measured 3.4e-3 m at most, 2.7 % of the droplets above 2e-4 m)
+            np.testing.assert_allclose(hip.get_attr("x").astype(np.float64)[same], orc.get_attr("x")[same], rtol=0, atol=1e-2)
         h.copy_state(orc, hip)
 
 
