@@ -1562,6 +1562,9 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // reference (coal.ipp:209,233-267) because the kappa update (and tests) read them.
 // TAB (as k_move's SPEC: uniform branches are dear): the production configuration compiled for itself -- a tabulated-efficiency
 // kernel (hall*, vohl*), random numbers from Philox, no per-particle rc2 / in-cloud time, used-up super-droplets marked in ijk
+// (Measured and dropped, round 3: the terminal velocities of hskpng_vterm_all computed HERE by the lane that owns the pair, from the wet
+// radii it has gathered anyway, and stored -- instead of the separate streaming pass (28 B per SD, 0.81 ms on C3).  Same values, but
+// k_coal 1.55 -> 2.56 ms and k_move +0.1: the scattered 8-byte stores of vt and the logarithm per droplet cost more than the pass.)
 template <class T, bool ONISHI, bool TAB = false>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
