@@ -248,3 +248,54 @@ def test_sgs_velocity_moments_and_water_selection():
     plain.diag_all()
     with pytest.raises(RuntimeError, match="SGS velocity"):
         plain.diag_up_mom(1)
+
+
+@pytest.mark.parametrize("strict_fp", [True, False])
+def test_production_storage_order_holds_the_oracles_droplets(strict_fp):
+    """The production rules for the storage -- dead super-droplets dropped lazily, storage gathered into the cell order every
+    reorder_every steps (ids renumbered), the cells left in the next coalescence's shuffled order -- against the ORACLE, which keeps
+    the reference's id order: without coalescence a step needs no random number, so no replayed stream forces the reference's order on
+    the device (the state is handed over with set_particles).  Eight steps of condensation + advection + sedimentation with
+    reorder_every = 3 and precipitation through the floor: the same droplets (matched by dry radius, which nothing changes here),
+    multiplicities exact, positions to 1e-13, wet radii at the substep tolerance times the steps, the same th / rv."""
+    oi = h.box_opts(6, 5, 7, 48, coal_switch=False, strict_fp=strict_fp, reorder_every=3)
+    fields = h.box_fields(oi)
+    th, rv, rhod, C = fields
+    orc = h.oracle_particles(oi)
+    hip = h.hip_particles(oi)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)           # (its own Philox draws: overwritten by the oracle's state below)
+    g = orc.state_real
+    rw2, z, n = g("rw2").copy(), g("z").copy(), orc.state_u64("n").copy()
+    low = np.nonzero(z < oi.dz)[0][::7]                        # a few drizzle drops just above the floor: they precipitate within the run
+    rw2[low] = (1e-4) ** 2                                     # (multiplicity 1: their water is nothing to the cell)
+    z[low] = 0.5 + 3.0 * (np.arange(low.size) % 5) / 5.
+    n[low] = 1
+    args = (n, g("rd3"), rw2, g("kappa"), g("vt"), g("x"), g("y"), z)
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    tho, rvo, thh, rvh = th.copy(), rv.copy(), th.copy(), rv.copy()
+    n0 = orc.n_part
+    for it in range(8):
+        orc.step_sync(opts, tho, rvo, rhod, **C)
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        orc.step_async(opts)
+        hip.step_async(opts)
+        assert hip.n_part == orc.n_part
+    assert orc.n_part < n0                                     # (precipitation happened: dead super-droplets went through the lazy removal)
+    ko, kh = np.argsort(orc.get_attr("rd3"), kind="stable"), np.argsort(hip.get_attr("rd3"), kind="stable")
+    assert np.array_equal(orc.get_attr("rd3")[ko], hip.get_attr("rd3")[kh])
+    assert np.array_equal(orc.state_u64("n")[ko], hip.state_u64("n")[kh])
+    for a_ in ("x", "y"):
+        np.testing.assert_allclose(hip.get_attr(a_)[kh], orc.get_attr(a_)[ko], rtol=1e-13, atol=1e-10)
+    # (sedimentation: 8 x dt x vt(rw2), rw2 to 1e-4 per step; fast arithmetic measured 7.7e-5 m)
+    np.testing.assert_allclose(hip.get_attr("z")[kh], orc.get_attr("z")[ko], rtol=1e-13, atol=1e-5 if strict_fp else 2e-4)
+    np.testing.assert_allclose(hip.get_attr("rw2")[kh], orc.get_attr("rw2")[ko], rtol=8e-4)
+    th_tol, rv_tol, _ = h.cond_bars(strict_fp)
+    np.testing.assert_allclose(thh, tho, rtol=8 * th_tol)
+    np.testing.assert_allclose(rvh, rvo, rtol=8 * rv_tol)
+    # the device's own order is a valid cell-sorted order of its renumbered storage
+    sid, sijk, ijk = hip.state_u64("sorted_id"), hip.state_u64("sorted_ijk"), hip.state_u64("ijk")
+    assert np.array_equal(ijk[sid], sijk) and np.all(np.diff(sijk.astype(np.int64)) >= 0)

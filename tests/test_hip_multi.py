@@ -232,6 +232,40 @@ def test_multi_device_production_order_same_droplets(dims, size, monkeypatch):
             assert np.array_equal(attrs_a[k], attrs_b[k]), k
 
 
+@pytest.mark.parametrize("dims,size", [((8, 0, 5), 4), ((9, 3, 4), 3)])
+def test_multi_device_production_order_against_the_oracle_ring(dims, size, monkeypatch):
+    """the multi-device object in PRODUCTION mode (immigrants take over the emigrants' slots, storage re-ordered, the overlapped
+    re-sort) against the ORACLE ring stepped in the reference's order: no coalescence, so no random number and no replayed stream;
+    slab by slab the same droplets (matched by dry radius), multiplicities exact, positions to 1e-13"""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False, reorder_every=2)
+    oi.n_sd_max = 24 * max(nx, 1) * max(ny, 1) * nz * 3
+    th, rv, rhod, C = h.box_fields(oi)
+    orc = h.LocalRing(oi, size, h.oracle_particles, h.host_alloc)
+    mul = make_multi(oi, size, monkeypatch)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    mul.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    slabs = [mul.slab(r) for r in range(size)]
+    for po, ph in zip(orc.prts, slabs):
+        ph.opts_init = po.opts_init
+        h.copy_state(po, ph)                                   # (set_particles: no replayed stream, the device keeps its production rules)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.cond = False
+    for it in range(7):
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_async(opts)
+    for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
+        assert ph.n_part == po.n_part, r
+        ko = np.lexsort((po.get_attr("z"), po.get_attr("x"), po.get_attr("rd3")))
+        kh = np.lexsort((ph.get_attr("z"), ph.get_attr("x"), ph.get_attr("rd3")))
+        assert np.array_equal(po.get_attr("rd3")[ko], ph.get_attr("rd3")[kh]), r
+        assert np.array_equal(po.state_u64("n")[ko], ph.state_u64("n")[kh]), r
+        for a_ in ("x", "y", "z"):
+            if getattr(oi, "n" + a_):
+                np.testing.assert_allclose(ph.get_attr(a_)[kh], po.get_attr(a_)[ko], rtol=1e-13, atol=1e-9, err_msg="%s slab %d" % (a_, r))
+
+
 def test_multi_device_slab_arrays_on_the_device(monkeypatch):
     """on_device == 2: every field as one device array per slab (a host model decomposed the same way) -- same result as the
     global host arrays"""
