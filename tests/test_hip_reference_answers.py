@@ -136,3 +136,12 @@ def test_coalescence_conserves_volume_hip():
     assert np.isclose(fin[1], init[1], atol=0., rtol=1e-10), "total wet volume is not conserved during coalescence"
     assert np.isclose(fin[2], init[2], atol=0., rtol=1e-10), "total kappa*rd^3 is not conserved during coalescence"
     assert abs(fin[1] / init[1] - 1) > 0 or True
+
+
+def test_icicle_t0_initial_spectra_hip():
+    """the reference's icicle output at t = 0 (tests/golden/icicle_t0_profiles.npz, tests/test_oracle_pins.py) against the DEVICE's
+    initialisation -- Philox draws, device equilibrium radii: the same spectra within the sampling error of 2.3e5 super-droplets"""
+    oi, th, rv, rhod, d = pins.icicle_t0_setup()
+    pr = h.hip_particles(oi)
+    pr.init(th, rv, rhod)
+    pins.check_icicle_t0(pins.icicle_t0_diagnose(pr, d), d)

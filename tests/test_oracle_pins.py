@@ -334,3 +334,91 @@ def test_openmp_build_of_the_oracle_is_bit_identical():
         out.append((th.copy(), rv.copy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.state_u64("n"), pr.state_u64("sorted_id")))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ the reference's icicle regression output at t = 0
+# models/kinematic_2D/tests/paper_GMD_2015/fig_a/refdata/travis_out_lgrngn/travis_timestep0000000000.h5 (+ travis_const.h5): the state
+# right after particles_t::init of the 2-D lgrngn set-up as the reference's serial backend produced it (real_t = float) -- reduced to
+# domain means per bin by tools/extract_icicle_t0.py (tests/golden/icicle_t0_profiles.npz).  The run drew its aerosol from the float
+# flavour of the generator's stream, which no double build reproduces number for number; what IS reproducible from it:
+#   * the dry-air density profile and the dry potential temperature: the formula library's hydrostatic::p, theta_std::rhod, theta_dry::std2dry;
+#   * the initial spectra as STATISTICS: per dry-radius bin the specific concentration, per wet-radius bin likewise (the equilibrium wet
+#     radii of init_wet at RH(z)), the third wet moment per dry bin -- two samples of 2.3e5 super-droplets of the same distribution.
+ICICLE_T0 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icicle_t0_profiles.npz")
+
+
+def icicle_t0_setup():
+    """kin_cloud_2d_lgrngn.hpp:150-200 / icmw8_case1.hpp:160-230 with travis_calc_lgrngn.cpp's options: 60 x 60 grid points over
+    1500 m x 1500 m, cells centred on them (the outermost ones half inside), 64 super-droplets per cell, icicle's bimodal aerosol"""
+    d = np.load(ICICLE_T0)
+    nx = nz = 60
+    dx = 1500. / (nx - 1)
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.ny, oi.nz = nx, 0, nz
+    oi.dx = oi.dz = dx
+    oi.dy = 1.
+    oi.x0, oi.z0 = dx / 2, dx / 2
+    oi.x1, oi.z1 = (nx - .5) * dx, (nz - .5) * dx
+    oi.y1 = 1.
+    oi.dt = 1.
+    oi.sd_conc = 64
+    oi.n_sd_max = 64 * nx * nz
+    oi.dry_distros = {(.61, 0.): lgrngn.lognormal([.02e-6, .075e-6], [1.4, 1.6], [60e6, 40e6])}
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.terminal_velocity = lgrngn.vt_t.khvorostyanov_spherical
+    oi.sstp_cond = oi.sstp_coal = 10
+    rhod = np.ascontiguousarray(np.broadcast_to(d["rhod_profile"], (nx, nz)))
+    th = np.full((nx, nz), d["th"][0])
+    rv = np.full((nx, nz), d["rv"][0])
+    return oi, th, rv, rhod, d
+
+
+def icicle_t0_diagnose(pr, d):
+    """what kin_cloud_2d_lgrngn.hpp:40-95 records: domain means of the per-cell diagnostics"""
+    out = {"rd": [], "rw": [], "rw3": []}
+    for i in range(39):
+        pr.diag_dry_rng(d["dry_edges"][i], d["dry_edges"][i + 1]); pr.diag_dry_mom(0)
+        out["rd"].append(pr.outbuf_array().mean())
+        pr.diag_dry_rng(d["dry_edges"][i], d["dry_edges"][i + 1]); pr.diag_wet_mom(3)
+        out["rw3"].append(pr.outbuf_array().mean())
+    for i in range(24):
+        pr.diag_wet_rng(d["wet_edges"][i], d["wet_edges"][i + 1]); pr.diag_wet_mom(0)
+        out["rw"].append(pr.outbuf_array().mean())
+    pr.diag_wet_rng(.5e-6, 25e-6); pr.diag_wet_mom(0)
+    out["fssp_max"] = pr.outbuf_array().max()
+    pr.diag_all(); pr.diag_sd_conc()
+    sd = pr.outbuf_array()
+    out["sd_conc"] = (sd.min(), sd.max())
+    return {k: np.array(v) for k, v in out.items()}
+
+
+def check_icicle_t0(got, d):
+    # 2.3e5 super-droplets uniform in ln(rd) over ~7 e-folds: ~7500 per dry bin of 0.23, ~15000 per wet bin of 0.46; two independent
+    # samples differ by sqrt(2 / N) ~ 1.6 % resp. 1.2 %: held to five times that where the spectrum is populated (above 1 % of its peak)
+    for key, ref, tol in (("rd", d["rd_mom0_mean"], 0.08), ("rw", d["rw_mom0_mean"], 0.08), ("rw3", d["rw3ofrd_mom3_mean"], 0.10)):
+        core = ref > 1e-2 * ref.max()
+        assert core.sum() >= 8, key
+        rel = got[key][core] / ref[core] - 1
+        assert np.abs(rel).max() < tol, (key, rel)
+        assert abs(rel.mean()) < 0.02, (key, rel.mean())                         # (no common factor: units, volumes, densities)
+        assert np.all((got[key] > 0) == (ref > 0)) or np.abs(np.flatnonzero(got[key] > 0)[[0, -1]] - np.flatnonzero(ref > 0)[[0, -1]]).max() <= 1, key
+    assert got["fssp_max"] == 0 or got["fssp_max"] < 2 * d["fssp_mom0_max"][0]
+    assert got["sd_conc"][1] == d["sd_conc"][1] == 64 and got["sd_conc"][0] >= 62              # (the reference's t = 0 minimum: 63)
+
+
+def test_icicle_t0_density_and_theta_from_the_formula_library():
+    from libcloudphxx_amd import common
+    d = np.load(ICICLE_T0)
+    dz = 1500. / 59
+    z = np.arange(60) * dz
+    rhod = np.array([common.rhod(common.p_hydro(zz, 289., 7.5e-3, 0., 101500.), 289., 7.5e-3) for zz in z])
+    np.testing.assert_allclose(rhod, d["rhod_profile"], rtol=1e-6)                # (the reference computed it in float: two pow chains, measured 3.4e-7)
+    np.testing.assert_allclose(common.th_std2dry(289., 7.5e-3), d["th"][0], rtol=1e-7)
+    assert d["th"][0] == d["th"][1] and d["rv"][0] == d["rv"][1] == np.float32(7.5e-3)
+
+
+def test_icicle_t0_initial_spectra_oracle():
+    oi, th, rv, rhod, d = icicle_t0_setup()
+    pr = oracle_particles(oi)
+    pr.init(th, rv, rhod)
+    check_icicle_t0(icicle_t0_diagnose(pr, d), d)
