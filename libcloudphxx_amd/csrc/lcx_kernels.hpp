@@ -971,6 +971,12 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
   a.m3_after[pos] = nn * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
 }
 
+// Growth-rate evaluations per droplet (an offline count over 2.1e6 droplets of the oracle's state on the bench's fields): 3 for 72 % of the
+// droplets, 4 for 19 %, 5...8 for 2.4 % (haze far from its equilibrium, droplets activating), 1 for the 7 % that take an early out -- mean
+// 3.1, and 5.2 for the slowest droplet of a wave of 64 (TOMS748: 4.1 and 7.7).
+// (Measured and dropped: an iteration budget of two secant updates with the 2.4 % of the droplets that exceed it solved by a dense second
+// launch, as k_cond_fast does -- bit-identical, and no faster: 4.16 ms against 4.09 for the same kernel without budget and 3.9 for this
+// plain form; the tail of the iteration counts is not what the kernel's time is made of.)
 // (Measured and dropped: two droplets per lane with all index loads and attribute gathers of both issued up front, so that the second
 // droplet's memory latency passes behind the first one's root search -- 126 VGPRs, no scratch, 3.96 against 3.89 ms: the 42 % of
 // wave-cycles that the counters show as waiting are not the gathers at the head of the kernel.)
