@@ -101,9 +101,34 @@ def test_multi_device_uneven_slabs_at_courant_one(dims, size, cx, monkeypatch):
     assert mul.n_part == sum(p.n_part for p in orc.prts)
 
 
-@pytest.mark.parametrize("dims,size", [((8, 0, 5), 2), ((9, 3, 4), 3)])
+def test_multi_device_crowded_cells_in_the_overlapped_resort(monkeypatch):
+    """cells above k_cellrank's limit (300 super-droplets per cell: listed and sorted by one wave each) on slabs with neighbours: the
+    interior's crowded cells are listed before the messages arrive, the boundary planes' behind the unpack, all of them sorted once
+    the host knows the counts -- plain and shuffled order (coalescence on, replayed streams) against the oracle ring"""
+    nx, ny, nz, size = 8, 0, 3, 2
+    oi = h.box_opts(nx, ny, nz, 300, dx=20.)
+    oi.n_sd_max = 300 * nx * nz * 3
+    fields = h.box_fields(oi)
+    orc, mul, slabs = multi_pair(oi, size, fields, monkeypatch)
+    th, rv, rhod, C = fields
+    opts = lgrngn.opts_t()
+    opts.cond = False
+    for it in range(3):
+        for po, ph in zip(orc.prts, slabs):
+            h.push_coal_replay(po, ph)
+        orc.step(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_sync(opts, th.copy(), rv.copy(), rhod, **C)
+        mul.step_async(opts)
+        compare_slabs(orc, slabs, oi, it, attrs=("x", "z", "rw2", "rd3"))
+        for ph in slabs:
+            cnt = np.diff(ph.state_u64("cell_start").astype(np.int64))
+            assert cnt.max() > 256
+
+
+@pytest.mark.parametrize("dims,size", [((8, 0, 5), 2), ((9, 3, 4), 3), ((16, 0, 5), 2)])
 def test_multi_device_pred_corr_and_open_walls(dims, size, monkeypatch):
-    """pred_corr (Courant halo of two planes per side) and open side walls through the multi-device object"""
+    """pred_corr (Courant halo of two planes per side; (16, 0, 5) over 2 slabs: 8 planes each, so that the overlapped re-sort runs with
+    its two boundary planes per side) and open side walls through the multi-device object"""
     nx, ny, nz = dims
     for kw in (dict(adve_scheme=lgrngn.as_t.pred_corr), dict(open_side_walls=True)):
         oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False, **kw)
