@@ -480,25 +480,35 @@ LCX_HD double exp_reduced_core(double x)            // |x| < 700 is the caller's
 // exp of the Kelvin term A / r_w (0 < x < ~2; anything finite below 700 works): the same reduction and the same degree-13 polynomial as
 // exp_reduced_core, evaluated as two interleaved Horner chains in r^2 (even and odd coefficients) -- half the dependent length -- and
 // without the range check, whose library fallback would end the caller's scheduling region.  <= 1 ulp like exp_reduced (math probe 8).
+// (the polynomial's coefficients sit in constant memory: gfx950's VOP3 takes no 64-bit literal, and a literal addend of a Horner step is
+// materialised with two v_mov_b32 per step in front of a v_fmac -- read through the scalar cache they arrive in SGPRs, which a v_fma
+// takes as they are: see DESIGN.md for what that saves)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ double lcx_expk_c[14] = {
+  1.4426950408889634, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+  2.08767569878681e-09, 1.6059043836821613e-10, 2.755731922398589e-07, 2.505210838544172e-08, 2.48015873015873e-05, 2.7557319223985893e-06,
+  1.3888888888888889e-03, 1.984126984126984e-04, 4.1666666666666664e-02, 8.333333333333333e-03, 1.6666666666666666e-01};
+#endif
 LCX_HD double exp_kelvin(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const double k = __builtin_rint(x * 1.4426950408889634);
-  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
-  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+  const double *c = lcx_expk_c;
+  const double k = __builtin_rint(x * c[0]);
+  double r = __builtin_fma(-k, c[1], x);
+  r = __builtin_fma(-k, c[2], r);
   const double r2 = r * r;
-  double pe = 2.08767569878681e-09;                          // 1/12!
-  double po = 1.6059043836821613e-10;                        // 1/13!
-  pe = __builtin_fma(pe, r2, 2.755731922398589e-07);         // 1/10!
-  po = __builtin_fma(po, r2, 2.505210838544172e-08);         // 1/11!
-  pe = __builtin_fma(pe, r2, 2.48015873015873e-05);          // 1/8!
-  po = __builtin_fma(po, r2, 2.7557319223985893e-06);        // 1/9!
-  pe = __builtin_fma(pe, r2, 1.3888888888888889e-03);        // 1/6!
-  po = __builtin_fma(po, r2, 1.984126984126984e-04);         // 1/7!
-  pe = __builtin_fma(pe, r2, 4.1666666666666664e-02);        // 1/4!
-  po = __builtin_fma(po, r2, 8.333333333333333e-03);         // 1/5!
+  double pe = c[3];                                          // 1/12!
+  double po = c[4];                                          // 1/13!
+  pe = __builtin_fma(pe, r2, c[5]);                          // 1/10!
+  po = __builtin_fma(po, r2, c[6]);                          // 1/11!
+  pe = __builtin_fma(pe, r2, c[7]);                          // 1/8!
+  po = __builtin_fma(po, r2, c[8]);                          // 1/9!
+  pe = __builtin_fma(pe, r2, c[9]);                          // 1/6!
+  po = __builtin_fma(po, r2, c[10]);                         // 1/7!
+  pe = __builtin_fma(pe, r2, c[11]);                         // 1/4!
+  po = __builtin_fma(po, r2, c[12]);                         // 1/5!
   pe = __builtin_fma(pe, r2, 0.5);                           // 1/2!
-  po = __builtin_fma(po, r2, 1.6666666666666666e-01);        // 1/3!
+  po = __builtin_fma(po, r2, c[13]);                         // 1/3!
   // 1 + r + r^2 (pe + r po)
   const double p = __builtin_fma(r2, __builtin_fma(po, r, pe), r) + 1.0;
   return __builtin_ldexp(p, int(k));
@@ -522,28 +532,31 @@ LCX_HD float exp_reduced(float x) { return exp(x); }
 // ln(r)-uniform table is taken from it): mantissa in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) as an odd series.
 // <= 2 ulp (math probe 5); the library call costs about twice as many instructions.
 #if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ double lcx_logl_c[14] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
+                                                 1.0 / 3.0, 0.70710678118654752, 6.93147180369123816490e-01, 1.90821492927058770002e-10};
 LCX_HD double log_lean_core(double x)               // positive normal x is the caller's business
 {
+  const double *c = lcx_logl_c;                      // (coefficients through the scalar cache, see exp_kelvin)
   int e = __builtin_amdgcn_frexp_exp(x);
   double m = __builtin_amdgcn_frexp_mant(x);                     // [0.5, 1)
-  if (m < 0.70710678118654752) { m = m + m; e -= 1; }
+  if (m < c[11]) { m = m + m; e -= 1; }
   const double s = (m - 1.0) * rcp_refined(m + 1.0);
   const double z = s * s;
-  double p = 1.0 / 23.0;
-  p = __builtin_fma(p, z, 1.0 / 21.0);
-  p = __builtin_fma(p, z, 1.0 / 19.0);
-  p = __builtin_fma(p, z, 1.0 / 17.0);
-  p = __builtin_fma(p, z, 1.0 / 15.0);
-  p = __builtin_fma(p, z, 1.0 / 13.0);
-  p = __builtin_fma(p, z, 1.0 / 11.0);
-  p = __builtin_fma(p, z, 1.0 / 9.0);
-  p = __builtin_fma(p, z, 1.0 / 7.0);
-  p = __builtin_fma(p, z, 1.0 / 5.0);
-  p = __builtin_fma(p, z, 1.0 / 3.0);
+  double p = c[0];
+  p = __builtin_fma(p, z, c[1]);
+  p = __builtin_fma(p, z, c[2]);
+  p = __builtin_fma(p, z, c[3]);
+  p = __builtin_fma(p, z, c[4]);
+  p = __builtin_fma(p, z, c[5]);
+  p = __builtin_fma(p, z, c[6]);
+  p = __builtin_fma(p, z, c[7]);
+  p = __builtin_fma(p, z, c[8]);
+  p = __builtin_fma(p, z, c[9]);
+  p = __builtin_fma(p, z, c[10]);
   const double two_s = s + s;
   const double lm = __builtin_fma(two_s * z, p, two_s);
   const double ed = double(e);
-  return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
+  return __builtin_fma(ed, c[12], __builtin_fma(ed, c[13], lm));
 }
 #endif
 LCX_HD double log_lean(double x)
@@ -600,6 +613,9 @@ template <bool SERIES, class T> LCX_HD T cbrt1p(T x)
   }
   return cbrt_seeded(T(1) + x);
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10. / 243, 22. / 729};
+#endif
 // OPT (measurement / tuning switches, all inside the fast arithmetic's few-ulp envelope): bit 0 the root finder's reciprocals
 // with one Newton step instead of two; bit 1 the ventilation factors' cube roots by series for small arguments
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
@@ -643,8 +659,14 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       // droplets repair Sh and Nu behind it in one rarely taken branch.  (cond on C3: 7.0 -> 6.7 ms with the two cube roots behind one
       // branch instead of two; -> see DESIGN.md for this form.)
       const T xS = Re * Sc, xN = Re * Pr;
+#if defined(__HIP_DEVICE_COMPILE__)
+      const double *q = lcx_cbrt1p_c;                  // (coefficients through the scalar cache, see exp_kelvin)
+      T cS = T(1) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
+      T cN = T(1) + xN * (T(q[0]) + xN * (T(q[1]) + xN * (T(q[2]) + xN * (T(q[3]) + xN * T(q[4])))));
+#else
       T cS = T(1) + xS * (T(1. / 3) + xS * (T(-1. / 9) + xS * (T(5. / 81) + xS * (T(-10. / 243) + xS * T(22. / 729)))));
       T cN = T(1) + xN * (T(1. / 3) + xN * (T(-1. / 9) + xN * (T(5. / 81) + xN * (T(-10. / 243) + xN * T(22. / 729)))));
+#endif
       klv = exp_kelvin(A * irw);
       Sh = T(1) + cS; Nu = T(1) + cN;
       if (!(mx(fabs(xS), fabs(xN)) < T(0x1p-8))) {
