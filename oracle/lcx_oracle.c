@@ -141,10 +141,25 @@ const char *orc_last_error(void) { return orc_err; }
 #include <omp.h>
 const char *orc_version(void) { return "lcx-oracle 1 (double, OpenMP elementwise loops)"; }
 int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
+void orc_set_num_threads(int n) { (void)n; }
 const char *orc_version(void) { return "lcx-oracle 1 (double, serial)"; }
 int orc_num_threads(void) { return 1; }
 #endif
+/* Stage timers of the oracle itself (ORC_TIMERS=1 in the environment; orc_timers_dump prints and clears them): used once to see
+ * which stages of the OpenMP build were still serial (bench.py's cpu_baseline leg). */
+#include <time.h>
+enum { TM_SORT, TM_COND, TM_MOMS, TM_TPR, TM_VTERM, TM_COAL, TM_MOVE, TM_POST, TM_OTHER, TM_N };
+static double tm_acc[TM_N];
+static int tm_on = -1;
+static double tm_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#define TMR(k, stmt) do { if (tm_on < 0) tm_on = getenv("ORC_TIMERS") != NULL; if (tm_on) { const double t0_ = tm_now(); stmt; tm_acc[k] += tm_now() - t0_; } else { stmt; } } while (0)
+void orc_timers_dump(void)
+{
+  static const char *nm[TM_N] = {"sort", "cond", "th_rv", "Tpr", "vterm", "coal", "adve+sedi+bcnd", "post_copy", "other"};
+  for (int k = 0; k < TM_N; ++k) { fprintf(stderr, "orc timer %-16s %9.3f s\n", nm[k], tm_acc[k]); tm_acc[k] = 0; }
+}
 
 void orc_opts_init_default(lcx_opts_init_t *o)
 {                                           /* opts_init.hpp:186-247 */
@@ -296,6 +311,7 @@ static void sync_out_arr(const orc_particles *s, const double *from, const lcx_a
 /* hskpng_Tpr.ipp:219-305 */
 static void hskpng_Tpr(orc_particles *s)
 {
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) {
     if (s->o.th_dry) s->T[c] = theta_dry_T(s->th[c], s->rhod[c]);
     else             s->T[c] = s->th[c] * theta_std_exner(s->p[c]);
@@ -308,6 +324,7 @@ static void hskpng_Tpr(orc_particles *s)
 /* hskpng_mfp.ipp:42-51 */
 static void hskpng_mfp(orc_particles *s)
 {
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) {
     s->lambda_D[c] = lambda_D_of(s->T[c]);
     s->lambda_K[c] = lambda_K_of(s->T[c], s->p[c]);
@@ -329,9 +346,102 @@ static void hskpng_ijk(orc_particles *s)
   }
   s->sorted = 0;
 }
+#ifdef _OPENMP
+/* ---- The OpenMP build's counterparts of the reference backend's parallel primitives (thrust::omp sort_by_key, reduce_by_key,
+ * copy_if / remove_if): every one of them returns what the serial loop beside it returns, bit for bit (a stable sort has one answer;
+ * a run of equal keys is summed by ONE thread in the serial order; selections keep the index order), which
+ * tests/test_oracle_pins.py checks against the serial build.  Only bench.py's cpu_baseline leg and the production-size parity tests
+ * load this build. */
+/* Work arrays of these primitives: kept between calls (fresh gigabyte allocations are page-faulted in on every call, and 128 threads
+ * faulting at once serialise in the kernel).  One set per process: the OpenMP build is driven by one host thread at a time. */
+enum { SCR_K, SCR_V, SCR_START, SCR_FLAG, SCR_IDX, SCR_TMP, SCR_UN, SCR_N };
+static void *scr_buf[SCR_N];
+static size_t scr_cap[SCR_N];
+static void *scr_get(int slot, size_t bytes)
+{
+  if (scr_cap[slot] < bytes) { free(scr_buf[slot]); scr_cap[slot] = bytes + bytes / 8 + 64; scr_buf[slot] = malloc(scr_cap[slot]); }
+  return scr_buf[slot];
+}
+static void omp_chunk(sz n, int t, int T, sz *lo, sz *hi)
+{
+  const sz per = (n + (sz)T - 1) / (sz)T;
+  *lo = per * (sz)t > n ? n : per * (sz)t;
+  *hi = *lo + per > n ? n : *lo + per;
+}
+/* one stable pass of an LSD radix sort on the digit (key >> sh) & mask: per-thread histograms over contiguous chunks */
+static void par_sort_pass(const sz *key, const sz *val, sz *k2, sz *v2, sz n, int sh, sz mask)
+{
+  const sz nb = mask + 1;
+  const int Tmax = omp_get_max_threads();
+  const sz n_hist = (sz)Tmax * nb;
+  sz *hist = NEW(sz, n_hist);
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num(), T = omp_get_num_threads();
+    sz lo, hi; omp_chunk(n, t, T, &lo, &hi);
+    sz *h = hist + (sz)t * nb;
+    for (sz i = lo; i < hi; ++i) h[(key[i] >> sh) & mask]++;
+#pragma omp barrier
+#pragma omp single
+    { sz acc = 0; for (sz b = 0; b < nb; ++b) for (int u = 0; u < T; ++u) { const sz c = hist[(sz)u * nb + b]; hist[(sz)u * nb + b] = acc; acc += c; } }
+    for (sz i = lo; i < hi; ++i) { const sz d = h[(key[i] >> sh) & mask]++; k2[d] = key[i]; v2[d] = val[i]; }
+  }
+  free(hist);
+}
+/* indices p (ascending) with flag[p] != 0 into idx; returns their number */
+static sz par_select(const unsigned char *flag, sz n, sz *idx)
+{
+  const int Tmax = omp_get_max_threads();
+  sz *cnt = NEW(sz, (sz)Tmax + 1);
+#pragma omp parallel
+  {
+    const int t = omp_get_thread_num(), T = omp_get_num_threads();
+    sz lo, hi; omp_chunk(n, t, T, &lo, &hi);
+    sz c = 0;
+    for (sz i = lo; i < hi; ++i) c += flag[i] != 0;
+    cnt[t + 1] = c;
+#pragma omp barrier
+#pragma omp single
+    for (int u = 0; u < T; ++u) cnt[u + 1] += cnt[u];
+    sz w = cnt[t];
+    for (sz i = lo; i < hi; ++i) if (flag[i]) idx[w++] = i;
+  }
+  sz total = 0;                                      /* cnt[T] of the team that ran (entries behind it stay 0) */
+  for (int u = 0; u <= Tmax; ++u) if (cnt[u] > total) total = cnt[u];
+  free(cnt);
+  return total;
+}
+/* first index of every run of equal keys (key sorted) into start[0 .. runs], start[runs] = n; returns the number of runs */
+static sz par_runs(const sz *key, sz n, sz *start)
+{
+  unsigned char *head = (unsigned char *)scr_get(SCR_FLAG, n);
+  OMP_FOR
+  for (sz p = 0; p < n; ++p) head[p] = p == 0 || key[p] != key[p - 1];
+  const sz runs = par_select(head, n, start);
+  start[runs] = n;
+  return runs;
+}
+#endif
 /* stable sort of (key,val) pairs by key; keys < nkeys when nkeys>0 (counting sort) else 32-bit LSD radix */
 static void stable_sort_by_key(sz *key, sz *val, sz n, sz nkeys)
 {
+#ifdef _OPENMP
+  {                                                  /* LSD radix, 11 bits per pass, over the bits the keys can have */
+    sz *ka = key, *va = val, *kb = (sz *)scr_get(SCR_K, n * sizeof(sz)), *vb = (sz *)scr_get(SCR_V, n * sizeof(sz));
+    int bits = 32;
+    if (nkeys) { bits = 1; while (((sz)1 << bits) < nkeys) ++bits; }
+    for (int sh = 0; sh < bits; sh += 11) {
+      const int w = bits - sh < 11 ? bits - sh : 11;
+      par_sort_pass(ka, va, kb, vb, n, sh, ((sz)1 << w) - 1);
+      sz *t = ka; ka = kb; kb = t; t = va; va = vb; vb = t;
+    }
+    if (ka != key) {
+      OMP_FOR
+      for (sz i = 0; i < n; ++i) { key[i] = ka[i]; val[i] = va[i]; }
+    }
+    return;
+  }
+#endif
   sz *k2 = NEW(sz, n), *v2 = NEW(sz, n);
   if (nkeys) {
     sz *cnt = NEW(sz, nkeys + 1);
@@ -357,29 +467,51 @@ static void stable_sort_by_key(sz *key, sz *val, sz n, sz nkeys)
 static void hskpng_sort_helper(orc_particles *s, int shuffle)
 {
   const sz n = s->n_part;
+  OMP_FOR
   for (sz p = 0; p < n; ++p) s->sorted_id[p] = p;
   if (!shuffle) memcpy(s->sorted_ijk, s->ijk, n * sizeof(sz));
   else {
+#ifdef _OPENMP
+    sz *un = (sz *)scr_get(SCR_UN, n * sizeof(sz));
+#else
     sz *un = NEW(sz, n);
+#endif
     for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un(&s->rng);
     stable_sort_by_key(un, s->sorted_id, n, 0);
+    OMP_FOR
     for (sz p = 0; p < n; ++p) s->sorted_ijk[p] = s->ijk[s->sorted_id[p]];
+#ifndef _OPENMP
     free(un);
+#endif
   }
   stable_sort_by_key(s->sorted_ijk, s->sorted_id, n, s->n_cell);
   s->sorted = 1;
 }
 static void hskpng_sort(orc_particles *s) { if (!s->sorted) hskpng_sort_helper(s, 0); }
-/* hskpng_count.ipp:16-48 */
-static void hskpng_count(orc_particles *s)
+/* hskpng_count.ipp:16-48: cells in use and their populations from the sorted cell numbers */
+static void count_runs(orc_particles *s)
 {
-  hskpng_sort(s);
+#ifdef _OPENMP
+  {
+    sz *start = (sz *)scr_get(SCR_START, (s->n_part + 1) * sizeof(sz));
+    const sz runs = par_runs(s->sorted_ijk, s->n_part, start);
+    OMP_FOR
+    for (sz i = 0; i < runs; ++i) { s->count_ijk[i] = s->sorted_ijk[start[i]]; s->count_num[i] = (n_t)(start[i + 1] - start[i]); }
+    s->count_n = runs;
+    return;
+  }
+#endif
   sz cn = 0;
   for (sz p = 0; p < s->n_part; ++p) {
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_num[cn] = 0; ++cn; }
     s->count_num[cn - 1] += 1;
   }
   s->count_n = cn;
+}
+static void hskpng_count(orc_particles *s)
+{
+  hskpng_sort(s);
+  count_runs(s);
 }
 /* hskpng_vterm.ipp:15-33,185-342 */
 static int vt0_bin(const orc_particles *s, double rw2)
@@ -422,6 +554,32 @@ static int mig_attrs(orc_particles *s, double **a);
 static int hskpng_remove_n0(orc_particles *s)
 {
   double *attrs[24]; const int na = mig_attrs(s, attrs);       /* every registered attribute (distmem_real_vctrs) + n */
+#ifdef _OPENMP
+  {
+    const sz n = s->n_part;
+    unsigned char *keep = (unsigned char *)scr_get(SCR_FLAG, n);
+    sz *idx = (sz *)scr_get(SCR_IDX, n * sizeof(sz));
+    OMP_FOR
+    for (sz p = 0; p < n; ++p) keep[p] = s->n[p] != 0;
+    const sz m = par_select(keep, n, idx);
+    if (m != n) {
+      double *tmp = (double *)scr_get(SCR_TMP, m * sizeof(double));
+      for (int a = 0; a < na; ++a) {
+        OMP_FOR
+        for (sz i = 0; i < m; ++i) tmp[i] = attrs[a][idx[i]];
+        OMP_FOR
+        for (sz i = 0; i < m; ++i) attrs[a][i] = tmp[i];
+      }
+      n_t *tn = (n_t *)tmp;                              /* (n_t and double are both 8 bytes) */
+      OMP_FOR
+      for (sz i = 0; i < m; ++i) tn[i] = s->n[idx[i]];
+      OMP_FOR
+      for (sz i = 0; i < m; ++i) s->n[i] = tn[i];
+    }
+    s->n_part = m;
+    return 0;
+  }
+#endif
   sz w = 0;
   for (sz p = 0; p < s->n_part; ++p) {
     if (s->n[p] == 0) continue;
@@ -439,6 +597,7 @@ static int hskpng_remove_n0(orc_particles *s)
 static void moms_all(orc_particles *s)
 {
   hskpng_sort(s);
+  OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = (double)s->n[p];
   s->selected_before_counting = 1;
 }
@@ -470,13 +629,27 @@ static void moms_calc(orc_particles *s, const double *vec, double power, int spe
   double *vals = s->mom_vals;            /* not tmp_part: diag_precip_rate passes that one as vec */
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) { const sz id = s->sorted_id[p]; vals[p] = moment_counter(s->n_filtered[id], vec[id], power); }
+#ifdef _OPENMP
+  {                                      /* reduce_by_key: one thread per run of a cell, summed in the serial order */
+    sz *start = (sz *)scr_get(SCR_START, (s->n_part + 1) * sizeof(sz));
+    cn = par_runs(s->sorted_ijk, s->n_part, start);
+    OMP_FOR
+    for (sz i = 0; i < cn; ++i) {
+      double acc = vals[start[i]];
+      for (sz p = start[i] + 1; p < start[i + 1]; ++p) acc = acc + vals[p];
+      s->count_ijk[i] = s->sorted_ijk[start[i]]; s->count_mom[i] = acc;
+    }
+  }
+#else
   for (sz p = 0; p < s->n_part; ++p) {
     const double v = vals[p];
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
     else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
   }
+#endif
   s->count_n = cn;
   if (specific && s->n_dims > 0)
+    OMP_FOR
     for (sz i = 0; i < cn; ++i) {
       s->count_mom[i] = s->count_mom[i] / s->dv[s->count_ijk[i]];
       s->count_mom[i] = s->count_mom[i] / s->rhod[s->count_ijk[i]];
@@ -521,6 +694,7 @@ static void save_liq_before(orc_particles *s)
   moms_all(s);
   moms_calc(s, s->rw2, 3. / 2., 1);
   if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = 0.;
+  OMP_FOR
   for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = -s->count_mom[i];
 }
 /* percell/particles_impl_cond.ipp:13-139 */
@@ -529,7 +703,8 @@ static void cond(orc_particles *s, double dt, double RH_max, int step, int turb_
   hskpng_sort(s);
   if (step == 0) { if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->rw_mom3[c] = 0.; }
   else for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = -s->rw_mom3[c];
-  OMP_FOR
+  /* (dynamic chunks: the root finder's iteration count differs between haze and cloud droplets, i.e. between regions of the box) */
+  _Pragma("omp parallel for schedule(dynamic, 2048)")
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
     cond_ctx cc = {s->rw2[p], dt / s->sstp_cond, s->rhod[c], s->rv[c], s->T[c], s->p[c], s->RH[c] + (turb_cond ? s->ssp[p] : 0.), s->eta[c],
@@ -542,14 +717,20 @@ static void cond(orc_particles *s, double dt, double RH_max, int step, int turb_
     for (sz i = 0; i < s->count_n; ++i) s->rw_mom3[s->count_ijk[i]] = s->count_mom[i];
     for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = s->rw_mom3[c] + s->drw_mom3[c];
   } else
+  {
+    OMP_FOR
     for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = s->count_mom[i] + s->drw_mom3[s->count_ijk[i]];
+  }
 }
 /* particles_impl_update_th_rv.ipp:74-191 */
 static void update_th_rv(orc_particles *s)
 {
   const double mlt = rho_w * (4. / 3) * ORC_PI;
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = s->drw_mom3[c] * mlt;
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) s->rv[c] = s->rv[c] - s->drw_mom3[c];
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) s->th[c] = s->th[c] - s->drw_mom3[c] * d_th_d_rv(s->T[c], s->th[c]);
 }
 /* ---------------- per-particle condensation substepping (src/impl/condensation/perparticle/, particles_step.ipp:199-236) ---------------- */
@@ -942,13 +1123,10 @@ static void coal(orc_particles *s, double dt, int turb_coal)
 {
   hskpng_sort_helper(s, 1);
   s->sorted = 1;
-  { sz cn = 0;                                   /* hskpng_count on the shuffled order */
-    for (sz p = 0; p < s->n_part; ++p) {
-      if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_num[cn] = 0; ++cn; }
-      s->count_num[cn - 1] += 1;
-    }
-    s->count_n = cn; }
+  count_runs(s);                                 /* hskpng_count on the shuffled order */
+  OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) { s->scl[c] = 0.; s->off[c] = 0; }
+  OMP_FOR
   for (sz i = 0; i < s->count_n; ++i) {
     const n_t n = s->count_num[i];
     s->scl[s->count_ijk[i]] = n > 1 ? ((double)(n * (n - 1)) / 2) / (n / 2) : 0;      /* scale_factor, coal.ipp:99-107 */
@@ -1123,7 +1301,7 @@ static void bcnd(orc_particles *s)
   const lcx_opts_init_t *o = &s->o;
   if (!distmem(s)) {
     if (!o->open_side_walls) { OMP_FOR for (sz p = 0; p < s->n_part; ++p) s->x[p] = periodic(s->x[p], o->x0, o->x1); }
-    else for (sz p = 0; p < s->n_part; ++p) if (s->x[p] >= o->x1 || s->x[p] < o->x0) s->n[p] = 0;
+    else { OMP_FOR for (sz p = 0; p < s->n_part; ++p) if (s->x[p] >= o->x1 || s->x[p] < o->x0) s->n[p] = 0; }
   } else {
     s->lft_count = s->rgt_count = 0;
     for (sz p = 0; p < s->n_part; ++p) if (s->x[p] < o->x0) s->lft_id[s->lft_count++] = p;
@@ -1133,21 +1311,40 @@ static void bcnd(orc_particles *s)
   }
   if (s->n_dims == 3) {
     if (!o->open_side_walls) { OMP_FOR for (sz p = 0; p < s->n_part; ++p) s->y[p] = periodic(s->y[p], o->y0, o->y1); }
-    else for (sz p = 0; p < s->n_part; ++p) if (s->y[p] >= o->y1 || s->y[p] < o->y0) s->n[p] = 0;
+    else { OMP_FOR for (sz p = 0; p < s->n_part; ++p) if (s->y[p] >= o->y1 || s->y[p] < o->y0) s->n[p] = 0; }
   }
   if (s->n_dims > 1) {
     if (!o->periodic_topbot_walls) {
+      OMP_FOR
       for (sz p = 0; p < s->n_part; ++p) if (s->z[p] >= o->z1) s->n[p] = 0;
       double liq_vol = 0, dry_vol = 0, liq_num = 0, prtcl_num = 0;
+      OMP_FOR
       for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = s->z[p] < o->z0 ? (double)s->n[p] : 0.;
+#ifdef _OPENMP
+      {                        /* the four sums over the SDs below the floor only, in index order: every other term is +0.0, which
+                                  leaves a non-negative running sum as it is -- the same bits as the full serial loops below */
+        const sz n = s->n_part;
+        unsigned char *below = (unsigned char *)scr_get(SCR_FLAG, n);
+        sz *idx = (sz *)scr_get(SCR_IDX, n * sizeof(sz));
+        OMP_FOR
+        for (sz p = 0; p < n; ++p) below[p] = s->n_filtered[p] != 0.;
+        const sz m = par_select(below, n, idx);
+        for (sz i = 0; i < m; ++i) { const sz p = idx[i]; liq_vol = liq_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rw2[p], 3. / 2.); }
+        for (sz i = 0; i < m; ++i) { const sz p = idx[i]; dry_vol = dry_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rd3[p], 1.); }
+        for (sz i = 0; i < m; ++i) { const sz p = idx[i]; liq_num = liq_num + (s->rw2[p] == 0. ? 0. : s->n_filtered[p]); }
+        for (sz i = 0; i < m; ++i) { const sz p = idx[i]; prtcl_num = prtcl_num + s->n_filtered[p]; }
+      }
+#else
       for (sz p = 0; p < s->n_part; ++p) liq_vol = liq_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rw2[p], 3. / 2.);
       for (sz p = 0; p < s->n_part; ++p) dry_vol = dry_vol + 4. / 3. * ORC_PI * s->n_filtered[p] * pow(s->rd3[p], 1.);
       for (sz p = 0; p < s->n_part; ++p) liq_num = liq_num + (s->rw2[p] == 0. ? 0. : s->n_filtered[p]);
       for (sz p = 0; p < s->n_part; ++p) prtcl_num = prtcl_num + s->n_filtered[p];
+#endif
       s->puddle[LCX_OUT_LIQ_VOL] += liq_vol; s->puddle[LCX_OUT_DRY_VOL] += dry_vol;
       s->puddle[LCX_OUT_LIQ_NUM] += liq_num; s->puddle[LCX_OUT_PRTCL_NUM] += prtcl_num;
+      OMP_FOR
       for (sz p = 0; p < s->n_part; ++p) if (s->z[p] < o->z0) s->n[p] = 0;
-    } else for (sz p = 0; p < s->n_part; ++p) s->z[p] = periodic(s->z[p], o->z0, o->z1);
+    } else { OMP_FOR for (sz p = 0; p < s->n_part; ++p) s->z[p] = periodic(s->z[p], o->z0, o->z1); }
   }
 }
 /* post_copy.ipp:18-35 */
@@ -1240,7 +1437,9 @@ static int resize_npart(orc_particles *s)
 static void init_finalize(orc_particles *s, double kappa)
 {
   const lcx_opts_init_t *o = &s->o;
+  OMP_FOR
   for (sz p = s->n_part_old; p < s->n_part; ++p) s->kpa[p] = kappa;
+  OMP_FOR
   for (sz p = s->n_part_old; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
     s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
@@ -1252,6 +1451,7 @@ static void init_finalize(orc_particles *s, double kappa)
   for (int ix = 0; ix < 3; ++ix) {
     if (nn[ix] == 0) continue;
     for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+    OMP_FOR
     for (sz g = 0; g < s->n_part_to_init; ++g) {
       const sz p = s->n_part_old + g, c = s->ijk[p];
       sz ii;
@@ -1406,18 +1606,22 @@ static int init_SD_with_distros(orc_particles *s)
     s->n_part_to_init = (sz)per_cell * s->n_cell;
     s->n_part += s->n_part_to_init;
     if (resize_npart(s)) return 1;
+    OMP_FOR
     for (sz p = s->n_part_old; p < s->n_part; ++p) { s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
     /* init_ijk.ipp:36-52 */
-    { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
+    OMP_FOR
+    for (sz g = 0; g < s->n_part_to_init; ++g) s->ijk[s->n_part_old + g] = g / (sz)per_cell;
     /* init_dry_sd_conc.ipp:43-86 */
     for (sz g = 0; g < s->n_part_to_init; ++g) s->tmp_part[g] = rng_u01(&s->rng);
+    OMP_FOR
     for (sz g = 0; g < s->n_part_to_init; ++g) {
       const sz c = s->ijk[s->n_part_old + g];
       const sz ptr = (sz)per_cell * c;
       const double lnrd = s->log_rd_min + ((double)(g - ptr) + s->tmp_part[g]) * (s->log_rd_max - s->log_rd_min) / (double)s->count_num[c];
       s->rd3[s->n_part_old + g] = exp(3 * lnrd);
     }
-    /* init_n.ipp:48-143 */
+    /* init_n.ipp:48-143 (a distribution given as a function pointer may be a Python callback: those stay on one thread) */
+#pragma omp parallel for schedule(static) if (dd->fn == NULL)
     for (sz g = 0; g < s->n_part_to_init; ++g) {
       const sz p = s->n_part_old + g, c = s->ijk[p];
       const double lnrd = log(s->rd3[p]) / 3.;
@@ -1675,18 +1879,18 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
       if (s->rw2[p] > rc2) s->ict[p] += s->dt; else s->ict[p] = 0;
     }
   if (opts->cond) {
-    hskpng_sort(s);
-    hskpng_mfp(s);
+    TMR(TM_SORT, hskpng_sort(s));
+    TMR(TM_TPR, hskpng_mfp(s));
     if (s->o.exact_sstp_cond && (s->sstp_cond > 1 || s->sstp_cond_act > 1)) cond_perparticle(s, opts->RH_max, opts->turb_cond);
     else for (int step = 0; step < s->sstp_cond; ++step) {
-      sstp_percell_step(s, step);
+      TMR(TM_OTHER, sstp_percell_step(s, step));
       if (opts->turb_cond) for (sz p = 0; p < s->n_part; ++p) s->ssp[p] = s->ssp[p] + s->dt / s->sstp_cond * s->dot_ssp[p];   /* apply_perparticle_sgs_supersat.ipp */
-      hskpng_Tpr(s);
-      if (step == 0) save_liq_before(s);
-      cond(s, s->dt, opts->RH_max, step, opts->turb_cond);
-      update_th_rv(s);
+      TMR(TM_TPR, hskpng_Tpr(s));
+      if (step == 0) TMR(TM_MOMS, save_liq_before(s));
+      TMR(TM_COND, cond(s, s->dt, opts->RH_max, step, opts->turb_cond));
+      TMR(TM_MOMS, update_th_rv(s));
     }
-    sstp_save(s);
+    TMR(TM_OTHER, sstp_save(s));
     sync_out_arr(s, s->th, th, s->n_cell);
     sync_out_arr(s, s->rv, rv, s->n_cell);
   }
@@ -1715,30 +1919,30 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
   if (opts->src) FAIL("libcloudph++: aerosol source was switched off in opts_init");
   if (opts->rlx) FAIL("libcloudph++: aerosol relaxation was switched off in opts_init");
   if (adjust_timesteps(s, opts->dt)) return 1;
-  hskpng_Tpr(s);
-  if (opts->sedi || opts->coal || opts->cond) hskpng_vterm(s, 0);
+  TMR(TM_TPR, hskpng_Tpr(s));
+  if (opts->sedi || opts->coal || opts->cond) TMR(TM_VTERM, hskpng_vterm(s, 0));
   if (opts->coal) {
     for (int step = 0; step < s->sstp_coal; ++step) {
-      coal(s, s->dt / s->sstp_coal, opts->turb_coal);
+      TMR(TM_COAL, coal(s, s->dt / s->sstp_coal, opts->turb_coal));
       if (step + 1 != s->sstp_coal) hskpng_vterm(s, 1);
     }
     if (s->increase_sstp_coal) { ++s->sstp_coal; s->increase_sstp_coal = 0; }
-    hskpng_approximate_rc2_invalid(s);       /* particles_step.ipp:402-403 */
+    TMR(TM_OTHER, hskpng_approximate_rc2_invalid(s));       /* particles_step.ipp:402-403 */
   }
   if (opts->turb_adve || opts->turb_cond) hskpng_tke(s);                     /* particles_step.ipp:406-427 */
   if (opts->turb_adve) hskpng_turb_vel(s, s->dt, 0);
   else if (opts->turb_cond) hskpng_turb_vel(s, s->dt, 1);
   if (opts->turb_cond) hskpng_turb_dot_ss(s);
-  if (opts->adve) adve(s);
+  if (opts->adve) TMR(TM_MOVE, adve(s));
   s->adve_scheme = s->o.adve_scheme;
   if (opts->turb_adve) {                                                      /* turb_adve.ipp:13-33: x, z, y get up, wp, vp */
     double *pos[3] = {s->x, s->z, s->y}, *vel[3] = {s->up, s->wp, s->vp};
     for (int i = 0; i < s->n_dims; ++i) for (sz p = 0; p < s->n_part; ++p) pos[i][p] = pos[i][p] + vel[i][p] * s->dt;
   }
-  if (opts->sedi) sedi(s, s->dt);
+  if (opts->sedi) TMR(TM_MOVE, sedi(s, s->dt));
   if (opts->subs) subs(s, s->dt);
-  bcnd(s);
-  if (!distmem(s)) { if (post_copy(s, opts)) return 1; }
+  TMR(TM_MOVE, bcnd(s));
+  if (!distmem(s)) { int e_ = 0; TMR(TM_POST, e_ = post_copy(s, opts)); if (e_) return 1; }
   s->selected_before_counting = 0;
   return 0;
 }

@@ -316,22 +316,37 @@ def test_puddle_known_totals(seed):
     check_puddle(*run_puddle(oracle_particles, seed))
 
 
-def test_openmp_build_of_the_oracle_is_bit_identical():
-    """liblcx_oracle_omp.so (bench.py's cpu_baseline leg) spreads only elementwise loops over the cores; reductions and
-    scans stay serial, so its results equal the serial oracle's bit for bit"""
+@pytest.mark.parametrize("native_modes", [False, True])
+def test_openmp_build_of_the_oracle_is_bit_identical(native_modes):
+    """liblcx_oracle_omp.so (bench.py's cpu_baseline leg, the production-size parity tests) runs the elementwise loops, the stable
+    sort, the per-cell counts and sums, the compaction and the boundary selections on all cores the way the reference's OpenMP
+    backend does (thrust::omp); a run of a cell is summed by one thread in the serial order and the generator stays serial, so its
+    results equal the serial oracle's bit for bit -- including the puddle's global sums and the storage order after SDs were removed"""
     from _harness import oracle_omp_particles, box_opts, box_fields
-    oi = box_opts(5, 4, 6, 32)
+    oi = box_opts(9, 4, 7, 32)
+    if native_modes:                                     # (a distribution without a Python callback: the parallel init_n path)
+        oi.dry_distros = {(.61, 0.): lgrngn.lognormal([.02e-6, .075e-6], [1.4, 1.6], [60e6, 40e6])}
     th0, rv0, rhod, C = box_fields(oi)
     out = []
     for make in (oracle_particles, oracle_omp_particles):
         pr = make(oi)
         th, rv = th0.copy(), rv0.copy()
         pr.init(th, rv, rhod, **C)
+        rw2 = pr.get_attr("rw2")
+        z = pr.get_attr("z")
+        big = (np.arange(rw2.size) % 37 == 0) & (z < 1.5 * oi.dz)          # drizzle near the floor: falls out, feeds the puddle
+        rw2[big] = (150e-6) ** 2
+        pr.set_particles(pr.state_u64("n"), pr.get_attr("rd3"), rw2, pr.get_attr("kappa"), np.full(rw2.size, -1.),
+                         pr.get_attr("x"), pr.get_attr("y"), z)
         opts = lgrngn.opts_t()
         for _ in range(3):
             pr.step_sync(opts, th, rv, rhod, **C)
             pr.step_async(opts)
-        out.append((th.copy(), rv.copy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.state_u64("n"), pr.state_u64("sorted_id")))
+        pud = pr.diag_puddle()
+        assert max(pud.values()) > 0 and pr.n_part < rw2.size, "no super-droplet left through the floor"
+        out.append((th.copy(), rv.copy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.get_attr("z"), pr.state_real("vt"), pr.get_attr("kappa"),
+                    pr.state_u64("n"), pr.state_u64("sorted_id"), pr.state_u64("ijk"),
+                    np.array([pud[k] for k in sorted(pud)])))
     for a, b in zip(*out):
         assert np.array_equal(a, b)
 
