@@ -105,26 +105,6 @@ def host_cpu():
     return model, len(cores) or (os.cpu_count() or 1)
 
 
-def cpu_quota():
-    """CPUs this process may use at once: the cgroup's CFS quota (cpu.max, or cpu.cfs_quota_us / cpu.cfs_period_us) if one is set, and
-    never more than the affinity mask.  A GPU box that shows 256 hardware threads but grants 16 CPUs of run time is throttled, not
-    sped up, by 128 OpenMP threads (measured: 1.2e7 super-droplets/s on 128 threads, 2.0e7 on 16)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            n = min(n, max(1, int(float(q) / float(per) + .5)))
-    except (OSError, ValueError):
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, int(q / per + .5)))
-        except (OSError, ValueError):
-            pass
-    return n
-
-
 def mem_available_gb():
     try:
         for ln in open("/proc/meminfo"):
@@ -151,8 +131,7 @@ def cpu_baseline(args):
     oi = make_opts_init(n, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44)
     th, rv, rhod, Cx, Cy, Cz = make_fields(n, n, n, 0, n, np, np.float64)
     lib = h.oracle_omp_lib()
-    quota = cpu_quota()
-    lib.orc_set_num_threads(min(quota, int(lib.orc_num_threads())))
+    quota = h.cpu_quota()                                           # (oracle_omp_lib has already set the thread count to it)
     threads = int(lib.orc_num_threads())
     pr = h.oracle_omp_particles(oi)
     model, phys = host_cpu()

@@ -44,7 +44,7 @@ def get_dev_nx(nx, rank, size):
     return n
 
 
-def distmem_opts(opts_init, rank, size):
+def distmem_opts(opts_init, rank, size, self_ring=False):
     """Per-rank copy of opts_init for the slab owned by `rank` (distmem_opts.hpp:20-52).
     Returns (local opts_init, n_x_bfr)."""
     oi = copy.copy(opts_init)
@@ -60,7 +60,7 @@ def distmem_opts(opts_init, rank, size):
     oi.n_sd_max = opts_init.n_sd_max // size + 1
     oi.n_x_tot = opts_init.nx
     oi.n_x_bfr = n_x_bfr
-    if size > 1:
+    if size > 1 or self_ring:
         if not opts_init.open_side_walls:
             oi.bcond_lft = oi.bcond_rgt = BCOND_DISTMEM
         else:
@@ -93,7 +93,7 @@ class particles_multi_t:
                None    -- "rccl" when the engine runs on a GPU and the process group has a device backend, else "host".
     """
 
-    def __init__(self, opts_init, real_t=np.float64, make_particles=None, device=None, global_arrays=False, transport=None):
+    def __init__(self, opts_init, real_t=np.float64, make_particles=None, device=None, global_arrays=False, transport=None, self_ring=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -106,7 +106,13 @@ class particles_multi_t:
             raise RuntimeError("libcloudph++: number of devices exceeds nx")                  # :62
         self.real_t = np.dtype(real_t)
         self.glob_opts_init = opts_init
-        oi, self.n_x_bfr = distmem_opts(opts_init, self.rank, self.size)
+        # self_ring: ONE rank whose left and right neighbour is the rank itself (periodic side walls): every message of the protocol
+        # travels through the transport to the sender's own inbox.  What a one-GPU box can run of the RCCL path (RCCL refuses two
+        # ranks on one device): tests/test_hip_spmd.py drives it; a production run has no use for it.
+        self.self_ring = bool(self_ring) and self.size == 1
+        if self.self_ring and opts_init.open_side_walls:
+            raise RuntimeError("libcloudph++: a ring of one rank needs periodic side walls")
+        oi, self.n_x_bfr = distmem_opts(opts_init, self.rank, self.size, self.self_ring)
         if not global_arrays:
             oi.n_x_bfr = 0
             oi.n_x_tot = oi.nx        # slab-local arrays: a Courant halo wraps inside the slab, the exchange below overwrites it
@@ -125,8 +131,9 @@ class particles_multi_t:
         periodic = not opts_init.open_side_walls
         self.lft = (self.rank - 1) % self.size if (periodic or self.rank > 0) else None
         self.rgt = (self.rank + 1) % self.size if (periodic or self.rank < self.size - 1) else None
-        if self.size == 1:
+        if self.size == 1 and not self.self_ring:
             self.lft = self.rgt = None
+        self.exchanging = self.size > 1 or self.self_ring
         # neighbours' domain edges in THEIR local frames (xchng_domains.ipp:23-52)
         self.lft_x1 = get_dev_nx(opts_init.nx, self.lft, self.size) * opts_init.dx if self.lft is not None else -1.
         if self.lft is not None and self.lft == self.size - 1:
@@ -148,7 +155,7 @@ class particles_multi_t:
             raise RuntimeError("libcloudph++: the rccl transport needs the engine's buffers on a GPU")
         self.transport = transport
         self._halo_bufs = {}
-        if self.size > 1:
+        if self.exchanging:
             self._setup_exchange()
 
     # ---- message buffers: owned by the engine, wrapped once
@@ -203,6 +210,15 @@ class particles_multi_t:
     def _p2p(self, send_l, send_r, recv_r, recv_l, between=None):
         """between: called after the operations have been STARTED and before they are waited for (work that overlaps the transfer)"""
         dist = self.dist
+        if self.self_ring and self.transport == "host":
+            # (gloo has no connection from a rank to itself: what goes out to the left comes in from the right)
+            if between is not None:
+                between()
+            if send_l is not None:
+                recv_r.copy_(send_l)
+            if send_r is not None:
+                recv_l.copy_(send_r)
+            return
         ops = []
         if send_l is not None:
             ops.append(dist.P2POp(dist.isend, send_l, self.lft))
@@ -260,7 +276,7 @@ class particles_multi_t:
         (impl_multi_gpu/..._step_async_and_copy.ipp:28-206 without the thread barriers)"""
         p = self.prt
         p.step_async(opts)
-        if self.size == 1:
+        if not self.exchanging:
             return
         hl, hr = self.lft is not None, self.rgt is not None
         nxt = [self._next_cap(0), self._next_cap(1)]
@@ -301,7 +317,7 @@ class particles_multi_t:
     def _exchange_courant_halo(self):
         """pred_corr advection reads Courant numbers up to two x-planes outside the slab: every rank sends the planes next
         to its edges to the neighbours (particles_impl_xchng_courants.ipp:15-160), three small messages per side"""
-        if self.size == 1:
+        if not self.exchanging:
             return
         torch = self.torch
         isz = self.real_t.itemsize

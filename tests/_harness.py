@@ -52,6 +52,26 @@ def oracle_fastmath_particles(opts_init):
 _oracle_omp = None
 
 
+def cpu_quota():
+    """CPUs this process may use at once: the cgroup's CFS quota (cpu.max, or cpu.cfs_quota_us / cpu.cfs_period_us) if one is set, and
+    never more than the affinity mask.  A GPU box that shows 256 hardware threads but grants 16 CPUs of run time is throttled, not
+    sped up, by 128 OpenMP threads (measured: 1.2e7 super-droplets/s on 128 threads, 2.0e7 on 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + .5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + .5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def oracle_omp_lib():
     """the strict oracle source with its elementwise loops spread over the host cores (-fopenmp); bench.py's CPU baseline"""
     global _oracle_omp
@@ -59,6 +79,7 @@ def oracle_omp_lib():
         oracle_lib()
         _oracle_omp = ctypes.CDLL(os.path.join(ORACLE_DIR, "liblcx_oracle_omp.so"))
         _oracle_omp.orc_num_threads.restype = ctypes.c_int
+        _oracle_omp.orc_set_num_threads(ctypes.c_int(min(cpu_quota(), int(_oracle_omp.orc_num_threads()))))
     return _oracle_omp
 
 

@@ -28,7 +28,8 @@ def run(rank, world, port, nx, nz, Cx_val, result_path, scheme="euler", sd_conc=
         oi.n_sd_max = sd_conc * nx * nz * 2
         oi.adve_scheme = lgrngn.as_t[scheme]         # pred_corr: the Courant halo is exchanged between the ranks as well
         oi.rng_seed = 44 + rank                      # mpi_adve_test.cpp:95 seeds every rank differently
-        prt = multi.particles_multi_t(oi, np.float64, make_particles=h.oracle_particles)
+        # one rank: a ring of one (its neighbours are the rank itself) -- the protocol with every message delivered to the sender
+        prt = multi.particles_multi_t(oi, np.float64, make_particles=h.oracle_particles, self_ring=(world == 1))
         nxl = prt.opts_init.nx
         assert sum(multi.get_dev_nx(nx, r, world) for r in range(world)) == nx
         th, rv, rhod = 300. * np.ones((nxl, nz)), .01 * np.ones((nxl, nz)), np.ones((nxl, nz))

@@ -43,10 +43,17 @@ def run(mode, rank, world, port, res, transport):
     import torch.distributed as dist
     import _harness as h
     from libcloudphxx_amd import lgrngn, multi
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    # RCCL refuses two ranks on one device: on the one-GPU test box it carries the messages of ONE rank whose neighbours are the rank
+    # itself (self_ring) -- every send and receive of the protocol is a real RCCL operation on the engine's stream
+    self_ring = mode.startswith("self")
+    if self_ring:
+        assert world == 1
+        mode = mode[4:]
+    dist.init_process_group("nccl" if transport == "rccl" else "gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world,
+                            **({"device_id": dev} if transport == "rccl" else {}))
     try:
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
         if mode == "ring":
             nx, nz = 8, 4
             oi = lgrngn.opts_init_t()
@@ -60,7 +67,8 @@ def run(mode, rank, world, port, res, transport):
             oi.adve_scheme = lgrngn.as_t.euler
             oi.rng_seed = 44 + rank
             oi.dev_id = 0
-            prt = multi.particles_multi_t(oi, np.float64, device=dev, transport=transport)
+            prt = multi.particles_multi_t(oi, np.float64, device=dev, transport=transport, self_ring=self_ring)
+            assert prt.transport == transport
             nxl = prt.opts_init.nx
             th, rv, rhod = 300. * np.ones((nxl, nz)), .01 * np.ones((nxl, nz)), np.ones((nxl, nz))
             Cx, Cz = np.ones((nxl + 1, nz)), np.zeros((nxl, nz + 1))
@@ -90,10 +98,10 @@ def run(mode, rank, world, port, res, transport):
         if mode == "uneven":
             C["Cx"] = 0.95 * np.ones_like(C["Cx"])
         oi.dev_id = 0
-        prt = multi.particles_multi_t(oi, np.float64, device=dev, transport=transport, global_arrays=True)
+        prt = multi.particles_multi_t(oi, np.float64, device=dev, transport=transport, global_arrays=True, self_ring=self_ring)
         prt.init(th, rv, rhod, **C)
         opts = lgrngn.opts_t()
-        opts.coal = mode == "steps"
+        opts.coal = mode == "steps" and not self_ring
         n_tot0 = None
         for it in range(3 if mode == "steps" else 5):
             prt.step_sync(opts, th, rv, rhod, **C)       # (global arrays: every rank writes its planes of its own copy)
@@ -102,6 +110,8 @@ def run(mode, rank, world, port, res, transport):
         b, n = prt.n_x_bfr, prt.opts_init.nx
         st["th"], st["rv"] = th[b:b + n], rv[b:b + n]
         st["host_syncs"] = np.array([prt.host_syncs])
+        st["bytes_moved"] = np.array([prt.bytes_moved])
+        st["y"] = prt.get_attr("y") if ny else np.zeros(0)
         np.savez(res % rank, **st)
         sys.exit(0)
     finally:

@@ -44,9 +44,9 @@ def wait_all(procs, limit_s):
         time.sleep(0.05)
 
 
-def launch(mode, world, res):
+def launch(mode, world, res, transport="host"):
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_spmd_worker.py"), mode, str(r), str(world), str(port), res, "host"])
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "_spmd_worker.py"), mode, str(r), str(world), str(port), res, transport])
              for r in range(world)]
     codes = wait_all(procs, 240)
     assert codes == [0] * world, codes
@@ -97,3 +97,48 @@ def test_spmd_hip_engine_equals_the_native_multi_device_object(mode, world, tmp_
         b, n = r * per, (per if r < world - 1 else nx - r * per)
         assert np.array_equal(d["th"], th[b:b + n]) and np.array_equal(d["rv"], rv[b:b + n]), r
     assert tot == mul.n_part and n0 - 4 <= tot <= n0      # (no coalescence in "uneven": at most a droplet or two through the floor)
+
+
+# ---- the RCCL transport itself.  RCCL refuses two ranks on one device, and the test box has one: ONE rank whose left and right neighbour
+# is the rank itself (particles_multi_t(self_ring=True)) sends every message of the protocol to its own inbox through RCCL -- the engine's
+# buffers handed to torch.distributed as device tensors, the operations queued on the engine's own stream (ExternalStream), the unpack
+# kernels ordered behind them by that stream and nothing else.  What a node with one GPU per rank adds to this is other peers.
+def test_rccl_transport_ring_of_one_round_trip_bit_identical(tmp_path):
+    res = str(tmp_path / "r%d.npy")
+    launch("selfring", 1, res, "rccl")
+    d = np.load(res % 0)
+    assert np.array_equal(d[0], d[1]) and d[0][0].sum() > 0
+
+
+def test_rccl_transport_ring_of_one_three_steps_equal_the_periodic_box(tmp_path):
+    """condensation + advection + sedimentation, three steps: the super-droplets of the ring of one (every droplet that leaves the slab
+    comes back through RCCL) are the super-droplets of the plain periodic single-device run -- as a set: the immigrants take other
+    storage slots.  (No coalescence here: its pairing follows the storage order.)"""
+    import _spmd_worker as w
+    res = str(tmp_path / "s%d.npz")
+    launch("selfsteps", 1, res, "rccl")
+    d = np.load(res % 0)
+    assert d["bytes_moved"][0] > 0
+    oi = w.box(8, 3, 4, 24, 44, coal_switch=True)
+    th, rv, rhod, C = h.box_fields(oi)
+    prt = lgrngn.particles_t(oi, np.float64)
+    prt.init(th, rv, rhod, **C)
+    opts = lgrngn.opts_t()
+    opts.coal = False
+    for it in range(3):
+        prt.step_sync(opts, th, rv, rhod, **C)
+        prt.step_async(opts)
+    assert int(d["n_part"][0]) == prt.n_part
+    key = lambda rd3, rw2, x, z: np.lexsort((z, x, rw2, rd3))
+    a = {k: d[k] for k in ("rd3", "rw2", "x", "z")}
+    b = {k: prt.get_attr(k) for k in ("rd3", "rw2", "x", "z")}
+    ia, ib = key(**a), key(**b)
+    assert np.array_equal(a["rd3"][ia], b["rd3"][ib])
+    assert np.array_equal(d["n"][ia], prt.state_u64("n")[ib])
+    np.testing.assert_allclose(a["rw2"][ia], b["rw2"][ib], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a["z"][ia], b["z"][ib], rtol=0, atol=1e-9)
+    # x: the periodic box wraps with fmod, the ring re-bases by the neighbour's edge -- the same number up to the rounding of one subtraction
+    dx = np.abs(a["x"][ia] - b["x"][ib])
+    assert np.all(np.minimum(dx, oi.x1 - dx) < 1e-9)
+    np.testing.assert_allclose(d["th"], th, rtol=1e-12)
+    np.testing.assert_allclose(d["rv"], rv, rtol=1e-12)

@@ -39,7 +39,8 @@ def test_distmem_opts_follow_reference_split():
 
 
 @pytest.mark.parametrize("world,nx,Cx,scheme,sd_conc", [(2, 6, 1., "euler", 8), (2, 5, -1., "euler", 8), (3, 7, 1., "euler", 8), (2, 8, 1., "pred_corr", 8),
-                                                        (3, 10, -1., "pred_corr", 8), (2, 6, 1., "euler", 80), (3, 7, -1., "euler", 80)])
+                                                        (3, 10, -1., "pred_corr", 8), (2, 6, 1., "euler", 80), (3, 7, -1., "euler", 80),
+                                                        (1, 5, 1., "euler", 80), (1, 6, -1., "pred_corr", 8)])
 def test_ring_round_trip_is_bit_identical(world, nx, Cx, scheme, sd_conc, tmp_path):
     """sd_conc = 80: 320 super-droplets cross each face per step, more than the one-tile first part the ranks start with -- the
     protocol's second batch (libcloudphxx_amd/multi.py) runs in the first step and the announced capacity covers the later ones"""
