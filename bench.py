@@ -199,10 +199,20 @@ def main():
                     help="under torch.distributed.run: rank 0 drives all N devices with the native multi_HIP object (one host thread per "
                          "device, migrants written into the neighbour's memory), the other ranks only join the barriers; default "
                          "there: one single-device object per rank with the migrants over RCCL (libcloudphxx_amd.multi)")
+    ap.add_argument("--self-ring", action="store_true",
+                    help="ONE rank of the one-object-per-rank path whose neighbours on both sides are the rank itself: its migrants leave "
+                         "and arrive through RCCL -- what a one-GPU box can measure of that path (with --nx: one slab of an N-way split, "
+                         "its exchange included).  The droplets are those of the periodic box; only their route differs.")
     ap.add_argument("--transport", choices=["rccl", "host"], default=None,
                     help="one object per rank: how the migrants travel -- device buffers over RCCL (default with one GPU per rank), or "
                          "staged through the host over gloo (default when the ranks share a GPU)")
     args = ap.parse_args()
+
+    # stdout carries ONE line, the result.  Libraries that write to file descriptor 1 on their own (RCCL prints a version banner from
+    # C stdio when its first communicator comes up, flushed at exit, i.e. AFTER the result) go to stderr instead.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))          # > 1: launched by torch.distributed.run, one process per GPU
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +225,9 @@ def main():
     # into the neighbour's memory over xGMI).  Under torch.distributed.run (WORLD_SIZE = N) every rank owns one slab on its own GPU
     # and the migrants travel over RCCL (libcloudphxx_amd.multi) -- the launcher's N processes are N working ranks; --native lets
     # rank 0 drive all N devices with the native object instead (the other ranks then only join the barriers).
-    spmd = world > 1 and not args.native
+    if args.self_ring and (world > 1 or args.gpus > 1):
+        raise SystemExit("--self-ring is the one-rank form of the one-object-per-rank path: no launcher, --gpus 1")
+    spmd = (world > 1 and not args.native) or args.self_ring
     native_multi = args.gpus > 1 and not spmd
     idle = native_multi and rank > 0
     n_slabs = args.gpus
@@ -238,6 +250,13 @@ def main():
         # host-side collectives (barriers, the timing reduction) over gloo, so that a waiting rank sleeps on the host instead of
         # spinning in a kernel on a GPU that rank 0 is driving; device tensors (the SPMD path's migrants) go over RCCL
         dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(minutes=60))
+    elif args.self_ring:
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("cpu:gloo,cuda:nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
 
     from libcloudphxx_amd import lgrngn, multi
     real_t = np.float64 if args.real == "f64" else np.float32
@@ -284,9 +303,10 @@ def main():
     def setup_local():
         """a single-device object: the whole domain, or this rank's slab of the one-object-per-rank run"""
         oi.dev_count, oi.dev_id, oi.n_sd_max = 0, dev_index, n_sd_max0
-        if world > 1:
+        if spmd:
             shared_gpu = torch.cuda.device_count() < world           # several ranks on one device: RCCL refuses that, stage through the host
-            prt = multi.particles_multi_t(oi, real_t, device=dev, transport=args.transport or ("host" if shared_gpu else "rccl"))
+            prt = multi.particles_multi_t(oi, real_t, device=dev, transport=args.transport or ("host" if shared_gpu else "rccl"),
+                                          self_ring=args.self_ring)
             nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
         else:
             prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
@@ -470,7 +490,8 @@ def main():
                 "; all slabs on device 0" if args.oversubscribe else "",
                 "; driven by rank 0 of the launcher, ranks 1..%d idle" % (world - 1) if world > 1 else "")
         elif spmd:
-            decomposition_note = " (one single-device object per rank, migrants %s, %d second-part exchanges on rank 0%s)" % (
+            decomposition_note = " (%s, migrants %s, %d second-part exchanges on rank 0%s)" % (
+                "ONE rank whose neighbours are the rank itself (--self-ring)" if args.self_ring else "one single-device object per rank",
                 "over RCCL" if prt.transport == "rccl" else "staged through the host over gloo (ranks share a GPU)", prt.second_rounds,
                 "; fallback: " + fallback_reason if fallback_reason else "")
         else:
@@ -497,7 +518,7 @@ def main():
             "stage_ms_per_step": {k: (v / args.steps if k != "rendezvous_hidden_share" else v) for k, v in stage_ms.items()},
             "stage_roofline": stage_roof,
         }
-        if world_out == 1 and not args.strict_fp and not args.no_strict_leg and args.cond_mode == "percell":
+        if world_out == 1 and not args.strict_fp and not args.no_strict_leg and args.cond_mode == "percell" and not args.self_ring:
             # the API default (opts_init.strict_fp = 1; both host mirrors): the same box, the same steps, IEEE operation order in the
             # condensation kernel and the reference's ordered per-cell sums -- what a driver that changes nothing gets
             del prt
@@ -528,9 +549,10 @@ def main():
                                              "algorithmic_bytes_per_sd": cond_bytes_per_sd},
                                 "stage_ms_per_step": {k: v / args.strict_leg_steps for k, v in st_s.items()}}
             del prt_s
-        if world_out == 1 and not args.no_cpu_baseline:
+        if world_out == 1 and not args.no_cpu_baseline and not args.self_ring:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()

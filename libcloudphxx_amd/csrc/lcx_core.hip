@@ -186,7 +186,8 @@ struct Particles : IParticles {
   DevBuf<uint32_t> sorted_alt;          // (exchange only) the in-cell ranking's output while `rank` still holds the boundary SDs' arrival ranks
   uint32_t *sid() const { return sorted_id.p + sort_base; }
   uint32_t *sijk() const { return sorted_ijk.p + sort_base; }
-  DevBuf<uint8_t> mig, cond_pre; DevBuf<uint32_t> defer_cnt;
+  DevBuf<uint8_t> mig, cond_pre; DevBuf<uint32_t> defer_cnt, wg_mig;
+  void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
   // ---- cell fields ----
@@ -290,7 +291,7 @@ struct Particles : IParticles {
     d_flag.alloc_zero(1, st);
     puddle_partial.alloc(size_t(nblk(cap)) * 4); puddle_sum.alloc(4 + 256 * 4); puddle_acc.alloc_zero(4, st);
     outbuf_h.assign(ncell, T(0));
-    if (distmem()) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
+    if (distmem()) alloc_mig();
   }
   ~Particles() override { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (pinned) (void)hipHostFree(pinned); }
   // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
@@ -1062,7 +1063,7 @@ struct Particles : IParticles {
     const bool want_puddle = do_bcnd && n_dims > 1 && !o.periodic_topbot_walls;
     const unsigned blocks = nblk(nphys);
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
-    a.mig = mig.p;
+    a.mig = mig.p; a.wg_mig = (do_bcnd && distmem()) ? wg_mig.p : nullptr;
     // (no memsets: every lane stores its migrant flag, and the histogram and the dead count are cleared behind each sort's scan)
     a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead_p();
     a.check_n = !coal_marks_dead || zero_n_unmarked;
@@ -1102,12 +1103,15 @@ struct Particles : IParticles {
   }
   void build_migrant_lists()
   {
-    const size_t tiles = (nphys + SCAN_TILE - 1) / SCAN_TILE;
+    // from the per-workgroup counts of k_move (one word per 256 SDs): tiles of BS such words
+    const size_t n_wg = nblk(nphys), tiles = (n_wg + BS - 1) / BS;
     size_t *cnt[2] = {&lft_count, &rgt_count};
     if (!tiles) { lft_count = rgt_count = 0; if (dev_exchange) HIPCHK(hipMemsetAsync(scan_total.p, 0, 2 * sizeof(uint32_t), st)); return; }
-    hipLaunchKernelGGL(k_mig_tiles2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p);
+    uint32_t *off_l = wg_mig.p + (size_t(nblk(cap)) + 1), *off_r = off_l + (size_t(nblk(cap)) + 1);
+    hipLaunchKernelGGL(k_mig_tiles3, dim3(unsigned(tiles)), dim3(BS), 0, st, wg_mig.p, n_wg, uint32_t(tiles), tile_sums.p, d_dead_p());
     hipLaunchKernelGGL(k_scan_sums2, dim3(2), dim3(1024), 0, st, tile_sums.p, tiles, scan_total.p);
-    hipLaunchKernelGGL(k_mig_ids2, dim3(unsigned(tiles)), dim3(BS), 0, st, mig.p, nphys, uint32_t(tiles), tile_sums.p, mig_ids[0].p, mig_ids[1].p);
+    hipLaunchKernelGGL(k_mig_off, dim3(unsigned(tiles)), dim3(BS), 0, st, wg_mig.p, n_wg, uint32_t(tiles), tile_sums.p, off_l, off_r);
+    hipLaunchKernelGGL(k_mig_ids4, dim3(nblk(n_wg, BS / WAVE)), dim3(BS), 0, st, mig.p, nphys, wg_mig.p, n_wg, off_l, off_r, mig_ids[0].p, mig_ids[1].p);
     if (dev_exchange) return;                         // multi_HIP: the counts stay on the device (scan_total[0..1]), see exch_*
     uint32_t tot[2];
     read_back(tot, scan_total.p, 2);                  // one host sync for both directions
@@ -1870,7 +1874,7 @@ struct Particles : IParticles {
     for (auto &b : inbox) { inbox_finegrained = b.alloc_finegrained(exch_bytes(inbox_cap_rec)) && inbox_finegrained; HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
     if (with_outbox) for (auto &b : outbox) { b.alloc(exch_bytes(inbox_cap_rec)); HIPCHK(hipMemsetAsync(b.p, 0, EXCH_HDR, st)); }
     xcnt.alloc_zero(24, st);
-    if (!mig.p) { mig.alloc(cap); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); }
+    if (!wg_mig.p) alloc_mig();
     // headroom in front of the sorted order (see sort_base): as many entries as a message can bring.  `rank` and `ijk` trade places
     // with the sorted arrays now and then (order_cells, reorder_storage), so all of them get it; nothing is stored in them yet
     sort_headroom = inbox_cap_rec;

@@ -1672,6 +1672,9 @@ struct move_args {
   int do_adve, scheme, halo, do_sedi, do_subs, do_bcnd, distmem, bcond_lft, bcond_rgt, open_side_walls, periodic_topbot;
   double *puddle_partial;      // [gridDim][4]: liq_vol, dry_vol, liq_num, prtcl_num
   uint8_t *mig;                // distmem: 1 = left the domain through the left face, 2 = right
+  uint32_t *wg_mig;            // distmem: per workgroup, the number of its SDs flagged 1 (bits 0-9), flagged 2 (bits 10-19) and dead
+                               // (bits 20-29): what the id lists and the dead count are built from without another pass over the
+                               // flags and without an atomic in this kernel (k_mig_tiles3 / k_mig_off / k_mig_ids4)
   // fused re-indexing (single-device runs): the new cell index, the cell histogram with per-SD rank and the number of
   // dead SDs come out of the same pass, so post_copy needs no further sweep over the positions
   int reindex; uint32_t *ijk_out, *cnt, *rank; unsigned int *dead_count;
@@ -1713,13 +1716,16 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
   if (SPEC & MOVE_FULL) {
     a.do_adve = a.do_sedi = a.do_bcnd = a.reindex = 1; a.do_subs = 0; a.halo = 0; a.open_side_walls = 0; a.periodic_topbot = 0;
     a.distmem = (SPEC & MOVE_DISTMEM) ? 1 : 0; a.scheme = (SPEC & MOVE_IMPLICIT) ? LCX_ADVE_IMPLICIT : LCX_ADVE_EULER;
+    if (!(SPEC & MOVE_DISTMEM)) a.wg_mig = nullptr;
   }
   __shared__ double red[4][BS / WAVE];
   const size_t i = gid();
   double pl = 0, pd = 0, pn = 0, pp = 0;
+  unsigned int n_dead_wave = 0;
   uint32_t c = i < a.n_part ? a.ijk[i] : DEAD_CELL;
   bool dead_now = false;         // counted in dead_count: was dead already, or dies in this pass
   uint32_t c_new = DEAD_CELL;
+  uint8_t mig_stored = 0;        // the migrant flag this lane stores (0 for a dead slot and for a lane behind the end)
   if (a.reindex && i < a.n_part) {
     if (c == DEAD_CELL) dead_now = true;                               // (incl. those that coalescence has just used up: k_coal marks them)
     else if (a.check_n && a.n[i] == 0) { dead_now = true; c = DEAD_CELL; }   // zero multiplicities from the initialisation / set_particles
@@ -1840,7 +1846,7 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     // (every living SD stores its flag byte, dead slots are cleared at the end of the pass: no memset ahead of the launch.)  An SD that dies in this very pass
     // -- open wall, top, precipitation -- is not shipped: the reference sends it with n == 0 and the receiver's
     // hskpng_remove_n0 drops it, so the neighbour never sees it either way, and its puddle contribution stays on this slab
-    if (a.distmem && a.do_bcnd) a.mig[i] = kill ? uint8_t(0) : mig_flag;
+    if (a.distmem && a.do_bcnd) { mig_stored = kill ? uint8_t(0) : mig_flag; a.mig[i] = mig_stored; }
     if (kill) { a.n[i] = 0; dead_now = true; }
     else if (a.reindex) {
       // an emigrant leaves the cell-sorted order at once (it is packed by id and its multiplicity zeroed in migrate_finish)
@@ -1853,7 +1859,22 @@ __global__ void __launch_bounds__(BS) k_move(move_args<T> a)
     const uint32_t r = wave_hist_rank(a.cnt, c_new, live);
     if (i < a.n_part) { a.ijk_out[i] = c_new; if (live) a.rank[i] = r; }
     const unsigned long long db = __ballot(dead_now);
-    if (db && lane_id() == 0) atomicAdd(a.dead_count, (unsigned int)__popcll(db));
+    // a slab with neighbours: the dead count goes into the workgroup's word below and is summed by k_mig_tiles3.  (Every wave of the
+    // two boundary planes holds emigrants: 3e4 atomics on ONE address per step, device scope -- 0.1 ms of a 16-plane slab's 0.32 ms pass,
+    // whatever the slab's size)
+    if (a.wg_mig) n_dead_wave = (unsigned int)__popcll(db);
+    else if (db && lane_id() == 0) atomicAdd(a.dead_count, (unsigned int)__popcll(db));
+  }
+  if (a.wg_mig) {
+    __shared__ uint32_t wsum[BS / WAVE];
+    const uint32_t packed = uint32_t(__popcll(__ballot(mig_stored == 1))) | (uint32_t(__popcll(__ballot(mig_stored == 2))) << 10) | (n_dead_wave << 20);
+    if (lane_id() == 0) wsum[wave_id()] = packed;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t m = 0;
+      for (int w = 0; w < BS / WAVE; ++w) m += wsum[w];      // (at most 256 per field of ten bits: no carry between the fields)
+      a.wg_mig[blockIdx.x] = m;
+    }
   }
   if (a.puddle_partial) {
     // deterministic block reduction (fixed shuffle tree), one partial per workgroup, summed by the host in order
@@ -2216,6 +2237,68 @@ __global__ void k_scan_sums2(uint32_t *sums, size_t m, uint32_t *total)
     run += tot;
   }
   if (threadIdx.x == 0) total[blockIdx.x] = run;
+}
+// The same lists from the per-workgroup words that k_move leaves (wg_mig: left-going, right-going, dead -- ten bits each, one word per
+// 256 SDs): the flags are read only where a count says there is something to find -- the boundary planes, a few per cent of a slab.
+// (k_mig_tiles2 + k_scan_sums2 + k_mig_ids2 read every flag twice, a byte per lane: 0.36 ms per step on C3, 0.05 on a 16-plane slab;
+// these four: see DESIGN.md.)  A tile is BS workgroups of k_move, one per thread.  The step's dead count is the sum of the third
+// field: one atomic per tile that has any.
+__global__ void __launch_bounds__(BS) k_mig_tiles3(const uint32_t *wg_mig, size_t n_wg, uint32_t n_tiles, uint32_t *tile_sums, unsigned int *dead_count)
+{
+  __shared__ uint32_t lds[3][BS / WAVE];
+  const size_t e = size_t(blockIdx.x) * BS + threadIdx.x;
+  const uint32_t m = e < n_wg ? wg_mig[e] : 0u;
+  uint32_t cl = m & 0x3ffu, cr = (m >> 10) & 0x3ffu, cd = m >> 20;
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) { cl += __shfl_down(cl, d); cr += __shfl_down(cr, d); cd += __shfl_down(cd, d); }
+  if (lane_id() == 0) { lds[0][wave_id()] = cl; lds[1][wave_id()] = cr; lds[2][wave_id()] = cd; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    uint32_t s = 0;
+    for (int w = 0; w < BS / WAVE; ++w) s += lds[threadIdx.x][w];
+    if (threadIdx.x < 2) tile_sums[threadIdx.x * n_tiles + blockIdx.x] = s;
+    else if (s) atomicAdd(dead_count, s);
+  }
+}
+// offsets of every k_move workgroup's migrants in the two lists (behind k_scan_sums2 over the tiles)
+__global__ void __launch_bounds__(BS) k_mig_off(const uint32_t *wg_mig, size_t n_wg, uint32_t n_tiles, const uint32_t *tile_offs, uint32_t *off_l, uint32_t *off_r)
+{
+  __shared__ uint32_t lds[SCAN_MAX_WAVES];
+  const size_t e = size_t(blockIdx.x) * BS + threadIdx.x;
+  const uint32_t pk = e < n_wg ? wg_mig[e] : 0u;
+  uint32_t tot;
+  const uint32_t ex_l = block_exclusive_scan(pk & 0x3ffu, tot, lds);
+  __syncthreads();
+  const uint32_t ex_r = block_exclusive_scan((pk >> 10) & 0x3ffu, tot, lds);
+  if (e < n_wg) { off_l[e] = tile_offs[blockIdx.x] + ex_l; off_r[e] = tile_offs[n_tiles + blockIdx.x] + ex_r; }
+}
+// one WAVE per k_move workgroup: four flags per lane, ids written in ascending order behind the workgroup's offsets; a wave whose
+// workgroup has no migrant (nearly all of them) ends after one scalar load
+__global__ void __launch_bounds__(BS) k_mig_ids4(const uint8_t *mig, size_t n_part, const uint32_t *wg_mig, size_t n_wg,
+                                                 const uint32_t *off_l, const uint32_t *off_r, uint32_t *ids_l, uint32_t *ids_r)
+{
+  const size_t e = size_t(blockIdx.x) * (BS / WAVE) + wave_id();
+  if (e >= n_wg) return;
+  if (!(wg_mig[e] & 0xfffffu)) return;
+  const unsigned l = lane_id();
+  const unsigned long long below = (1ull << l) - 1ull;
+  const size_t i4 = e * BS + size_t(l) * 4;
+  const uint32_t w = i4 < n_part ? *reinterpret_cast<const uint32_t *>(mig + i4) : 0u;      // (the flag array is allocated in whole workgroups)
+  bool is_l[4], is_r[4];
+  uint32_t pre_l = 0, pre_r = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const uint32_t m = (w >> (8 * b)) & 0xffu;
+    const bool valid = i4 + b < n_part;                // (bytes behind the last SD are stale)
+    is_l[b] = valid && m == 1; is_r[b] = valid && m == 2;
+    pre_l += __popcll(__ballot(is_l[b]) & below); pre_r += __popcll(__ballot(is_r[b]) & below);
+  }
+  size_t pl = size_t(off_l[e]) + pre_l, pr = size_t(off_r[e]) + pre_r;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if (is_l[b]) ids_l[pl++] = uint32_t(i4 + b);
+    if (is_r[b]) ids_r[pr++] = uint32_t(i4 + b);
+  }
 }
 __global__ void __launch_bounds__(BS) k_mig_ids2(const uint8_t *mig, size_t n_part, uint32_t n_tiles, const uint32_t *tile_offs, uint32_t *ids_l, uint32_t *ids_r)
 {
