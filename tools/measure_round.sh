@@ -9,6 +9,9 @@ mkdir -p $out
 B="python3 bench.py --no-cpu-baseline --no-strict-leg"
 # one slab of the strong-scaling split of C3 on a device of its own (what each GPU of an N-GPU run computes, without exchange)
 for nx in 64 32 16; do $B --nx $nx --steps 100 > $out/slab_nx$nx.json 2> $out/slab_nx$nx.err; done
+# the same slabs as ONE RANK of the one-object-per-rank path whose neighbours are the rank itself: the whole exchange (pack, RCCL send and
+# receive on the engine's stream, overlapped re-sort, unpack) on top of the slab's own step
+for nx in 128 64 32 16; do $B --nx $nx --self-ring --steps 100 > $out/selfring_nx$nx.json 2> $out/selfring_nx$nx.err; done
 # the native multi_HIP object with all slabs on this one device: concurrent (exchange overlapped) and one slab at a time
 for N in 2 4 8; do
   $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_concurrent.json 2> $out/multi_${N}_concurrent.err
