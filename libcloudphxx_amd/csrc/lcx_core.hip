@@ -186,7 +186,8 @@ struct Particles : IParticles {
   DevBuf<uint32_t> sorted_alt;          // (exchange only) the in-cell ranking's output while `rank` still holds the boundary SDs' arrival ranks
   uint32_t *sid() const { return sorted_id.p + sort_base; }
   uint32_t *sijk() const { return sorted_ijk.p + sort_base; }
-  DevBuf<uint8_t> mig, cond_pre; DevBuf<uint32_t> defer_cnt, wg_mig;
+  DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig;
+  const bool use_wave_flags = !getenv("LCX_NO_WAVE_FLAGS");
   void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
@@ -1913,8 +1914,9 @@ struct Particles : IParticles {
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, nullptr, nullptr, 0, scan_total.p + 3);      // (scan_total[0..1]: the emigrant counts)
     ++cells_version;
     uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
+    if (use_wave_flags && !wave_flag.p) wave_flag.alloc_zero(cap / WAVE + 64, st);
     hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
-                       sort_part{ov_c_lo, ov_c_hi, 1, nullptr, nullptr});
+                       sort_part{ov_c_lo, ov_c_hi, 1, nullptr, nullptr}, use_wave_flags ? wave_flag.p : (uint8_t *)nullptr);
     overlap_rs = rng_src{nullptr, 0, 0, 0u, 0u};
     if (overlap_preshuffle) overlap_rs = rand_un(nphys);
     launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{cell_start.p + ov_c_lo, cell_start.p + ov_c_hi, nullptr}, nblk(nphys));
@@ -1966,7 +1968,8 @@ struct Particles : IParticles {
     if (ov && retry) hipLaunchKernelGGL(k_csr_to_counts, dim3(nblk(ncell)), dim3(BS), 0, st, cell_start.p, cell_cnt.p, ncell);
     hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, in_l, in_r, have_l, have_r,
                        nphys, cap, aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, n_free,
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, int(ov), ov_c_lo, ov_c_hi, big_meta_p(), xcnt.p + 22, int(retry));
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, int(ov), ov_c_lo, ov_c_hi, big_meta_p(), xcnt.p + 22, int(retry),
+                       (ov && use_wave_flags) ? wave_flag.p : (uint8_t *)nullptr);
     if (ov) {
       const uint32_t *shift = xcnt.p + 17, *extent = xcnt.p + 18;
       // crowded boundary cells from the completed histogram, then the final offsets of every cell (the histogram is cleared behind them)
@@ -1976,8 +1979,12 @@ struct Particles : IParticles {
                          big_meta_p(), big_meta_p() + 1, (const uint32_t *)cell_cnt.p, ov_c_hi);
       exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, cell_cnt.p, nullptr, 0, scan_total.p + 3);
       uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom;
-      hipLaunchKernelGGL(k_scatter_outside4, dim3(nblk((ext_max + 3) / 4)), dim3(BS), 0, st, ext_max, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
-                         sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
+      if (use_wave_flags)
+        hipLaunchKernelGGL(k_scatter_flagged, dim3(nblk((ext_max + 16 * WAVE - 1) / (16 * WAVE), BS / WAVE)), dim3(BS), 0, st, ext_max, wave_flag.p, ijk.p, rank.p,
+                           cell_start.p, sid_h, sijk_h, sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
+      else
+        hipLaunchKernelGGL(k_scatter_outside4, dim3(nblk((ext_max + 3) / 4)), dim3(BS), 0, st, ext_max, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
+                           sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
       rank_boundary(bnd_blocks);
     }
     else if (fused_pending) list_big_from_hist();       // the histogram is complete now: crowded cells for order_cells, same read-back

@@ -325,20 +325,55 @@ k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const 
 struct sort_part { uint32_t c_lo, c_hi; int mode; const uint32_t *n_dev, *shift; };
 __device__ __forceinline__ bool part_has(const sort_part &sp, uint32_t c)
 { return sp.mode == 0 || ((c >= sp.c_lo && c < sp.c_hi) == (sp.mode == 1)); }
+// skipped != nullptr (the interior pass of the overlapped re-sort): one byte per wave of 64 super-droplets, set when the wave holds a
+// living super-droplet that this pass leaves out -- the boundary pass (k_scatter_flagged) then reads the cell indices of those waves only
 __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
-                                 uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp = sort_part{0u, 0u, 0, nullptr, nullptr})
+                                 uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp = sort_part{0u, 0u, 0, nullptr, nullptr}, uint8_t *skipped = nullptr)
 {
   if (sp.n_dev) n = *sp.n_dev;
-  const size_t i = gid(); if (i >= n) return;
-  const uint32_t c = ijk[i];
+  const size_t i = gid();
+  const uint32_t c = i < n ? ijk[i] : DEAD_CELL;
+  if (skipped) {
+    const bool left_out = c != DEAD_CELL && !part_has(sp, c);
+    const unsigned long long b = __ballot(left_out);
+    if (lane_id() == 0 && (i & ~size_t(63)) < n) skipped[i >> 6] = b ? uint8_t(1) : uint8_t(0);
+  }
   if (c == DEAD_CELL || !part_has(sp, c)) return;
   const size_t pos = size_t(cell_start[c]) + rank[i] - (sp.shift ? *sp.shift : 0u);      // (shift <= the headroom in front of the arrays)
   (sorted_id + pos)[0] = uint32_t(i);
   (sorted_ijk + pos)[0] = c;
 }
 
-// the boundary pass of the overlapped re-sort: only one SD in eight or sixteen has anything to store, the pass is the read of ijk -- four
-// ids per lane with one 16-byte load (37 -> see DESIGN.md us on a 16.7e6-SD slab)
+// The boundary pass of the overlapped re-sort over the waves that are flagged: those in which the interior pass left a super-droplet
+// out (k_scatter_sorted's `skipped`) and those that have just taken an immigrant (k_unpack_dev).  One wave looks at sixteen flags and
+// visits the flagged sixty-fours; on a 16-plane slab one wave in eight is flagged, on C3 one in sixty-four.
+__global__ void __launch_bounds__(BS)
+k_scatter_flagged(size_t n_max, const uint8_t *wave_flag, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
+                  uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp)
+{
+  const size_t n = sp.n_dev ? size_t(*sp.n_dev) : n_max;
+  const size_t cb = (size_t(blockIdx.x) * (BS / WAVE) + wave_id()) * 16;             // first of this wave's sixteen chunks
+  if (cb * WAVE >= n) return;
+  const unsigned l = lane_id();
+  const uint8_t f = (l < 16 && (cb + l) * WAVE < n) ? wave_flag[cb + l] : uint8_t(0);
+  unsigned long long todo = __ballot(f != 0);
+  if (!todo) return;
+  const uint32_t shift = sp.shift ? *sp.shift : 0u;
+  while (todo) {
+    const int k = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const size_t i = (cb + size_t(k)) * WAVE + l;
+    if (i >= n) continue;
+    const uint32_t c = ijk[i];
+    if (c == DEAD_CELL || (c >= sp.c_lo && c < sp.c_hi)) continue;
+    const size_t pos = size_t(cell_start[c]) + rank[i] - shift;
+    sorted_id[pos] = uint32_t(i);
+    sorted_ijk[pos] = c;
+  }
+}
+// the same pass over every cell index (kept for LCX_NO_WAVE_FLAGS=1 and as the flagged form's reference): only one SD in eight or
+// sixteen has anything to store, the pass is the read of ijk -- four ids per lane with one 16-byte load (41 us on a 16.7e6-SD slab,
+// 117 on C3)
 __global__ void __launch_bounds__(BS)
 k_scatter_outside4(size_t n_max, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start, uint32_t *sorted_id, uint32_t *sorted_ijk, sort_part sp)
 {
@@ -2435,7 +2470,7 @@ __global__ void __launch_bounds__(BS)
 k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, uint32_t have_l, uint32_t have_r, size_t n_old, size_t cap, attr_set<T> s, grid_t g, T x0, T x1, T tol,
              const uint32_t *free_l, const uint32_t *free_r, const uint32_t *n_free /* [2] on the device, nullptr: no slot re-use */,
              uint32_t *ijk, uint32_t *cnt, uint32_t *rank, uint32_t *flags, int ov, uint32_t c_lo, uint32_t c_hi,
-             uint32_t *big_count, uint32_t *big_mark, int retry)
+             uint32_t *big_count, uint32_t *big_mark, int retry, uint8_t *wave_flag = nullptr)
 {
   auto hdr_count = [](const uint8_t *b) { const uint32_t *h = reinterpret_cast<const uint32_t *>(b); return b && !h[1] ? h[0] : 0u; };
   const uint32_t cl = hdr_count(inbox_l), cr = hdr_count(inbox_r);
@@ -2470,6 +2505,7 @@ k_unpack_dev(const uint8_t *inbox_l, const uint8_t *inbox_r, uint32_t have_l, ui
       if (g.nz) { z = t.at(a++); s.z[d] = z; }
       for (int e = 0; e < s.n_ext; ++e) s.ext[e][d] = t.at(a++);
       if (cnt) { c = nn == 0 ? DEAD_CELL : cell_of(g, x, y, z); ijk[d] = c; }
+      if (wave_flag) wave_flag[d >> 6] = uint8_t(1);         // (the boundary pass of the re-sort visits this wave of the storage)
     }
   }
   if (cnt) {                                           // every lane of the wave takes part (ballots inside)
