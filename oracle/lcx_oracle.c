@@ -137,6 +137,8 @@ static int m1(int n) { return n == 0 ? 1 : n; }
 #define OMP_FOR _Pragma("omp parallel for schedule(static)")
 
 const char *orc_last_error(void) { return orc_err; }
+/* see orc_physics.h: the root finders iterate to the tolerance of a real_t of that many bytes from now on */
+void orc_set_real_bytes(int bytes) { orc_real_bytes_v = bytes == 4 ? 4u : 8u; }
 #ifdef _OPENMP
 #include <omp.h>
 const char *orc_version(void) { return "lcx-oracle 1 (double, OpenMP elementwise loops)"; }
@@ -214,7 +216,7 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->halo = oi->adve_scheme == LCX_ADVE_PRED_CORR ? 2 : 0;
   if (s->o.n_x_tot == 0) s->o.n_x_tot = oi->nx;
   mt_seed(&s->rng, (uint32_t)oi->rng_seed);
-  s->eps_tol = orc_eps_tolerance(sizeof(double) * 8 / 4);   /* src/detail/config.hpp:39 */
+  s->eps_tol = orc_real_eps();                               /* src/detail/config.hpp:39: eps_tolerance(sizeof(real_t) * 8 / 4) */
   s->vt0_ln_r_min = log(5e-7); s->vt0_ln_r_max = log(3e-3); /* config.hpp:36-38 */
   s->cap = (sz)oi->n_sd_max;
   sz c = s->cap, nc = s->n_cell;

@@ -126,6 +126,13 @@ static inline double orc_eps_tolerance(unsigned bits)
 {
   return dmax((double)ldexpf(1.0f, 1 - (int)bits), 4 * DBL_EPSILON);
 }
+/* The root finders' tolerance follows sizeof(real_t) in the reference (eps_tolerance<real_t>(sizeof(real_t) * 8 / 4), config.hpp:39,
+ * toms748.hpp:445-471): 2^-15 for double, 2^-7 for float.  This oracle computes in double; orc_set_real_bytes(4) makes it iterate to
+ * FLOAT's tolerance, so that a float build of the product is compared with the iterates its own arithmetic is meant to take
+ * (tests/test_hip_configs.py, the icicle set-up, which the reference runs in float).  Process-wide: an object takes its condensation
+ * tolerance from it when it is created, rw3_eq reads it at every call -- a test sets it for the length of its run and resets it to 8. */
+static unsigned orc_real_bytes_v = 8;
+static inline double orc_real_eps(void) { return orc_eps_tolerance(orc_real_bytes_v * 8 / 4); }
 static inline double t748_safe_div(double num, double denom, double r)
 {                                                   /* toms748.hpp:124-138 */
   if (fabs(denom) < 1 && fabs(denom * DBL_MAX) <= fabs(num)) return r;
@@ -247,8 +254,7 @@ static inline double rw3_eq(double rd3, double kappa, double RH, double T)
   rw3eq_ctx c = {RH, rd3, kappa, T};
   const double a = rd3, b = rw3_eq_nokelvin(rd3, kappa, RH);
   uintmax_t it = 100;      /* toms748.hpp:445-471: default n_iter 100, eps_tolerance(sizeof(T)*8/4) */
-  return orc_toms748(rw3_eq_minfun, &c, a, b, rw3_eq_minfun(a, &c), rw3_eq_minfun(b, &c),
-                     orc_eps_tolerance(sizeof(double) * 8 / 4), &it);
+  return orc_toms748(rw3_eq_minfun, &c, a, b, rw3_eq_minfun(a, &c), rw3_eq_minfun(b, &c), orc_real_eps(), &it);
 }
 
 /* ---- critical radius, kappa_koehler.hpp:88-166 (always evaluated in double) ---- */

@@ -123,56 +123,66 @@ def test_c2_icicle_2d_full_size_double_vs_oracle(strict_fp):
 
 @pytest.mark.parametrize("strict_fp", [True, False])
 def test_c2_icicle_2d_float_against_the_double_oracle(strict_fp):
-    """C2 in the arithmetic icicle runs it in, real_t = float (fig_a/calc.cpp:36-39; root-finder tolerance 2^-7, config.hpp:39), at its
-    full size against the DOUBLE oracle, step by step from the same state (replayed random streams, state copied back each step):
-    what float changes is bounded by what float is.
+    """C2 in the arithmetic icicle runs it in, real_t = float (fig_a/calc.cpp:36-39), at its full size against the oracle ITERATING AS A
+    FLOAT BUILD DOES: `orc_set_real_bytes(4)` gives its root finders float's tolerance, eps_tolerance(sizeof(float) * 8 / 4) = 2^-7
+    (config.hpp:39, toms748.hpp:445-471) -- the one thing that makes a float run of the reference a different algorithm and not just a
+    rounded one (with the double tolerance 2^-15 in the oracle this test measured a median of 2e-3 in rw2; now 1e-4).  The oracle's
+    arithmetic stays double.  Step by step from the same state (replayed random streams, state copied back each step); what float's
+    rounding changes is bounded by what float is:
       * cell index and sort: a position differs by 1e-7 of the domain, so a droplet within that of a cell face lands next door:
-        at most 1e-4 of the droplets, and everywhere else the permutation inside a cell is the oracle's;
+        at most 1e-4 of the droplets (measured 5e-5), and everywhere else the permutation inside a cell is the oracle's;
       * multiplicities under the replayed stream: equal except around those droplets (a different partner) and where a collision
-        probability sits within float's resolution of the random number: at most 1e-3;
-      * wet radii: every substep ends on the midpoint of a bracket 2^-7 wide instead of 2^-15: 99.9 % of the droplets within 3e-2
-        of the double answer after ten substeps, the median within 2e-3;
-      * th, rv: sums of the same changes in 24-bit arithmetic, ten substeps: 2e-6 and 2e-4; positions: 1e-2 m of 1500 (5e-4 of a cell).
-    (No float build of the oracle exists: it would have to restate every literal's type of the reference's templates a second time;
-    this holds the float product to the pinned double oracle instead of to a conservation bound.)"""
+        probability sits within float's resolution of the random number: at most 1e-4 (measured 3e-6);
+      * wet radii after ten substeps: the median within 2e-4 (strict; measured 8e-5) / 5e-4 (fast; 2e-4), 99 % within 6e-3, 99.9 %
+        within 1e-2 / 2.5e-2: a bracket 2^-7 = 8e-3 wide whose next cut falls on the other side of a 24-bit rounding ends one
+        bisection earlier or later, and ten substeps give it ten chances (the tail: a handful of droplets at their critical radius);
+      * th, rv: sums of the same changes in 24-bit arithmetic, ten substeps: 2e-6 and 6e-5 (measured 1.4e-6, 3.0e-5);
+        positions: 1e-2 m of 1500 (5e-4 of a cell).
+    (A float BUILD of the oracle does not exist: it would have to restate every literal's type of the reference's templates a second
+    time, and its libm would still not be the device's.)"""
     nx = nz = 76
     oi = icicle_opts(nx, nz, 64, sstp=10)
     oi.strict_fp = strict_fp
     th, rv, rhod, C = icicle_fields(nx, nz, np.float32)
     f64 = (th.astype(np.float64), rv.astype(np.float64), rhod.astype(np.float64), {k: v.astype(np.float64) for k, v in C.items()})
-    orc = h.oracle_particles(oi)
-    hip = h.hip_particles(oi, np.float32)
-    for arr in h.oracle_rng_preview(orc, h.init_replay_calls(oi)):
-        hip.rng_replay_push(0, arr)
-    orc.init(f64[0].copy(), f64[1].copy(), f64[2].copy(), **f64[3])
-    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
-    assert hip.n_part == orc.n_part == nx * nz * 64
-    h.copy_state(orc, hip)
-    opts = lgrngn.opts_t()
-    n_sd = orc.n_part
-    for it in range(2):
-        tho, rvo, thh, rvh = f64[0].copy(), f64[1].copy(), th.copy(), rv.copy()
-        orc.step_sync(opts, tho, rvo, f64[2], **f64[3])
-        hip.step_sync(opts, thh, rvh, rhod, **C)
-        h.push_coal_replay(orc, hip, oi.sstp_coal)
-        orc.step_async(opts)
-        hip.step_async(opts)
-        np.testing.assert_allclose(thh, tho, rtol=2e-6)
-        np.testing.assert_allclose(rvh, rvo, rtol=2e-4)
-        assert abs(hip.n_part - orc.n_part) <= 1e-4 * n_sd
-        if hip.n_part == orc.n_part:
-            ijk_h, ijk_o = hip.state_u64("ijk"), orc.state_u64("ijk")
-            moved = ijk_h != ijk_o
-            assert moved.mean() < 1e-4, moved.mean()
-            n_h, n_o = hip.state_u64("n"), orc.state_u64("n")
-            assert (n_h != n_o).mean() < 1e-3, (n_h != n_o).mean()
-            same = ~moved & (n_h == n_o)
-            err = np.abs(hip.get_attr("rw2").astype(np.float64)[same] / orc.get_attr("rw2")[same] - 1)
-            assert np.quantile(err, .999) < 3e-2 and np.median(err) < 2e-3, (np.quantile(err, .999), np.median(err), err.max())
-            # (positions: the implicit scheme's x + dx (C_l - i (C_r - C_l)) cancels at i ~ 75: a few dozen ulps of the 1500 m domain;
-            # measured 3.4e-3 m at most, 2.7 % of the droplets above 2e-4 m)
-            np.testing.assert_allclose(hip.get_attr("x").astype(np.float64)[same], orc.get_attr("x")[same], rtol=0, atol=1e-2)
+    h.oracle_lib().orc_set_real_bytes(4)               # the oracle's root finders stop at float's tolerance, 2^-7 (config.hpp:39)
+    try:
+        orc = h.oracle_particles(oi)
+        hip = h.hip_particles(oi, np.float32)
+        for arr in h.oracle_rng_preview(orc, h.init_replay_calls(oi)):
+            hip.rng_replay_push(0, arr)
+        orc.init(f64[0].copy(), f64[1].copy(), f64[2].copy(), **f64[3])
+        hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+        assert hip.n_part == orc.n_part == nx * nz * 64
         h.copy_state(orc, hip)
+        opts = lgrngn.opts_t()
+        n_sd = orc.n_part
+        for it in range(2):
+            tho, rvo, thh, rvh = f64[0].copy(), f64[1].copy(), th.copy(), rv.copy()
+            orc.step_sync(opts, tho, rvo, f64[2], **f64[3])
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            h.push_coal_replay(orc, hip, oi.sstp_coal)
+            orc.step_async(opts)
+            hip.step_async(opts)
+            np.testing.assert_allclose(thh, tho, rtol=2e-6)
+            np.testing.assert_allclose(rvh, rvo, rtol=6e-5)
+            assert abs(hip.n_part - orc.n_part) <= 1e-4 * n_sd
+            if hip.n_part == orc.n_part:
+                ijk_h, ijk_o = hip.state_u64("ijk"), orc.state_u64("ijk")
+                moved = ijk_h != ijk_o
+                assert moved.mean() < 1e-4, moved.mean()
+                n_h, n_o = hip.state_u64("n"), orc.state_u64("n")
+                assert (n_h != n_o).mean() < 1e-4, (n_h != n_o).mean()
+                same = ~moved & (n_h == n_o)
+                err = np.abs(hip.get_attr("rw2").astype(np.float64)[same] / orc.get_attr("rw2")[same] - 1)
+                q50, q99, q999 = np.median(err), np.quantile(err, .99), np.quantile(err, .999)
+                assert q50 < (2e-4 if strict_fp else 5e-4) and q99 < 6e-3 and q999 < (1e-2 if strict_fp else 2.5e-2), (q50, q99, q999, err.max())
+                # (positions: the implicit scheme's x + dx (C_l - i (C_r - C_l)) cancels at i ~ 75: a few dozen ulps of the 1500 m domain;
+                # measured 3.4e-3 m at most, 2.7 % of the droplets above 2e-4 m)
+                np.testing.assert_allclose(hip.get_attr("x").astype(np.float64)[same], orc.get_attr("x")[same], rtol=0, atol=1e-2)
+            h.copy_state(orc, hip)
+    finally:
+        h.oracle_lib().orc_set_real_bytes(8)
 
 
 def test_c2_icicle_2d_full_size_float():

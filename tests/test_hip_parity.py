@@ -659,7 +659,8 @@ def test_float_build_runs_and_tracks_double():
         res[rt] = (tt.astype(np.float64), rr.astype(np.float64), pr.n_part)
     # real_t=float follows the reference's float configuration: the root finder's tolerance is 2^-7 there
     # (src/detail/config.hpp:39, sizeof(real_t)*8/4 bits), which biases the condensate by O(1%) -- so this is a
-    # "same physics" check, not a precision claim
+    # "same physics" check, not a precision claim (the float build against the oracle iterating to float's tolerance:
+    # tests/test_hip_configs.py::test_c2_icicle_2d_float_against_the_double_oracle)
     np.testing.assert_allclose(res[np.float32][0], res[np.float64][0], rtol=5e-3)
     np.testing.assert_allclose(res[np.float32][1], res[np.float64][1], rtol=0.15)
     assert res[np.float32][2] == res[np.float64][2]
