@@ -860,14 +860,19 @@ struct Particles : IParticles {
       cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
-                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 (or LCX_COND_TOMS=1) keeps round 2's kernels
       // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
       const bool cond_toms = o.cond_solver == 1 || getenv("LCX_COND_TOMS") != nullptr;
       if (fast && !cond_toms) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
-        hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);
+        cond_in_storage_order = cond_storage_order;
+        if (cond_in_storage_order) {
+          a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
+          hipLaunchKernelGGL((k_cond_lean<T, 3>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
+        }
+        else hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
@@ -893,24 +898,27 @@ struct Particles : IParticles {
     }
     {
       Range r(this, "cond_cellfinish");
-      launch_cellfinish(step, sstp_cond, fast);
+      launch_cellfinish(step, sstp_cond, fast, cond_in_storage_order ? sid() : (const uint32_t *)nullptr);
+      cond_in_storage_order = false;
     }
   }
+  const bool cond_storage_order = getenv("LCX_COND_SORTED_ORDER") == nullptr;      // (measurement switch: the positional form)
+  bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
   // reference's summation order); fast: eight lanes per cell, or a whole wave per cell where cells are crowded
-  void launch_cellfinish(int step, int sstp, bool delta = false)
+  void launch_cellfinish(int step, int sstp, bool delta = false, const uint32_t *gather = nullptr)
   {
     const int dl = delta ? 1 : 0;
     if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)
       hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl, gather);
     else if (!o.strict_fp) {
       const int cfc = std::min(cf_cells(), BS / 8);
       hipLaunchKernelGGL((k_cond_cellfinish<T, 8>), dim3(nblk(ncell, cfc)), dim3(BS), 0, st, ncell, cfc, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl, gather);
     } else
       hipLaunchKernelGGL((k_cond_cellfinish<T, 1>), dim3(nblk(ncell, cf_cells())), dim3(BS), 0, st, ncell, cf_cells(), cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
-                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl);
+                         rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl, gather);
   }
   // hskpng_rc2.ipp:14-32
   void hskpng_approximate_rc2_invalid()

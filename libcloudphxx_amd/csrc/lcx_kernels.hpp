@@ -829,6 +829,7 @@ struct cond_args {
   unsigned xcd_group;     // workgroups per XCD run (gid_xcd)
   const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
   const cond_cell_fast<T> *pre;   // fast arithmetic without turb_cond: the droplet-independent set-up, per cell (k_cond_cellpre)
+  const uint32_t *storage_ijk;    // k_cond_lean in storage order (see there), else nullptr
 };
 template <class T>
 __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
@@ -867,6 +868,15 @@ __device__ __forceinline__ T seg_sum(const T *lds, const T *glob, bool staged, u
   if (s >= e) return acc;                  // (G > 1: a lane beyond the end of a short segment)
   if (staged) { acc = lds[s - base]; for (uint32_t q = s + G; q < e; q += G) acc = acc + lds[q - base]; }
   else        { acc = glob[s];       for (uint32_t q = s + G; q < e; q += G) acc = acc + glob[q]; }
+  return acc;
+}
+template <class T, int G = 1>
+__device__ __forceinline__ T seg_sum_gather(const T *glob, const uint32_t *gather, uint32_t s, uint32_t e)
+{
+  T acc = 0;
+  if (s >= e) return acc;
+  acc = glob[gather[s]];
+  for (uint32_t q = s + G; q < e; q += G) acc = acc + glob[gather[q]];
   return acc;
 }
 // moment bookkeeping across substeps + update_th_rv for one cell, given its sums of n rw^3 before / after the substep
@@ -989,8 +999,13 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <class T, int OPT = 3>
 __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
 {
-  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
-  const uint32_t id = a.sorted_id[pos], c = a.sorted_ijk[pos];
+  // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
+  // attributes and the change (m3_after, storage-indexed; the per-cell finish gathers it through sorted_id) are read and written
+  // coalesced.  A droplet's answer does not depend on who computes it, and the sums per cell keep their order.
+  size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
+  uint32_t id, c;
+  if (a.storage_ijk) { id = uint32_t(pos); c = a.storage_ijk[pos]; if (c == DEAD_CELL) return; }
+  else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
   T rw2_old = a.rw2[id], rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
   T nn = T(a.n[id]);
   cond_cell_fast<T> cc = a.pre[c];
@@ -1109,7 +1124,8 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <class T, int G>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
-                  const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0)
+                  const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0,
+                  const uint32_t *gather = nullptr /* m3_after is indexed by gather[position] (the storage-order condensation kernel) */)
 {
   // delta: m3_after holds the droplets' CHANGES n (rw_new^3 - rw_old^3) (k_cond_fast): their sum is the whole answer of every substep
   if (delta) { step = 0; sstp = 1; }
@@ -1134,9 +1150,9 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     const uint32_t base = cs[cb], end = cs[ce];
     const bool staged = (end - base) <= uint32_t(CF_CAP);
     const bool in_run = mine && has && cl >= cb && cl < ce;
-    if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
+    if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[gather ? gather[q] : q];
     __syncthreads();
-    if (in_run) after = seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
+    if (in_run) after = (gather && !staged) ? seg_sum_gather<T, G>(m3_after, gather, s + sub, e) : seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
     if (step == 0 && !delta) {
       __syncthreads();
       if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
@@ -1160,14 +1176,15 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
 template <class T>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish_wave(size_t n_cell, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
-                       const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0)
+                       const T *dv, const T *rhod, T *rv, T *th, const T *Tk, T *rw_mom3, int step, int sstp, int ndims, int delta = 0,
+                       const uint32_t *gather = nullptr)
 {
   const size_t c = size_t(blockIdx.x) * (BS / WAVE) + wave_id();
   if (c >= n_cell) return;
   if (delta) { step = 0; sstp = 1; }
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T after = 0, before = 0;
-  for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[q]; if (step == 0 && !delta) before = before + m3_before[q]; }
+  for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[gather ? gather[q] : q]; if (step == 0 && !delta) before = before + m3_before[q]; }
 #pragma unroll
   for (int d = WAVE / 2; d > 0; d >>= 1) { after = after + __shfl_down(after, d); before = before + __shfl_down(before, d); }
   if (lane_id() == 0) cellfinish_apply(c, e > s, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);

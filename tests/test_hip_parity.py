@@ -834,6 +834,38 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("sd_conc,steps", [(64, 6), (400, 3)])
+def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monkeypatch, sd_conc, steps):
+    """k_cond_lean takes the droplets in STORAGE order (coalesced attribute reads and writes; the per-cell finish gathers the droplets'
+    changes through sorted_id) -- LCX_COND_SORTED_ORDER=1 selects the positional form it replaced (every attribute gathered through
+    sorted_id).  A droplet's answer does not depend on the lane that computes it and a cell's sum keeps its order: the same bits, in a
+    full step with coalescence, advection and sedimentation (dead slots in the storage, the shuffled order of the next coalescence in
+    place when condensation runs), for ordinary cells and for crowded ones (400 per cell: the wave-per-cell finish)"""
+    oi = h.box_opts(6, 5, 7, sd_conc, sstp_cond=2, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for positional in (False, True):
+        if positional:
+            monkeypatch.setenv("LCX_COND_SORTED_ORDER", "1")
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        rw2 = hip.get_attr("rw2")
+        rw2[::7] = (60e-6) ** 2                                  # some drizzle: collisions use super-droplets up, a few fall out
+        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), np.full(rw2.size, -1.),
+                          hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(steps):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part))
+    assert res[0][4] == res[1][4] and res[0][4] < oi.nx * oi.ny * oi.nz * sd_conc      # (super-droplets were used up)
+    for a_, b_ in zip(res[0][:4], res[1][:4]):
+        assert np.array_equal(a_, b_)
+    assert np.abs(res[0][2] - rv).max() > 0
+
+
 @pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
 def test_rcyc_matches_oracle(dims):
     """opts.rcyc: the SDs freed by coalescence / precipitation are re-used as halves of the SDs with the highest
