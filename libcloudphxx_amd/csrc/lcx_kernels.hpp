@@ -782,9 +782,11 @@ k_vterm_b77(size_t n, int only_invalid, vt_cfg v, const T *rw2, const uint32_t *
 #pragma unroll
   for (int k = 0; k < VT_CHUNKS; ++k) {
     const size_t i = base + size_t(k) * 2 * BS;
+    // (the old velocities are read only by the pass that refreshes the invalid ones: a third of the all-droplets pass's reads otherwise)
     if (i + 1 < n) {
-      r2[k] = *reinterpret_cast<const pairT *>(rw2 + i); c[k] = *reinterpret_cast<const pairU *>(ijk + i); o[k] = *reinterpret_cast<const pairT *>(vt + i);
-    } else if (i < n) { r2[k] = pairT{rw2[i], T(0)}; c[k] = pairU{ijk[i], DEAD_CELL}; o[k] = pairT{vt[i], T(0)}; }
+      r2[k] = *reinterpret_cast<const pairT *>(rw2 + i); c[k] = *reinterpret_cast<const pairU *>(ijk + i);
+      o[k] = only_invalid ? *reinterpret_cast<const pairT *>(vt + i) : pairT{T(0), T(0)};
+    } else if (i < n) { r2[k] = pairT{rw2[i], T(0)}; c[k] = pairU{ijk[i], DEAD_CELL}; o[k] = pairT{only_invalid ? vt[i] : T(0), T(0)}; }
     else { r2[k] = pairT{T(0), T(0)}; c[k] = pairU{DEAD_CELL, DEAD_CELL}; o[k] = r2[k]; }
   }
 #pragma unroll
