@@ -1,5 +1,8 @@
+"""Stage timers of the CPU oracle's OpenMP build on the bench workload (what bench.py's cpu_baseline leg times), to see which stages
+still run on one thread:   ORC_TIMERS=1 [OMP_NUM_THREADS=k] python3 tools/cpu_leg_probe.py <cells per dimension> <steps>"""
 import sys, os, time, ctypes
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import bench, _harness as h
 from libcloudphxx_amd import lgrngn
