@@ -1152,7 +1152,18 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     const uint32_t base = cs[cb], end = cs[ce];
     const bool staged = (end - base) <= uint32_t(CF_CAP);
     const bool in_run = mine && has && cl >= cb && cl < ce;
-    if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[gather ? gather[q] : q];
+    if (staged && gather) {
+      // two dependent loads per value: all of a thread's ids first, then all of its gathers (CF_CAP / BS of each in flight)
+      constexpr int PER = CF_CAP / BS;
+      uint32_t gi[PER]; T gv[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const uint32_t q = base + threadIdx.x + uint32_t(k) * BS; gi[k] = q < end ? gather[q] : 0u; }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const uint32_t q = base + threadIdx.x + uint32_t(k) * BS; gv[k] = q < end ? m3_after[gi[k]] : T(0); }
+#pragma unroll
+      for (int k = 0; k < PER; ++k) { const uint32_t q = base + threadIdx.x + uint32_t(k) * BS; if (q < end) lds[q - base] = gv[k]; }
+    }
+    else if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
     __syncthreads();
     if (in_run) after = (gather && !staged) ? seg_sum_gather<T, G>(m3_after, gather, s + sub, e) : seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
     if (step == 0 && !delta) {
