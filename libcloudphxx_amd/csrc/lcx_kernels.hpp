@@ -325,6 +325,8 @@ k_ijk_hist(size_t first, size_t n, grid_t g, const n_t *mult, const T *x, const 
 struct sort_part { uint32_t c_lo, c_hi; int mode; const uint32_t *n_dev, *shift; };
 __device__ __forceinline__ bool part_has(const sort_part &sp, uint32_t c)
 { return sp.mode == 0 || ((c >= sp.c_lo && c < sp.c_hi) == (sp.mode == 1)); }
+// (Measured and dropped: four consecutive super-droplets per lane with 16-byte loads of ijk and rank -- the re-sort 1.83 -> 2.09 ms on C3:
+// a lane's four targets are neighbours, the wave's stores no longer are.)
 // skipped != nullptr (the interior pass of the overlapped re-sort): one byte per wave of 64 super-droplets, set when the wave holds a
 // living super-droplet that this pass leaves out -- the boundary pass (k_scatter_flagged) then reads the cell indices of those waves only
 __global__ void k_scatter_sorted(size_t n, const uint32_t *ijk, const uint32_t *rank, const uint32_t *cell_start,
