@@ -372,6 +372,10 @@ template <class T> LCX_HD T S_cr(T rd3, T kappa, T Tk)
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet
 // (the reference recomputes it in every drw2_dt call); each hoisted quantity is the same
 // expression, so the values entering the formulas are bit-identical.
+// (Considered and dropped: the strict growth rate's fourteen IEEE divisions as the compiler's own reciprocal refinement without its
+// scaling and fix-up instructions -- eight operations instead of eleven, the same bits for operands in the normal range.  But a cell
+// without vapour has RH_eff = rho_v = 0: the IEEE quotients are inf and the growth rate a clean 0, the unscaled sequence returns NaN;
+// six of the fourteen divisions sit downstream of those two, and what is left is not worth a second code path.)
 template <class T> struct cond_fun {
   T rw2_old, dt, rd3, kpa;
   T vt, rhod, eta;
