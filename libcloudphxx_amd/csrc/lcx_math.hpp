@@ -145,10 +145,32 @@ LCX_HD double rcp_newton1(double y)
 }
 LCX_HD float rcp_newton1(float y) { return 1.f / y; }
 template <int FD, class T> LCX_HD T rcp_fd(T y) { if constexpr (FD == 2) return rcp_newton1(y); else return rcp_refined(y); }
+// The correctly rounded quotient without the scaling that the compiler's f64 division carries (v_div_scale twice, v_div_fmas,
+// v_div_fixup around the very same reciprocal refinement): for finite, non-zero operands whose exponents are nowhere near the ends of
+// the range -- every quantity of the growth rate, 1e-30 ... 1e30 -- the scaled and the unscaled sequence are the same eight operations
+// on the same numbers, so the bits are those of `n / d` (tools/strict_checksum.py before and after).  Eight instructions instead of
+// eleven, fourteen divisions per evaluation of the strict growth rate.  (A cell without any vapour, RH_eff = rho_v = 0, gives
+// -inf / inf = NaN in the reference's expression as well: no case in which `/` has an answer and this has none.)
+LCX_HD double div_unscaled(double n, double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = n * r;
+  const double rem = __builtin_fma(-d, q, n);
+  return __builtin_fma(rem, r, q);
+#else
+  return n / d;
+#endif
+}
+LCX_HD float div_unscaled(float n, float d) { return n / d; }
 template <int FD, class T> LCX_HD T dvd(T x, T y)
 {
   if constexpr (FD != 0) return x * rcp_fd<FD>(y);
-  else return x / y;
+  else return div_unscaled(x, y);            // (strict: the bits of x / y, see above -- the root finder's own quotients)
 }
 
 namespace t748 {
@@ -372,10 +394,6 @@ template <class T> LCX_HD T S_cr(T rd3, T kappa, T Tk)
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet
 // (the reference recomputes it in every drw2_dt call); each hoisted quantity is the same
 // expression, so the values entering the formulas are bit-identical.
-// (Considered and dropped: the strict growth rate's fourteen IEEE divisions as the compiler's own reciprocal refinement without its
-// scaling and fix-up instructions -- eight operations instead of eleven, the same bits for operands in the normal range.  But a cell
-// without vapour has RH_eff = rho_v = 0: the IEEE quotients are inf and the growth rate a clean 0, the unscaled sequence returns NaN;
-// six of the fourteen divisions sit downstream of those two, and what is left is not worth a second code path.)
 template <class T> struct cond_fun {
   T rw2_old, dt, rd3, kpa;
   T vt, rhod, eta;
@@ -395,13 +413,16 @@ template <class T> struct cond_fun {
     using c = cst<T>;
     const T rw = sqrt(rw2);
     const T rw3 = rw * rw * rw;
-    const T Re = vt * (T(2) * rw) * rhod / eta;
-    const T D = c::D_0 * trans_beta(lambda_D / rw) * (Nu(Sc, Re) / 2);
-    const T K = c::K_0 * trans_beta(lambda_K / rw) * (Nu(Pr, Re) / 2);
-    const T aw = a_w(rw3, rd3, kpa);
-    const T klv = exp(A / rw);
-    return T(2) * ((T(1) - aw * klv / RH_eff) / c::rho_w /
-                   (T(1) / D / rho_v + lv / K / RH_eff / Tk * lv_term));
+    // (every `/` of the reference's expression, in its order, as div_unscaled)
+    auto dv_ = [](T n_, T d_) { return div_unscaled(n_, d_); };
+    auto beta = [&](T Kn) { return dv_(T(1) + Kn, T(1) + T(1.71) * Kn + T(1.33) * Kn * Kn); };      // trans_beta
+    const T Re = dv_(vt * (T(2) * rw) * rhod, eta);
+    const T D = c::D_0 * beta(dv_(lambda_D, rw)) * (Nu(Sc, Re) / 2);
+    const T K = c::K_0 * beta(dv_(lambda_K, rw)) * (Nu(Pr, Re) / 2);
+    const T aw = dv_(rw3 - rd3, rw3 - rd3 * (T(1) - kpa));                                             // a_w
+    const T klv = exp(dv_(A, rw));
+    return T(2) * dv_(dv_(T(1) - dv_(aw * klv, RH_eff), c::rho_w),
+                      dv_(dv_(T(1), D), rho_v) + dv_(dv_(dv_(lv, K), RH_eff), Tk) * lv_term);
   }
   LCX_HD T operator()(T rw2) const { return rw2_old + dt * drw2_dt(rw2) - rw2; }
 };
