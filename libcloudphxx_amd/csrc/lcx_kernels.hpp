@@ -410,7 +410,7 @@ template <class KEY> constexpr int cr_cap = 1024;                               
 // un == nullptr: the device generator.  The random key of the in-cell shuffle is then un(id) = mix(mix(id ^ s1) + s2) with the 32-bit
 // finaliser of MurmurHash3 for mix -- a BIJECTION of the 32-bit ids, salted per call with two words of Philox(call, seed) that the host
 // draws (rand_un): the keys of a call are all different, so 32 bits order a cell without a tie-break (half the LDS traffic of the
-// ranking, and a dozen integer operations per key instead of Philox's ten rounds: re-sort on C3 2.0 -> see DESIGN.md).  Any function
+// ranking, and a dozen integer operations per key instead of Philox's ten rounds: re-sort on C3 2.0 -> 1.7 ms).  Any function
 // of (id, call, seed) alone is as deterministic as any other; the reference draws un from its generator's stream the same way
 // (hskpng_sort.ipp:38-46, urand.hpp:57-86).
 struct rng_src { const uint32_t *un; uint64_t call, seed; uint32_t s1, s2; };
@@ -2308,7 +2308,7 @@ __global__ void k_scan_sums2(uint32_t *sums, size_t m, uint32_t *total)
 // The same lists from the per-workgroup words that k_move leaves (wg_mig: left-going, right-going, dead -- ten bits each, one word per
 // 256 SDs): the flags are read only where a count says there is something to find -- the boundary planes, a few per cent of a slab.
 // (k_mig_tiles2 + k_scan_sums2 + k_mig_ids2 read every flag twice, a byte per lane: 0.36 ms per step on C3, 0.05 on a 16-plane slab;
-// these four: see DESIGN.md.)  A tile is BS workgroups of k_move, one per thread.  The step's dead count is the sum of the third
+// these four: 0.05 and 0.024 ms.)  A tile is BS workgroups of k_move, one per thread.  The step's dead count is the sum of the third
 // field: one atomic per tile that has any.
 __global__ void __launch_bounds__(BS) k_mig_tiles3(const uint32_t *wg_mig, size_t n_wg, uint32_t n_tiles, uint32_t *tile_sums, unsigned int *dead_count)
 {
