@@ -192,7 +192,8 @@ def main():
     ap.add_argument("--strict-leg-steps", type=int, default=20)
     ap.add_argument("--cpu-sample-n", type=int, default=128)
     ap.add_argument("--cpu-sample-steps", type=int, default=2)
-    ap.add_argument("--no-stage-timers", action="store_true", help="do not record per-stage hipEvents in the timed region")
+    ap.add_argument("--no-stage-timers", action="store_true", help="no hipEvents at all (neither the condensation stage's in the timed region nor the stage pass)")
+    ap.add_argument("--stage-steps", type=int, default=20, help="extra steps behind the timed region with every stage's hipEvents on: the stage table (0: none)")
     ap.add_argument("--oversubscribe", action="store_true", help="--gpus N in one process with all N slabs on device 0")
     ap.add_argument("--spmd", action="store_true", help="(the default under torch.distributed.run; kept for older command lines)")
     ap.add_argument("--native", action="store_true",
@@ -391,8 +392,11 @@ def main():
         for _ in range(args.warmup):
             one_step()
         p1 = prt.prt if spmd else prt
+        # the timed region carries the events of the dominant kernel's stage only (the roofline's launch duration, two records per
+        # step); the stage table comes from a few EXTRA steps with every stage's events on -- each record is a packet between two kernels,
+        # and fifty of them per step cost a 16-plane slab 0.11 ms of its 1.33 ms step (0.04 of C3's 10)
         if not args.no_stage_timers:
-            p1.set_profiling(True)
+            p1.set_profiling(2)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -400,7 +404,18 @@ def main():
             sd_done += p1.n_part
         barrier()
         elapsed = time.perf_counter() - t0
-        stage_ms = p1.timings() if not args.no_stage_timers else {}
+        cond_ms = p1.timings().get("cond") if not args.no_stage_timers else None
+        stage_ms = {}
+        if not args.no_stage_timers and args.stage_steps > 0:
+            p1.set_profiling(1)
+            for _ in range(args.stage_steps):
+                one_step()
+            sync_all()                                       # (no rendezvous with the other ranks: they are in the same loop, or idle)
+            stage_ms = {k: (v * args.steps / args.stage_steps if k != "rendezvous_hidden_share" else v) for k, v in p1.timings().items()}
+        if not args.no_stage_timers:
+            p1.set_profiling(0)
+        if cond_ms is not None:
+            stage_ms["cond"] = cond_ms                       # (the timed region's own)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -515,7 +530,9 @@ def main():
                                                                                              else "the reference's TOMS748 iterates"),
                        "init_s": t_init},
             "roofline": roof,
+            # `cond` from the timed region; the other stages from args.stage_steps extra steps (scaled to the same per-step unit)
             "stage_ms_per_step": {k: (v / args.steps if k != "rendezvous_hidden_share" else v) for k, v in stage_ms.items()},
+            "stage_pass_steps": 0 if args.no_stage_timers else args.stage_steps,
             "stage_roofline": stage_roof,
         }
         if world_out == 1 and not args.strict_fp and not args.no_strict_leg and args.cond_mode == "percell" and not args.self_ring:

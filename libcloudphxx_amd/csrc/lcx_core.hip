@@ -216,7 +216,7 @@ struct Particles : IParticles {
   std::deque<Replay> replay;
   std::vector<std::unique_ptr<DevBuf<T>>> replay_keep_T; std::vector<std::unique_ptr<DevBuf<uint32_t>>> replay_keep_u;
   // profiling
-  bool profiling = false;
+  int profiling = 0;
   std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_events;
   std::map<std::string, double> prof_ms; std::vector<std::string> prof_order;
 
@@ -327,12 +327,24 @@ struct Particles : IParticles {
   void sync() { HIPCHK(hipStreamSynchronize(st)); }
 
   // ---- profiling ranges (hipEvents on OUR stream) ----
+  // profiling: 0 off; 1 every stage; 2 the condensation kernel's stage only -- two event records per step instead of fifty: every record
+  // is a packet between two kernels, and on a 16-plane slab of C3 the full set costs 0.11 ms of a 1.33 ms step (bench.py times with
+  // level 2 and takes the stage table from a few extra steps at level 1)
   struct Range {
-    Particles *self; std::string name; hipEvent_t a = nullptr, b = nullptr;
+    Particles *self; const char *name; hipEvent_t a = nullptr, b = nullptr;
     Range(Particles *s, const char *nm) : self(s), name(nm)
-    { if (self->profiling) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, self->st); } }
-    ~Range() { if (self->profiling && a) { (void)hipEventRecord(b, self->st); self->prof_events.push_back({name, {a, b}}); } }
+    {
+      if (self->profiling == 1 || (self->profiling == 2 && !strcmp(nm, "cond"))) { a = self->prof_event(); b = self->prof_event(); (void)hipEventRecord(a, self->st); }
+    }
+    ~Range() { if (a) { (void)hipEventRecord(b, self->st); self->prof_events.push_back({std::string(name), {a, b}}); } }
   };
+  std::vector<hipEvent_t> prof_pool;
+  hipEvent_t prof_event()
+  {
+    hipEvent_t e = nullptr;
+    if (!prof_pool.empty()) { e = prof_pool.back(); prof_pool.pop_back(); } else (void)hipEventCreate(&e);
+    return e;
+  }
   void collect_profile()
   {
     if (!profiling) return;
@@ -341,11 +353,11 @@ struct Particles : IParticles {
       float ms = 0; (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
       if (!prof_ms.count(e.first)) prof_order.push_back(e.first);
       prof_ms[e.first] += ms;
-      (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second);
+      prof_pool.push_back(e.second.first); prof_pool.push_back(e.second.second);
     }
     prof_events.clear();
   }
-  void set_profiling(int on) override { collect_profile(); profiling = on != 0; prof_ms.clear(); prof_order.clear(); }
+  void set_profiling(int on) override { collect_profile(); profiling = on < 0 ? 0 : on > 2 ? 1 : on; prof_ms.clear(); prof_order.clear(); }
   void timings(const char **names, double *ms, size_t capn, size_t *n) override
   {
     collect_profile();
