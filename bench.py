@@ -301,13 +301,40 @@ def main():
         arrays = [lgrngn.DeviceArrays([parts[r][k].data_ptr() for r in range(args.gpus)], parts[0][k].shape) for k in range(6)]
         return prt, parts, arrays, sorted(set(slab_dev))
 
+    def rccl_ring_works():
+        """one small message to either neighbour and back, the way libcloudphxx_amd/multi.py posts them (a batch of isend / irecv on
+        device tensors); every rank learns whether EVERY rank got through -- a node whose RCCL cannot do that still gets measured"""
+        ok = 1
+        try:
+            lft, rgt = (rank - 1) % world, (rank + 1) % world
+            out_l = torch.full((256,), float(rank), device=dev); out_r = out_l.clone()
+            in_l = torch.empty(256, device=dev); in_r = torch.empty(256, device=dev)
+            ops = [dist.P2POp(dist.isend, out_l, lft), dist.P2POp(dist.isend, out_r, rgt),
+                   dist.P2POp(dist.irecv, in_r, rgt), dist.P2POp(dist.irecv, in_l, lft)]
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            torch.cuda.synchronize(dev)
+            if float(in_l[0]) != float(lft) or float(in_r[0]) != float(rgt):
+                ok = 0
+        except Exception as e:                               # (RuntimeError / DistBackendError: no link, no IPC, ...)
+            print("bench.py rank %d: RCCL ring probe: %s" % (rank, e), file=sys.stderr, flush=True)
+            ok = 0
+        t = torch.tensor([ok])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)             # (gloo)
+        return bool(int(t.item()))
+
     def setup_local():
         """a single-device object: the whole domain, or this rank's slab of the one-object-per-rank run"""
         oi.dev_count, oi.dev_id, oi.n_sd_max = 0, dev_index, n_sd_max0
         if spmd:
             shared_gpu = torch.cuda.device_count() < world           # several ranks on one device: RCCL refuses that, stage through the host
-            prt = multi.particles_multi_t(oi, real_t, device=dev, transport=args.transport or ("host" if shared_gpu else "rccl"),
-                                          self_ring=args.self_ring)
+            transport = args.transport or ("host" if shared_gpu else "rccl")
+            if transport == "rccl" and world > 1 and not rccl_ring_works():
+                transport = "host"
+                if rank == 0:
+                    print("bench.py: a device-to-device ring exchange over RCCL failed on this node; the migrants are staged through the host",
+                          file=sys.stderr, flush=True)
+            prt = multi.particles_multi_t(oi, real_t, device=dev, transport=transport, self_ring=args.self_ring)
             nx_loc, x_off = prt.opts_init.nx, prt.n_x_bfr
         else:
             prt = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
