@@ -1043,16 +1043,18 @@ struct Particles : IParticles {
     const bool onishi = o.kernel == LCX_KERNEL_ONISHI_HALL || o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS;
     // diss == nullptr stands for the reference's constant-zero dissipation rate when opts.turb_coal is off (coal.ipp:392-403,439-451)
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p, eta.p, rhod.p, turb_coal ? diss_rate.p : nullptr};
-    auto launch = [&](auto kern) {
+    const bool kappa_pass = o.n_dry_distros + n_size_keys > 1;
+    auto launch = [&](auto kern, bool need_col = true) {
       hipLaunchKernelGGL(kern, dim3(nblk((npart + 1) / 2)), dim3(BS), 0, st, npart, sid(), sijk(), cell_start.p, A.n.p, A.rw2.p, A.vt.p,
-                         A.rd3.p, col.p, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
+                         A.rd3.p, need_col ? col.p : (T *)nullptr, dv.p, T(dt_sub), kc, rs, int(pure_const_multi), d_flag.p, use_rc2 ? A.ext[ix_rc2].p : nullptr,
                          ix_ict >= 0 ? A.ext[ix_ict].p : nullptr, coal_marks_dead ? ijk.p : nullptr);
     };
     const bool tabulated = o.kernel != LCX_KERNEL_GOLOVIN && o.kernel != LCX_KERNEL_GEOMETRIC && o.kernel != LCX_KERNEL_LONG;
     if (onishi) launch(k_coal<T, true>);
-    else if (tabulated && !pure_const_multi && !rs.arr && !use_rc2 && ix_ict < 0 && coal_marks_dead) launch(k_coal<T, false, true>);
+    // (the production kernel writes the collision record only for the kappa pass: nothing else reads it outside a replayed run)
+    else if (tabulated && !pure_const_multi && !rs.arr && !use_rc2 && ix_ict < 0 && coal_marks_dead) launch(k_coal<T, false, true>, kappa_pass);
     else launch(k_coal<T, false>);
-    if (o.n_dry_distros + n_size_keys > 1)
+    if (kappa_pass)
       hipLaunchKernelGGL(k_coal_kappa<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), col.p, A.kpa.p, A.rd3.p);
   }
 

@@ -1632,7 +1632,8 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // start at 2t+1.  Every pair of the reference (even in-cell offset a, b = a+1 in the same cell, coal.ipp:198-212) is
 // owned by exactly one lane and all 64 lanes of a wave carry work.  Pairs are disjoint, so the read-modify-write
 // of the two SDs needs no atomics.  The collision count / who-was-bigger flags go to col[] exactly as in the
-// reference (coal.ipp:209,233-267) because the kappa update (and tests) read them.
+// reference (coal.ipp:209,233-267) because the kappa update (and tests) read them -- col == nullptr: nobody will (one kappa, the
+// production kernel): 8 bytes per super-droplet and step that were written for nothing, 1.55 -> 1.40 ms on C3.
 // TAB (as k_move's SPEC: uniform branches are dear): the production configuration compiled for itself -- a tabulated-efficiency
 // kernel (hall*, vohl*), random numbers from Philox, no per-particle rc2 / in-cloud time, used-up super-droplets marked in ijk
 // (Measured and dropped, round 3: the terminal velocities of hskpng_vterm_all computed HERE by the lane that owns the pair, from the wet
@@ -1659,12 +1660,12 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
   {
     const bool even0 = ((uint32_t(p) - off) & 1u) == 0;
     if (!(even0 && c1 == ca)) {
-      if (even0) col[p] = T(0);                        // last SD of a cell with an odd count: no partner
+      if (even0 && col) col[p] = T(0);                 // last SD of a cell with an odd count: no partner
       p = p0 + 1;
       if (!has2) return;
       if (c1 != ca) { ca = c1; off = off1; end = end1; }
       if ((uint32_t(p) - off) & 1u) return;            // odd offset: this SD is the b of the previous lane's pair
-      if (c2 != ca) { col[p] = T(0); return; }
+      if (c2 != ca) { if (col) col[p] = T(0); return; }
       a = i1; b = i2;
     }
   }
@@ -1679,7 +1680,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
   if (pure_const_multi && col_no >= 1) *increase_sstp_coal = 1;
   const T u = rs.arr ? rs.arr[p] : philox::u01<T>(p, rs.call, rs.seed);
   if (u < prob - col_no) ++col_no;
-  if (col_no == 0) { col[p] = T(0); col[p + 1] = T(0); return; }
+  if (col_no == 0) { if (col) { col[p] = T(0); col[p + 1] = T(0); } return; }
   if (na >= nb) {                                                            // collide<>, coal.ipp:110-143
     if (nb > 0) { const n_t q = na / nb; if (q < col_no) col_no = q; }
     n[a] = na - col_no * nb;
@@ -1691,7 +1692,7 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     vt[b] = T(-1);
     if (rc2) rc2[b] = T(-1);                                                 // invalidator, coal.ipp:33-44,527-545
     if (ict) ict[b] = mx(ict[a], ict[b]);                                    // selector, coal.ipp:17-31,505-525
-    col[p + 1] = T(-2);
+    if (col) col[p + 1] = T(-2);
   } else {
     if (na > 0) { const n_t q = nb / na; if (q < col_no) col_no = q; }
     n[b] = nb - col_no * na;
@@ -1702,9 +1703,9 @@ k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, con
     vt[a] = T(-1);
     if (rc2) rc2[a] = T(-1);
     if (ict) ict[a] = mx(ict[a], ict[b]);
-    col[p + 1] = T(-1);
+    if (col) col[p + 1] = T(-1);
   }
-  col[p] = T(col_no);
+  if (col) col[p] = T(col_no);
 }
 // weighted_summator, coal.ipp:57-97,458-480 (only with more than one kappa in the run)
 template <class T>
