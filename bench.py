@@ -468,6 +468,16 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
+            # On a single device the storage-order kernel also does the SCATTER of the previous step's re-sort (k_scatter_sorted's loads
+            # and stores, 3I + 2I = 20 B per SD: cell index and arrival rank read, cell offset gathered, sorted id and sorted cell written)
+            # in every step but the storage re-ordering ones.  `achieved` / `frac` stay on the condensation's own 56 B;
+            # the launch's whole algorithmic traffic is given beside them.
+            if (not args.strict_fp and args.cond_solver == "lean" and world_out == 1 and not args.self_ring and args.sstp_cond == 1
+                    and "LCX_NO_DEFERRED_SORT" not in os.environ and "LCX_COND_SORTED_ORDER" not in os.environ):
+                carried = 5 * 4
+                roof["carries"] = "the scatter of the previous step's re-sort (k_scatter_sorted: %d B per SD), except in storage re-ordering steps" % carried
+                roof["achieved_with_carried"] = (cond_bytes_per_sd + carried) * n_local / (avg_ms * 1e-3) / 1e9
+                roof["frac_with_carried"] = roof["achieved_with_carried"] / HBM_PEAK_GBS
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
             # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
             default_cfg = (world_out == 1 and n == 128 and not (args.nx or args.ny or args.nz) and args.sd_conc == 64 and args.real == "f64"

@@ -549,22 +549,47 @@ struct Particles : IParticles {
   // meta_known: {number of cells above CELLRANK_MAX, largest occupancy} already on the host (listed from the histogram ahead of the
   // step's read-back), else order_cells lists them from the CSR offsets and pays a host round trip of its own
   uint32_t big_n = 0, big_mx = 0; uint64_t meta_version = ~0ull;
-  void sort_from_hist(bool shuffle, const uint32_t *meta_known = nullptr)
+  // defer: the scan only -- the scatter and the in-cell ranking are left to the next step's condensation (finish_deferred_sort, or the
+  // storage-order kernel that carries the scatter, cond_substep); the random keys of a shuffle are drawn NOW, at their place in the
+  // generator's sequence
+  bool sort_deferred = false, deferred_shuffle = false; rng_src deferred_rs{nullptr, 0, 0, 0u, 0u};
+  const bool defer_sort_ok = getenv("LCX_NO_DEFERRED_SORT") == nullptr;
+  void sort_from_hist(bool shuffle, const uint32_t *meta_known = nullptr, bool defer = false)
   {
+    sort_deferred = false;
     // (the scan leaves the histogram and the step's counters cleared for the next fused move)
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, cell_cnt.p, step_cnt.p, 3);
     ++cells_version;
     if (meta_known) { big_n = meta_known[0]; big_mx = meta_known[1]; meta_version = cells_version; }
+    if (defer && nphys && npart) {
+      deferred_shuffle = shuffle;
+      deferred_rs = shuffle ? rand_un(npart) : rng_src{nullptr, 0, 0, 0u, 0u};
+      sort_deferred = true; sorted = false;
+      return;
+    }
     if (nphys)
       hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid(), sijk());
     order_cells(shuffle);
   }
-  // puts every cell segment of sorted_id into the reference's order: ascending id, or ascending (un[id], id)
-  void order_cells(bool shuffle)
+  // scattered == false: nobody has carried the scatter
+  void finish_deferred_sort(bool scattered = false)
   {
+    if (!sort_deferred) return;
+    sort_deferred = false;
+    Range r(this, "post_copy");
+    if (!scattered && nphys)
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid(), sijk());
+    order_cells(deferred_shuffle, &deferred_rs);
+    shuffle_fresh = deferred_shuffle;
+  }
+  // puts every cell segment of sorted_id into the reference's order: ascending id, or ascending (un[id], id)
+  void order_cells(bool shuffle, const rng_src *drawn = nullptr)
+  {
+    sort_deferred = false;
     if (npart) {
       rng_src rs{nullptr, 0, 0, 0u, 0u};
-      if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
+      if (drawn) rs = *drawn;
+      else if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
       else {
         // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
@@ -612,12 +637,13 @@ struct Particles : IParticles {
   void hskpng_sort_helper(bool shuffle)
   {
     Range r(this, shuffle ? "hskpng_shuffle_and_sort" : "hskpng_sort");
+    finish_deferred_sort();
     if (sorted && shuffle && sorted_shuffled && shuffle_fresh && replay.empty()) { shuffle_fresh = false; return; }   // post_copy has shuffled for us already
     if (sorted && shuffle) { order_cells(true); return; }   // cells unchanged since the last sort: re-order the segments only
     ijk_and_hist(0, true);
     sort_from_hist(shuffle);
   }
-  void hskpng_sort() { if (!sorted) hskpng_sort_helper(false); }
+  void hskpng_sort() { finish_deferred_sort(); if (!sorted) hskpng_sort_helper(false); }
   void hskpng_count() { hskpng_sort(); }
   void hskpng_vterm(bool only_invalid)
   {
@@ -793,8 +819,10 @@ struct Particles : IParticles {
     // as it finds it, so the cells must not be left in the shuffled order there -- the in-cell ranking by id stays, coalescence
     // shuffles for itself)
     const bool preshuffle = !strict_order && !o.strict_fp && last_async_coal && o.coal_switch && !reorder_due && npart >= 2;
-    sort_from_hist(preshuffle, meta_p);
-    shuffle_fresh = preshuffle;
+    // (the scatter rides on the next condensation kernel when that will be the storage-order one: a single device, no re-ordering due)
+    const bool defer = defer_sort_ok && lean_storage_cond() && !distmem() && !reorder_due && meta_p != nullptr && replay.empty();
+    sort_from_hist(preshuffle, meta_p, defer);
+    shuffle_fresh = preshuffle && !sort_deferred;
     // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
     if (compact_now || (!strict_order && ++steps_since_reorder >= every_)) reorder_storage();
   }
@@ -849,9 +877,12 @@ struct Particles : IParticles {
     for (int ix = 0; ix < (var_rho ? 3 : 2); ++ix)
       hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
   }
+  bool lean_storage_cond() const
+  { return !o.strict_fp && !no_cond_pre && cond_storage_order && o.cond_solver != 1 && getenv("LCX_COND_TOMS") == nullptr && !o.exact_sstp_cond; }
   void cond_substep(double RH_max, int step, bool turb_cond = false)
   {
-    hskpng_sort();
+    const bool carry_scatter = sort_deferred && lean_storage_cond() && !turb_cond && npart;
+    if (!carry_scatter) hskpng_sort();
     // fast arithmetic (no SGS supersaturation): per-cell set-up hoisted (k_cond_cellpre) and one scratch value per droplet (the
     // change of n rw^3); strict arithmetic: n rw^3 before and after in position order + the ordered per-cell walk
     const bool fast = !o.strict_fp && !turb_cond && !no_cond_pre;
@@ -872,7 +903,7 @@ struct Particles : IParticles {
       cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
-                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 (or LCX_COND_TOMS=1) keeps round 2's kernels
       // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
@@ -882,6 +913,7 @@ struct Particles : IParticles {
         cond_in_storage_order = cond_storage_order;
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
+          if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
           hipLaunchKernelGGL((k_cond_lean<T, 3>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
         }
         else hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);
@@ -908,6 +940,7 @@ struct Particles : IParticles {
       else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
       else hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a);
     }
+    if (carry_scatter) finish_deferred_sort(true);           // the in-cell ranking, behind the kernel that scattered
     {
       Range r(this, "cond_cellfinish");
       launch_cellfinish(step, sstp_cond, fast, cond_in_storage_order ? sid() : (const uint32_t *)nullptr);
@@ -1517,7 +1550,7 @@ struct Particles : IParticles {
     if (ix_ict >= 0 && nphys)                                                            // update_incloud_time, particles_step.ipp:180-181
       hipLaunchKernelGGL(k_incloud_time<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, A.rd3.p, A.kpa.p, A.rw2.p, Tk.p, T(dt), A.ext[ix_ict].p);
     if (opts.cond) {
-      hskpng_sort();
+      if (!(sort_deferred && lean_storage_cond() && !opts.turb_cond && !(o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)))) hskpng_sort();
       if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) { hskpng_mfp(); cond_perparticle(opts.RH_max, opts.turb_cond); }
       else for (int step = 0; step < sstp_cond; ++step) {
         sstp_percell_step(step);

@@ -834,6 +834,9 @@ struct cond_args {
   const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
   const cond_cell_fast<T> *pre;   // fast arithmetic without turb_cond: the droplet-independent set-up, per cell (k_cond_cellpre)
   const uint32_t *storage_ijk;    // k_cond_lean in storage order (see there), else nullptr
+  // the scatter of the re-sort that the end of the previous step left undone (k_scatter_sorted's two loads and two stores per droplet),
+  // carried by the storage-order condensation kernel, whose memory pipes idle while its vector ALU is the bottleneck; else sc_rank == nullptr
+  const uint32_t *sc_rank, *sc_cell_start; uint32_t *sc_sorted_id, *sc_sorted_ijk;
 };
 template <class T>
 __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
@@ -1008,7 +1011,11 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
   // coalesced.  A droplet's answer does not depend on who computes it, and the sums per cell keep their order.
   size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
   uint32_t id, c;
-  if (a.storage_ijk) { id = uint32_t(pos); c = a.storage_ijk[pos]; if (c == DEAD_CELL) return; }
+  if (a.storage_ijk) {
+    id = uint32_t(pos); c = a.storage_ijk[pos];
+    if (c == DEAD_CELL) return;
+    if (a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; }
+  }
   else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
   T rw2_old = a.rw2[id], rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
   T nn = T(a.n[id]);

@@ -866,6 +866,43 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
     assert np.abs(res[0][2] - rv).max() > 0
 
 
+@pytest.mark.parametrize("sd_conc,reorder_every,cond_every", [(64, 0, 1), (64, 3, 1), (300, 4, 1), (48, 5, 2)])
+def test_deferred_sort_is_bit_identical_to_the_immediate_one(monkeypatch, sd_conc, reorder_every, cond_every):
+    """The end-of-step re-sort of a single device leaves its scatter and in-cell ranking to the next step: the storage-order condensation
+    kernel carries the scatter (its memory pipes idle while its vector ALU is the bottleneck), the ranking follows it, and whoever
+    else needs the sorted order first (a diagnostic, a step without condensation, coalescence) finishes the sort where it stands.
+    LCX_NO_DEFERRED_SORT=1 sorts at once.  The random keys are drawn at the same place of the generator's sequence either way: the
+    same bits after full steps with coalescence -- across storage re-orderings (no deferral in those steps), with crowded cells (300 per
+    cell: the listed-cell sorts), with condensation switched off every other step, and with a diagnostic between the steps"""
+    oi = h.box_opts(6, 5, 7, sd_conc, strict_fp=False)
+    oi.reorder_every = reorder_every
+    fields = h.box_fields(oi)
+    res = []
+    for immediate in (False, True):
+        if immediate:
+            monkeypatch.setenv("LCX_NO_DEFERRED_SORT", "1")
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        rw2 = hip.get_attr("rw2")
+        rw2[::7] = (60e-6) ** 2
+        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), np.full(rw2.size, -1.),
+                          hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+        thh, rvh = th.copy(), rv.copy()
+        conc = []
+        for it in range(9):
+            opts = lgrngn.opts_t()
+            opts.cond = it % cond_every == 0
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+            if it in (2, 6):                                      # a reader of the sorted order between two steps
+                hip.diag_all(); hip.diag_sd_conc(); conc.append(hip.outbuf_array())
+        res.append((hip.get_attr("rw2"), hip.get_attr("x"), thh, rvh, hip.state_u64("n"), np.stack(conc), hip.n_part))
+    assert res[0][6] == res[1][6] and res[0][6] < oi.nx * oi.ny * oi.nz * sd_conc
+    for a_, b_ in zip(res[0][:6], res[1][:6]):
+        assert np.array_equal(a_, b_)
+
+
 @pytest.mark.parametrize("dims", [(0, 0, 0), (4, 3, 5)])
 def test_rcyc_matches_oracle(dims):
     """opts.rcyc: the SDs freed by coalescence / precipitation are re-used as halves of the SDs with the highest
