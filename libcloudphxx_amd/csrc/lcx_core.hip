@@ -544,7 +544,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, size_t(0), nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
                          do_hist ? cell_cnt.p : nullptr, rank.p, do_ijk);
   }
-  void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(2, false); sorted = false; }
+  void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(2, false); sorted = false; sort_deferred = false; }   // (a sort left undone is void)
   // finish a sort given cell_cnt/rank: scan -> scatter -> per-cell order
   // meta_known: {number of cells above CELLRANK_MAX, largest occupancy} already on the host (listed from the histogram ahead of the
   // step's read-back), else order_cells lists them from the CSR offsets and pays a host round trip of its own
@@ -1508,7 +1508,7 @@ struct Particles : IParticles {
     hskpng_vterm(true);
     hskpng_approximate_rc2_invalid();                                                    // particles_init.ipp:116-117
     sstp_save();
-    sorted = false;
+    sorted = false; sort_deferred = false;
     hskpng_count();
     if (!B.n.p) alloc_attrs(B);      // the compaction target: allocated here, not inside the first step that compacts (GBs of hipMalloc)
     sync();

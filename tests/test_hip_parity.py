@@ -897,6 +897,11 @@ def test_deferred_sort_is_bit_identical_to_the_immediate_one(monkeypatch, sd_con
             hip.step_async(opts)
             if it in (2, 6):                                      # a reader of the sorted order between two steps
                 hip.diag_all(); hip.diag_sd_conc(); conc.append(hip.outbuf_array())
+            if it == 4:                                           # the caller replaces the droplets while a sort is left undone: that sort is void
+                r2 = hip.get_attr("rw2")
+                r2[::11] *= 1.5
+                hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), r2, hip.get_attr("kappa"), np.full(r2.size, -1.),
+                                  hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
         res.append((hip.get_attr("rw2"), hip.get_attr("x"), thh, rvh, hip.state_u64("n"), np.stack(conc), hip.n_part))
     assert res[0][6] == res[1][6] and res[0][6] < oi.nx * oi.ny * oi.nz * sd_conc
     for a_, b_ in zip(res[0][:6], res[1][:6]):
