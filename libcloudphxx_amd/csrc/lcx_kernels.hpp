@@ -848,6 +848,9 @@ __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const 
 // Strict arithmetic, and the fast arithmetic with an SGS supersaturation perturbation per droplet (turb_cond); the production
 // fast path is k_cond_fast below.  Register budget: 128 VGPRs = 4 waves per SIMD (the kernel wants 136; 3 waves: 10.7 ms,
 // 4 waves with 24 B of scratch per lane: 10.1 ms, 5 waves: 13.0 ms).
+// (Measured and dropped: this kernel in storage order with the re-sort's scatter on the side, as k_cond_lean -- the same bits, and the
+// strict step 19.06 ms against 19.01: at four waves per SIMD and 32 B of scratch the extra loads and stores cost the kernel what the
+// re-sort saves, and the per-cell finish pays for two gathers.)
 template <class T, bool FAST>
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4))) k_cond(size_t n_part, cond_args<T> a)
 {
