@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "host"], default=None,
                     help="one object per rank: how the migrants travel -- device buffers over RCCL (default with one GPU per rank), or "
                          "staged through the host over gloo (default when the ranks share a GPU)")
+    ap.add_argument("--dbg", default="",
+                    help="comma-separated names of opts_init.dbg_flags bits (libcloudphxx_amd.lgrngn.dbg: test / measurement switches, "
+                         "e.g. NO_DEFERRED_SORT,COND_SORTED_ORDER,MULTI_SERIALIZE); the library reads no such switch from the environment")
     args = ap.parse_args()
 
     # stdout carries ONE line, the result.  Libraries that write to file descriptor 1 on their own (RCCL prints a version banner from
@@ -272,6 +275,8 @@ def main():
     oi.strict_fp = args.strict_fp
     oi.cond_solver = 1 if args.cond_solver == "toms748" else 0
     oi.reorder_every = args.reorder_every
+    for name in filter(None, args.dbg.split(",")):
+        oi.dbg_flags |= int(lgrngn.dbg[name.strip()])
     if args.cond_mode != "percell":
         oi.exact_sstp_cond = True
         oi.sstp_cond_mix = args.cond_mode == "pp_mix"
@@ -473,7 +478,7 @@ def main():
             # in every step but the storage re-ordering ones.  `achieved` / `frac` stay on the condensation's own 56 B;
             # the launch's whole algorithmic traffic is given beside them.
             if (not args.strict_fp and args.cond_solver == "lean" and world_out == 1 and not args.self_ring and args.sstp_cond == 1
-                    and "LCX_NO_DEFERRED_SORT" not in os.environ and "LCX_COND_SORTED_ORDER" not in os.environ):
+                    and not oi.dbg_flags & int(lgrngn.dbg.NO_DEFERRED_SORT | lgrngn.dbg.COND_SORTED_ORDER)):
                 carried = 5 * 4
                 roof["carries"] = "the scatter of the previous step's re-sort (k_scatter_sorted: %d B per SD), except in storage re-ordering steps" % carried
                 roof["achieved_with_carried"] = (cond_bytes_per_sd + carried) * n_local / (avg_ms * 1e-3) / 1e9

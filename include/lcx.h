@@ -120,7 +120,34 @@ typedef struct {
                          * A re-ordering renumbers the ids: SDs keep their relative order inside a cell, the relative order of SDs of
                          * different cells and the id -> random-number association change (statistically equivalent).  An object
                          * that was ever fed a replayed random stream (lcx_rng_replay_push, i.e. a parity run) behaves like -1. */
+  /* --- test / measurement switches (no reference counterpart; all 0 in production).  They used to be LCX_* environment variables read
+   * here and there in the library; a stray variable in a user's environment silently changed the kernel path.  Now they are part of the
+   * options an object is created with, read once, and the library reads no environment variable but LCX_DATA_DIR (where the collision
+   * efficiency tables live) and LCX_MULTI_DEVICE_MAP (slab -> device map of a multi-device object). */
+  unsigned dbg_flags;   /* LCX_DBG_* bits below */
+  int dbg_cond_budget;  /* cond_solver = 1: iteration budget of the first condensation pass (stragglers go to a dense second launch);
+                         * 0: the library's choice (6 from 2^25 super-droplets, else one pass), > 0: that budget, < 0: one pass */
+  int dbg_pack_delay_us;/* multi-device tests: slabs with an odd first plane send their messages so many microseconds late */
 } lcx_opts_init_t;
+
+enum lcx_dbg {
+  LCX_DBG_NO_COND_PRE = 1 << 0,        /* fast arithmetic: evaluate the per-cell set-up of the growth rate per droplet (k_cond<T, true>) */
+  LCX_DBG_NO_WAVE_FLAGS = 1 << 1,      /* exchange: scatter the boundary super-droplets without the per-wave flags */
+  LCX_DBG_EAGER_COMPACT = 1 << 2,      /* compact dead super-droplets away in every step (the reference's remove_n0) */
+  LCX_DBG_SHUFFLE_PHILOX = 1 << 3,     /* shuffle keys drawn from Philox, ranked on 64 bits (round 2's form) */
+  LCX_DBG_NO_DEFERRED_SORT = 1 << 4,   /* the end-of-step re-sort finished at once instead of riding on the next condensation kernel */
+  LCX_DBG_COND_NO_FOLD = 1 << 5,       /* cond_solver = 1: k_cond_fast instead of k_cond_fast_fold */
+  LCX_DBG_COND_SORTED_ORDER = 1 << 6,  /* k_cond_lean over the sorted order (gathers) instead of the storage order */
+  LCX_DBG_NO_OVERLAP = 1 << 7,         /* exchange: no re-sort of the interior while the messages travel */
+  LCX_DBG_MULTI_NO_PEER = 1 << 8,      /* multi-device object: treat the devices as unable to map each other's memory (staged copies) */
+  LCX_DBG_MULTI_SERIALIZE = 1 << 9,    /* multi-device object: the slabs take turns (per-slab timing on one GPU) */
+  LCX_DBG_TAG = 1 << 10,               /* every super-droplet carries a persistent tag (its index at init / set_particles) as one more
+                                        * attribute that is compacted, re-ordered and migrates with it (lcx_get_state_real "raw_tag"), and
+                                        * every coalescence call records what it consumed of the random generator (lcx_rng_dump) */
+  LCX_DBG_COND_NO_DEAL = 1 << 11,      /* k_cond_lean: one droplet per lane in storage order, no dealing of a workgroup's droplets by their
+                                        * last iteration count */
+  LCX_DBG_HOST_SYNC_LOOP = 1 << 12     /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
+};
 
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */
 typedef struct {
@@ -226,7 +253,10 @@ int lcx_real_kind(lcx_particles *, int *kind);
 /* integer state: "n","ijk","sorted_id","sorted_ijk","count_ijk","count_num","cell_start" (as uint64) */
 int lcx_get_state_u64(lcx_particles *, const char *name, unsigned long long *out, size_t cap, size_t *n);
 /* real state not covered by get_attr: "vt","T","p","RH","eta","th","rv","rhod","dv","lambda_D","lambda_K",
- * "courant_x","courant_y","courant_z","vt_0" (as double whatever the real kind) */
+ * "courant_x","courant_y","courant_z","vt_0" (as double whatever the real kind).
+ * Names that begin with "raw_" ("raw_n","raw_ijk" as u64; "raw_rw2","raw_rd3","raw_kappa","raw_vt","raw_x","raw_y","raw_z","raw_tag" as
+ * reals) return the STORAGE as it is -- its whole extent, dead slots (n == 0) included, nothing compacted or sorted on the way: reading
+ * them does not disturb a production run, whereas every other particle-state getter first puts the storage into the reference's order. */
 int lcx_get_state_real(lcx_particles *, const char *name, double *out, size_t cap, size_t *n);
 /* overwrite particle state (all arrays of length n; x/y/z may be NULL for absent dimensions);
  * lets a test start the device from an oracle state */
@@ -239,6 +269,14 @@ int lcx_set_particles(lcx_particles *, size_t n, const unsigned long long *mult,
  * with the reference CPU backends (src/detail/urand.hpp:24-86). */
 int lcx_rng_replay_push(lcx_particles *, int kind, const double *data, size_t n);
 int lcx_rng_replay_pending(lcx_particles *, size_t *n_arrays);
+/* the reverse of the replay (needs LCX_DBG_TAG): what coalescence call `call` of the LAST lcx_step_async (0 .. sstp_coal-1) consumed of the
+ * device's generator, so that the oracle can be run on the DEVICE's stream while the device stays on its production path (no replay,
+ * production storage order, pre-shuffled deferred sort): which = 0: the uniforms u01[p] of the candidate pair that starts at position p
+ * of the sorted order (n_part values, coal.ipp:369-450), 1: the shuffle key un[id] that ordered super-droplet `id` inside its cell
+ * (hskpng_sort.ipp:28-47), by STORAGE index at coalescence time (storage extent values, dead slots included),
+ * 2: the tags by storage index at coalescence time, 3: the cell index by storage index at coalescence time (0xFFFFFFFF: a dead slot).
+ * out == NULL queries the length. */
+int lcx_rng_dump(lcx_particles *, int call, int which, double *out, size_t cap, size_t *n);
 /* run single housekeeping stages (for stage-level parity tests) */
 int lcx_stage(lcx_particles *, const char *stage, const lcx_opts_t *opts);
 /* per-stage device time of the last step in ms: fills names/values up to cap, returns count in *n */

@@ -66,6 +66,7 @@ namespace libcloudphxx { namespace lgrngn {
     // x-planes owned by the ranks to the left, and the kind of the two x-faces (0 this process owns the whole domain, 1 neighbour
     // slab: leaving SDs are listed for lcx_migrate_pack, 3 open wall)
     int n_x_bfr = 0, bcond_lft = 0, bcond_rgt = 0;
+    unsigned dbg_flags = 0;    // test / measurement switches (lcx.h, enum lcx_dbg): all off in production
     int reorder_every = 0;     // storage re-ordering into the cell-sorted order: every N steps and with every compaction (0: N = 64), -1 never (lcx.h)
   };
 } }

@@ -112,6 +112,7 @@ struct IParticles {
                              const double *vt, const double *x, const double *y, const double *z) = 0;
   virtual void rng_replay_push(int kind, const double *data, size_t n) = 0;
   virtual size_t rng_replay_pending() = 0;
+  virtual void rng_dump(int call, int which, double *out, size_t cap, size_t *n) = 0;
   virtual void stage(const char *name, const lcx_opts_t *opts) = 0;
   virtual void timings(const char **names, double *ms, size_t cap, size_t *n) = 0;
   virtual void set_profiling(int on) = 0;
@@ -169,11 +170,13 @@ struct Particles : IParticles {
   bool in_init = false;
   long long seed_now() const { return in_init && o.rng_seed_init_switch ? o.rng_seed_init : o.rng_seed; }
   bool replay_used = false;   // a parity run: storage stays in the reference's id order (see opts_init.reorder_every)
-  bool no_cond_pre = getenv("LCX_NO_COND_PRE") != nullptr;   // test switch: evaluate the per-cell set-up per droplet instead
+  bool dbg(unsigned f) const { return (o.dbg_flags & f) != 0; }      // test / measurement switches (include/lcx.h, lcx_dbg): read from the options, never from the environment
+  bool no_cond_pre = dbg(LCX_DBG_NO_COND_PRE);   // test switch: evaluate the per-cell set-up per droplet instead
   uint64_t cells_version = 0;   // order_cells: the list of cells above CELLRANK_MAX is remembered per cell_start
   bool exact = false, use_rc2 = false; int sstp_cond_act = 1, n_ext = 0, ix_rv = -1, ix_th = -1, ix_rh = -1, ix_p = -1, ix_rc2 = -1;
   DevBuf<T> pp_dlt[4], pp_rw3s, pp_dst_rv, pp_dst_th;
   int ix_up = -1, ix_vp = -1, ix_wp = -1, ix_ssp = -1, ix_dot_ssp = -1;
+  int ix_tag = -1;                    // LCX_DBG_TAG: a persistent tag per super-droplet (parity tests match droplets across re-orderings by it)
   int ix_ict = -1;                    // opts_init.diag_incloud_time: time spent activated, travels with the SD (particles_impl.ipp:475-476)
   std::vector<double> SGS_mix_len_h; DevBuf<T> SGS_mix_len, diss_rate, tau_cell, tau_rlx;
   bool turb() const { return o.turb_adve_switch || o.turb_cond_switch; }
@@ -187,7 +190,7 @@ struct Particles : IParticles {
   uint32_t *sid() const { return sorted_id.p + sort_base; }
   uint32_t *sijk() const { return sorted_ijk.p + sort_base; }
   DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig;
-  const bool use_wave_flags = !getenv("LCX_NO_WAVE_FLAGS");
+  const bool use_wave_flags = !dbg(LCX_DBG_NO_WAVE_FLAGS);
   void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
   DevBuf<uint64_t> sort_scratch;
   DevBuf<T> col, m3_before, m3_after, n_filtered, fvals;
@@ -256,6 +259,7 @@ struct Particles : IParticles {
     if (oi.turb_adve_switch) { if (oi.nx) ix_up = n_ext++; if (oi.ny) ix_vp = n_ext++; if (oi.nz) ix_wp = n_ext++; }
     if (oi.turb_cond_switch) { if (ix_wp < 0) ix_wp = n_ext++; ix_ssp = n_ext++; ix_dot_ssp = n_ext++; }
     if (oi.diag_incloud_time) ix_ict = n_ext++;
+    if (dbg(LCX_DBG_TAG)) ix_tag = n_ext++;
     SGS_mix_len_h.assign(oi.SGS_mix_len, oi.SGS_mix_len + oi.n_SGS_mix_len);
     o.SGS_mix_len = nullptr;
     pure_const_multi = (oi.sd_conc == 0) && (oi.sd_const_multi > 0 || oi.n_dry_sizes > 0);
@@ -266,7 +270,7 @@ struct Particles : IParticles {
     eps_tol = eps_tolerance<T>(sizeof(T) * 8 / 4);                                   // src/detail/config.hpp:39
     vtc = vt_cfg{oi.terminal_velocity, double(T(std::log(5e-7))), double(T(std::log(3e-3))), 10000};   // config.hpp:27-38
     cap = size_t(oi.n_sd_max);
-    eager_compact = getenv("LCX_EAGER_COMPACT") != nullptr;
+    eager_compact = dbg(LCX_DBG_EAGER_COMPACT);
     for (double &v : puddle) v = 0;
     if (oi.dev_id >= 0) HIPCHK(hipSetDevice(oi.dev_id));                             // particles_ctor.ipp:60-63
     HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -477,7 +481,7 @@ struct Particles : IParticles {
     }
     return u01_src<T>{nullptr, ++rng_call, uint64_t(uint32_t(seed_now()))};
   }
-  const bool shuffle_philox = getenv("LCX_SHUFFLE_PHILOX") != nullptr;      // measurement switch: round 2's shuffle keys (Philox, 64-bit ranking)
+  const bool shuffle_philox = dbg(LCX_DBG_SHUFFLE_PHILOX);      // measurement switch: round 2's shuffle keys (Philox, 64-bit ranking)
   rng_src rand_un(size_t n)
   {
     if (!replay.empty()) {
@@ -512,6 +516,32 @@ struct Particles : IParticles {
     replay.push_back(std::move(r));
   }
   size_t rng_replay_pending() override { return replay.size(); }
+  // LCX_DBG_TAG: what each coalescence call of the last step_async consumed (lcx_rng_dump, include/lcx.h)
+  struct RngRec { DevBuf<T> u01, tag; DevBuf<uint32_t> un, ijk; size_t n_pos = 0, n_store = 0; };
+  std::vector<std::unique_ptr<RngRec>> rng_recs;
+  rng_src last_shuffle_rs{nullptr, 0, 0, 0u, 0u};      // the keys that put the cells into their present shuffled order
+  void record_rng(const u01_src<T> &ru)
+  {
+    std::unique_ptr<RngRec> r(new RngRec);
+    r->n_pos = npart; r->n_store = nphys;
+    r->u01.alloc(npart); r->tag.alloc(nphys); r->un.alloc(nphys); r->ijk.alloc(nphys);
+    hipLaunchKernelGGL(k_rng_record<T>, dim3(nblk(std::max(npart, nphys))), dim3(BS), 0, st, npart, nphys, last_shuffle_rs, ru, A.ext[ix_tag].p, ijk.p,
+                       r->u01.p, r->un.p, r->tag.p, r->ijk.p);
+    rng_recs.push_back(std::move(r));
+  }
+  void rng_dump(int call, int which, double *out, size_t capn, size_t *n) override
+  {
+    if (ix_tag < 0) throw lcx_error("libcloudph++: lcx_rng_dump needs opts_init.dbg_flags & LCX_DBG_TAG");
+    if (call < 0 || size_t(call) >= rng_recs.size()) throw lcx_error("libcloudph++: lcx_rng_dump: the last step_async made no such coalescence call");
+    if (which < 0 || which > 3) throw lcx_error("libcloudph++: lcx_rng_dump: which must be 0 ... 3");
+    RngRec &r = *rng_recs[size_t(call)];
+    const size_t len = which == 0 ? r.n_pos : r.n_store;
+    *n = len;
+    if (!out) return;
+    if (capn < len) throw lcx_error("buffer too small");
+    if (which == 0 || which == 2) { auto h = d2h(which == 0 ? r.u01.p : r.tag.p, len); for (size_t i = 0; i < len; ++i) out[i] = double(h[i]); }
+    else { auto h = d2h(which == 1 ? r.un.p : r.ijk.p, len); for (size_t i = 0; i < len; ++i) out[i] = double(h[i]); }
+  }
 
   // ------------------------------------------------------------------------------------------
   // housekeeping
@@ -553,7 +583,7 @@ struct Particles : IParticles {
   // storage-order kernel that carries the scatter, cond_substep); the random keys of a shuffle are drawn NOW, at their place in the
   // generator's sequence
   bool sort_deferred = false, deferred_shuffle = false; rng_src deferred_rs{nullptr, 0, 0, 0u, 0u};
-  const bool defer_sort_ok = getenv("LCX_NO_DEFERRED_SORT") == nullptr;
+  const bool defer_sort_ok = !dbg(LCX_DBG_NO_DEFERRED_SORT);
   void sort_from_hist(bool shuffle, const uint32_t *meta_known = nullptr, bool defer = false)
   {
     sort_deferred = false;
@@ -590,6 +620,7 @@ struct Particles : IParticles {
       rng_src rs{nullptr, 0, 0, 0u, 0u};
       if (drawn) rs = *drawn;
       else if (shuffle) rs = rand_un(npart);     // (a replayed stream is indexed by compact ids: coal() compacts first)
+      if (shuffle) last_shuffle_rs = rs;
       if (ncell == 1 && !shuffle && nphys == npart) hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
       else {
         // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
@@ -878,7 +909,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
   }
   bool lean_storage_cond() const
-  { return !o.strict_fp && !no_cond_pre && cond_storage_order && o.cond_solver != 1 && getenv("LCX_COND_TOMS") == nullptr && !o.exact_sstp_cond; }
+  { return !o.strict_fp && !no_cond_pre && cond_storage_order && o.cond_solver != 1 && !o.exact_sstp_cond; }
   void cond_substep(double RH_max, int step, bool turb_cond = false)
   {
     const bool carry_scatter = sort_deferred && lean_storage_cond() && !turb_cond && npart;
@@ -905,9 +936,9 @@ struct Particles : IParticles {
                      xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
-      // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 (or LCX_COND_TOMS=1) keeps round 2's kernels
+      // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 keeps round 2's kernels
       // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
-      const bool cond_toms = o.cond_solver == 1 || getenv("LCX_COND_TOMS") != nullptr;
+      const bool cond_toms = o.cond_solver == 1;
       if (fast && !cond_toms) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         cond_in_storage_order = cond_storage_order;
@@ -923,13 +954,12 @@ struct Particles : IParticles {
         // two passes: a short iteration budget first, the droplets that need more in a dense second launch (k_cond_fast)
         // The second launch costs what its slowest wave costs (~60 us) however few droplets it holds, and the first pass saves ~2.3 us
         // per million droplets: one pass below 2^25 droplets (a 16-plane slab of C3, 16.7e6 SDs: 0.96 ms in two passes, 0.91 in one).
-        // LCX_COND_BUDGET: test / measurement switch (the parity tests force the two-pass form at their small sizes with it)
-        const char *budget_env = getenv("LCX_COND_BUDGET");
-        const int budget = budget_env ? atoi(budget_env) : (npart >= (size_t(1) << 25) ? 6 : 0);
+        // opts_init.dbg_cond_budget: test / measurement switch (the parity tests force the two-pass form at their small sizes with it)
+        const int budget = o.dbg_cond_budget > 0 ? o.dbg_cond_budget : o.dbg_cond_budget < 0 ? 0 : (npart >= (size_t(1) << 25) ? 6 : 0);
         // (`rank` is free between the sorts; part s holds at most the positions of the workgroups b with b % DEFER_SHARDS == s)
         cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
-        const bool fold = getenv("LCX_COND_NO_FOLD") == nullptr;                             // (test / measurement switch)
+        const bool fold = !dbg(LCX_DBG_COND_NO_FOLD);                             // (test / measurement switch)
         if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 3>), gr, bl, 0, st, npart, a, df);
         else hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
         if (df.budget) {
@@ -947,7 +977,7 @@ struct Particles : IParticles {
       cond_in_storage_order = false;
     }
   }
-  const bool cond_storage_order = getenv("LCX_COND_SORTED_ORDER") == nullptr;      // (measurement switch: the positional form)
+  const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
   // reference's summation order); fast: eight lanes per cell, or a whole wave per cell where cells are crowded
@@ -1073,6 +1103,7 @@ struct Particles : IParticles {
     if (npart < 2) { if (npart) (void)rand_u01(npart); return; }
     Range r(this, "coal");
     const u01_src<T> rs = rand_u01(npart);
+    if (ix_tag >= 0) record_rng(rs);
     const bool onishi = o.kernel == LCX_KERNEL_ONISHI_HALL || o.kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS;
     // diss == nullptr stands for the reference's constant-zero dissipation rate when opts.turb_coal is off (coal.ipp:392-403,439-451)
     coal_kernel_cfg<T> kc{o.kernel, n_user_params, T(kernel_r_max), kparams.p, eta.p, rhod.p, turb_coal ? diss_rate.p : nullptr};
@@ -1505,6 +1536,7 @@ struct Particles : IParticles {
       vt_0.alloc(size_t(vtc.n_bin));
       hipLaunchKernelGGL(k_init_vt0<T>, dim3(nblk(size_t(vtc.n_bin))), dim3(BS), 0, st, vt_0.p, vtc);
     }
+    if (ix_tag >= 0 && nphys) hipLaunchKernelGGL(k_fill_index<T>, dim3(nblk(nphys)), dim3(BS), 0, st, A.ext[ix_tag].p, nphys);
     hskpng_vterm(true);
     hskpng_approximate_rc2_invalid();                                                    // particles_init.ipp:116-117
     sstp_save();
@@ -1579,6 +1611,7 @@ struct Particles : IParticles {
     if (opts.src) throw lcx_error("libcloudph++: aerosol source was switched off in opts_init");
     if (opts.rlx) throw lcx_error("libcloudph++: aerosol relaxation was switched off in opts_init");
     adjust_timesteps(opts.dt);
+    rng_recs.clear();
     last_async_coal = opts.coal != 0;
     coal_marks_dead = n_dims > 0 && nphys > 0 && !opts.rcyc && sstp_coal == 1;   // (= the fused move below; with coalescence
                                                        // substeps a used-up SD still takes part in the later ones and keeps its cell)
@@ -1733,10 +1766,14 @@ struct Particles : IParticles {
   template <class S> std::vector<S> d2h(const S *p_, size_t n) { std::vector<S> h(n); if (n) { HIPCHK(hipMemcpyAsync(h.data(), p_, n * sizeof(S), hipMemcpyDeviceToHost, st)); sync(); } return h; }
   void get_state_u64(const char *name, unsigned long long *out, size_t capn, size_t *n) override
   {
-    ensure_compact();
     const std::string s(name);
     std::vector<unsigned long long> v;
-    if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
+    // "raw_*": the storage as it is (whole extent, dead slots included), nothing compacted or sorted on the way
+    const bool raw = s.rfind("raw_", 0) == 0;
+    if (!raw) ensure_compact();
+    if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
+    else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
+    else if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "sorted_id") {
       hskpng_sort();
@@ -1758,10 +1795,13 @@ struct Particles : IParticles {
   }
   void get_state_real(const char *name, double *out, size_t capn, size_t *n) override
   {
-    ensure_compact();
     const std::string s(name);
+    if (s.rfind("raw_", 0) != 0) ensure_compact();
     struct E { const char *nm; const T *p; size_t len; };
-    const E tab[] = {{"vt", A.vt.p, npart}, {"T", Tk.p, ncell}, {"p", p.p, ncell}, {"RH", RH.p, ncell}, {"eta", eta.p, ncell}, {"th", th.p, ncell},
+    const E tab[] = {{"raw_rw2", A.rw2.p, nphys}, {"raw_rd3", A.rd3.p, nphys}, {"raw_kappa", A.kpa.p, nphys}, {"raw_vt", A.vt.p, nphys},
+      {"raw_x", A.x.p, A.x.p ? nphys : 0}, {"raw_y", A.y.p, A.y.p ? nphys : 0}, {"raw_z", A.z.p, A.z.p ? nphys : 0},
+      {"raw_tag", ix_tag >= 0 ? A.ext[ix_tag].p : nullptr, ix_tag >= 0 ? nphys : 0}, {"tag", ix_tag >= 0 ? A.ext[ix_tag].p : nullptr, ix_tag >= 0 ? npart : 0},
+      {"vt", A.vt.p, npart}, {"T", Tk.p, ncell}, {"p", p.p, ncell}, {"RH", RH.p, ncell}, {"eta", eta.p, ncell}, {"th", th.p, ncell},
       {"rv", rv.p, ncell}, {"rhod", rhod.p, ncell}, {"dv", dv.p, ncell}, {"lambda_D", lambda_D.p, ncell}, {"lambda_K", lambda_K.p, ncell},
       {"courant_x", courant_x.p, n_cx}, {"courant_y", courant_y.p, n_cy}, {"courant_z", courant_z.p, n_cz},
       {"vt_0", vt_0.p, vt_0.p ? size_t(vtc.n_bin) : 0}, {"count_mom", count_mom.p, ncell}, {"col", col.p, col.p ? npart : 0},
@@ -1804,6 +1844,7 @@ struct Particles : IParticles {
     if (n) HIPCHK(hipMemsetAsync(ijk.p, 0, n * sizeof(uint32_t), st));     // every SD is in the order again, n == 0 included
     hskpng_ijk();
     for (int ix : {ix_up, ix_vp, ix_wp, ix_ssp, ix_dot_ssp, ix_ict}) if (ix >= 0 && n) HIPCHK(hipMemsetAsync(A.ext[ix].p, 0, n * sizeof(T), st));
+    if (ix_tag >= 0 && n) hipLaunchKernelGGL(k_fill_index<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_tag].p, n);
     if (use_rc2 && n) { hipLaunchKernelGGL(k_fill<T>, dim3(nblk(n)), dim3(BS), 0, st, A.ext[ix_rc2].p, n, T(-1)); hskpng_approximate_rc2_invalid(); }
     sstp_save();
     hskpng_count();
@@ -1940,7 +1981,7 @@ struct Particles : IParticles {
   // x-planes at either end of the slab that an immigrant can reach (a Courant number of 1; pred_corr: 2)
   int bnd_planes() const { return halo ? halo : 1; }
   size_t plane_cells() const { return ncell / size_t(std::max(o.nx, 1)); }
-  const bool no_overlap = getenv("LCX_NO_OVERLAP") != nullptr;      // measurement / test switch: the exchange without the overlapped re-sort
+  const bool no_overlap = dbg(LCX_DBG_NO_OVERLAP);      // measurement / test switch: the exchange without the overlapped re-sort
   // the overlapped re-sort needs the fused move's histogram, an interior, and the production rules for the storage order are not in
   // its way: a slab so thin that every plane is a boundary plane, rcyc and the unfused paths take the plain sequence
   bool overlap_possible() const
@@ -1994,7 +2035,7 @@ struct Particles : IParticles {
   // emigrants of both faces -> the neighbours' inboxes (pointers this device can write: peer-mapped, inboxes on this very device, or
   // this slab's own outboxes; nullptr: no neighbour behind that face), their multiplicities cleared in the same launch.
   // cap_l / cap_r: the capacity of the inbox behind each pointer; next_l / next_r: header word 2 (see k_pack_dev)
-  const unsigned test_pack_delay_us = getenv("LCX_TEST_PACK_DELAY_US") ? unsigned(atoi(getenv("LCX_TEST_PACK_DELAY_US"))) : 0u;
+  const unsigned test_pack_delay_us = o.dbg_pack_delay_us > 0 ? unsigned(o.dbg_pack_delay_us) : 0u;
   void exch_pack(uint8_t *dst_l, double lft_x1, size_t cap_l, uint8_t *dst_r, double rgt_x0, size_t cap_r, uint32_t next_l = 0, uint32_t next_r = 0)
   {
     // test / measurement: the slabs with an odd first plane are late with their messages by so many microseconds
@@ -2089,6 +2130,7 @@ struct Particles : IParticles {
     npart = nphys - dead;
     big_n = n_big; big_mx = max_big; meta_version = cells_version;
     sorted = true; sorted_shuffled = overlap_preshuffle; shuffle_fresh = overlap_preshuffle;
+    if (overlap_preshuffle) last_shuffle_rs = overlap_rs;
     const bool strict = strict_order();
     const bool compact_now = dead && (eager_compact || dead * 32 > nphys);
     if (compact_now && strict) { post_copy(opts, true); return; }
@@ -2289,6 +2331,7 @@ int lcx_set_particles(lcx_particles *h, size_t n, const unsigned long long *mult
                       const double *vt, const double *x, const double *y, const double *z) { LCX_TRY(H->set_particles(n, mult, rd3, rw2, kpa, vt, x, y, z)) }
 int lcx_rng_replay_push(lcx_particles *h, int kind, const double *data, size_t n) { LCX_TRY(H->rng_replay_push(kind, data, n)) }
 int lcx_rng_replay_pending(lcx_particles *h, size_t *n) { LCX_TRY(*n = H->rng_replay_pending()) }
+int lcx_rng_dump(lcx_particles *h, int call, int which, double *out, size_t cap, size_t *n) { LCX_TRY(H->rng_dump(call, which, out, cap, n)) }
 int lcx_stage(lcx_particles *h, const char *stage, const lcx_opts_t *o) { LCX_TRY(H->stage(stage, o)) }
 int lcx_timings(lcx_particles *h, const char **names, double *ms, size_t cap, size_t *n) { LCX_TRY(H->timings(names, ms, cap, n)) }
 int lcx_set_profiling(lcx_particles *h, int on) { LCX_TRY(H->set_profiling(on)) }

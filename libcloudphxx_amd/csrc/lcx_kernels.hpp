@@ -2685,6 +2685,17 @@ __global__ void k_vel_div(size_t n_cell, grid_t g, int halo, T dt, const T *cx, 
   d = d + (cx[rgt] - cx[ce]) / dt;
   out[c] = d;
 }
+// parity hook (LCX_DBG_TAG, lcx_rng_dump): what a coalescence call consumes of the generator, evaluated by the very device functions that
+// the consumers call (sort_key: k_cellrank / k_cellsort_*; the u01 expression of k_coal), and the tags and cells by storage index
+template <class T>
+__global__ void k_rng_record(size_t n_pos, size_t n_store, rng_src r_un, u01_src<T> r_u01, const T *tag, const uint32_t *ijk,
+                             T *out_u01, uint32_t *out_un, T *out_tag, uint32_t *out_ijk)
+{
+  const size_t i = gid();
+  if (i < n_pos) out_u01[i] = r_u01.arr ? r_u01.arr[i] : philox::u01<T>(i, r_u01.call, r_u01.seed);
+  if (i < n_store) { out_un[i] = uint32_t(sort_key(uint32_t(i), 1, r_un) >> 32); out_tag[i] = tag[i]; out_ijk[i] = ijk[i]; }
+}
+template <class T> __global__ void k_fill_index(T *a, size_t n) { size_t i = gid(); if (i < n) a[i] = T(i); }
 // parity hook (lcx_philox_probe): raw Philox4x32-10 blocks for given (index, call, seed) triples
 __global__ void k_philox_probe(const uint64_t *ics, size_t n, uint32_t *out)
 {

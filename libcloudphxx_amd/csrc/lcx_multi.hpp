@@ -144,7 +144,7 @@ struct MultiParticles : IParticles {
     dev.resize(D); nx_loc.resize(D); n_x_bfr.resize(D);
     for (int i = 0; i < D; ++i) dev[i] = map.empty() ? i : map[i];
     // peer access between neighbouring devices (particles_multi_gpu_impl.ipp:100-125)
-    peer_ok.assign(D, getenv("LCX_MULTI_NO_PEER") ? 0 : 1);      // (LCX_MULTI_NO_PEER: tests drive the staged path on one device)
+    peer_ok.assign(D, (oi.dbg_flags & LCX_DBG_MULTI_NO_PEER) ? 0 : 1);      // (LCX_DBG_MULTI_NO_PEER: tests drive the staged path on one device)
     if (D > 1)
       for (int i = 0; i < D; ++i)
         for (int nb : {lft_of(i), rgt_of(i)}) {
@@ -199,7 +199,7 @@ struct MultiParticles : IParticles {
           if (nb >= 0 && dev[nb] != dev[i] && !slab[nb]->inbox_finegrained) peer_ok[i] = 0;
     pool.reset(new WorkerPool(D));
     barrier.reset(new HostBarrier(D));
-    if (serialize) fprintf(stderr, "libcloudph++ (multi_HIP): LCX_MULTI_SERIALIZE is set -- the %d slabs take turns (measurement mode)\n", D);
+    if (serialize) fprintf(stderr, "libcloudph++ (multi_HIP): LCX_DBG_MULTI_SERIALIZE is set -- the %d slabs take turns (measurement mode)\n", D);
     pool->run([this](int i) { HIPCHK(hipSetDevice(dev[i])); });                    // each worker stays on its device
   }
   // slabs and events are freed with their own device current (the caller's device is put back by the C ABI's guard)
@@ -220,10 +220,10 @@ struct MultiParticles : IParticles {
   int real_kind() const override { return int(sizeof(T)); }
 
   // ---- fan-out helpers ----
-  // LCX_MULTI_SERIALIZE=1 (measurement only): the slab threads take turns, so that with all slabs on ONE device the wall time of a
+  // opts_init.dbg_flags & LCX_DBG_MULTI_SERIALIZE (measurement only): the slab threads take turns, so that with all slabs on ONE device the wall time of a
   // call is the SUM of what each slab would spend alone on a device of its own (kernels + its host round trips), not their overlap
   std::mutex serial_mx;
-  const bool serialize = getenv("LCX_MULTI_SERIALIZE") != nullptr;
+  const bool serialize = (glob.dbg_flags & LCX_DBG_MULTI_SERIALIZE) != 0;
   template <class F> void each(F f)
   {
     barrier->reset();
@@ -383,6 +383,7 @@ struct MultiParticles : IParticles {
                      const double *, const double *) override { per_slab(); }
   void rng_replay_push(int, const double *, size_t) override { per_slab(); }
   size_t rng_replay_pending() override { size_t n = 0; for (auto &s : slab) n += s->rng_replay_pending(); return n; }
+  void rng_dump(int, int, double *, size_t, size_t *) override { per_slab(); }
   void stage(const char *, const lcx_opts_t *) override { per_slab(); }
   void migrate_counts(size_t *, size_t *) override { per_slab(); }
   size_t migrate_record_bytes() override { return slab[0]->migrate_record_bytes(); }

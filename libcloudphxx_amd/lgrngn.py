@@ -87,6 +87,23 @@ class chem_species_t(_bp_enum):        # common/chem.hpp via bindings/python/lib
     S_VI = 7
 
 
+class dbg(enum.IntFlag):
+    """opts_init.dbg_flags: test / measurement switches (include/lcx.h, enum lcx_dbg; no reference counterpart)"""
+    NO_COND_PRE = 1 << 0
+    NO_WAVE_FLAGS = 1 << 1
+    EAGER_COMPACT = 1 << 2
+    SHUFFLE_PHILOX = 1 << 3
+    NO_DEFERRED_SORT = 1 << 4
+    COND_NO_FOLD = 1 << 5
+    COND_SORTED_ORDER = 1 << 6
+    NO_OVERLAP = 1 << 7
+    MULTI_NO_PEER = 1 << 8
+    MULTI_SERIALIZE = 1 << 9
+    TAG = 1 << 10
+    COND_NO_DEAL = 1 << 11
+    HOST_SYNC_LOOP = 1 << 12
+
+
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8
     off = 0
     simple = 1
@@ -142,6 +159,7 @@ class _opts_init_c(C.Structure):
         ("dry_sizes", C.POINTER(_dry_size_c)), ("n_dry_sizes", C.c_int),
         ("n_x_tot", C.c_int), ("n_x_bfr", C.c_int), ("bcond_lft", C.c_int), ("bcond_rgt", C.c_int),
         ("strict_fp", C.c_int), ("cond_solver", C.c_int), ("reorder_every", C.c_int),
+        ("dbg_flags", C.c_uint), ("dbg_cond_budget", C.c_int), ("dbg_pack_delay_us", C.c_int),
     ]
 
 
@@ -236,6 +254,10 @@ class opts_init_t:
         self.strict_fp = True
         self.cond_solver = 0          # fast arithmetic only: 0 lean bracketed secant, 1 the reference's TOMS748 iterates (include/lcx.h)
         self.reorder_every = 0
+        # test / measurement switches (include/lcx.h, enum lcx_dbg): all off in production
+        self.dbg_flags = 0
+        self.dbg_cond_budget = 0
+        self.dbg_pack_delay_us = 0
 
     def _to_c(self, keep):
         c = _opts_init_c()
@@ -555,6 +577,20 @@ class particles_t:
     def rng_replay_push(self, kind, data):
         a = np.ascontiguousarray(data, dtype=np.float64)
         self._chk(self._f("rng_replay_push")(self._h, C.c_int(kind), a.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(a.size)))
+
+    def rng_replay_pending(self):
+        n = C.c_size_t()
+        self._chk(self._f("rng_replay_pending")(self._h, C.byref(n)))
+        return n.value
+
+    def rng_dump(self, call, which):
+        """what coalescence call `call` of the last step_async consumed of the generator (lcx_rng_dump; needs dbg.TAG)"""
+        n = C.c_size_t()
+        self._chk(self._f("rng_dump")(self._h, C.c_int(call), C.c_int(which), None, C.c_size_t(0), C.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        self._chk(self._f("rng_dump")(self._h, C.c_int(call), C.c_int(which), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                      C.c_size_t(out.size), C.byref(n)))
+        return out
 
     def stage(self, name, opts=None):
         oc = opts._to_c() if opts is not None else None

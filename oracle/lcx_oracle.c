@@ -101,6 +101,12 @@ struct orc_particles {
   /* SGS turbulence (turb_adve / turb_cond): cell field diss_rate (holds TKE after hskpng_tke), SGS mixing length profile,
    * per-particle velocity perturbations and supersaturation perturbation (particles_impl.ipp:141-144,461-473) */
   double *diss_rate, *SGS_mix_len, *tau_cell;
+  /* test hooks of the "reverse replay" (tests/test_hip_reverse_replay.py; no reference counterpart): LCX_DBG_TAG gives every super-droplet
+   * a persistent tag that is compacted and migrates with it like any attribute, and orc_rng_replay_push queues random arrays that the
+   * next hskpng_shuffle_and_sort / coal consume INSTEAD of drawing from the engine -- so that this restatement can be run on the
+   * device generator's stream while the device stays on its production path */
+  double *tag;
+  struct { int kind; double *v; sz n; } rq[64]; int rq_head, rq_tail;
   double *ict;     /* opts_init.diag_incloud_time: time each SD has been activated (particles_impl.ipp:93,475-476) */
   double *up, *vp, *wp, *ssp, *dot_ssp;
   /* particle attributes */
@@ -237,6 +243,7 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   }
   if (s->use_rc2) s->rc2 = NEW(double, c);
   if (oi->diag_incloud_time) s->ict = NEW(double, c);                    /* init_incloud_time.ipp:14-17: zero */
+  if (oi->dbg_flags & LCX_DBG_TAG) s->tag = NEW(double, c);
   if (oi->turb_coal_switch && !(oi->turb_adve_switch || oi->turb_cond_switch)) s->diss_rate = NEW(double, nc);
   if (oi->turb_adve_switch || oi->turb_cond_switch) {
     s->diss_rate = NEW(double, nc); s->tau_cell = NEW(double, nc);
@@ -255,12 +262,13 @@ void orc_destroy(orc_particles *s)
   if (!s) return;
   void *ptrs[] = {s->distros, s->sizes, s->kernel_parameters, s->w_LS, s->aerosol_conc_factor, s->n, s->rd3, s->rw2,
     s->kpa, s->x, s->y, s->z, s->vt, s->ijk, s->sorted_id, s->sorted_ijk, s->n_filtered, s->tmp_part, s->col, s->mom_vals,
-    s->diss_rate, s->SGS_mix_len, s->tau_cell, s->up, s->vp, s->wp, s->ssp, s->dot_ssp, s->ict,
+    s->diss_rate, s->SGS_mix_len, s->tau_cell, s->up, s->vp, s->wp, s->ssp, s->dot_ssp, s->ict, s->tag,
     s->pp_rv, s->pp_th, s->pp_rh, s->pp_p, s->rc2, s->dlt_rv, s->dlt_th, s->dlt_rh, s->dlt_p, s->rwX, s->drwX, s->Tp, s->pp_sstp,
     s->lft_id, s->rgt_id, s->rhod, s->th, s->rv, s->p, s->T, s->RH, s->eta, s->dv, s->lambda_D, s->lambda_K,
     s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh, s->drw_mom3, s->rw_mom3, s->scl, s->count_ijk, s->off,
     s->count_num, s->count_mom, s->outbuf, s->courant_x, s->courant_y, s->courant_z, s->xbox[0], s->xbox[1], s->xbox[2], s->xbox[3]};
   for (sz i = 0; i < sizeof ptrs / sizeof *ptrs; ++i) free(ptrs[i]);
+  while (s->rq_head != s->rq_tail) { free(s->rq[s->rq_head].v); s->rq_head = (s->rq_head + 1) % 64; }
   free(s);
 }
 
@@ -465,6 +473,15 @@ static void stable_sort_by_key(sz *key, sz *val, sz n, sz nkeys)
   }
   free(k2); free(v2);
 }
+/* next queued random array of the given kind (orc_rng_replay_push), or NULL when the queue is empty: the engine draws then */
+static double *replay_pop(orc_particles *s, int kind, sz n)
+{
+  if (s->rq_head == s->rq_tail) return NULL;
+  if (s->rq[s->rq_head].kind != kind || s->rq[s->rq_head].n < n) { fprintf(stderr, "oracle: rng replay queue does not match the request (kind %d, %zu values)\n", kind, (size_t)n); abort(); }
+  double *v = s->rq[s->rq_head].v;
+  s->rq_head = (s->rq_head + 1) % 64;
+  return v;
+}
 /* hskpng_sort.ipp:15-57 */
 static void hskpng_sort_helper(orc_particles *s, int shuffle)
 {
@@ -478,7 +495,9 @@ static void hskpng_sort_helper(orc_particles *s, int shuffle)
 #else
     sz *un = NEW(sz, n);
 #endif
-    for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un(&s->rng);
+    double *rq = replay_pop(s, 1, n);
+    if (rq) { for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rq[p]; free(rq); }
+    else for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un(&s->rng);
     stable_sort_by_key(un, s->sorted_id, n, 0);
     OMP_FOR
     for (sz p = 0; p < n; ++p) s->sorted_ijk[p] = s->ijk[s->sorted_id[p]];
@@ -1136,7 +1155,9 @@ static void coal(orc_particles *s, double dt, int turb_coal)
   }
   { sz acc = 0; for (sz c = 0; c < s->n_cell; ++c) { sz t = s->off[c]; s->off[c] = acc; acc += t; } }
   double *u01 = s->col;
-  for (sz p = 0; p < s->n_part; ++p) u01[p] = rng_u01(&s->rng);
+  { double *rq = replay_pop(s, 0, s->n_part);
+    if (rq) { memcpy(u01, rq, s->n_part * sizeof(double)); free(rq); }
+    else for (sz p = 0; p < s->n_part; ++p) u01[p] = rng_u01(&s->rng); }
   const sz n_pairs_end = s->n_part ? s->n_part - 1 : 0;
   OMP_FOR
   for (sz p = 0; p < n_pairs_end; ++p) {                   /* collider::operator(), coal.ipp:180-267 */
@@ -1836,6 +1857,7 @@ int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
   sstp_save(s);
   hskpng_count(s);
   mt_seed(&s->rng, (uint32_t)s->o.rng_seed);
+  if (s->tag) for (sz p = 0; p < s->n_part; ++p) s->tag[p] = (double)p;
   return 0;
 }
 
@@ -2134,7 +2156,7 @@ int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t c
     {"sstp_tmp_p", s->pp_p, s->exact && s->o.const_p ? s->n_part : 0}, {"rc2", s->rc2, s->use_rc2 ? s->n_part : 0},
     {"up", s->up, s->up ? s->n_part : 0}, {"vp", s->vp, s->vp ? s->n_part : 0}, {"wp", s->wp, s->wp ? s->n_part : 0},
     {"incloud_time", s->ict, s->ict ? s->n_part : 0}, {"ssp", s->ssp, s->ssp ? s->n_part : 0}, {"dot_ssp", s->dot_ssp, s->dot_ssp ? s->n_part : 0},
-    {"diss_rate", s->diss_rate, s->diss_rate ? s->n_cell : 0}};
+    {"tag", s->tag, s->tag ? s->n_part : 0}, {"diss_rate", s->diss_rate, s->diss_rate ? s->n_cell : 0}};
   for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
     if (!strcmp(name, tab[i].nm)) {
       *n = tab[i].len;
@@ -2158,6 +2180,7 @@ int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult
   if (s->up) { memset(s->up, 0, n * 8); memset(s->vp, 0, n * 8); memset(s->wp, 0, n * 8); }
   if (s->ssp) { memset(s->ssp, 0, n * 8); memset(s->dot_ssp, 0, n * 8); }
   if (s->ict) memset(s->ict, 0, n * 8);
+  if (s->tag) for (sz p = 0; p < n; ++p) s->tag[p] = (double)p;
   sstp_save(s);
   hskpng_count(s);
   return 0;
@@ -2172,6 +2195,18 @@ int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int 
     for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : kinds[c] == 1 ? rng_un(&g) : rng_normal(&g, &ns);
   return 0;
 }
+/* queue a random array for the next consumer of its kind (0: the u01 of a coalescence call, 1: the un of a shuffle), see struct */
+int orc_rng_replay_push(orc_particles *s, int kind, const double *data, size_t n)
+{
+  if ((s->rq_tail + 1) % 64 == s->rq_head) FAIL("oracle: rng replay queue is full");
+  if (kind != 0 && kind != 1) FAIL("oracle: rng replay kind must be 0 (u01) or 1 (un)");
+  double *v = NEW(double, n);
+  memcpy(v, data, n * sizeof(double));
+  s->rq[s->rq_tail].kind = kind; s->rq[s->rq_tail].v = v; s->rq[s->rq_tail].n = n;
+  s->rq_tail = (s->rq_tail + 1) % 64;
+  return 0;
+}
+int orc_rng_replay_pending(orc_particles *s, size_t *n) { *n = (size_t)((s->rq_tail - s->rq_head + 64) % 64); return 0; }
 int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
 {
   if (!strcmp(st, "hskpng_Tpr")) hskpng_Tpr(s);
@@ -2206,6 +2241,7 @@ static int mig_attrs(orc_particles *s, double **a)
   if (s->o.turb_cond_switch) { if (!(s->o.turb_adve_switch && s->o.nz != 0)) a[k++] = s->wp; a[k++] = s->ssp; a[k++] = s->dot_ssp; }
   if (s->o.diag_incloud_time) a[k++] = s->ict;
   if (s->use_rc2) a[k++] = s->rc2;
+  if (s->tag) a[k++] = s->tag;
   return k;
 }
 size_t orc_migrate_record_bytes(orc_particles *s) { double *a[24]; return 8 + 8 * (size_t)mig_attrs(s, a); }

@@ -365,11 +365,11 @@ def test_multi_device_api_rules(monkeypatch):
 
 
 def test_multi_device_without_peer_mapping(monkeypatch):
-    """devices that cannot map each other's memory (LCX_MULTI_NO_PEER forces it here): emigrants are packed at home and moved by a
+    """devices that cannot map each other's memory (opts_init.dbg_flags & MULTI_NO_PEER forces it here): emigrants are packed at home and moved by a
     peer copy of exactly the bytes used -- same slabs as the direct path, against the oracle ring"""
-    monkeypatch.setenv("LCX_MULTI_NO_PEER", "1")
     nx, ny, nz, size = 9, 3, 4, 3
     oi = h.box_opts(nx, ny, nz, 24, dx=20., coal_switch=False)
+    oi.dbg_flags = int(lgrngn.dbg.MULTI_NO_PEER)
     oi.n_sd_max = 24 * nx * ny * nz * 3
     fields = h.box_fields(oi)
     orc, mul, slabs = multi_pair(oi, size, fields, monkeypatch)
@@ -385,13 +385,10 @@ def test_multi_device_without_peer_mapping(monkeypatch):
 
 def _run_skewed(monkeypatch, overlap, delay_us, steps=12):
     import bench
-    if overlap:
-        monkeypatch.delenv("LCX_NO_OVERLAP", raising=False)
-    else:
-        monkeypatch.setenv("LCX_NO_OVERLAP", "1")
-    monkeypatch.setenv("LCX_TEST_PACK_DELAY_US", str(delay_us))
     nx, ny, nz, size = 64, 128, 128, 4
     oi = bench.make_opts_init(nx, ny, nz, 64, 40., 1, 1, 44)
+    oi.dbg_flags = 0 if overlap else int(lgrngn.dbg.NO_OVERLAP)
+    oi.dbg_pack_delay_us = delay_us
     oi.n_sd_max = int(oi.n_sd_max * 1.1)
     th, rv, rhod, Cx, Cy, Cz = bench.make_fields(nx, ny, nz, 0, nx, np, np.float64)
     mul = make_multi(oi, size, monkeypatch)

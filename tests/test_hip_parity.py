@@ -458,11 +458,8 @@ def test_move_and_post_copy(scheme, dims):
 def test_lazy_compaction_is_unobservable(eager, monkeypatch):
     """Dead SDs stay in storage until a compaction is due (post_copy in lcx_core.hip); nothing observable may depend on
     that: run several precipitating steps WITHOUT touching any getter, then compare everything with the oracle."""
-    if eager:
-        monkeypatch.setenv("LCX_EAGER_COMPACT", "1")
-    else:
-        monkeypatch.delenv("LCX_EAGER_COMPACT", raising=False)
     oi = h.box_opts(5, 4, 6, 48, dx=30., coal_switch=False)
+    oi.dbg_flags = int(lgrngn.dbg.EAGER_COMPACT) if eager else 0
     fields = h.box_fields(oi)
     orc, hip = h.make_pair(oi, fields)
     n0 = orc.n_part
@@ -733,14 +730,13 @@ def test_fast_math_accuracy():
 
 def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
     """k_cond_fast (per-cell set-up hoisted into k_cond_cellpre, tuned root-finder arithmetic, one scratch value per droplet)
-    against the plain fast form that evaluates everything per droplet (LCX_NO_COND_PRE=1 selects it)"""
+    against the plain fast form that evaluates everything per droplet (opts_init.dbg_flags & NO_COND_PRE selects it)"""
     oi = h.box_opts(4, 3, 5, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
     oi.cond_solver = 1                                 # (round 2's fast kernels: TOMS748 iterates in fast arithmetic)
     res = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("LCX_NO_COND_PRE", "1")
+        oi.dbg_flags = int(lgrngn.dbg.NO_COND_PRE) if off else 0
         orc, hip = h.make_pair(oi, fields)
         opts = lgrngn.opts_t()
         opts.coal = opts.adve = opts.sedi = False
@@ -758,7 +754,7 @@ def test_production_cond_kernel_against_the_plain_fast_form(monkeypatch):
 
 
 def test_lean_solver_against_toms748_in_fast_arithmetic(monkeypatch):
-    """The fast arithmetic's bracketed secant (k_cond_lean) against TOMS748 on the SAME growth-rate arithmetic (LCX_COND_TOMS=1: round 2's
+    """The fast arithmetic's bracketed secant (k_cond_lean) against TOMS748 on the SAME growth-rate arithmetic (opts_init.cond_solver = 1: round 2's
     kernels), 2^20 droplets, two steps: both solve rw2_new = rw2_old + dt f(rw2_new) on the reference's bracket to 2^-15 -- every
     droplet's answers within that tolerance of each other (no droplet on another root), th and rv to 1e-9"""
     oi = h.box_opts(32, 16, 32, 64, strict_fp=False)
@@ -782,17 +778,17 @@ def test_lean_solver_against_toms748_in_fast_arithmetic(monkeypatch):
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=2e-7)
 
 
-@pytest.mark.parametrize("budget", ["6", "3", "1"])
+@pytest.mark.parametrize("budget", [6, 3, 1])
 def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget):
     """k_cond_fast with a short iteration budget + the dense second launch over the droplets that ran out of it (the production
-    form from 2^25 super-droplets upwards; LCX_COND_BUDGET forces it here) does the same arithmetic per droplet as the single pass:
+    form from 2^25 super-droplets upwards; opts_init.dbg_cond_budget forces it here) does the same arithmetic per droplet as the single pass:
     identical bits in rw2, th and rv.  Budget 6 defers the far tail, 3 and 1 defer most of the droplets that iterate at all."""
     oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
     oi.cond_solver = 1
     res = []
-    for b in ("0", budget):
-        monkeypatch.setenv("LCX_COND_BUDGET", b)
+    for b in (-1, budget):
+        oi.dbg_cond_budget = b
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -808,18 +804,17 @@ def test_two_pass_condensation_is_bit_identical_to_one_pass(monkeypatch, budget)
     assert np.abs(res[0][2] - rv).max() > 0                       # (condensation did happen)
 
 
-@pytest.mark.parametrize("budget", ["0", "6", "2"])
+@pytest.mark.parametrize("budget", [-1, 6, 2])
 def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatch, budget):
     """k_cond_fast_fold (the workgroup's droplets that enter the root finder's loop handed through LDS to its lowest lanes; the
-    production first pass) against k_cond_fast (LCX_COND_NO_FOLD=1): the same arithmetic per droplet on another lane"""
+    production first pass) against k_cond_fast (opts_init.dbg_flags & COND_NO_FOLD): the same arithmetic per droplet on another lane"""
     oi = h.box_opts(16, 8, 8, 64, sstp_cond=2, strict_fp=False)
     fields = h.box_fields(oi)
-    monkeypatch.setenv("LCX_COND_BUDGET", budget)
+    oi.dbg_cond_budget = budget
     oi.cond_solver = 1
     res = []
     for plain in (False, True):
-        if plain:
-            monkeypatch.setenv("LCX_COND_NO_FOLD", "1")
+        oi.dbg_flags = int(lgrngn.dbg.COND_NO_FOLD) if plain else 0
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -837,7 +832,7 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
 @pytest.mark.parametrize("sd_conc,steps", [(64, 6), (400, 3)])
 def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monkeypatch, sd_conc, steps):
     """k_cond_lean takes the droplets in STORAGE order (coalesced attribute reads and writes; the per-cell finish gathers the droplets'
-    changes through sorted_id) -- LCX_COND_SORTED_ORDER=1 selects the positional form it replaced (every attribute gathered through
+    changes through sorted_id) -- opts_init.dbg_flags & COND_SORTED_ORDER selects the positional form it replaced (every attribute gathered through
     sorted_id).  A droplet's answer does not depend on the lane that computes it and a cell's sum keeps its order: the same bits, in a
     full step with coalescence, advection and sedimentation (dead slots in the storage, the shuffled order of the next coalescence in
     place when condensation runs), for ordinary cells and for crowded ones (400 per cell: the wave-per-cell finish)"""
@@ -845,8 +840,7 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
     fields = h.box_fields(oi)
     res = []
     for positional in (False, True):
-        if positional:
-            monkeypatch.setenv("LCX_COND_SORTED_ORDER", "1")
+        oi.dbg_flags = int(lgrngn.dbg.COND_SORTED_ORDER) if positional else 0
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -871,7 +865,7 @@ def test_deferred_sort_is_bit_identical_to_the_immediate_one(monkeypatch, sd_con
     """The end-of-step re-sort of a single device leaves its scatter and in-cell ranking to the next step: the storage-order condensation
     kernel carries the scatter (its memory pipes idle while its vector ALU is the bottleneck), the ranking follows it, and whoever
     else needs the sorted order first (a diagnostic, a step without condensation, coalescence) finishes the sort where it stands.
-    LCX_NO_DEFERRED_SORT=1 sorts at once.  The random keys are drawn at the same place of the generator's sequence either way: the
+    opts_init.dbg_flags & NO_DEFERRED_SORT sorts at once.  The random keys are drawn at the same place of the generator's sequence either way: the
     same bits after full steps with coalescence -- across storage re-orderings (no deferral in those steps), with crowded cells (300 per
     cell: the listed-cell sorts), with condensation switched off every other step, and with a diagnostic between the steps"""
     oi = h.box_opts(6, 5, 7, sd_conc, strict_fp=False)
@@ -879,8 +873,7 @@ def test_deferred_sort_is_bit_identical_to_the_immediate_one(monkeypatch, sd_con
     fields = h.box_fields(oi)
     res = []
     for immediate in (False, True):
-        if immediate:
-            monkeypatch.setenv("LCX_NO_DEFERRED_SORT", "1")
+        oi.dbg_flags = int(lgrngn.dbg.NO_DEFERRED_SORT) if immediate else 0
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)

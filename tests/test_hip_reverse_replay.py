@@ -1,0 +1,168 @@
+"""Reverse replay: the ORACLE run on the DEVICE's random stream, the device on its production path.
+
+Every other exact coalescence test feeds the oracle's random arrays into the device (lcx_rng_replay_push), which also switches the
+device to the reference's storage order.  Here nothing is pushed into the device: it keeps its production path -- Philox uniforms
+drawn inside k_coal<T, false, true>, the salted-bijection shuffle keys, the re-sort at the end of step_async pre-shuffled for the next
+coalescence and left to the storage-order condensation kernel (deferred scatter), lazy compaction, storage re-ordering -- and
+lcx_rng_dump (include/lcx.h) hands what each coalescence call consumed to the oracle (orc_rng_replay_push): the shuffle key un[id] of
+every super-droplet (hskpng_sort.ipp:28-47) and the uniform u01[p] of every candidate pair (coal.ipp:369-450).  Super-droplets are
+matched by a persistent tag (LCX_DBG_TAG): the device renumbers its ids when it re-orders its storage, the oracle compacts eagerly.
+
+The box collides: the exponential-in-volume spectrum of the reference's Golovin test (tests/python/physics/coalescence_golovin.py:
+31-44,68-74: r_zero = 30.084 um, n_zero = 2^23, kappa = 1e-10) under the hall_davis_no_waals kernel, drizzle falling out of the bottom.
+"""
+import numpy as np
+import pytest
+
+import _harness as h
+from libcloudphxx_amd import lgrngn
+
+pytestmark = pytest.mark.gpu
+
+DEAD = 0xFFFFFFFF
+
+
+def golovin_spectrum(lnr, r_zero=30.084e-6, n_zero=2 ** 23):
+    r = np.exp(lnr)
+    return n_zero * 3. * np.power(r, 3) / np.power(r_zero, 3) * np.exp(-np.power((r / r_zero), 3))
+
+
+def colliding_box(nx, ny, nz, sd_conc, dt, kernel=None, **kw):
+    oi = h.box_opts(nx, ny, nz, sd_conc, dx=10., strict_fp=False, **kw)
+    oi.dt = dt
+    oi.dry_distros = {(1e-10, 0.): golovin_spectrum}
+    oi.kernel = kernel if kernel is not None else lgrngn.kernel_t.hall_davis_no_waals
+    oi.terminal_velocity = lgrngn.vt_t.beard77fast
+    oi.dbg_flags = int(lgrngn.dbg.TAG)
+    oi.n_sd_max = int(sd_conc * nx * ny * nz * 1.1) + 64
+    return oi
+
+
+def device_by_tag(hip):
+    """the device's living super-droplets in tag order, read without disturbing the production storage ("raw_*")"""
+    ijk = hip.state_u64("raw_ijk")
+    alive = ijk != DEAD
+    tag = hip.state_real("raw_tag")[alive]
+    order = np.argsort(tag, kind="stable")
+    out = {"tag": tag[order], "ijk": ijk[alive][order], "n": hip.state_u64("raw_n")[alive][order]}
+    for nm in ("rw2", "rd3", "kappa", "x", "y", "z"):
+        out[nm] = hip.state_real("raw_" + nm)[alive][order]
+    return out
+
+
+def oracle_by_tag(orc):
+    tag = orc.state_real("tag")
+    order = np.argsort(tag, kind="stable")
+    out = {"tag": tag[order], "ijk": orc.state_u64("ijk")[order], "n": orc.state_u64("n")[order]}
+    for nm in ("rw2", "rd3", "kappa", "x", "y", "z"):
+        out[nm] = orc.state_real(nm)[order]
+    return out
+
+
+def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1):
+    """one full step of both; returns (collisions in the oracle, device storage extent before the step's end)"""
+    orc.step_sync(opts, fo[0], fo[1], rhod, **C)
+    hip.step_sync(opts, fh[0], fh[1], rhod, **C)
+    tag_o = orc.state_real("tag")                       # the oracle's ids at coalescence time (it compacts at the END of step_async)
+    n_before = orc.state_u64("n").copy()
+    hip.step_async(opts)
+    if opts.coal:
+        for call in range(sstp_coal):
+            u01 = hip.rng_dump(call, 0)
+            un_dev, tag_dev, ijk_dev = hip.rng_dump(call, 1), hip.rng_dump(call, 2), hip.rng_dump(call, 3)
+            alive = ijk_dev != DEAD
+            assert int(alive.sum()) == u01.size == tag_o.size, (int(alive.sum()), u01.size, tag_o.size)
+            # un[oracle id] = the key of the device's copy of that super-droplet
+            order = np.argsort(tag_dev[alive], kind="stable")
+            tags_sorted, keys_sorted = tag_dev[alive][order], un_dev[alive][order]
+            assert np.unique(tags_sorted).size == tags_sorted.size
+            pos = np.searchsorted(tags_sorted, tag_o)
+            assert np.array_equal(tags_sorted[pos], tag_o)
+            orc.rng_replay_push(1, keys_sorted[pos])
+            orc.rng_replay_push(0, u01)
+    orc.step_async(opts)
+    assert orc.rng_replay_pending() == 0
+    col = orc.state_real("col") if opts.coal else np.zeros(0)
+    return int((col >= 1).sum()) if col.size else 0, n_before
+
+
+@pytest.mark.parametrize("cond", [True, False])
+def test_production_coalescence_on_the_devices_own_stream_matches_the_oracle(cond):
+    nx, ny, nz, sd_conc, steps = 6, 5, 7, 64, 12
+    oi = colliding_box(nx, ny, nz, sd_conc, dt=5.)
+    fields = h.box_fields(oi)
+    th, rv, rhod, C = fields
+    orc = h.oracle_particles(oi)
+    hip = h.hip_particles(oi)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)           # (its own Philox stream: no replay is ever pushed into the device)
+    # spin-up on the oracle: the drops of this spectrum are far from equilibrium with the box's humidity and move th by 3.7 K in their
+    # first steps; the comparison starts from the settled state
+    so = lgrngn.opts_t()
+    so.coal = so.adve = so.sedi = False
+    for _ in range(8):
+        orc.step_sync(so, th, rv, rhod, **C)
+        orc.step_async(so)
+    h.copy_state(orc, hip)
+    assert hip.rng_replay_pending() == 0
+    opts = lgrngn.opts_t()
+    opts.cond = cond
+    fo, fh = [th.copy(), rv.copy()], [th.copy(), rv.copy()]
+    n0 = orc.n_part
+    collisions, multi, reorderings, last_first_tag = 0, 0, 0, None
+    bar_th, bar_rv, _ = h.cond_bars(False)
+    for it in range(steps):
+        ncol, _ = reverse_replay_step(orc, hip, opts, fo, fh, rhod, C)
+        collisions += ncol
+        multi += int((orc.state_real("col") > 1).sum())
+        assert hip.n_part == orc.n_part, it
+        d, o = device_by_tag(hip), oracle_by_tag(orc)
+        assert np.array_equal(d["tag"], o["tag"]), it                       # the same super-droplets are alive
+        assert np.array_equal(d["n"], o["n"]), (it, int((d["n"] != o["n"]).sum()))
+        assert np.array_equal(d["ijk"], o["ijk"]), it
+        assert np.array_equal(d["kappa"], o["kappa"]), it
+        np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14, err_msg="rd3, step %d" % it)
+        np.testing.assert_allclose(d["rw2"], o["rw2"], rtol=1e-4 if cond else 1e-13, err_msg="rw2, step %d" % it)
+        for a in ("x", "y", "z"):
+            np.testing.assert_allclose(d[a], o[a], rtol=1e-13, atol=1e-10, err_msg=a)
+        if cond:
+            np.testing.assert_allclose(fh[0], fo[0], rtol=bar_th)
+            np.testing.assert_allclose(fh[1], fo[1], rtol=bar_rv)
+        # a storage re-ordering shows as the device's storage beginning with another super-droplet / shrinking to the living ones
+        raw_tag = hip.state_real("raw_tag")
+        if last_first_tag is not None and (raw_tag.size == hip.n_part and raw_tag[0] != last_first_tag):
+            reorderings += 1
+        last_first_tag = raw_tag[0]
+    # the run did what it is meant to cover: collisions (some of them multiple), super-droplets lost, the storage compacted and re-ordered
+    assert collisions > 50 * steps / 12 and multi > 0, (collisions, multi)
+    assert orc.n_part < n0 * 31 // 32
+    assert reorderings >= 1
+    # and the observable state at the end, through the ordinary getters (the storage is put into the reference's order for them)
+    assert np.array_equal(hip.state_u64("n"), orc.state_u64("n"))
+    assert np.array_equal(hip.state_u64("ijk"), orc.state_u64("ijk"))
+    print("collisions %d (multiple %d), super-droplets %d -> %d, re-orderings %d" % (collisions, multi, n0, orc.n_part, reorderings))
+
+
+def test_reverse_replay_with_crowded_cells_and_substeps():
+    """400 super-droplets per cell (the listed-cell sorts: one wave per cell) and two coalescence substeps (no fused death marks, the
+    plain re-sort path), the geometric kernel"""
+    nx, ny, nz, sd_conc, steps = 3, 2, 3, 400, 5
+    oi = colliding_box(nx, ny, nz, sd_conc, dt=4., kernel=lgrngn.kernel_t.geometric, sstp_coal=2)
+    fields = h.box_fields(oi)
+    th, rv, rhod, C = fields
+    orc = h.oracle_particles(oi)
+    hip = h.hip_particles(oi)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    h.copy_state(orc, hip)
+    opts = lgrngn.opts_t()
+    opts.cond = False
+    fo, fh = [th.copy(), rv.copy()], [th.copy(), rv.copy()]
+    for it in range(steps):
+        # (two coalescence calls per step; the oracle's ids do not change between them: it compacts at the end of step_async)
+        reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=2)
+        assert hip.n_part == orc.n_part, it
+        d, o = device_by_tag(hip), oracle_by_tag(orc)
+        assert np.array_equal(d["tag"], o["tag"]) and np.array_equal(d["n"], o["n"]) and np.array_equal(d["ijk"], o["ijk"]), it
+        np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14)
+        np.testing.assert_allclose(d["rw2"], o["rw2"], rtol=1e-13)

@@ -3,7 +3,7 @@ stream): the reference's analytic Golovin test, tests/python/physics/coalescence
 const_multi variant, RMSD < 3e-5).
 
 How much of the RMSD is the draw (tools/golovin_ensemble.py, 12 seeds each, MI355X): const_multi 1.7e-5 +- 0.7e-5 (max 3.1e-5) with the
-shuffle keys of this round, 1.7e-5 +- 0.5e-5 (max 3.0e-5) with round 2's Philox keys (LCX_SHUFFLE_PHILOX=1); sd_conc 1.0e-5 +- 0.2e-5
+shuffle keys of this round, 1.7e-5 +- 0.5e-5 (max 3.0e-5) with round 2's Philox keys (opts_init.dbg_flags & SHUFFLE_PHILOX); sd_conc 1.0e-5 +- 0.2e-5
 against 0.9e-5 +- 0.2e-5 -- the two generators are indistinguishable here, and the reference's thresholds sit about two standard
 deviations above the mean of either (a seed in forty fails them; the default seed does not)."""
 import numpy as np

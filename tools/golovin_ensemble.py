@@ -1,5 +1,6 @@
 """RMSD of the Golovin test (tests/test_hip_statistical.py, const_multi and sd_conc variants) over a range of seeds: how much of the
-distance to the analytic solution is the draw.  python tools/golovin_ensemble.py [n_seeds]"""
+distance to the analytic solution is the draw.  python tools/golovin_ensemble.py [n_seeds] [philox]
+(philox: round 2's shuffle keys, opts_init.dbg_flags & SHUFFLE_PHILOX)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,6 +21,7 @@ def one(init, opts_dt, seed):
     oi.dry_distros = {(1e-10, 0.): expvolumelnr}
     oi.kernel = lgrngn.kernel_t.golovin; oi.terminal_velocity = lgrngn.vt_t.beard77
     oi.kernel_parameters = np.array([b]); oi.rng_seed = seed
+    oi.dbg_flags = int(lgrngn.dbg.SHUFFLE_PHILOX) if PHILOX else 0
     if init == "sd_conc":
         oi.sd_conc = 2 ** 14; oi.n_sd_max = 2 ** 14
     else:
@@ -44,7 +46,8 @@ def one(init, opts_dt, seed):
     return float(np.sqrt(np.sum((res[sel] - ana[sel]) ** 2) / np.sum(sel)))
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+PHILOX = len(sys.argv) > 2 and sys.argv[2] == "philox"
 for init in ("const_multi", "sd_conc"):
     for dt in (-1, 400.):
         v = np.array([one(init, dt, 44 + s) for s in range(n)])
-        print(os.environ.get("LCX_SHUFFLE_PHILOX", "hashed"), init, dt, "mean %.3e sd %.3e min %.3e max %.3e" % (v.mean(), v.std(), v.min(), v.max()), np.round(v * 1e5, 2), flush=True)
+        print("philox" if PHILOX else "hashed", init, dt, "mean %.3e sd %.3e min %.3e max %.3e" % (v.mean(), v.std(), v.min(), v.max()), np.round(v * 1e5, 2), flush=True)

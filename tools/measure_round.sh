@@ -15,12 +15,12 @@ for nx in 128 64 32 16; do $B --nx $nx --self-ring --steps 100 > $out/selfring_n
 # the native multi_HIP object with all slabs on this one device: concurrent (exchange overlapped) and one slab at a time
 for N in 2 4 8; do
   $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_concurrent.json 2> $out/multi_${N}_concurrent.err
-  LCX_MULTI_SERIALIZE=1 $B --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_serialized.json 2> $out/multi_${N}_serialized.err
+  $B --dbg MULTI_SERIALIZE --gpus $N --oversubscribe --steps 40 > $out/multi_${N}_serialized.json 2> $out/multi_${N}_serialized.err
 done
 # C4 at full size (256 x 256 x 128 x 64 = 5.4e8 SDs, 8 slabs of 32 x-planes), all slabs on this device: concurrently, and one slab at a time
 C4="--nx 256 --ny 256 --nz 128 --gpus 8 --oversubscribe --steps 10 --warmup 2"
 $B $C4 > $out/c4_8slabs_concurrent.json 2> $out/c4_8slabs_concurrent.err
-LCX_MULTI_SERIALIZE=1 $B $C4 > $out/c4_8slabs_serialized.json 2> $out/c4_8slabs_serialized.err
+$B --dbg MULTI_SERIALIZE $C4 > $out/c4_8slabs_serialized.json 2> $out/c4_8slabs_serialized.err
 # one C4 slab alone on the device (no neighbours)
 $B --nx 32 --ny 256 --nz 128 --steps 40 > $out/c4_slab_alone.json 2> $out/c4_slab_alone.err
 # C5: 128^3 x 512 SD/cell
