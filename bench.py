@@ -36,17 +36,24 @@ def bimodal():
     return lgrngn.lognormal([.02e-6, .075e-6], [1.4, 1.6], [60e6, 40e6])
 
 
-def make_opts_init(nx, ny, nz, sd_conc, dx, sstp_cond, sstp_coal, seed):
+def make_opts_init(nx, ny, nz, sd_conc, dx, sstp_cond, sstp_coal, seed, workload="stratocumulus", dt=1., kernel=None):
     from libcloudphxx_amd import lgrngn
     oi = lgrngn.opts_init_t()
     oi.nx, oi.ny, oi.nz = nx, ny, nz
     oi.dx = oi.dy = oi.dz = dx
     oi.x1, oi.y1, oi.z1 = nx * dx, ny * dx, nz * dx
-    oi.dt = 1.
+    oi.dt = dt
     oi.sd_conc = sd_conc
     oi.n_sd_max = int(nx * ny * nz * sd_conc * 1.15) + 1024
-    oi.dry_distros = {(.61, 0.): bimodal()}
-    oi.kernel = lgrngn.kernel_t.hall_pinsky_stratocumulus       # (init fails loudly if its efficiency table is missing)
+    if workload == "coal-stress":
+        # SURVEY 8(d), C5 variant (ii): the exponential-in-volume spectrum of the reference's Golovin test (tests/python/physics/
+        # coalescence_golovin.py:31-44,68-74: r_zero = 30.084 um, n_zero = 2^23 per m^3, kappa = 1e-10) under a gravitational kernel
+        # with tabulated efficiencies -- drizzle-sized drops that DO collide (a per cent of the candidate pairs per second)
+        oi.dry_distros = {(1e-10, 0.): lgrngn.expvolume(30.084e-6, 2 ** 23)}
+        oi.kernel = lgrngn.kernel_t[kernel] if kernel else lgrngn.kernel_t.hall_davis_no_waals
+    else:
+        oi.dry_distros = {(.61, 0.): bimodal()}
+        oi.kernel = lgrngn.kernel_t[kernel] if kernel else lgrngn.kernel_t.hall_pinsky_stratocumulus   # (init fails loudly if its efficiency table is missing)
     oi.terminal_velocity = lgrngn.vt_t.beard77fast
     oi.adve_scheme = lgrngn.as_t.euler
     oi.sstp_cond, oi.sstp_coal = sstp_cond, sstp_coal
@@ -128,7 +135,7 @@ def cpu_baseline(args):
     if mem_available_gb() < 1.5 * need_gb and n > 64:
         note = " (host memory %.0f GB: sample reduced from %d^3)" % (mem_available_gb(), n)
         n = 64
-    oi = make_opts_init(n, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44)
+    oi = make_opts_init(n, n, n, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44, args.workload, args.dt, args.kernel)
     th, rv, rhod, Cx, Cy, Cz = make_fields(n, n, n, 0, n, np, np.float64)
     lib = h.oracle_omp_lib()
     quota = h.cpu_quota()                                           # (oracle_omp_lib has already set the thread count to it)
@@ -185,7 +192,20 @@ def main():
                     help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
                          "many steps (0 = the library default, every 64 steps -- 32 for slabs with neighbours -- and with every compaction; -1 = never, the reference's "
                          "storage order)")
+    ap.add_argument("--workload", choices=["stratocumulus", "coal-stress"], default="stratocumulus",
+                    help="stratocumulus (default): BASELINE configs[2], activating aerosol, few collisions; coal-stress: SURVEY 8(d) C5 variant "
+                         "(ii), the Golovin test's drizzle spectrum under hall_davis_no_waals -- a per cent of the candidate pairs collide "
+                         "per second; the result line then carries `coal_stress` (collided pairs per step, k_coal's rate with its write-back)")
+    ap.add_argument("--kernel", default=None, help="collision kernel by its name in lgrngn.kernel_t (default: the workload's)")
+    ap.add_argument("--dt", type=float, default=1., help="time step in seconds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true",
+                    help="skip the short measurement with the Eulerian arrays in HOST memory (numpy arrays through arrinfo_t, what an "
+                         "unchanged icicle / UWLCM passes), reported as `host_arrays` next to the headline figure")
+    ap.add_argument("--no-toms-leg", action="store_true",
+                    help="skip the short measurement with opts_init.cond_solver = 1 (the reference's TOMS748 iterates in fast arithmetic), "
+                         "reported as `cond_solver_toms748` next to the headline figure")
+    ap.add_argument("--leg-steps", type=int, default=20, help="steps of the host-array and cond_solver legs")
     ap.add_argument("--no-strict-leg", action="store_true",
                     help="skip the second, short measurement with opts_init.strict_fp = 1 (the API's default arithmetic: IEEE operation "
                          "order, what a caller who changes nothing gets), reported as `strict_fp` next to the headline figure")
@@ -270,7 +290,7 @@ def main():
     if args.nx:
         nx_tot = args.nx
     ny, nz = args.ny or n, args.nz or n
-    oi = make_opts_init(nx_tot, ny, nz, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank)
+    oi = make_opts_init(nx_tot, ny, nz, args.sd_conc, args.dx, args.sstp_cond, args.sstp_coal, 44 + rank, args.workload, args.dt, args.kernel)
     oi.dev_id = -1 if native_multi else dev_index
     oi.strict_fp = args.strict_fp
     oi.cond_solver = 1 if args.cond_solver == "toms748" else 0
@@ -306,24 +326,42 @@ def main():
         arrays = [lgrngn.DeviceArrays([parts[r][k].data_ptr() for r in range(args.gpus)], parts[0][k].shape) for k in range(6)]
         return prt, parts, arrays, sorted(set(slab_dev))
 
+    probe_state = {"hung": False}
+
     def rccl_ring_works():
         """one small message to either neighbour and back, the way libcloudphxx_amd/multi.py posts them (a batch of isend / irecv on
         device tensors); every rank learns whether EVERY rank got through -- a node whose RCCL cannot do that still gets measured"""
-        ok = 1
-        try:
-            lft, rgt = (rank - 1) % world, (rank + 1) % world
-            out_l = torch.full((256,), float(rank), device=dev); out_r = out_l.clone()
-            in_l = torch.empty(256, device=dev); in_r = torch.empty(256, device=dev)
-            ops = [dist.P2POp(dist.isend, out_l, lft), dist.P2POp(dist.isend, out_r, rgt),
-                   dist.P2POp(dist.irecv, in_r, rgt), dist.P2POp(dist.irecv, in_l, lft)]
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            torch.cuda.synchronize(dev)
-            if float(in_l[0]) != float(lft) or float(in_r[0]) != float(rgt):
-                ok = 0
-        except Exception as e:                               # (RuntimeError / DistBackendError: no link, no IPC, ...)
-            print("bench.py rank %d: RCCL ring probe: %s" % (rank, e), file=sys.stderr, flush=True)
+        # The probe runs in a thread of its own with a deadline: a point-to-point operation that HANGS (instead of raising) must not hold
+        # every rank until the process group's time-out.  A probe that has not come back after 90 s counts as failed; its thread is left
+        # behind (it sits in a blocking wait that nothing can cancel), the run goes on over the host transport, and the process ends
+        # with os._exit so that the abandoned communicator cannot block the interpreter's shutdown.
+        import threading
+        res = {"ok": 0, "err": None}
+
+        def probe():
+            try:
+                torch.cuda.set_device(dev)
+                lft, rgt = (rank - 1) % world, (rank + 1) % world
+                out_l = torch.full((256,), float(rank), device=dev); out_r = out_l.clone()
+                in_l = torch.empty(256, device=dev); in_r = torch.empty(256, device=dev)
+                ops = [dist.P2POp(dist.isend, out_l, lft), dist.P2POp(dist.isend, out_r, rgt),
+                       dist.P2POp(dist.irecv, in_r, rgt), dist.P2POp(dist.irecv, in_l, lft)]
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+                torch.cuda.synchronize(dev)
+                res["ok"] = int(float(in_l[0]) == float(lft) and float(in_r[0]) == float(rgt))
+            except Exception as e:                           # (RuntimeError / DistBackendError: no link, no IPC, ...)
+                res["err"] = str(e)
+        th_ = threading.Thread(target=probe, daemon=True)
+        th_.start()
+        th_.join(90.)
+        ok = res["ok"]
+        if th_.is_alive():
             ok = 0
+            probe_state["hung"] = True
+            print("bench.py rank %d: the RCCL ring probe did not return within 90 s" % rank, file=sys.stderr, flush=True)
+        elif res["err"]:
+            print("bench.py rank %d: RCCL ring probe: %s" % (rank, res["err"]), file=sys.stderr, flush=True)
         t = torch.tensor([ok])
         dist.all_reduce(t, op=dist.ReduceOp.MIN)             # (gloo)
         return bool(int(t.item()))
@@ -430,12 +468,14 @@ def main():
         if not args.no_stage_timers:
             p1.set_profiling(2)
         barrier()
+        n_part_start = p1.n_part
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
             sd_done += p1.n_part
         barrier()
         elapsed = time.perf_counter() - t0
+        n_part_end = p1.n_part
         cond_ms = p1.timings().get("cond") if not args.no_stage_timers else None
         stage_ms = {}
         if not args.no_stage_timers and args.stage_steps > 0:
@@ -536,6 +576,17 @@ def main():
         stage_ms_r = dict(stage_ms)
         stage_ms_r["re-sort (post_copy + in-cell shuffle)"] = sort_ms
         stage_roof = {}
+        coal_stress = None
+        if args.workload == "coal-stress" and world_out == 1 and not args.self_ring:
+            # pairs that collided in the last step: the living super-droplets that carry coalescence's invalid terminal velocity
+            # (the one of each pair that grew); a collided pair writes back N + 3R bytes (n of the one, rw2, rd3, vt of the other)
+            pairs = int(p1.state_u64("raw_collided")[0])
+            wb = (8 + 3 * R) * pairs / max(n_local, 1.)
+            stage_bytes["coal"] += wb
+            coal_stress = {"collided_pairs_per_step": pairs, "share_of_candidate_pairs": pairs / max(n_local / 2., 1.),
+                           "write_back_bytes_per_sd": wb, "super_droplets_lost_per_step": (n_part_start - n_part_end) / max(args.steps, 1),
+                           "spectrum": "n(ln r) = 3 n0 (r/r0)^3 exp(-(r/r0)^3), r0 = 30.084 um, n0 = 2^23 m^-3, kappa = 1e-10 "
+                                       "(ref tests/python/physics/coalescence_golovin.py:31-44)"}
         for k_, bsd in stage_bytes.items():
             if k_ in stage_ms_r and stage_ms_r[k_] > 0:
                 gbs = bsd * n_local / (stage_ms_r[k_] / args.steps * 1e-3) / 1e9
@@ -553,6 +604,8 @@ def main():
                 "; fallback: " + fallback_reason if fallback_reason else "")
         else:
             decomposition_note = ""
+        prt_transport = getattr(prt, "transport", None) if spmd else None
+        prt_second_rounds = getattr(prt, "second_rounds", None) if spmd else None
         out = {
             "metric": "super-droplets/sec (cond+coal substep), 128^3 x 64 SD/cell",
             "value": sd_total / elapsed,
@@ -577,43 +630,98 @@ def main():
             "stage_pass_steps": 0 if args.no_stage_timers else args.stage_steps,
             "stage_roofline": stage_roof,
         }
-        if world_out == 1 and not args.strict_fp and not args.no_strict_leg and args.cond_mode == "percell" and not args.self_ring:
-            # the API default (opts_init.strict_fp = 1; both host mirrors): the same box, the same steps, IEEE operation order in the
-            # condensation kernel and the reference's ordered per-cell sums -- what a driver that changes nothing gets
-            del prt
+        if spmd or native_multi:
+            # what ran, for a reader of an N-GPU record: how many ranks did work, how the migrants travelled, how often a message needed
+            # its second part
+            out["config"]["ranks_working"] = 1 if (native_multi and world > 1) else world_out
+            out["config"]["transport"] = ("peer writes / peer copies inside one process (native multi_HIP object)" if native_multi
+                                          else prt_transport)
+            out["config"]["second_rounds"] = None if native_multi else prt_second_rounds
+        if coal_stress is not None:
+            coal_stress["coal_ms"] = out["stage_ms_per_step"].get("coal")
+            coal_stress["reorder_storage_ms"] = out["stage_ms_per_step"].get("reorder_storage")
+            coal_stress["post_copy_ms"] = out["stage_ms_per_step"].get("post_copy")
+            out["coal_stress"] = coal_stress
+        legs_ok = world_out == 1 and args.cond_mode == "percell" and not args.self_ring
+        if legs_ok:
+            # Further SHORT measurements on the same box, each on an object of its own built from the headline's options with one thing
+            # changed.  The headline object goes first (its two attribute sets and housekeeping are tens of GB), and every leg gets
+            # fresh input fields (the headline run has evolved th and rv in place).
+            import gc
+            prt = p1 = state = fields_t = None
+            th = rv = rhod = Cx = Cy = Cz = None
+            gc.collect()
             torch.cuda.synchronize()
-            oi.strict_fp = True
-            prt_s = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
-            prt_s.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
-            for _ in range(3):
-                prt_s.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
-                prt_s.step_async(opts)
-            prt_s.set_profiling(True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            done_s = 0
-            for _ in range(args.strict_leg_steps):
-                prt_s.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
-                prt_s.step_async(opts)
-                done_s += prt_s.n_part
-            torch.cuda.synchronize()
-            dt_s = time.perf_counter() - t0
-            st_s = prt_s.timings()
-            cond_ms = st_s.get("cond", 0.) / max(args.strict_leg_steps * args.sstp_cond, 1)
-            ach_s = cond_bytes_per_sd * (done_s / args.strict_leg_steps) / (cond_ms * 1e-3) / 1e9 if cond_ms else None
-            out["strict_fp"] = {"value": done_s / dt_s, "unit": "super-droplets/s", "ms_per_step": dt_s / args.strict_leg_steps * 1e3, "steps": args.strict_leg_steps,
-                                "fp_mode": "strict IEEE order (opts_init.strict_fp = 1, the API default)",
-                                "roofline": {"bound": "hbm", "kernel": "k_cond", "achieved": ach_s, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": ach_s / HBM_PEAK_GBS if ach_s else None, "avg_launch_ms": cond_ms,
-                                             "algorithmic_bytes_per_sd": cond_bytes_per_sd},
-                                "stage_ms_per_step": {k: v / args.strict_leg_steps for k, v in st_s.items()}}
-            del prt_s
+
+            def run_leg(change, steps, host_arrays=False):
+                keep = {k: getattr(oi, k) for k in change}
+                for k, v in change.items():
+                    setattr(oi, k, v)
+                try:
+                    f = device_fields(nx_tot, 0, dev)
+                    arrs = [t.cpu().numpy() for t in f] if host_arrays else [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in f]
+                    pr = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
+                    pr.init(arrs[0], arrs[1], arrs[2], Cx=arrs[3], Cy=arrs[4], Cz=arrs[5])
+                    for _ in range(3):
+                        pr.step_sync(opts, *arrs)
+                        pr.step_async(opts)
+                    pr.set_profiling(1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    done = 0
+                    for _ in range(steps):
+                        pr.step_sync(opts, *arrs)
+                        pr.step_async(opts)
+                        done += pr.n_part
+                    torch.cuda.synchronize()
+                    dt_ = time.perf_counter() - t0
+                    st_ = pr.timings()
+                    cond_ms_ = st_.get("cond", 0.) / max(steps * args.sstp_cond, 1)
+                    ach_ = cond_bytes_per_sd * (done / steps) / (cond_ms_ * 1e-3) / 1e9 if cond_ms_ else None
+                    res = {"value": done / dt_, "unit": "super-droplets/s", "ms_per_step": dt_ / steps * 1e3, "steps": steps,
+                           "roofline": {"bound": "hbm", "achieved": ach_, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": ach_ / HBM_PEAK_GBS if ach_ else None, "avg_launch_ms": cond_ms_,
+                                        "algorithmic_bytes_per_sd": cond_bytes_per_sd},
+                           "stage_ms_per_step": {k: v / steps for k, v in st_.items()}}
+                    del pr, f, arrs
+                    gc.collect()
+                    torch.cuda.synchronize()
+                    return res
+                finally:
+                    for k, v in keep.items():
+                        setattr(oi, k, v)
+
+            if not args.strict_fp and not args.no_strict_leg:
+                # the API default (opts_init.strict_fp = 1; both host mirrors): IEEE operation order in the condensation kernel and the
+                # reference's ordered per-cell sums -- what a driver that changes no option gets
+                out["strict_fp"] = run_leg({"strict_fp": True}, args.strict_leg_steps)
+                out["strict_fp"]["fp_mode"] = "strict IEEE order (opts_init.strict_fp = 1, the API default)"
+                out["strict_fp"]["roofline"]["kernel"] = "k_cond"
+            if not args.strict_fp and args.cond_solver == "lean" and not args.no_toms_leg:
+                # the reference-faithful fast mode: TOMS748's iterates (the reference's answer is the midpoint of ITS last bracket) in fast
+                # arithmetic -- held to SURVEY 8a's bars in every test, where the lean solver is held to its own (tests/_harness.py)
+                out["cond_solver_toms748"] = run_leg({"cond_solver": 1}, args.leg_steps)
+                out["cond_solver_toms748"]["fp_mode"] = "fast arithmetic, the reference's TOMS748 iterates (opts_init.cond_solver = 1)"
+                out["cond_solver_toms748"]["roofline"]["kernel"] = "k_cond_fast_fold + k_cond_fast"
+            if not args.no_host_leg:
+                # what an unchanged icicle / UWLCM gets: the Eulerian arrays in HOST memory (numpy arrays through arrinfo_t), every option
+                # as in the headline -- sync_in / sync_out include the PCIe transfers and the host-side row copies
+                out["host_arrays"] = run_leg({}, args.leg_steps, host_arrays=True)
+                out["host_arrays"]["arrays"] = "th, rv, rhod, Cx, Cy, Cz as host (numpy) arrays: %.1f MB in, %.1f MB out per step" % (
+                    (3 * nx_tot * ny * nz + (nx_tot + 1) * ny * nz + nx_tot * (ny + 1) * nz + nx_tot * ny * (nz + 1)) * R / 1e6, 2 * nx_tot * ny * nz * R / 1e6)
+                out["host_arrays"]["extra_ms_per_step"] = out["host_arrays"]["ms_per_step"] - out["ms_per_step"]
+                if not args.strict_fp and not args.no_strict_leg:
+                    # ... and with the API's default arithmetic as well: the caller that changes nothing at all
+                    out["host_arrays_strict_fp"] = run_leg({"strict_fp": True}, args.leg_steps, host_arrays=True)
         if world_out == 1 and not args.no_cpu_baseline and not args.self_ring:
             out["cpu_baseline"] = cpu_baseline(args)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.all_reduce(torch.zeros(1))
+        if probe_state["hung"]:                              # (an abandoned RCCL operation: do not wait for its communicator)
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

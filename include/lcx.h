@@ -59,7 +59,10 @@ typedef struct {
   lcx_distro_fn fn;              /* used when fn != NULL */
   void *user;
   /* built-in alternative (fn == NULL): sum of n_modes lognormal modes
-   * n_stp/ (sqrt(2pi) ln sdev) exp(-(lnrd-ln mean_rd)^2 / (2 ln^2 sdev)), common/lognormal.hpp:25-37 */
+   * n_stp/ (sqrt(2pi) ln sdev) exp(-(lnrd-ln mean_rd)^2 / (2 ln^2 sdev)), common/lognormal.hpp:25-37;
+   * n_modes = -1: the exponential-in-volume spectrum of Shima et al. 2009 that the reference's Golovin test passes as a Python function
+   * (tests/python/physics/coalescence_golovin.py:41-44), n(ln r) = 3 n_stp[0] (r / mean_rd[0])^3 exp(-(r / mean_rd[0])^3), so that
+   * a 1e8-droplet box of it can be initialised without a host callback per droplet */
   int n_modes;
   double mean_rd[4], sdev[4], n_stp[4];
 } lcx_distro_t;
@@ -256,7 +259,9 @@ int lcx_get_state_u64(lcx_particles *, const char *name, unsigned long long *out
  * "courant_x","courant_y","courant_z","vt_0" (as double whatever the real kind).
  * Names that begin with "raw_" ("raw_n","raw_ijk" as u64; "raw_rw2","raw_rd3","raw_kappa","raw_vt","raw_x","raw_y","raw_z","raw_tag" as
  * reals) return the STORAGE as it is -- its whole extent, dead slots (n == 0) included, nothing compacted or sorted on the way: reading
- * them does not disturb a production run, whereas every other particle-state getter first puts the storage into the reference's order. */
+ * them does not disturb a production run, whereas every other particle-state getter first puts the storage into the reference's order.
+ * "raw_collided" (u64, one value): living super-droplets that carry coalescence's invalid terminal velocity, i.e. the number of pairs that
+ * collided in the last lcx_step_async (bench.py's coal-stress workload reports it). */
 int lcx_get_state_real(lcx_particles *, const char *name, double *out, size_t cap, size_t *n);
 /* overwrite particle state (all arrays of length n; x/y/z may be NULL for absent dimensions);
  * lets a test start the device from an oracle state */

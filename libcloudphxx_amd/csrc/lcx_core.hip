@@ -16,10 +16,12 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lcx.h"
 #include "lcx_kernels.hpp"
+#include "lcx_pool.hpp"
 
 namespace lcx {
 
@@ -298,7 +300,15 @@ struct Particles : IParticles {
     outbuf_h.assign(ncell, T(0));
     if (distmem()) alloc_mig();
   }
-  ~Particles() override { if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); } if (pinned) (void)hipHostFree(pinned); }
+  ~Particles() override
+  {
+    if (st) (void)hipStreamSynchronize(st);
+    for (auto &e : prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
+    for (hipEvent_t e : prof_pool) (void)hipEventDestroy(e);
+    if (st) (void)hipStreamDestroy(st);
+    if (pinned) (void)hipHostFree(pinned);
+    for (HostStage *h : {&hstage_in, &hstage_out}) if (h->p) (void)hipHostFree(h->p);
+  }
   // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
   template <class S> void read_back(S *dst, const S *src, size_t n)
   {
@@ -328,7 +338,7 @@ struct Particles : IParticles {
     for (int e = 0; e < n_ext; ++e) s.ext[e] = a.ext[e].p;
     return s;
   }
-  void sync() { HIPCHK(hipStreamSynchronize(st)); }
+  void sync() { HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
 
   // ---- profiling ranges (hipEvents on OUR stream) ----
   // profiling: 0 off; 1 every stage; 2 the condensation kernel's stage only -- two event records per step instead of fifty: every record
@@ -431,9 +441,19 @@ struct Particles : IParticles {
       add_job(jobs_in, to.p, (const T *)a->data, n, n1, n2, s0, s1, s2, (local ? 0l : long(o.n_x_bfr)) - halo_planes, wrap);
       return;
     }
+    const long ioff = long(o.n_x_bfr) - halo_planes;
+    if (!dbg(LCX_DBG_HOST_SYNC_LOOP)) {
+      // the caller's HOST array (what an unchanged icicle / UWLCM passes, particles_impl_sync.ipp:15-68): its rows are gathered into
+      // page-locked staging by a few host threads and ONE asynchronous copy takes the field straight into the library's array; nothing
+      // waits here -- the staging area is not the caller's memory, the caller's array is read completely before this returns
+      T *stg = stage_reserve(hstage_in, n);
+      host_copy_rows(true, stg, (T *)a->data, n, n1, n2, s0, s1, s2, ioff, wrap);
+      HIPCHK(hipMemcpyAsync(to.p, stg, n * sizeof(T), hipMemcpyHostToDevice, st));
+      hstage_busy = true;
+      return;
+    }
     stage_host.resize(n);
     const T *d = (const T *)a->data;
-    const long ioff = long(o.n_x_bfr) - halo_planes;
     auto pl = [&](long i) { i += ioff; if (wrap) { if (i >= wrap) i -= wrap; else if (i < 0) i += wrap; } return i; };
     switch (n_dims) {
       case 0: stage_host[0] = d[0]; break;
@@ -444,6 +464,66 @@ struct Particles : IParticles {
     HIPCHK(hipMemcpyAsync(to.p, stage_host.data(), n * sizeof(T), hipMemcpyHostToDevice, st));
     sync();     // stage_host is reused by the next field
   }
+  // ---- page-locked staging for host arrays + the host threads that fill / drain it.  One area per direction, sized once for all the
+  // fields of a call (4 cell fields + the three Courant arrays in; th and rv out); `used` starts from zero in every call
+  struct HostStage { void *p = nullptr; size_t cap = 0, used = 0; } hstage_in, hstage_out;
+  bool hstage_busy = false;        // copies out of / into the staging areas are queued and not yet waited for
+  std::unique_ptr<WorkerPool> hpool;
+  void stage_begin() { if (hstage_busy) sync(); hstage_in.used = hstage_out.used = 0; }
+  T *stage_reserve(HostStage &h, size_t n)
+  {
+    if (h.used + n > h.cap / sizeof(T)) {
+      if (h.used) { sync(); h.used = 0; }                         // (more fields than planned for: wait, start over)
+      if (n > h.cap / sizeof(T)) {
+        const size_t want = std::max(n, &h == &hstage_in ? 4 * ncell + n_cx + n_cy + n_cz : 2 * ncell) * sizeof(T);
+        if (h.p) HIPCHK(hipHostFree(h.p));
+        h.p = nullptr; h.cap = 0;
+        HIPCHK(hipHostMalloc(&h.p, want, hipHostMallocDefault));
+        h.cap = want;
+      }
+    }
+    T *r = (T *)h.p + h.used;
+    h.used += n;
+    return r;
+  }
+  int host_threads() const
+  {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    return int(std::max(1u, std::min({8u / unsigned(std::max(o.dev_count, 1)), hw, 8u})));
+  }
+  // rows of the library's array (its innermost extent, contiguous there) <-> the caller's strided array; in: caller -> dense
+  void host_copy_rows(bool in, T *dense, T *user, size_t n, int n1, int n2, long s0, long s1, long s2, long ioff, long wrap)
+  {
+    const int nd = n_dims;
+    const size_t inner = nd >= 2 ? size_t(n2) : 1, rows = nd == 0 ? 1 : n / inner;
+    const long s_in = nd == 3 ? s2 : nd == 2 ? s1 : 1;
+    auto work = [=](size_t r0, size_t r1) {
+      for (size_t r = r0; r < r1; ++r) {
+        long i = nd == 3 ? long(r / size_t(n1)) : long(r);
+        i += ioff; if (wrap) { if (i >= wrap) i -= wrap; else if (i < 0) i += wrap; }
+        const long base = nd == 0 ? 0 : nd == 3 ? i * s0 + long(r % size_t(n1)) * s1 : i * s0;
+        T *d = dense + r * inner, *u = user + base;
+        if (s_in == 1) { if (in) memcpy(d, u, inner * sizeof(T)); else memcpy(u, d, inner * sizeof(T)); }
+        else if (in) for (size_t k = 0; k < inner; ++k) d[k] = u[long(k) * s_in];
+        else for (size_t k = 0; k < inner; ++k) u[long(k) * s_in] = d[k];
+      }
+    };
+    const int nt = host_threads();
+    if (nt == 1 || n * sizeof(T) < (size_t(1) << 18)) { work(0, rows); return; }
+    if (!hpool) hpool.reset(new WorkerPool(nt));
+    hpool->run([&](int t) { work(rows * size_t(t) / size_t(nt), rows * size_t(t + 1) / size_t(nt)); });
+  }
+  // host arrays of sync_out: the copies into the staging area are queued by sync_out_arr, the rows go to the caller's arrays once the
+  // stream has been waited for (finish_sync_out)
+  struct OutJob { T *stg, *user; size_t n; int n1, n2; long s0, s1, s2, ioff; };
+  std::vector<OutJob> out_jobs;
+  void finish_sync_out()
+  {
+    if (out_jobs.empty()) return;
+    sync();
+    for (const OutJob &j : out_jobs) host_copy_rows(false, j.stg, j.user, j.n, j.n1, j.n2, j.s0, j.s1, j.s2, j.ioff, 0);
+    out_jobs.clear();
+  }
   void sync_out_arr(DevBuf<T> &from, const lcx_arrinfo_t *a, size_t n)
   {
     if (is_null(a)) return;
@@ -452,6 +532,13 @@ struct Particles : IParticles {
     if (a->on_device) {
       if (jobs_out.n_jobs == MAX_SYNC_JOBS) flush_sync_jobs();
       add_job(jobs_out, from.p, (const T *)a->data, n, n1, n2, s0, s1, s2, a->on_device == 3 ? 0l : long(o.n_x_bfr), 0);
+      return;
+    }
+    if (!dbg(LCX_DBG_HOST_SYNC_LOOP)) {
+      T *stg = stage_reserve(hstage_out, n);
+      HIPCHK(hipMemcpyAsync(stg, from.p, n * sizeof(T), hipMemcpyDeviceToHost, st));
+      hstage_busy = true;
+      out_jobs.push_back(OutJob{stg, (T *)a->data, n, n1, n2, s0, s1, s2, long(o.n_x_bfr)});
       return;
     }
     stage_host.resize(n);
@@ -1212,6 +1299,7 @@ struct Particles : IParticles {
   {
     if (d.fn) return d.fn(lnrd, d.user);
     double res = 0;
+    if (d.n_modes < 0) { const double q = std::pow(std::exp(lnrd), 3) / std::pow(d.mean_rd[0], 3); return d.n_stp[0] * 3. * q * std::exp(-q); }
     for (int m = 0; m < d.n_modes; ++m)
       res += d.n_stp[m] / std::sqrt(2 * M_PI) / std::log(d.sdev[m]) * std::exp(-std::pow((lnrd - std::log(d.mean_rd[m])), 2) / 2. / std::pow(std::log(d.sdev[m]), 2));
     return res;
@@ -1519,6 +1607,7 @@ struct Particles : IParticles {
       default: break;
     }
     courant_x.alloc_zero(n_cx, st); courant_y.alloc_zero(n_cy, st); courant_z.alloc_zero(n_cz, st);
+    stage_begin();
     if (!w_LS_h.empty()) { std::vector<T> h(w_LS_h.begin(), w_LS_h.end()); w_LS.alloc(h.size()); h2d(w_LS.p, h.data(), h.size() * sizeof(T)); }
     if (!conc_factor_h.empty()) { std::vector<T> h(conc_factor_h.begin(), conc_factor_h.end()); conc_factor.alloc(h.size()); h2d(conc_factor.p, h.data(), h.size() * sizeof(T)); }
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
@@ -1560,6 +1649,7 @@ struct Particles : IParticles {
     if (!turb_any() && !is_null(diss)) throw lcx_error("libcloudph++: turbulent advection, coalescence and condesation are switched off and diss_rate is not empty");
     Range r(this, "sync_in");
     var_rho = !is_null(rhod_);
+    stage_begin();
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     if (turb_any()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
@@ -1594,6 +1684,7 @@ struct Particles : IParticles {
       { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); flush_sync_jobs(); }
     }
     sync();
+    finish_sync_out();
     should_now_run_async = true;
     selected_before_counting = false;
   }
@@ -1771,7 +1862,14 @@ struct Particles : IParticles {
     // "raw_*": the storage as it is (whole extent, dead slots included), nothing compacted or sorted on the way
     const bool raw = s.rfind("raw_", 0) == 0;
     if (!raw) ensure_compact();
-    if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
+    if (s == "raw_collided") {
+      DevBuf<unsigned long long> cnt; cnt.alloc_zero(64 * 8, st);
+      if (nphys) hipLaunchKernelGGL(k_count_collided<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, A.vt.p, ijk.p, cnt.p);
+      auto h = d2h(cnt.p, 64 * 8);
+      unsigned long long tot = 0; for (auto x : h) tot += x;
+      v.assign(1, tot);
+    }
+    else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }

@@ -2215,6 +2215,10 @@ __global__ void k_init_n(size_t n_new, size_t n_old, const T *rd3, const uint32_
   else {
     const T lnrd = log(rd3[p]) / 3.;
     f = 0;
+    if (lm.n < 0) {                 // the built-in exponential-in-volume spectrum (lcx_distro_t, n_modes = -1)
+      const T r = exp(lnrd), q = pow(r, T(3)) / pow(T(lm.mean_rd[0]), T(3));
+      f = T(lm.n_stp[0]) * T(3.) * q * exp(-q);
+    }
     for (int m = 0; m < lm.n; ++m)
       f += T(lm.n_stp[m]) / sqrt(2 * cst<T>::pi) / log(T(lm.sdev[m])) *
            exp(-pow((lnrd - log(T(lm.mean_rd[m]))), T(2)) / T(2.) / pow(log(T(lm.sdev[m])), T(2)));
@@ -2696,6 +2700,15 @@ __global__ void k_rng_record(size_t n_pos, size_t n_store, rng_src r_un, u01_src
   if (i < n_store) { out_un[i] = uint32_t(sort_key(uint32_t(i), 1, r_un) >> 32); out_tag[i] = tag[i]; out_ijk[i] = ijk[i]; }
 }
 template <class T> __global__ void k_fill_index(T *a, size_t n) { size_t i = gid(); if (i < n) a[i] = T(i); }
+// measurement hook ("raw_collided"): living super-droplets whose terminal velocity carries coalescence's invalid flag (vt = -1: the one
+// that grew in a collision of the last step_async, coal.ipp:33-44) -- the number of pairs that collided; one atomic per wave
+template <class T> __global__ void k_count_collided(size_t n, const T *vt, const uint32_t *ijk, unsigned long long *out)
+{
+  const size_t i = gid();
+  const bool hit = i < n && ijk[i] != DEAD_CELL && vt[i] == T(-1);
+  const unsigned long long bal = __ballot(hit);
+  if (bal && lane_id() == unsigned(__ffsll((long long)bal) - 1)) atomicAdd(out + (blockIdx.x & 63u) * 8u, (unsigned long long)__popcll(bal));
+}
 // parity hook (lcx_philox_probe): raw Philox4x32-10 blocks for given (index, call, seed) triples
 __global__ void k_philox_probe(const uint64_t *ics, size_t n, uint32_t *out)
 {

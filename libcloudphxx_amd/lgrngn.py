@@ -189,6 +189,18 @@ class lognormal:
                             np.exp(-(lnrd - np.log(self.mean_rd)) ** 2 / 2. / np.log(self.sdev) ** 2)))
 
 
+class expvolume:
+    """Built-in exponential-in-volume spectrum n(ln r) = 3 n_zero (r / r_zero)^3 exp(-(r / r_zero)^3) (Shima et al. 2009; the function
+    the reference's Golovin test passes, tests/python/physics/coalescence_golovin.py:41-44); evaluated natively (lcx_distro_t.n_modes = -1)."""
+
+    def __init__(self, r_zero, n_zero):
+        self.r_zero, self.n_zero = float(r_zero), float(n_zero)
+
+    def __call__(self, lnrd):
+        q = np.exp(lnrd) ** 3 / self.r_zero ** 3
+        return float(self.n_zero * 3. * q * np.exp(-q))
+
+
 class opts_init_t:
     """opts_init_t<real_t> with the reference's field names and defaults (opts_init.hpp:29-253)."""
 
@@ -283,6 +295,9 @@ class opts_init_t:
                 darr[i].n_modes = len(fun.mean_rd)
                 for m in range(len(fun.mean_rd)):
                     darr[i].mean_rd[m], darr[i].sdev[m], darr[i].n_stp[m] = fun.mean_rd[m], fun.sdev[m], fun.n_stp[m]
+            elif isinstance(fun, expvolume):
+                darr[i].n_modes = -1
+                darr[i].mean_rd[0], darr[i].n_stp[0] = fun.r_zero, fun.n_zero
             else:
                 cb = DISTRO_FN(lambda lnrd, user, _f=fun: float(_f(lnrd)))
                 keep.append(cb)

@@ -239,6 +239,8 @@ class particles_multi_t:
         between: engine work that does not depend on the messages, queued once they are under way"""
         torch = self.torch
         out_l, out_r, in_l, in_r = self.box
+        for t, r in zip((out_l, out_r, in_r, in_l), ranges):
+            assert r is None or 0 <= r[0] <= r[1] <= t.numel(), (r, t.numel())      # (a slice beyond the box would be clamped silently)
         views = lambda t, r: None if r is None else t[r[0]:r[1]]
         if self.transport == "rccl":
             if self.ext_stream is not None:
@@ -288,6 +290,12 @@ class particles_multi_t:
         p.exch_unpack(hl, hr, rc[0], rc[1])
         done, rec = p.exch_finish(opts)
         out, inc = [rec[1], rec[2]], [rec[3], rec[4]]
+        # a message that outgrew the RECEIVER's inbox: the receiver raises in its exch_finish (flag 1 of its record); the sender must not
+        # go on to a second part that no receive will ever match (it would wait for the process group's time-out instead of saying why)
+        for k, has in ((0, hl), (1, hr)):
+            if has and out[k] > self.cap_rec:
+                raise RuntimeError("libcloudph++: more super-droplets crossed a slab face in one step than the exchange buffer holds (%d records); "
+                                   "raise opts_init.n_sd_max" % self.cap_rec)
         # the rare second part: a message that held more than its agreed first part (both ends see it in their own record)
         more_out = [hl and out[0] > sc[0], hr and out[1] > sc[1]]
         more_in = [hl and inc[0] > rc[0], hr and inc[1] > rc[1]]

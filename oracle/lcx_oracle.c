@@ -1422,6 +1422,7 @@ static double eval_distro(const lcx_distro_t *d, double lnrd)
 {
   if (d->fn) return d->fn(lnrd, d->user);
   double res = 0;                                   /* common/lognormal.hpp:25-37, sum of modes */
+  if (d->n_modes < 0) { const double q = pow(exp(lnrd), 3) / pow(d->mean_rd[0], 3); return d->n_stp[0] * 3. * q * exp(-q); }   /* lcx.h: exponential in volume */
   for (int m = 0; m < d->n_modes; ++m)
     res += d->n_stp[m] / sqrt(2 * ORC_PI) / log(d->sdev[m]) *
            exp(-pow((lnrd - log(d->mean_rd[m])), 2) / 2. / pow(log(d->sdev[m]), 2));

@@ -457,6 +457,47 @@ def test_strided_eulerian_arrays(make, layout):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["contiguous", "padded", "kij", "pred_corr"])
+def test_host_arrays_through_the_staged_rows_equal_the_plain_host_loop(layout):
+    """Host arrays (what an unchanged icicle / UWLCM passes) go through page-locked staging filled row by row by a few host threads and
+    one asynchronous copy per field (lcx_core.hip, host_copy_rows); opts_init.dbg_flags & HOST_SYNC_LOOP selects the single-threaded
+    element loop of rounds 1-3.  Same run bit for bit, on a box big enough for the thread pool (32 x 24 x 48 cells: 295 KB per field)
+    -- contiguous arrays, views into padded storage (libmpdata++'s halos), swapped horizontal axes (the innermost stride stays 1),
+    and the wrapped Courant halo of pred_corr"""
+    oi = h.box_opts(32, 24, 48, 4, coal_switch=False)
+    if layout == "pred_corr":
+        oi.adve_scheme = lgrngn.as_t.pred_corr
+    th, rv, rhod, C = h.box_fields(oi)
+
+    def view(a):
+        if layout == "padded":
+            big = np.full(tuple(s + 3 for s in a.shape), np.nan)
+            v = big[1:-2, 2:-1, 1:-2]
+        elif layout == "kij":
+            v = np.empty((a.shape[1], a.shape[0], a.shape[2])).transpose(1, 0, 2)
+        else:
+            return a.copy()
+        v[...] = a
+        return v
+    res = []
+    for loop in (False, True):
+        oi.dbg_flags = int(lgrngn.dbg.HOST_SYNC_LOOP) if loop else 0
+        a_th, a_rv, a_rhod = view(th), view(rv), view(rhod)
+        Cs = {k: view(v) for k, v in C.items()}
+        pr = h.hip_particles(oi)
+        pr.init(a_th, a_rv, a_rhod, **Cs)
+        opts = lgrngn.opts_t()
+        opts.coal = False
+        for _ in range(3):
+            pr.step_sync(opts, a_th, a_rv, a_rhod, **Cs)
+            pr.step_async(opts)
+        res.append((np.array(a_th), np.array(a_rv), pr.get_attr("rw2"), pr.get_attr("x"), pr.get_attr("z"), pr.state_real("courant_x"), pr.state_real("courant_z")))
+    assert not np.array_equal(res[0][0], th)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("make,alloc", [pytest.param(h.oracle_particles, h.host_alloc, id="oracle"),
                                         pytest.param(h.hip_particles, h.dev_alloc, id="hip", marks=pytest.mark.gpu)])
 def test_slabs_indexing_the_global_arrays(make, alloc):

@@ -18,7 +18,7 @@ REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 
 def test_cpu_baseline_leg_on_a_small_sample():
     import bench
-    a = types.SimpleNamespace(cpu_sample_n=6, sd_conc=16, dx=40., sstp_cond=1, sstp_coal=1, cpu_sample_steps=1)
+    a = types.SimpleNamespace(cpu_sample_n=6, sd_conc=16, dx=40., sstp_cond=1, sstp_coal=1, cpu_sample_steps=1, workload="stratocumulus", dt=1., kernel=None)
     r = bench.cpu_baseline(a)
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in r, k
@@ -48,7 +48,7 @@ def test_synthetic_fields_have_the_shapes_the_api_wants():
 @pytest.mark.parametrize("extra", [[], ["--self-ring"]])
 def test_bench_prints_one_json_line_with_the_agreed_keys(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "16", "--steps", "4", "--warmup", "1", "--cpu-sample-n", "6", "--cpu-sample-steps", "1",
-           "--strict-leg-steps", "2", "--stage-steps", "2"] + extra
+           "--strict-leg-steps", "2", "--leg-steps", "2", "--stage-steps", "2"] + extra
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.split("\n") if l.strip()]
@@ -68,3 +68,18 @@ def test_bench_prints_one_json_line_with_the_agreed_keys(extra):
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in c, k
         assert "strict_fp" in d and d["strict_fp"]["ms_per_step"] > 0
+        # the other legs: the reference-faithful fast solver, and the Eulerian arrays in host memory (what an unchanged caller passes)
+        assert d["cond_solver_toms748"]["ms_per_step"] > 0 and d["host_arrays"]["ms_per_step"] > 0 and d["host_arrays_strict_fp"]["ms_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_coal_stress_workload_reports_collisions():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "coal-stress", "--n", "16", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+           "--no-strict-leg", "--no-toms-leg", "--no-host-leg", "--stage-steps", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.split("\n") if l.strip()][0])
+    c = d["coal_stress"]
+    # a per cent of the candidate pairs collide per second in this spectrum (SURVEY 8d, C5 variant ii)
+    assert c["collided_pairs_per_step"] > 0 and 1e-4 < c["share_of_candidate_pairs"] < 0.2, c
+    assert d["stage_roofline"]["coal"]["bytes_per_sd"] > 2 * 4 + 4 + 8 + 3 * 8

@@ -123,8 +123,9 @@ def test_production_coalescence_on_the_devices_own_stream_matches_the_oracle(con
         assert np.array_equal(d["kappa"], o["kappa"]), it
         np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14, err_msg="rd3, step %d" % it)
         np.testing.assert_allclose(d["rw2"], o["rw2"], rtol=1e-4 if cond else 1e-13, err_msg="rw2, step %d" % it)
+        # (with condensation the wet radii agree to the root finder's tolerance, cond_bars; a drop falls by dt vt(rw2) per step)
         for a in ("x", "y", "z"):
-            np.testing.assert_allclose(d[a], o[a], rtol=1e-13, atol=1e-10, err_msg=a)
+            np.testing.assert_allclose(d[a], o[a], rtol=1e-13, atol=2e-3 if (cond and a == "z") else 1e-10, err_msg="%s, step %d" % (a, it))
         if cond:
             np.testing.assert_allclose(fh[0], fo[0], rtol=bar_th)
             np.testing.assert_allclose(fh[1], fo[1], rtol=bar_rv)
