@@ -93,6 +93,10 @@ struct IParticles {
   virtual void sync_in(const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,
                        const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) = 0;
   virtual void step_cond(const lcx_opts_t &, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv) = 0;
+  // particles_t::step_sync = sync_in + step_cond (particles_step.ipp:15-29); an implementation may interleave the two where that
+  // cannot be observed
+  virtual void step_sync(const lcx_opts_t &o, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod, const lcx_arrinfo_t *cx,
+                         const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) { sync_in(th, rv, rhod, cx, cy, cz, diss); step_cond(o, th, rv); }
   virtual void step_async(const lcx_opts_t &) = 0;
   virtual void diag_cell(int which) = 0;               // 0 p, 1 T, 2 RH
   virtual void diag_vel_div() = 0;
@@ -308,6 +312,9 @@ struct Particles : IParticles {
     if (st) (void)hipStreamDestroy(st);
     if (pinned) (void)hipHostFree(pinned);
     for (HostStage *h : {&hstage_in, &hstage_out}) if (h->p) (void)hipHostFree(h->p);
+    for (hipEvent_t e : out_events) (void)hipEventDestroy(e);
+    if (ev_courant) (void)hipEventDestroy(ev_courant);
+    if (st_copy) { (void)hipStreamSynchronize(st_copy); (void)hipStreamDestroy(st_copy); }
   }
   // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
   template <class S> void read_back(S *dst, const S *src, size_t n)
@@ -427,9 +434,10 @@ struct Particles : IParticles {
     if (jobs_out.n_jobs) hipLaunchKernelGGL((k_sync_multi<T, false>), dim3(jobs_out.first_block[jobs_out.n_jobs]), dim3(BS), 0, st, jobs_out);
     jobs_in.n_jobs = jobs_out.n_jobs = 0;
   }
-  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0)
+  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0, hipStream_t on = nullptr)
   {
     if (is_null(a)) return;
+    if (!on) on = st;
     int n1, n2; long s0, s1, s2;
     arr_geom(a, ex, ey, ez, n1, n2, s0, s1, s2);
     // on_device == 3 (set by the multi-device front end for per-slab arrays): a device array of THIS slab, indexed from 0; its
@@ -448,7 +456,7 @@ struct Particles : IParticles {
       // waits here -- the staging area is not the caller's memory, the caller's array is read completely before this returns
       T *stg = stage_reserve(hstage_in, n);
       host_copy_rows(true, stg, (T *)a->data, n, n1, n2, s0, s1, s2, ioff, wrap);
-      HIPCHK(hipMemcpyAsync(to.p, stg, n * sizeof(T), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(to.p, stg, n * sizeof(T), hipMemcpyHostToDevice, on));
       hstage_busy = true;
       return;
     }
@@ -515,14 +523,40 @@ struct Particles : IParticles {
   }
   // host arrays of sync_out: the copies into the staging area are queued by sync_out_arr, the rows go to the caller's arrays once the
   // stream has been waited for (finish_sync_out)
-  struct OutJob { T *stg, *user; size_t n; int n1, n2; long s0, s1, s2, ioff; };
+  struct OutJob { T *stg, *user; size_t n; int n1, n2; long s0, s1, s2, ioff; hipEvent_t done; };
   std::vector<OutJob> out_jobs;
+  std::vector<hipEvent_t> out_events;
+  // (a field's rows are written while the next field's copy is still in flight: an event per field)
   void finish_sync_out()
   {
-    if (out_jobs.empty()) return;
-    sync();
-    for (const OutJob &j : out_jobs) host_copy_rows(false, j.stg, j.user, j.n, j.n1, j.n2, j.s0, j.s1, j.s2, j.ioff, 0);
+    for (const OutJob &j : out_jobs) {
+      HIPCHK(hipEventSynchronize(j.done));
+      host_copy_rows(false, j.stg, j.user, j.n, j.n1, j.n2, j.s0, j.s1, j.s2, j.ioff, 0);
+    }
     out_jobs.clear();
+  }
+  // ---- the Courant numbers of a combined step_sync, when they are host arrays: nothing reads them before step_async, so their rows
+  // are gathered and copied (on a stream of their own) while the condensation kernels run, see step_sync
+  hipStream_t st_copy = nullptr; hipEvent_t ev_courant = nullptr;
+  const lcx_arrinfo_t *late_c[3] = {nullptr, nullptr, nullptr}; bool courants_late = false;
+  void late_courants()
+  {
+    if (!courants_late) return;
+    courants_late = false;
+    if (!st_copy) { HIPCHK(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_courant, hipEventDisableTiming)); }
+    sync_in_arr(late_c[0], courant_x, n_cx, 1, 0, 0, halo, st_copy); sync_in_arr(late_c[1], courant_y, n_cy, 0, 1, 0, halo, st_copy);
+    sync_in_arr(late_c[2], courant_z, n_cz, 0, 0, 1, halo, st_copy);
+    HIPCHK(hipEventRecord(ev_courant, st_copy));
+    HIPCHK(hipStreamWaitEvent(st, ev_courant, 0));       // (whatever is queued on the object's stream from here on sees them)
+  }
+  static bool on_host(const lcx_arrinfo_t *a) { return !is_null(a) && !a->on_device; }
+  void step_sync(const lcx_opts_t &opts, const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *cx,
+                 const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss) override
+  {
+    // (pred_corr looks at the Courant numbers inside sync_in: no deferral then)
+    courants_late = (on_host(cx) || on_host(cy) || on_host(cz)) && !dbg(LCX_DBG_HOST_SYNC_LOOP) && o.adve_scheme != LCX_ADVE_PRED_CORR && opts.cond;
+    late_c[0] = cx; late_c[1] = cy; late_c[2] = cz;
+    try { sync_in(th_, rv_, rhod_, cx, cy, cz, diss); step_cond(opts, th_, rv_); } catch (...) { courants_late = false; throw; }
   }
   void sync_out_arr(DevBuf<T> &from, const lcx_arrinfo_t *a, size_t n)
   {
@@ -538,7 +572,10 @@ struct Particles : IParticles {
       T *stg = stage_reserve(hstage_out, n);
       HIPCHK(hipMemcpyAsync(stg, from.p, n * sizeof(T), hipMemcpyDeviceToHost, st));
       hstage_busy = true;
-      out_jobs.push_back(OutJob{stg, (T *)a->data, n, n1, n2, s0, s1, s2, long(o.n_x_bfr)});
+      const size_t k = out_jobs.size();
+      while (out_events.size() <= k) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); out_events.push_back(e); }
+      HIPCHK(hipEventRecord(out_events[k], st));
+      out_jobs.push_back(OutJob{stg, (T *)a->data, n, n1, n2, s0, s1, s2, long(o.n_x_bfr), out_events[k]});
       return;
     }
     stage_host.resize(n);
@@ -1652,7 +1689,7 @@ struct Particles : IParticles {
     stage_begin();
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     if (turb_any()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
-    sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
+    if (!courants_late) { sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo); }
     flush_sync_jobs();
     if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
       HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
@@ -1683,8 +1720,9 @@ struct Particles : IParticles {
       sstp_save();
       { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); flush_sync_jobs(); }
     }
-    sync();
+    late_courants();               // (host rows and copies while the kernels queued above run)
     finish_sync_out();
+    sync();
     should_now_run_async = true;
     selected_before_counting = false;
   }
@@ -2389,7 +2427,7 @@ int lcx_sync_in(lcx_particles *h, const lcx_arrinfo_t *th, const lcx_arrinfo_t *
 int lcx_step_cond(lcx_particles *h, const lcx_opts_t *o, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv) { LCX_TRY(H->step_cond(*o, th, rv)) }
 int lcx_step_sync(lcx_particles *h, const lcx_opts_t *o, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
                   const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz, const lcx_arrinfo_t *diss)
-{ LCX_TRY({ H->sync_in(th, rv, rhod, cx, cy, cz, diss); H->step_cond(*o, th, rv); }) }
+{ LCX_TRY(H->step_sync(*o, th, rv, rhod, cx, cy, cz, diss)) }
 int lcx_step_async(lcx_particles *h, const lcx_opts_t *o) { LCX_TRY(H->step_async(*o)) }
 int lcx_diag_sd_conc(lcx_particles *h) { LCX_TRY(H->diag_sd_conc()) }
 int lcx_diag_pressure(lcx_particles *h) { LCX_TRY(H->diag_cell(0)) }

@@ -2196,6 +2196,16 @@ int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int 
     for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : kinds[c] == 1 ? rng_un(&g) : rng_normal(&g, &ns);
   return 0;
 }
+/* test hook of the reverse replay: overwrite ONE particle attribute in place ("rw2": the wet radii after a condensation step, so that
+ * the stages behind it are compared from identical inputs); nothing else is touched */
+int orc_set_state_real(orc_particles *s, const char *name, const double *data, size_t n)
+{
+  if (n != s->n_part) FAIL("oracle: set_state_real: %zu values for %zu super-droplets", n, (size_t)s->n_part);
+  double *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt : NULL;
+  if (!dst) FAIL("oracle: set_state_real: unknown attribute '%s'", name);
+  memcpy(dst, data, n * sizeof(double));
+  return 0;
+}
 /* queue a random array for the next consumer of its kind (0: the u01 of a coalescence call, 1: the un of a shuffle), see struct */
 int orc_rng_replay_push(orc_particles *s, int kind, const double *data, size_t n)
 {
