@@ -497,7 +497,7 @@ struct Particles : IParticles {
   int host_threads() const
   {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    return int(std::max(1u, std::min({8u / unsigned(std::max(o.dev_count, 1)), hw, 8u})));
+    return int(std::max(1u, std::min({16u / unsigned(std::max(o.dev_count, 1)), hw, 16u})));
   }
   // rows of the library's array (its innermost extent, contiguous there) <-> the caller's strided array; in: caller -> dense
   void host_copy_rows(bool in, T *dense, T *user, size_t n, int n1, int n2, long s0, long s1, long s2, long ioff, long wrap)

@@ -2200,8 +2200,10 @@ int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int 
  * the stages behind it are compared from identical inputs); nothing else is touched */
 int orc_set_state_real(orc_particles *s, const char *name, const double *data, size_t n)
 {
-  if (n != s->n_part) FAIL("oracle: set_state_real: %zu values for %zu super-droplets", n, (size_t)s->n_part);
-  double *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt : NULL;
+  const int cell = !strcmp(name, "th") || !strcmp(name, "rv");      /* (the cell fields that condensation has just updated) */
+  if (n != (cell ? s->n_cell : s->n_part)) FAIL("oracle: set_state_real: %zu values for '%s'", n, name);
+  double *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt :
+                !strcmp(name, "th") ? s->th : !strcmp(name, "rv") ? s->rv : NULL;
   if (!dst) FAIL("oracle: set_state_real: unknown attribute '%s'", name);
   memcpy(dst, data, n * sizeof(double));
   return 0;

@@ -87,6 +87,8 @@ def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1):
         orc.set_state_real("rw2", rw2_new)
         fo[0][...] = fh[0]
         fo[1][...] = fh[1]
+        orc.set_state_real("th", fh[0].ravel())          # (the cell fields that step_async derives T, p and the viscosity from)
+        orc.set_state_real("rv", fh[1].ravel())
     n_before = orc.state_u64("n").copy()
     hip.step_async(opts)
     if opts.coal:
