@@ -149,7 +149,8 @@ enum lcx_dbg {
                                         * every coalescence call records what it consumed of the random generator (lcx_rng_dump) */
   LCX_DBG_COND_NO_DEAL = 1 << 11,      /* k_cond_lean: one droplet per lane in storage order, no dealing of a workgroup's droplets by their
                                         * last iteration count */
-  LCX_DBG_HOST_SYNC_LOOP = 1 << 12     /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
+  LCX_DBG_HOST_SYNC_LOOP = 1 << 12,    /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
+  LCX_DBG_COND_LEAN_R3 = 1 << 13       /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
 };
 
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */

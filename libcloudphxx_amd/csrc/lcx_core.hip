@@ -313,7 +313,7 @@ struct Particles : IParticles {
     if (pinned) (void)hipHostFree(pinned);
     for (HostStage *h : {&hstage_in, &hstage_out}) if (h->p) (void)hipHostFree(h->p);
     for (hipEvent_t e : out_events) (void)hipEventDestroy(e);
-    if (ev_courant) (void)hipEventDestroy(ev_courant);
+    if (ev_copy) (void)hipEventDestroy(ev_copy);
     if (st_copy) { (void)hipStreamSynchronize(st_copy); (void)hipStreamDestroy(st_copy); }
   }
   // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
@@ -434,10 +434,9 @@ struct Particles : IParticles {
     if (jobs_out.n_jobs) hipLaunchKernelGGL((k_sync_multi<T, false>), dim3(jobs_out.first_block[jobs_out.n_jobs]), dim3(BS), 0, st, jobs_out);
     jobs_in.n_jobs = jobs_out.n_jobs = 0;
   }
-  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0, hipStream_t on = nullptr)
+  void sync_in_arr(const lcx_arrinfo_t *a, DevBuf<T> &to, size_t n, int ex, int ey, int ez, int halo_planes = 0)
   {
     if (is_null(a)) return;
-    if (!on) on = st;
     int n1, n2; long s0, s1, s2;
     arr_geom(a, ex, ey, ez, n1, n2, s0, s1, s2);
     // on_device == 3 (set by the multi-device front end for per-slab arrays): a device array of THIS slab, indexed from 0; its
@@ -452,11 +451,18 @@ struct Particles : IParticles {
     const long ioff = long(o.n_x_bfr) - halo_planes;
     if (!dbg(LCX_DBG_HOST_SYNC_LOOP)) {
       // the caller's HOST array (what an unchanged icicle / UWLCM passes, particles_impl_sync.ipp:15-68): its rows are gathered into
-      // page-locked staging by a few host threads and ONE asynchronous copy takes the field straight into the library's array; nothing
-      // waits here -- the staging area is not the caller's memory, the caller's array is read completely before this returns
+      // page-locked staging by a few host threads, ONE asynchronous copy on the COPY stream takes the field into a device-side staging
+      // area (it starts at once, whatever the object's own stream is still busy with -- the kernels of the previous step_async, or
+      // this step's condensation for the Courant numbers), and a device-to-device copy on the object's stream, behind an event, puts
+      // it into the library's array (flush_host_in).  Nothing waits here: the staging area is not the caller's memory, and the
+      // caller's array has been read completely when this returns
+      const size_t off = hstage_in.used;           // (stage_reserve may start over)
       T *stg = stage_reserve(hstage_in, n);
+      const size_t at = stg - (T *)hstage_in.p; (void)off;
       host_copy_rows(true, stg, (T *)a->data, n, n1, n2, s0, s1, s2, ioff, wrap);
-      HIPCHK(hipMemcpyAsync(to.p, stg, n * sizeof(T), hipMemcpyHostToDevice, on));
+      need_copy_stream();
+      HIPCHK(hipMemcpyAsync(dstage.p + at, stg, n * sizeof(T), hipMemcpyHostToDevice, st_copy));
+      host_in_jobs.push_back(InJob{to.p, dstage.p + at, n});
       hstage_busy = true;
       return;
     }
@@ -477,17 +483,33 @@ struct Particles : IParticles {
   struct HostStage { void *p = nullptr; size_t cap = 0, used = 0; } hstage_in, hstage_out;
   bool hstage_busy = false;        // copies out of / into the staging areas are queued and not yet waited for
   std::unique_ptr<WorkerPool> hpool;
-  void stage_begin() { if (hstage_busy) sync(); hstage_in.used = hstage_out.used = 0; }
+  void stage_begin() { if (hstage_busy) { flush_host_in(); sync(); } hstage_in.used = hstage_out.used = 0; }
+  DevBuf<T> dstage;                // device-side twin of hstage_in
+  struct InJob { T *lib; const T *stg; size_t n; };
+  std::vector<InJob> host_in_jobs;
+  hipStream_t st_copy = nullptr; hipEvent_t ev_copy = nullptr;
+  void need_copy_stream()
+  { if (!st_copy) { HIPCHK(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming)); } }
+  // the fields that the copy stream has been given so far -> the library's arrays, on the object's stream behind the copies
+  void flush_host_in()
+  {
+    if (host_in_jobs.empty()) return;
+    HIPCHK(hipEventRecord(ev_copy, st_copy));
+    HIPCHK(hipStreamWaitEvent(st, ev_copy, 0));
+    for (const InJob &j : host_in_jobs) HIPCHK(hipMemcpyAsync(j.lib, j.stg, j.n * sizeof(T), hipMemcpyDeviceToDevice, st));
+    host_in_jobs.clear();
+  }
   T *stage_reserve(HostStage &h, size_t n)
   {
     if (h.used + n > h.cap / sizeof(T)) {
-      if (h.used) { sync(); h.used = 0; }                         // (more fields than planned for: wait, start over)
+      if (h.used) { flush_host_in(); sync(); h.used = 0; }         // (more fields than planned for: wait, start over)
       if (n > h.cap / sizeof(T)) {
         const size_t want = std::max(n, &h == &hstage_in ? 4 * ncell + n_cx + n_cy + n_cz : 2 * ncell) * sizeof(T);
         if (h.p) HIPCHK(hipHostFree(h.p));
         h.p = nullptr; h.cap = 0;
         HIPCHK(hipHostMalloc(&h.p, want, hipHostMallocDefault));
         h.cap = want;
+        if (&h == &hstage_in) dstage.alloc(want / sizeof(T));
       }
     }
     T *r = (T *)h.p + h.used;
@@ -536,18 +558,15 @@ struct Particles : IParticles {
     out_jobs.clear();
   }
   // ---- the Courant numbers of a combined step_sync, when they are host arrays: nothing reads them before step_async, so their rows
-  // are gathered and copied (on a stream of their own) while the condensation kernels run, see step_sync
-  hipStream_t st_copy = nullptr; hipEvent_t ev_courant = nullptr;
+  // are gathered and copied while the condensation kernels run, see step_sync
   const lcx_arrinfo_t *late_c[3] = {nullptr, nullptr, nullptr}; bool courants_late = false;
   void late_courants()
   {
     if (!courants_late) return;
     courants_late = false;
-    if (!st_copy) { HIPCHK(hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&ev_courant, hipEventDisableTiming)); }
-    sync_in_arr(late_c[0], courant_x, n_cx, 1, 0, 0, halo, st_copy); sync_in_arr(late_c[1], courant_y, n_cy, 0, 1, 0, halo, st_copy);
-    sync_in_arr(late_c[2], courant_z, n_cz, 0, 0, 1, halo, st_copy);
-    HIPCHK(hipEventRecord(ev_courant, st_copy));
-    HIPCHK(hipStreamWaitEvent(st, ev_courant, 0));       // (whatever is queued on the object's stream from here on sees them)
+    sync_in_arr(late_c[0], courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(late_c[1], courant_y, n_cy, 0, 1, 0, halo);
+    sync_in_arr(late_c[2], courant_z, n_cz, 0, 0, 1, halo);
+    flush_host_in();                                     // (whatever is queued on the object's stream from here on sees them)
   }
   static bool on_host(const lcx_arrinfo_t *a) { return !is_null(a) && !a->on_device; }
   void step_sync(const lcx_opts_t &opts, const lcx_arrinfo_t *th_, const lcx_arrinfo_t *rv_, const lcx_arrinfo_t *rhod_, const lcx_arrinfo_t *cx,
@@ -988,7 +1007,9 @@ struct Particles : IParticles {
     if (!npart) return;
     Range r(this, "reorder_storage");
     if (!B.n.p) alloc_attrs(B);
-    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p);
+    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p,
+                       (const uint8_t *)cond_hint.p, cond_hint_alt.p);
+    if (cond_hint.p) cond_hint.swap(cond_hint_alt);
     swap_attr_sets();
     ijk.swap(rank);
     hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
@@ -1058,7 +1079,7 @@ struct Particles : IParticles {
       cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
-                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 keeps round 2's kernels
       // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
@@ -1069,9 +1090,13 @@ struct Particles : IParticles {
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
           if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
-          hipLaunchKernelGGL((k_cond_lean<T, 3>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
+          if (!cond_hint.p) { cond_hint.alloc_zero(cap, st); cond_hint_alt.alloc_zero(cap, st); }
+          a.hint = cond_hint.p;
+          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
+          else if (cond_deal) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
+          else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
         }
-        else hipLaunchKernelGGL((k_cond_lean<T, 3>), gr, bl, 0, st, npart, a);
+        else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gr, bl, 0, st, npart, a);
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
@@ -1101,6 +1126,8 @@ struct Particles : IParticles {
       cond_in_storage_order = false;
     }
   }
+  const bool cond_deal = !dbg(LCX_DBG_COND_NO_DEAL);      // (measurement / test switch: one droplet per lane in storage order, no dealing)
+  DevBuf<uint8_t> cond_hint, cond_hint_alt;               // k_cond_lean's iteration counts of the last step, by storage slot
   const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
@@ -1650,7 +1677,7 @@ struct Particles : IParticles {
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     sync_in_arr(p_, p, ncell, 0, 0, 0);
     sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo);
-    flush_sync_jobs();
+    flush_sync_jobs(); flush_host_in();
     if (n_dims > 0)
       hipLaunchKernelGGL(k_init_dv<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, dv.p, m1(o.ny), m1(o.nz), T(o.dx), T(o.dy), T(o.dz),
                          T(o.x0), T(o.y0), T(o.z0), T(o.x1), T(o.y1), T(o.z1));
@@ -1690,7 +1717,7 @@ struct Particles : IParticles {
     sync_in_arr(th_, th, ncell, 0, 0, 0); sync_in_arr(rv_, rv, ncell, 0, 0, 0); sync_in_arr(rhod_, rhod, ncell, 0, 0, 0);
     if (turb_any()) sync_in_arr(diss, diss_rate, ncell, 0, 0, 0);
     if (!courants_late) { sync_in_arr(cx, courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(cy, courant_y, n_cy, 0, 1, 0, halo); sync_in_arr(cz, courant_z, n_cz, 0, 0, 1, halo); }
-    flush_sync_jobs();
+    flush_sync_jobs(); flush_host_in();
     if (o.adve_scheme == LCX_ADVE_PRED_CORR && !is_null(cx) && n_cx) {                  // particles_step.ipp:127-142
       HIPCHK(hipMemsetAsync(d_flag.p, 0, sizeof(int), st));
       hipLaunchKernelGGL(k_flag_outside<T>, dim3(nblk(n_cx)), dim3(BS), 0, st, courant_x.p, n_cx, T(-2.), T(2.), d_flag.p);

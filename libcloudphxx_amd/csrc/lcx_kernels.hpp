@@ -837,6 +837,9 @@ struct cond_args {
   // the scatter of the re-sort that the end of the previous step left undone (k_scatter_sorted's two loads and two stores per droplet),
   // carried by the storage-order condensation kernel, whose memory pipes idle while its vector ALU is the bottleneck; else sc_rank == nullptr
   const uint32_t *sc_rank, *sc_cell_start; uint32_t *sc_sorted_id, *sc_sorted_ijk;
+  // k_cond_lean in storage order: the number of root-finder iterations each droplet needed in the last step (a byte per storage slot,
+  // written by the kernel, read by its next launch to deal a workgroup's droplets to its waves; nullptr: no dealing)
+  uint8_t *hint;
 };
 template <class T>
 __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
@@ -1006,13 +1009,43 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // Fast arithmetic's production kernel since round 3: the growth rate of k_cond_fast under the lean bracketed secant of lcx_math.hpp
 // (advance_rw2_lean_with) instead of TOMS748 -- no iteration budget, no second launch, no fold: the iteration counts are short and even.
-template <class T, int OPT = 3>
+// Round 4.  (i) The solver's bookkeeping pared down (advance_rw2_lean2_with: the same operations on the droplet's numbers, straight-line
+// loop body) and the growth rate's helper functions without the instructions that are identities here (OPT bit 2).  (ii) DEAL: a wave is
+// as slow as its slowest droplet -- three evaluations of the growth rate for 72 % of the droplets, four for 19 %, five to eight for the
+// haze that is re-equilibrating, so that nearly every wave of 64 pays for five.  How many a droplet needs changes little from one step
+// to the next, and a droplet's answer does not depend on the lane that computes it: the kernel keeps a byte per storage slot with the
+// droplet's last iteration count, and a workgroup deals its 256 droplets to its four waves by it -- the ones that needed at most one
+// iteration to the front, the others to the back (one ballot, four counters and a byte per lane in LDS, two barriers) -- so that three
+// waves of four run the short course.  Loads and stores stay inside the workgroup's 256 consecutive slots (the same cache lines).
+// R3: round 3's form of the solver and of the helper functions (advance_rw2_lean_with, OPT = 3), kept so that a test can show the droplets'
+// rw2 to be the same bits (opts_init.dbg_flags & LCX_DBG_COND_LEAN_R3)
+template <class T, int OPT = 7, bool DEAL = false, bool R3 = false>
 __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
   // attributes and the change (m3_after, storage-indexed; the per-cell finish gathers it through sorted_id) are read and written
   // coalesced.  A droplet's answer does not depend on who computes it, and the sums per cell keep their order.
-  size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
+  size_t pos = gid_xcd(a.xcd_group);
+  if (DEAL) {
+    __shared__ uint8_t perm[BS];
+    __shared__ uint32_t n_fast[BS / WAVE];
+    const size_t base = pos - threadIdx.x;
+    // (slots behind the end of the storage count as slow: they end up in the last lanes and leave)
+    const bool fast = pos < n_part && a.hint[pos] <= 1;
+    const unsigned long long bal = __ballot(fast);
+    if (lane_id() == 0) n_fast[wave_id()] = uint32_t(__popcll(bal));
+    __syncthreads();
+    uint32_t fast_before = 0, fast_all = 0;
+#pragma unroll
+    for (unsigned w = 0; w < BS / WAVE; ++w) { const uint32_t k = n_fast[w]; if (w < wave_id()) fast_before += k; fast_all += k; }
+    const uint32_t in_wave = uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)));
+    // stable: the fast ones keep their order at the front, the slow ones theirs behind them
+    const uint32_t slot = fast ? fast_before + in_wave : fast_all + (wave_id() * WAVE - fast_before) + (lane_id() - in_wave);
+    perm[slot] = uint8_t(threadIdx.x);
+    __syncthreads();
+    pos = base + perm[threadIdx.x];
+  }
+  if (pos >= n_part) return;
   uint32_t id, c;
   if (a.storage_ijk) {
     id = uint32_t(pos); c = a.storage_ijk[pos];
@@ -1025,14 +1058,21 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a)
   cond_cell_fast<T> cc = a.pre[c];
   asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
                "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
-  T r = rw2_old;
+  T delta = 0;
+  unsigned iters = 0;
   if (rw2_old > 0) {
     cond_fun_fast<T, OPT> ff;
     ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
-    r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    T r;
+    if constexpr (R3) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, iters);
     a.rw2[id] = r;
+    // n (rw_new^3 - rw_old^3), the radii as rw2 rsqrt(rw2)^-1... = rw2 * (rw2 * rsqrt(rw2)): the growth rate's own form of the radius
+    // (its first evaluation has computed the old one already)
+    delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
   }
-  a.m3_after[pos] = nn * (rw2_to_rw3_signed(r) - rw2_to_rw3_signed(rw2_old));
+  a.m3_after[pos] = delta;
+  if (a.hint) a.hint[pos] = uint8_t(iters < 255u ? iters : 255u);
 }
 
 // Growth-rate evaluations per droplet (an offline count over 2.1e6 droplets of the oracle's state on the bench's fields): 3 for 72 % of the
@@ -2059,10 +2099,12 @@ k_compact(size_t n_part, attr_set<T> src, attr_set<T> dst, const uint32_t *tile_
 // order becomes storage slot pos; dead SDs are not in the order, so this is a compaction as well
 template <class T>
 __global__ void __launch_bounds__(BS)
-k_reorder(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, attr_set<T> src, attr_set<T> dst, grid_t g, uint32_t *ijk_out)
+k_reorder(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, attr_set<T> src, attr_set<T> dst, grid_t g, uint32_t *ijk_out,
+          const uint8_t *hint_in = nullptr, uint8_t *hint_out = nullptr /* k_cond_lean's byte per slot travels with its droplet */)
 {
   const size_t pos = gid(); if (pos >= n_part) return;
   const uint32_t i = sorted_id[pos];
+  if (hint_in) hint_out[pos] = hint_in[i];
   dst.n[pos] = src.n[i]; dst.rd3[pos] = src.rd3[i]; dst.rw2[pos] = src.rw2[i]; dst.kpa[pos] = src.kpa[i]; dst.vt[pos] = src.vt[i];
   if (g.nx) dst.x[pos] = src.x[i];
   if (g.ny) dst.y[pos] = src.y[i];

@@ -542,6 +542,20 @@ LCX_HD double exp_kelvin(double x)
 #endif
 }
 LCX_HD float exp_kelvin(float x) { return exp(x); }
+// 1 / sqrt(x) for a positive NORMAL x: the operations of the device library's rsqrt (hardware seed, one refinement step in e = 1 - x y^2
+// with the second-order term) without its test for a seed that is zero, infinite or NaN -- the same bits for every argument the
+// condensation kernel has (a squared radius, or a bracket end not below the dry radius), four instructions fewer per evaluation
+LCX_HD double rsqrt_pos(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y0 = __builtin_amdgcn_rsq(x);
+  const double e = __builtin_fma(y0 * -x, y0, 1.0);
+  return __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+LCX_HD float rsqrt_pos(float x) { return rsqrt(x); }
 LCX_HD double exp_reduced(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -642,7 +656,11 @@ template <bool SERIES, class T> LCX_HD T cbrt1p(T x)
 __device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10. / 243, 22. / 729};
 #endif
 // OPT (measurement / tuning switches, all inside the fast arithmetic's few-ulp envelope): bit 0 the root finder's reciprocals
-// with one Newton step instead of two; bit 1 the ventilation factors' cube roots by series for small arguments
+// with one Newton step instead of two; bit 1 the ventilation factors' cube roots by series for small arguments; bit 2 (the lean
+// kernel, with bit 1): the same values from fewer instructions -- the reciprocal square root without the library's seed test (rsqrt_pos),
+// the series' range test as one v_max_f64.  (Measured and dropped: the Kelvin exponential without its range reduction where that is
+// the identity, A / r_w < 0.34 -- the same bits from five instructions fewer per evaluation, but the fallback's second code path costs
+// 23 VGPRs, 102 instead of 79: four waves per SIMD instead of six.)
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
   static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
   T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
@@ -668,7 +686,8 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
   LCX_HD T drw2_dt(T rw2) const
   {
 #pragma clang fp contract(fast)
-    const T irw = rsqrt(rw2);         // one v_rsq + Newton step; rw = rw2 / sqrt(rw2) to ~1 ulp
+    T irw;                            // one v_rsq + Newton step; rw = rw2 / sqrt(rw2) to ~1 ulp
+    if constexpr ((OPT & 4) != 0) irw = rsqrt_pos(rw2); else irw = rsqrt(rw2);
     const T rw = rw2 * irw;
     const T rw3 = rw2 * rw;
     const T Re = c_Re * rw;
@@ -694,7 +713,9 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
 #endif
       klv = exp_kelvin(A * irw);
       Sh = T(1) + cS; Nu = T(1) + cN;
-      if (!(mx(fabs(xS), fabs(xN)) < T(0x1p-8))) {
+      bool big;
+      if constexpr ((OPT & 4) != 0) big = !(T(__builtin_fmax(fabs(xS), fabs(xN))) < T(0x1p-8)); else big = !(mx(fabs(xS), fabs(xN)) < T(0x1p-8));
+      if (big) {
         // (no range check, whose library fallback is code in every copy: |1 + Re Sc| is below 1e30 for anything that is a droplet, and
         // the signed form takes the negative Reynolds number of a droplet whose vt is flagged invalid (-1) -- the series above is for
         // |Re Sc| < 2^-8 only: round 2 tested `Re Sc < 2^-8`, sent those droplets through the series at Re Sc ~ -0.7 and got their
@@ -842,6 +863,60 @@ LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond
       c = c_new;
     }
     if (!(r > mn(a, b) && r < mx(a, b))) r = x1;                                  // (never leave the reference's bracket)
+  }
+  if (r < rd2) r = rd2;
+  return r;
+}
+// The same solver with its bookkeeping pared down (round 4): the SAME operations on the droplet's numbers in the same order -- the
+// answer is the one of advance_rw2_lean_with bit for bit, except that (i) an iterate that rounding puts ON an end of its bracket is
+// evaluated where it is instead of being moved to the midpoint (a far end that is a root to twelve digits: never seen), -- but the loop
+// body is straight-line code (selects instead of the three divergent branches that mixed waves always took both ways), the exact-zero
+// test is left to the arithmetic (f(c) = 0 gives c_new = c and ends the loop through the convergence test with the same answer), and
+// minima / maxima of positive numbers are single instructions.  `iters` returns the number of evaluations inside the loop (the hint
+// by which k_cond_lean deals a workgroup's droplets to its waves in the next step).
+template <class T, class F>
+LCX_HD T advance_rw2_lean2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, unsigned &iters)
+{
+  constexpr int FD = fastdiv<F>::value;
+  iters = 0;
+  const T drw2 = dt * f.drw2_dt(rw2_old);
+  if (drw2 == 0) return rw2_old;
+  T rd;
+  if constexpr (FD != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);
+  const T rd2 = rd * rd;
+  const T a_un = rw2_old + mn(T(0), cond_mlt * drw2);
+  const T a = mx(rd2, a_un), b = rw2_old + mx(T(0), cond_mlt * drw2);
+  if (a == b) return rw2_old;
+  if (a == a_un && tol_reached(eps, a, b)) return (a + b) / 2;
+  const bool grows = drw2 > 0;
+  const T f_far = f(grows ? b : a);
+  const T fa = grows ? drw2 : f_far, fb = grows ? f_far : drw2;     // f(rw2_old) == drw2 (cond_common.ipp:296-305)
+  T r;
+  if (fa * fb > 0) r = rw2_old + drw2;
+  else if (fa == 0) r = a;
+  else if (fb == 0) r = b;
+  else {
+    T x0 = a, f0 = fa, x1 = b, f1 = fb;                              // (x1, f1): the latest point, (x0, f0): the retained end (opposite sign)
+    T c = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
+    r = c;
+    for (unsigned it = 0; it < n_iter; ++it) {
+      const T fc = f(c);
+      ++iters;
+      const bool opp = (fc < 0) != (f1 < 0);                        // the root is between the last two points
+      T m = T(1) - dvd<FD>(fc, f1);                                 // same side twice: Anderson-Bjorck scaling of the retained end
+      m = m > 0 ? m : T(0.5);
+      const T f0s = f0 * m;
+      f0 = opp ? f1 : f0s;
+      x0 = opp ? x1 : x0;
+      x1 = c; f1 = fc;
+      const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
+      r = c_new;
+      const bool done = fabs(c_new - c) <= eps * T(__builtin_fmin(fabs(c_new), fabs(c))) ||
+                        fabs(x0 - x1) <= eps * T(__builtin_fmin(fabs(x0), fabs(x1)));
+      if (done) break;
+      c = c_new;
+    }
+    if (!(r > T(__builtin_fmin(a, b)) && r < T(__builtin_fmax(a, b)))) r = x1;       // (never leave the reference's bracket)
   }
   if (r < rd2) r = rd2;
   return r;

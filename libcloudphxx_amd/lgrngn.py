@@ -102,6 +102,7 @@ class dbg(enum.IntFlag):
     TAG = 1 << 10
     COND_NO_DEAL = 1 << 11
     HOST_SYNC_LOOP = 1 << 12
+    COND_LEAN_R3 = 1 << 13
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -860,6 +860,39 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
     assert np.abs(res[0][2] - rv).max() > 0
 
 
+@pytest.mark.parametrize("sd_conc,steps,reorder_every", [(64, 8, 3), (400, 3, 0)])
+def test_lean_kernel_dealt_lanes_and_round3_solver_form_give_the_same_bits(sd_conc, steps, reorder_every):
+    """Round 4's k_cond_lean (i) deals a workgroup's droplets to its waves by the iteration count each needed in the last step (a byte
+    per storage slot, carried through the storage re-ordering) and (ii) runs the solver with its bookkeeping pared down (straight-line
+    loop body, helper functions without the instructions that are identities for a squared radius).  A droplet's answer depends on
+    neither: the same rw2, th, rv and multiplicities bit for bit as without the dealing (opts_init.dbg_flags & COND_NO_DEAL) and as with
+    round 3's form of the solver (COND_LEAN_R3), over full steps with coalescence, dead slots and storage re-orderings"""
+    oi = h.box_opts(12, 10, 14, sd_conc, sstp_cond=2, strict_fp=False)
+    oi.reorder_every = reorder_every
+    fields = h.box_fields(oi)
+    res = []
+    for flags in (0, int(lgrngn.dbg.COND_NO_DEAL), int(lgrngn.dbg.COND_LEAN_R3)):
+        oi.dbg_flags = flags
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        rw2 = hip.get_attr("rw2")
+        rw2[::7] = (60e-6) ** 2
+        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), np.full(rw2.size, -1.),
+                          hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(steps):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part))
+    assert res[0][4] == res[1][4] == res[2][4]
+    for k in (1, 2):
+        for a_, b_ in zip(res[0][:4], res[k][:4]):
+            assert np.array_equal(a_, b_), k
+    assert np.abs(res[0][2] - rv).max() > 0
+
+
 @pytest.mark.parametrize("sd_conc,reorder_every,cond_every", [(64, 0, 1), (64, 3, 1), (300, 4, 1), (48, 5, 2)])
 def test_deferred_sort_is_bit_identical_to_the_immediate_one(monkeypatch, sd_conc, reorder_every, cond_every):
     """The end-of-step re-sort of a single device leaves its scatter and in-cell ranking to the next step: the storage-order condensation
