@@ -1935,6 +1935,7 @@ struct Particles : IParticles {
       v.assign(1, tot);
     }
     else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
+    else if (s == "raw_cond_hint") { if (cond_hint.p) { auto h = d2h(cond_hint.p, nphys); v.assign(h.begin(), h.end()); } }   // k_cond_lean's iteration counts
     else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }

@@ -689,12 +689,14 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
     T irw;                            // one v_rsq + Newton step; rw = rw2 / sqrt(rw2) to ~1 ulp
     if constexpr ((OPT & 4) != 0) irw = rsqrt_pos(rw2); else irw = rsqrt(rw2);
     const T rw = rw2 * irw;
-    const T rw3 = rw2 * rw;
     const T Re = c_Re * rw;
     const T KnD = lambda_D * irw, KnK = lambda_K * irw;
     const T nD = T(1) + KnD, dD = T(1) + KnD * (T(1.71) + T(1.33) * KnD);
     const T nK = T(1) + KnK, dK = T(1) + KnK * (T(1.71) + T(1.33) * KnK);
-    const T na = rw3 - rd3, da = rw3 - rd3_1mk;
+    // rw^3 - rd^3 (1 - kappa) and rw^3 - rd^3 as ONE fused operation each, written out: left to `contract(fast)` the compiler fuses the
+    // product rw2 * rw into the subtractions only while nobody else uses it, so that a caller that also wants rw^3 (k_cond_lean's change of
+    // the third moment) would change the last bit of every evaluation
+    const T na = T(fma(rw2, rw, -rd3)), da = T(fma(rw2, rw, -rd3_1mk));
     T Sh, Nu, klv;
     if constexpr ((OPT & 2) != 0 && sizeof(T) == 8) {
       // ONE straight-line block for the common droplet (Re Sc < 2^-8: below ~8 um): the two cube-root series, the Knudsen terms and the
