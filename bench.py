@@ -296,7 +296,10 @@ def main():
     oi.cond_solver = 1 if args.cond_solver == "toms748" else 0
     oi.reorder_every = args.reorder_every
     for name in filter(None, args.dbg.split(",")):
-        oi.dbg_flags |= int(lgrngn.dbg[name.strip()])
+        if name.strip().startswith("budget="):
+            oi.dbg_cond_budget = int(name.split("=")[1])
+        else:
+            oi.dbg_flags |= int(lgrngn.dbg[name.strip()])
     if args.cond_mode != "percell":
         oi.exact_sstp_cond = True
         oi.sstp_cond_mix = args.cond_mode == "pp_mix"

@@ -1007,9 +1007,7 @@ struct Particles : IParticles {
     if (!npart) return;
     Range r(this, "reorder_storage");
     if (!B.n.p) alloc_attrs(B);
-    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p,
-                       (const uint8_t *)cond_hint.p, cond_hint_alt.p);
-    if (cond_hint.p) cond_hint.swap(cond_hint_alt);
+    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p);
     swap_attr_sets();
     ijk.swap(rank);
     hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
@@ -1079,7 +1077,7 @@ struct Particles : IParticles {
       cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
-                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
       // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 keeps round 2's kernels
       // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
@@ -1090,13 +1088,22 @@ struct Particles : IParticles {
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
           if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
-          if (!cond_hint.p) { cond_hint.alloc_zero(cap, st); cond_hint_alt.alloc_zero(cap, st); }
-          a.hint = cond_hint.p;
-          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
-          else if (cond_deal) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
-          else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), dim3(nblk(nphys)), bl, 0, st, nphys, a);
+          // two passes (see k_cond_lean): a first stretch of the root finder's loop for everybody, the droplets that have not converged by
+          // its end listed and finished by a dense second launch.  The list: 64 B per entry, an eighth of the storage (the settled
+          // box lists 9 % of its droplets; a part that is full leaves its droplets to finish in place)
+          const unsigned budget = dbg(LCX_DBG_COND_ONE_PASS) || (nphys < (size_t(1) << 16) && !dbg(LCX_DBG_COND_TWO_PASS)) ? 0u : o.dbg_cond_budget > 0 ? unsigned(o.dbg_cond_budget) : 1u;
+          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, 0, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a, lean_defer{nullptr, nullptr, 0u, 0u});
+          else if (!budget) hipLaunchKernelGGL((k_cond_lean<T, 7, 0>), dim3(nblk(nphys)), bl, 0, st, nphys, a, lean_defer{nullptr, nullptr, 0u, 0u});
+          else {
+            const uint32_t shard_cap = uint32_t(std::max<size_t>(nphys / 8 / DEFER_SHARDS, BS));
+            lean_list.alloc(size_t(shard_cap) * DEFER_SHARDS * sizeof(lean_entry<T>));
+            const lean_defer df{lean_list.p, defer_cnt.p, shard_cap, budget};
+            hipLaunchKernelGGL((k_cond_lean<T, 7, 1>), dim3(nblk(nphys)), bl, 0, st, nphys, a, df);
+            const unsigned per_shard = std::max(1u, std::min(nblk(nphys / 16 + 1), 256u * 32u) / DEFER_SHARDS);
+            hipLaunchKernelGGL((k_cond_lean<T, 7, 2>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, nphys, a, df);
+          }
         }
-        else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gr, bl, 0, st, npart, a);
+        else hipLaunchKernelGGL((k_cond_lean<T, 7, 0>), gr, bl, 0, st, npart, a, lean_defer{nullptr, nullptr, 0u, 0u});
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
@@ -1126,8 +1133,7 @@ struct Particles : IParticles {
       cond_in_storage_order = false;
     }
   }
-  const bool cond_deal = !dbg(LCX_DBG_COND_NO_DEAL);      // (measurement / test switch: one droplet per lane in storage order, no dealing)
-  DevBuf<uint8_t> cond_hint, cond_hint_alt;               // k_cond_lean's iteration counts of the last step, by storage slot
+  DevBuf<uint8_t> lean_list;                              // k_cond_lean's list of the droplets that its second pass finishes
   const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
@@ -1935,7 +1941,6 @@ struct Particles : IParticles {
       v.assign(1, tot);
     }
     else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
-    else if (s == "raw_cond_hint") { if (cond_hint.p) { auto h = d2h(cond_hint.p, nphys); v.assign(h.begin(), h.end()); } }   // k_cond_lean's iteration counts
     else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }

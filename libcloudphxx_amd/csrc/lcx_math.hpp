@@ -870,58 +870,86 @@ LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond
   return r;
 }
 // The same solver with its bookkeeping pared down (round 4): the SAME operations on the droplet's numbers in the same order -- the
-// answer is the one of advance_rw2_lean_with bit for bit, except that (i) an iterate that rounding puts ON an end of its bracket is
-// evaluated where it is instead of being moved to the midpoint (a far end that is a root to twelve digits: never seen), -- but the loop
-// body is straight-line code (selects instead of the three divergent branches that mixed waves always took both ways), the exact-zero
-// test is left to the arithmetic (f(c) = 0 gives c_new = c and ends the loop through the convergence test with the same answer), and
-// minima / maxima of positive numbers are single instructions.  `iters` returns the number of evaluations inside the loop (the hint
-// by which k_cond_lean deals a workgroup's droplets to its waves in the next step).
+// answer is the one of advance_rw2_lean_with bit for bit (tools/cond_solver_probe.hip: 4e6 random droplets on the device; tests/
+// test_hip_parity.py: the kernels) except that an iterate that rounding puts ON an end of its bracket is evaluated where it is instead of
+// being moved to the midpoint (a far end that is a root to twelve digits: never seen) -- but the loop body is straight-line code
+// (selects instead of the three divergent branches that mixed waves always took both ways), the exact-zero test is left to the
+// arithmetic (f(c) = 0 gives c_new = c and ends the loop through the convergence test with the same answer), and minima / maxima of
+// positive numbers are single instructions.  In three parts, so that a kernel can stop a droplet's loop after a few evaluations and
+// have another lane take it up where it stands (k_cond_lean):
+//   lean2_head   the reference's bracket and early outs (cond_common.ipp:197-305), the far end's evaluation, the first secant point
+//   lean2_loop   up to `budget` evaluations; false: the budget ran out, s.c is the next point to evaluate
+//   lean2_tail   the two clamps
+template <class T> struct lean_state { T x0, f0, x1, f1, c, a, b; };      // (x1, f1): the latest point, (x0, f0): the retained end (opposite sign)
 template <class T, class F>
-LCX_HD T advance_rw2_lean2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, unsigned &iters)
+LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, lean_state<T> &s, T &r, T &rd2)
 {
   constexpr int FD = fastdiv<F>::value;
-  iters = 0;
   const T drw2 = dt * f.drw2_dt(rw2_old);
-  if (drw2 == 0) return rw2_old;
+  r = rw2_old;
+  if (drw2 == 0) return true;
   T rd;
   if constexpr (FD != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);
-  const T rd2 = rd * rd;
+  rd2 = rd * rd;
   const T a_un = rw2_old + mn(T(0), cond_mlt * drw2);
   const T a = mx(rd2, a_un), b = rw2_old + mx(T(0), cond_mlt * drw2);
-  if (a == b) return rw2_old;
-  if (a == a_un && tol_reached(eps, a, b)) return (a + b) / 2;
+  if (a == b) return true;
+  if (a == a_un && tol_reached(eps, a, b)) { r = (a + b) / 2; return true; }
   const bool grows = drw2 > 0;
   const T f_far = f(grows ? b : a);
   const T fa = grows ? drw2 : f_far, fb = grows ? f_far : drw2;     // f(rw2_old) == drw2 (cond_common.ipp:296-305)
-  T r;
+  bool final = true;
   if (fa * fb > 0) r = rw2_old + drw2;
   else if (fa == 0) r = a;
   else if (fb == 0) r = b;
   else {
-    T x0 = a, f0 = fa, x1 = b, f1 = fb;                              // (x1, f1): the latest point, (x0, f0): the retained end (opposite sign)
-    T c = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
-    r = c;
-    for (unsigned it = 0; it < n_iter; ++it) {
-      const T fc = f(c);
-      ++iters;
-      const bool opp = (fc < 0) != (f1 < 0);                        // the root is between the last two points
-      T m = T(1) - dvd<FD>(fc, f1);                                 // same side twice: Anderson-Bjorck scaling of the retained end
-      m = m > 0 ? m : T(0.5);
-      const T f0s = f0 * m;
-      f0 = opp ? f1 : f0s;
-      x0 = opp ? x1 : x0;
-      x1 = c; f1 = fc;
-      const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
-      r = c_new;
-      const bool done = fabs(c_new - c) <= eps * T(__builtin_fmin(fabs(c_new), fabs(c))) ||
-                        fabs(x0 - x1) <= eps * T(__builtin_fmin(fabs(x0), fabs(x1)));
-      if (done) break;
-      c = c_new;
-    }
-    if (!(r > T(__builtin_fmin(a, b)) && r < T(__builtin_fmax(a, b)))) r = x1;       // (never leave the reference's bracket)
+    s.x0 = a; s.f0 = fa; s.x1 = b; s.f1 = fb; s.a = a; s.b = b;
+    s.c = s.x1 - s.f1 * dvd<FD>(T(s.x1 - s.x0), T(s.f1 - s.f0));
+    r = s.c;
+    final = false;
   }
+  if (final && r < rd2) r = rd2;
+  return final;
+}
+template <class T, class F>
+LCX_HD bool lean2_loop(const F &f, T eps, unsigned budget, lean_state<T> &s, T &r)
+{
+  constexpr int FD = fastdiv<F>::value;
+  T x0 = s.x0, f0 = s.f0, x1 = s.x1, f1 = s.f1, c = s.c;
+  bool done = false;
+  for (unsigned it = 0; it < budget; ++it) {
+    const T fc = f(c);
+    const bool opp = (fc < 0) != (f1 < 0);                          // the root is between the last two points
+    T m = T(1) - dvd<FD>(fc, f1);                                   // same side twice: Anderson-Bjorck scaling of the retained end
+    m = m > 0 ? m : T(0.5);
+    const T f0s = f0 * m;
+    f0 = opp ? f1 : f0s;
+    x0 = opp ? x1 : x0;
+    x1 = c; f1 = fc;
+    const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
+    r = c_new;
+    done = fabs(c_new - c) <= eps * T(__builtin_fmin(fabs(c_new), fabs(c))) || fabs(x0 - x1) <= eps * T(__builtin_fmin(fabs(x0), fabs(x1)));
+    c = c_new;
+    if (done) break;
+  }
+  s.x0 = x0; s.f0 = f0; s.x1 = x1; s.f1 = f1; s.c = c;
+  return done;
+}
+template <class T>
+LCX_HD T lean2_tail(const lean_state<T> &s, T r, T rd2)
+{
+  if (!(r > T(__builtin_fmin(s.a, s.b)) && r < T(__builtin_fmax(s.a, s.b)))) r = s.x1;       // (never leave the reference's bracket)
   if (r < rd2) r = rd2;
   return r;
+}
+template <class T, class F>
+LCX_HD T advance_rw2_lean2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+{
+  lean_state<T> s;
+  T r, rd2 = 0;
+  if (lean2_head(f, rw2_old, rd3, dt, eps, cond_mlt, s, r, rd2)) return r;
+  lean2_loop(f, eps, n_iter, s, r);       // (a budget that runs out leaves the last iterate in r, as the plain loop does)
+  return lean2_tail(s, r, rd2);
 }
 // per-cell part of with_cond_fun + cond_fun_fast::setup (same expressions, same order)
 template <class T>

@@ -861,17 +861,19 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
 
 
 @pytest.mark.parametrize("sd_conc,steps,reorder_every", [(64, 8, 3), (400, 3, 0)])
-def test_lean_kernel_dealt_lanes_and_round3_solver_form_give_the_same_bits(sd_conc, steps, reorder_every):
-    """Round 4's k_cond_lean (i) deals a workgroup's droplets to its waves by the iteration count each needed in the last step (a byte
-    per storage slot, carried through the storage re-ordering) and (ii) runs the solver with its bookkeeping pared down (straight-line
-    loop body, helper functions without the instructions that are identities for a squared radius).  A droplet's answer depends on
-    neither: the same rw2, th, rv and multiplicities bit for bit as without the dealing (opts_init.dbg_flags & COND_NO_DEAL) and as with
-    round 3's form of the solver (COND_LEAN_R3), over full steps with coalescence, dead slots and storage re-orderings"""
+def test_lean_kernel_two_passes_one_pass_and_round3_solver_form_give_the_same_bits(sd_conc, steps, reorder_every):
+    """Round 4's k_cond_lean (i) runs the solver with its bookkeeping pared down (straight-line loop body, helper functions without the
+    instructions that are identities for a squared radius) and (ii) stops every droplet's loop after one evaluation, lists the droplets
+    that have not converged with the loop's state and lets a dense second launch take them up where they stand (and a droplet whose part
+    of the list is full goes on in place).  A droplet's answer depends on neither: the same rw2, th, rv and multiplicities bit for
+    bit in two passes (the default from 2^16 super-droplets), in one (opts_init.dbg_flags & COND_ONE_PASS) and with round 3's form of the
+    solver (COND_LEAN_R3), over full steps with coalescence, dead slots and storage re-orderings -- the first steps with half of the
+    droplets on the list and its parts overflowing, the later ones with a few per cent"""
     oi = h.box_opts(12, 10, 14, sd_conc, sstp_cond=2, strict_fp=False)
     oi.reorder_every = reorder_every
     fields = h.box_fields(oi)
     res = []
-    for flags in (0, int(lgrngn.dbg.COND_NO_DEAL), int(lgrngn.dbg.COND_LEAN_R3)):
+    for flags in (int(lgrngn.dbg.COND_TWO_PASS), int(lgrngn.dbg.COND_ONE_PASS), int(lgrngn.dbg.COND_LEAN_R3)):
         oi.dbg_flags = flags
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields

@@ -21,7 +21,7 @@ __global__ void k(const In *in, size_t n, double *o3, double *o7, unsigned *its)
   unsigned it = 0;
   const double eps = eps_tolerance<double>(16);
   o3[i] = advance_rw2_lean_with(f3, q.rw2, q.rd3, 1.0, eps, 2.0, 100u);
-  o7[i] = advance_rw2_lean2_with(f7, q.rw2, q.rd3, 1.0, eps, 2.0, 100u, it);
+  o7[i] = advance_rw2_lean2_with(f7, q.rw2, q.rd3, 1.0, eps, 2.0, 100u);
   its[i] = it;
 }
 int main() {
