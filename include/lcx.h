@@ -147,9 +147,8 @@ enum lcx_dbg {
   LCX_DBG_TAG = 1 << 10,               /* every super-droplet carries a persistent tag (its index at init / set_particles) as one more
                                         * attribute that is compacted, re-ordered and migrates with it (lcx_get_state_real "raw_tag"), and
                                         * every coalescence call records what it consumed of the random generator (lcx_rng_dump) */
-  LCX_DBG_COND_ONE_PASS = 1 << 11,     /* k_cond_lean: one launch, every droplet finished by the lane that began it (no list of stragglers) */
+  LCX_DBG_KPA_ARRAY = 1 << 11,         /* k_cond_lean reads the hygroscopicity array even when the run has a single value (then passed as a scalar) */
   LCX_DBG_HOST_SYNC_LOOP = 1 << 12,    /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
-  LCX_DBG_COND_TWO_PASS = 1 << 14,     /* k_cond_lean: the two-pass form below the size from which it is the default (tests) */
   LCX_DBG_COND_LEAN_R3 = 1 << 13       /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
 };
 

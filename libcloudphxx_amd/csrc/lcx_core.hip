@@ -1088,22 +1088,13 @@ struct Particles : IParticles {
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
           if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
-          // two passes (see k_cond_lean): a first stretch of the root finder's loop for everybody, the droplets that have not converged by
-          // its end listed and finished by a dense second launch.  The list: 64 B per entry, an eighth of the storage (the settled
-          // box lists 9 % of its droplets; a part that is full leaves its droplets to finish in place)
-          const unsigned budget = dbg(LCX_DBG_COND_ONE_PASS) || (nphys < (size_t(1) << 16) && !dbg(LCX_DBG_COND_TWO_PASS)) ? 0u : o.dbg_cond_budget > 0 ? unsigned(o.dbg_cond_budget) : 1u;
-          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, 0, true>), dim3(nblk(nphys)), bl, 0, st, nphys, a, lean_defer{nullptr, nullptr, 0u, 0u});
-          else if (!budget) hipLaunchKernelGGL((k_cond_lean<T, 7, 0>), dim3(nblk(nphys)), bl, 0, st, nphys, a, lean_defer{nullptr, nullptr, 0u, 0u});
-          else {
-            const uint32_t shard_cap = uint32_t(std::max<size_t>(nphys / 8 / DEFER_SHARDS, BS));
-            lean_list.alloc(size_t(shard_cap) * DEFER_SHARDS * sizeof(lean_entry<T>));
-            const lean_defer df{lean_list.p, defer_cnt.p, shard_cap, budget};
-            hipLaunchKernelGGL((k_cond_lean<T, 7, 1>), dim3(nblk(nphys)), bl, 0, st, nphys, a, df);
-            const unsigned per_shard = std::max(1u, std::min(nblk(nphys / 16 + 1), 256u * 32u) / DEFER_SHARDS);
-            hipLaunchKernelGGL((k_cond_lean<T, 7, 2>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, nphys, a, df);
-          }
+          // (one hygroscopicity in the whole run: a scalar instead of 8 B per droplet, see kpa_uniform)
+          const dim3 gs(nblk(nphys));
+          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, true>), gs, bl, 0, st, nphys, a, T(0));
+          else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), gs, bl, 0, st, nphys, a, kpa_value);
+          else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gs, bl, 0, st, nphys, a, T(0));
         }
-        else hipLaunchKernelGGL((k_cond_lean<T, 7, 0>), gr, bl, 0, st, npart, a, lean_defer{nullptr, nullptr, 0u, 0u});
+        else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gr, bl, 0, st, npart, a, T(0));
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
@@ -1133,7 +1124,10 @@ struct Particles : IParticles {
       cond_in_storage_order = false;
     }
   }
-  DevBuf<uint8_t> lean_list;                              // k_cond_lean's list of the droplets that its second pass finishes
+  // every super-droplet of the run carries the same hygroscopicity: one dry distribution (or one (kappa, rd_insol) key of dry_sizes),
+  // nothing set by the caller (set_particles), so that coalescence never mixes two values -- the condensation kernel then takes it as
+  // a scalar.  (LCX_DBG_KPA_ARRAY: the array is read all the same.)
+  bool kpa_uniform = false; T kpa_value = T(0);
   const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the
@@ -1690,6 +1684,9 @@ struct Particles : IParticles {
     hskpng_Tpr();
     if (!o.no_ccn_at_init && !distros.empty()) init_SD_with_distros();
     if (!o.no_ccn_at_init && !sizes.empty()) init_SD_with_sizes();
+    // (a slab with neighbours takes in what they send: their caller may have set other values there)
+    kpa_uniform = !o.no_ccn_at_init && int(distros.size()) + n_size_keys == 1 && !distmem() && !dbg(LCX_DBG_KPA_ARRAY);
+    kpa_value = distros.size() == 1 ? T(distros[0].kappa) : !sizes.empty() ? T(sizes[0].kappa) : T(0);
     if (o.coal_switch) init_kernel();
     if (o.terminal_velocity == LCX_VT_BEARD77FAST) {
       vt_0.alloc(size_t(vtc.n_bin));
@@ -2003,6 +2000,7 @@ struct Particles : IParticles {
     check_npart(n);
     npart = nphys = n;
     zero_n_unmarked = true;
+    kpa_uniform = false;                 // (the caller's own values)
     auto up = [&](DevBuf<T> &b, const double *src) {
       if (!src || !b.p || !n) return;
       std::vector<T> h(n); for (size_t i = 0; i < n; ++i) h[i] = T(src[i]);

@@ -1006,112 +1006,54 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 // Fast arithmetic's production kernel since round 3: the growth rate of k_cond_fast under the lean bracketed secant of lcx_math.hpp
 // (advance_rw2_lean_with) instead of TOMS748 -- no iteration budget, no second launch, no fold: the iteration counts are short and even.
-// Round 4.  (i) The solver's bookkeeping pared down (lcx_math.hpp, lean2_*: the same operations on the droplet's numbers, straight-line
+// Round 4.  The solver's bookkeeping pared down (lcx_math.hpp, lean2_*: the same operations on the droplet's numbers, straight-line
 // loop body) and the growth rate's helper functions without the instructions that are identities here (OPT bit 2): 776 -> 671 vector
-// instructions per wave, the same rw2 bit for bit (R3 keeps round 3's form for the test that shows it).
-// (ii) Stragglers.  A wave is as slow as its slowest droplet.  In the settled box 17 % of the droplets take an early out, 74 % need ONE
-// evaluation inside the loop, 6 % two, 2 % three to six -- mean 0.94, but 2.5 for the slowest of 64 neighbours, and every loop
-// evaluation is 125 instructions for the whole wave.  PASS 1 gives every droplet the head (two evaluations) and `budget` loop
-// evaluations; a droplet that has not converged by then writes the loop's state (seven reals) to a list -- one atomic per wave, the list
-// in DEFER_SHARDS parts as in k_cond_fast -- and PASS 2, a dense launch over the list, takes each one up where it stands: the same
-// operations in the same order, the same bits.  A part of the list that is full (the spin-up steps, when half the droplets iterate
-// twice) leaves its droplets to finish in place.
-// Measured and dropped on the way: dealing a workgroup's droplets to its waves by the iteration count each needed in the previous step
-// (a byte per storage slot, one ballot, two barriers): the count does not repeat well enough -- 96 % of the droplets that needed at
-// most one evaluation need at most one again, but a wave of 64 then still holds two or three that do not, and the slowest of a wave came
-// down from 2.50 to 2.46 evaluations where a perfect sort of the workgroup gives 1.42 (tools/hint_stats.py in the history): +34
-// instructions per wave, the kernel 3.00 -> 3.34 ms.
-template <class T> struct alignas(16) lean_entry { T x0, f0, x1, f1, c, a, b; uint32_t pos, pad_; };
-struct lean_defer { void *list; uint32_t *count; uint32_t shard_cap; unsigned budget; };      // budget 0: one pass, no list
-// PASS: 0 the only pass (no list), 1 the first of two, 2 the second (over the list)
-template <class T, int OPT = 7, int PASS = 0, bool R3 = false>
-__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, lean_defer df = lean_defer{nullptr, nullptr, 0u, 0u})
+// instructions per wave in the spin-up steps that rounds 1-3 profiled (637 in the settled box), the same rw2 bit for bit (R3 keeps
+// round 3's form for the test that shows it); the launch 3.43 -> 3.0 ms.  At that point the kernel is no longer bound by its vector
+// ALU alone: 0.83 busy, and 10.4 GB of traffic (its own 56 B per droplet + the carried scatter's 20) in 2.9 ms is 3.6 of the 4.85 TB/s
+// that a copy reaches on the same box.  UNI: a run with ONE hygroscopicity (one dry distribution, no user-set particles) passes it as
+// a scalar -- 8 B per droplet that the kernel does not read.
+// Measured and dropped on the way (profiles/r04_*):
+//  * Dealing a workgroup's droplets to its waves by the iteration count each needed in the previous step (a byte per storage slot, one
+//    ballot, two barriers), so that the slow ones share a wave: the count does not repeat well enough -- 96 % of the droplets that needed at
+//    most one loop evaluation need at most one again, but a wave of 64 then still holds two or three that do not; the slowest of a wave
+//    came down from 2.50 to 2.46 evaluations where a perfect sort of the workgroup gives 1.42.  +34 instructions per wave, 3.00 -> 3.34 ms.
+//  * Two passes: every droplet's loop stopped after ONE evaluation, the 9 % that have not converged listed with the loop's state
+//    (seven reals, one atomic per wave) and taken up where they stand by a dense second launch -- the same bits; the first pass 637 -> 590
+//    instructions per wave and not a microsecond faster (2.98 against 3.00 ms: the memory side), the second pass 0.75 ms of gathers.
+template <class T, int OPT = 7, bool UNI = false, bool R3 = false>
+__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
   // attributes and the change (m3_after, storage-indexed; the per-cell finish gathers it through sorted_id) are read and written
   // coalesced.  A droplet's answer does not depend on who computes it, and the sums per cell keep their order.
-  if constexpr (PASS == 2) {
-    // the listed droplets: workgroup b walks part b % DEFER_SHARDS with the stride of the workgroups that share it (the host does not know the counts)
-    const unsigned shard = blockIdx.x % DEFER_SHARDS;
-    const uint32_t count = min(df.count[shard * DEFER_CNT_STRIDE], df.shard_cap);
-    const lean_entry<T> *part = reinterpret_cast<const lean_entry<T> *>(df.list) + size_t(shard) * df.shard_cap;
-    for (size_t q = size_t(blockIdx.x / DEFER_SHARDS) * BS + threadIdx.x; q < count; q += size_t(gridDim.x / DEFER_SHARDS) * BS) {
-      const lean_entry<T> e = part[q];
-      const uint32_t id = e.pos, c = a.storage_ijk[e.pos];
-      T rw2_old = a.rw2[id], rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
-      T nn = T(a.n[id]);
-      cond_cell_fast<T> cc = a.pre[c];
-      asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
-                   "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
-      cond_fun_fast<T, OPT> ff;
-      ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
-      lean_state<T> s{e.x0, e.f0, e.x1, e.f1, e.c, e.a, e.b};
-      T r = e.c;
-      lean2_loop(ff, a.eps, a.n_iter - df.budget, s, r);
-      const T rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30);            // (as in lean2_head)
-      r = lean2_tail(s, r, T(rd * rd));
-      a.rw2[id] = r;
-      a.m3_after[e.pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
-    }
-    return;
+  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
+  uint32_t id, c;
+  if (a.storage_ijk) {
+    id = uint32_t(pos); c = a.storage_ijk[pos];
+    if (c == DEAD_CELL) return;
+    if (a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; }
   }
-  const size_t pos = gid_xcd(a.xcd_group);
-  bool want_defer = false;
-  lean_state<T> s;
-  uint32_t id = 0, c = 0;
-  T rw2_old = 0, nn = 0, r = 0, rd2 = 0;
-  bool work = pos < n_part;
-  if (work) {
-    if (a.storage_ijk) {
-      id = uint32_t(pos); c = a.storage_ijk[pos];
-      work = c != DEAD_CELL;
-      if (work && a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; }
-    }
-    else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
+  else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
+  T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id];
+  T kpa = UNI ? kpa_uniform : a.kpa[id];
+  T nn = T(a.n[id]);
+  cond_cell_fast<T> cc = a.pre[c];
+  asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+  if (!UNI) asm volatile("" : "+v"(kpa));
+  T delta = 0;
+  if (rw2_old > 0) {
+    cond_fun_fast<T, OPT> ff;
+    ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+    T r;
+    if constexpr (R3) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    a.rw2[id] = r;
+    // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
+    delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
   }
-  if (PASS == 0 && !work) return;
-  if (work) {
-    T rd3 = a.rd3[id], kpa = a.kpa[id], vt = a.vt[id];
-    rw2_old = a.rw2[id];
-    nn = T(a.n[id]);
-    cond_cell_fast<T> cc = a.pre[c];
-    asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(kpa), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
-                 "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
-    T delta = 0;
-    if (rw2_old > 0) {
-      cond_fun_fast<T, OPT> ff;
-      ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
-      if constexpr (R3) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-      else if constexpr (PASS == 0) r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-      else if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2)) {
-        // a first stretch of the loop; whoever has not converged by its end asks for a place on the list (below, with the whole wave) and
-        // goes on in place if there is none
-        bool conv = lean2_loop(ff, a.eps, df.budget, s, r);
-        if (!conv) {
-          const unsigned long long bal = __ballot(true);                 // (the lanes of the wave that are here)
-          const int leader = __ffsll((long long)bal) - 1;
-          const unsigned shard = blockIdx.x % DEFER_SHARDS;
-          uint32_t base = 0;
-          if (int(lane_id()) == leader) base = atomicAdd(df.count + shard * DEFER_CNT_STRIDE, uint32_t(__popcll(bal)));
-          base = __shfl(base, leader);
-          const uint32_t slot = base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)));
-          if (slot < df.shard_cap) {
-            lean_entry<T> *part = reinterpret_cast<lean_entry<T> *>(df.list) + size_t(shard) * df.shard_cap;
-            part[slot] = lean_entry<T>{s.x0, s.f0, s.x1, s.f1, s.c, s.a, s.b, uint32_t(pos), 0u};
-            want_defer = true;
-          }
-          else lean2_loop(ff, a.eps, a.n_iter - df.budget, s, r);
-        }
-        if (!want_defer) r = lean2_tail(s, r, rd2);
-      }
-      if (!want_defer) {
-        a.rw2[id] = r;
-        // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
-        delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
-      }
-    }
-    if (!want_defer) a.m3_after[pos] = delta;
-  }
+  a.m3_after[pos] = delta;
 }
 
 // Growth-rate evaluations per droplet (an offline count over 2.1e6 droplets of the oracle's state on the bench's fields): 3 for 72 % of the

@@ -100,10 +100,9 @@ class dbg(enum.IntFlag):
     MULTI_NO_PEER = 1 << 8
     MULTI_SERIALIZE = 1 << 9
     TAG = 1 << 10
-    COND_ONE_PASS = 1 << 11
+    KPA_ARRAY = 1 << 11
     HOST_SYNC_LOOP = 1 << 12
     COND_LEAN_R3 = 1 << 13
-    COND_TWO_PASS = 1 << 14
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -861,27 +861,21 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
 
 
 @pytest.mark.parametrize("sd_conc,steps,reorder_every", [(64, 8, 3), (400, 3, 0)])
-def test_lean_kernel_two_passes_one_pass_and_round3_solver_form_give_the_same_bits(sd_conc, steps, reorder_every):
-    """Round 4's k_cond_lean (i) runs the solver with its bookkeeping pared down (straight-line loop body, helper functions without the
-    instructions that are identities for a squared radius) and (ii) stops every droplet's loop after one evaluation, lists the droplets
-    that have not converged with the loop's state and lets a dense second launch take them up where they stand (and a droplet whose part
-    of the list is full goes on in place).  A droplet's answer depends on neither: the same rw2, th, rv and multiplicities bit for
-    bit in two passes (the default from 2^16 super-droplets), in one (opts_init.dbg_flags & COND_ONE_PASS) and with round 3's form of the
-    solver (COND_LEAN_R3), over full steps with coalescence, dead slots and storage re-orderings -- the first steps with half of the
-    droplets on the list and its parts overflowing, the later ones with a few per cent"""
+def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, steps, reorder_every):
+    """Round 4's k_cond_lean runs the solver with its bookkeeping pared down (straight-line loop body, helper functions without the
+    instructions that are identities for a squared radius) and takes the run's single hygroscopicity as a scalar instead of reading
+    8 bytes per droplet.  A droplet's answer depends on neither: the same rw2, th, rv and multiplicities bit for bit with the array
+    read (opts_init.dbg_flags & KPA_ARRAY) and with round 3's form of the solver (COND_LEAN_R3), over full steps with coalescence, dead
+    slots and storage re-orderings"""
     oi = h.box_opts(12, 10, 14, sd_conc, sstp_cond=2, strict_fp=False)
     oi.reorder_every = reorder_every
     fields = h.box_fields(oi)
     res = []
-    for flags in (int(lgrngn.dbg.COND_TWO_PASS), int(lgrngn.dbg.COND_ONE_PASS), int(lgrngn.dbg.COND_LEAN_R3)):
+    for flags in (0, int(lgrngn.dbg.KPA_ARRAY), int(lgrngn.dbg.COND_LEAN_R3)):
         oi.dbg_flags = flags
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
-        hip.init(th, rv, rhod, **C)
-        rw2 = hip.get_attr("rw2")
-        rw2[::7] = (60e-6) ** 2
-        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), np.full(rw2.size, -1.),
-                          hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+        hip.init(th, rv, rhod, **C)            # (no set_particles: the run keeps its single hygroscopicity, the scalar form is the default)
         opts = lgrngn.opts_t()
         thh, rvh = th.copy(), rv.copy()
         for _ in range(steps):

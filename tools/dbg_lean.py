@@ -8,7 +8,7 @@ oi = h.box_opts(12, 10, 14, 64, sstp_cond=2, strict_fp=False)
 fields = h.box_fields(oi)
 th, rv, rhod, C = fields
 res = []
-for flags in (int(lgrngn.dbg.COND_TWO_PASS), int(lgrngn.dbg.COND_LEAN_R3)):
+for flags in (0, int(lgrngn.dbg.COND_LEAN_R3)):
     oi.dbg_flags = flags
     hip = h.hip_particles(oi)
     hip.init(th, rv, rhod, **C)
