@@ -149,6 +149,8 @@ enum lcx_dbg {
                                         * every coalescence call records what it consumed of the random generator (lcx_rng_dump) */
   LCX_DBG_KPA_ARRAY = 1 << 11,         /* k_cond_lean reads the hygroscopicity array even when the run has a single value (then passed as a scalar) */
   LCX_DBG_HOST_SYNC_LOOP = 1 << 12,    /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
+  LCX_DBG_EXCH_SORT_NOW = 1 << 14,     /* a slab with neighbours re-sorts inside its exchange (interior while the messages travel, boundary behind
+                                        * them) even when the next condensation kernel could carry the scatter */
   LCX_DBG_COND_LEAN_R3 = 1 << 13       /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
 };
 

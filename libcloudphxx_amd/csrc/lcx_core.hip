@@ -993,8 +993,9 @@ struct Particles : IParticles {
     // as it finds it, so the cells must not be left in the shuffled order there -- the in-cell ranking by id stays, coalescence
     // shuffles for itself)
     const bool preshuffle = !strict_order && !o.strict_fp && last_async_coal && o.coal_switch && !reorder_due && npart >= 2;
-    // (the scatter rides on the next condensation kernel when that will be the storage-order one: a single device, no re-ordering due)
-    const bool defer = defer_sort_ok && lean_storage_cond() && !distmem() && !reorder_due && meta_p != nullptr && replay.empty();
+    // (the scatter rides on the next condensation kernel when that will be the storage-order one and no re-ordering is due -- round 4: a
+    // slab with neighbours as well, once its immigrants are in the histogram; its exchange then skips the overlapped interior re-sort)
+    const bool defer = defer_sort_ok && lean_storage_cond() && !reorder_due && meta_p != nullptr && replay.empty();
     sort_from_hist(preshuffle, meta_p, defer);
     shuffle_fresh = preshuffle && !sort_deferred;
     // dropping the dead SDs costs one pass over all attributes either way: gather it in sorted order (opts_init.reorder_every)
@@ -2151,8 +2152,17 @@ struct Particles : IParticles {
   const bool no_overlap = dbg(LCX_DBG_NO_OVERLAP);      // measurement / test switch: the exchange without the overlapped re-sort
   // the overlapped re-sort needs the fused move's histogram, an interior, and the production rules for the storage order are not in
   // its way: a slab so thin that every plane is a boundary plane, rcyc and the unfused paths take the plain sequence
+  // Round 4: when the step's re-sort can be left to the next condensation kernel (post_copy_after_fused_move: the storage-order kernel
+  // carries the scatter, the in-cell ranking follows it) there is nothing to overlap -- the slab only scans its completed histogram behind
+  // the unpack.  The overlapped form stays for the steps that re-order the storage, for strict arithmetic and for the other solvers.
+  bool sort_will_be_deferred() const
+  {
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    const bool reorder_sched = !strict_order() && steps_since_reorder + 1 >= every_;
+    return defer_sort_ok && lean_storage_cond() && !reorder_sched && replay.empty() && !dbg(LCX_DBG_EXCH_SORT_NOW);
+  }
   bool overlap_possible() const
-  { return dev_exchange && !no_overlap && fused_pending && n_dims > 0 && o.nx > 2 * bnd_planes() && sort_headroom > 0 && nphys > 0; }
+  { return dev_exchange && !no_overlap && fused_pending && n_dims > 0 && o.nx > 2 * bnd_planes() && sort_headroom > 0 && nphys > 0 && !sort_will_be_deferred(); }
   // ---- phase A of the overlapped re-sort: everything that does not depend on the neighbours, queued behind the pack kernel while
   // their messages travel: the stayers' scan, scatter and in-cell ranking of the interior cells [c_lo, c_hi).
   bool overlap_active = false, overlap_preshuffle = false; rng_src overlap_rs{nullptr, 0, 0, 0u, 0u}; uint32_t ov_c_lo = 0, ov_c_hi = 0;

@@ -103,6 +103,7 @@ class dbg(enum.IntFlag):
     KPA_ARRAY = 1 << 11
     HOST_SYNC_LOOP = 1 << 12
     COND_LEAN_R3 = 1 << 13
+    EXCH_SORT_NOW = 1 << 14
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8
