@@ -547,16 +547,18 @@ def main():
                             roof["traffic_low"] = t["hbm_bytes_low"]
                         if "valu_insts" in t:
                             # the second roof: fp64 vector arithmetic.  78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 x 2.4 GHz.
-                            # A wave64 fp64 instruction occupies its SIMD for 4 cycles, any other VALU instruction for 2
-                            # (MI355X_MICROARCH.md); lane_util = share of the 64 lanes that were active per VALU instruction
+                            # lane_util = share of the 64 lanes that were active per VALU instruction
                             f64 = t.get("valu_f64_insts", 0)
-                            cyc = 4 * f64 + 2 * (t["valu_insts"] - f64)
                             flop = (2 * t.get("valu_fma_f64", 0) + t.get("valu_mul_f64", 0) + t.get("valu_add_f64", 0) + t.get("valu_trans_f64", 0)) * 64
                             lane = t["thread_cycles_valu"] / (t["valu_insts"] * 64) if t.get("thread_cycles_valu") else None
                             roof["fp64_valu"] = {"achieved_tflops": flop / (avg_ms * 1e-3) / 1e12, "peak_tflops": 78.6,
                                                  "frac": flop / (avg_ms * 1e-3) / 1e12 / 78.6,
                                                  "useful_tflops": (flop * lane / (avg_ms * 1e-3) / 1e12) if lane else None,
-                                                 "issue_frac": cyc / (1024 * 2.4e9 * avg_ms * 1e-3), "lane_util": lane,
+                                                 # share of the cycles in which the vector ALUs executed, from the counters of the same PMC
+                                                 # passes: SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)
+                                                 "issue_frac": (t["active_inst_valu"] * 4 / (1024 * t["grbm_gui_active"] / 8)
+                                                                if t.get("active_inst_valu") and t.get("grbm_gui_active") else None),
+                                                 "lane_util": lane,
                                                  "wave_insts_per_launch": t["valu_insts"], "f64_insts_per_launch": f64, "source": src}
         # attainable HBM bandwidth on this device (device-to-device copy of 1 GiB, read + write), SURVEY 8(d)
         a_ = torch.empty(1 << 30, dtype=torch.uint8, device=dev); b_ = torch.empty_like(a_)

@@ -22,7 +22,7 @@ with tempfile.TemporaryDirectory() as d:
 names = sorted(set(m.group(1) for m in re.finditer(r"^(_Z\S+):\s", s, re.M)))
 demangled = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
 pick = [(n, dm) for n, dm in zip(names, demangled) if pat in dm and "double" in dm]
-pick.sort(key=lambda nd: 0 if "k_cond_fast_fold<double, 3>" in nd[1] else 1 if "<double, 3, false>" in nd[1] else 2)   # the production first pass first
+pick.sort(key=lambda nd: 0 if "k_cond_fast_fold<double, 3>" in nd[1] else 1 if "<double, 3, false>" in nd[1] else 1 if "k_cond_lean<double, 7, true, false>" in nd[1] else 2)   # the production kernel first
 if not pick:
     sys.exit("no kernel matches " + pat)
 name, dm = pick[0]
@@ -96,6 +96,10 @@ if tj:
         print("   lane utilisation (SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64)): %.3f" % lane)
         print("   wave-cycles: active %.3g, waiting on instruction issue %.3g, waiting on memory / barriers %.3g  (of %.3g)" % (
             v.get("active_inst_any", 0), v.get("wait_inst_any", 0), v.get("wait_any", 0), v.get("wave_cycles", 0)))
-        print("   issue cycles at 4 per fp64 and 2 per other VALU instruction: %.4g = %.2f ms on 1024 SIMDs at 2.4 GHz" % (
-            4 * f64 + 2 * (v["valu_insts"] - f64), (4 * f64 + 2 * (v["valu_insts"] - f64)) / 1024 / 2.4e9 * 1e3))
+        # (the counter, not a guess at cycles per instruction -- SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's
+        # vector ALU is executing; every wave64 instruction takes four cycles, the fp64 transcendentals sixteen)
+        if v.get("active_inst_valu") and v.get("grbm_gui_active"):
+            print("   vector ALU busy: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = %.3f  (%.2f cycles per instruction; %.2f ms of issue at 2.4 GHz)" % (
+                v["active_inst_valu"] * 4 / (1024 * v["grbm_gui_active"] / 8), v["active_inst_valu"] * 4 / v["valu_insts"],
+                v["active_inst_valu"] * 4 / 1024 / 2.4e9 * 1e3))
         print("   HBM per launch: %.2f GB read (FETCH_SIZE x 2) + %.2f GB written" % (v["read_bytes"] / 1e9, v["write_bytes"] / 1e9))
