@@ -1524,17 +1524,27 @@ struct Particles : IParticles {
       const unsigned nb = nblk(n_new);
       {
         const u01_src<T> rs = rand_u01(n_new);
-        hipLaunchKernelGGL(k_init_dry<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, per_cell, T(log_rd_min), T(log_rd_max), rs, ijk.p, A.rd3.p, A.kpa.p, T(d.kappa), A.vt.p);
+        if (d.fn) fvals.alloc(n_new);
+        hipLaunchKernelGGL(k_init_dry<T>, dim3(nb), dim3(BS), 0, st, n_new, n_old, per_cell, T(log_rd_min), T(log_rd_max), rs, ijk.p, A.rd3.p, A.kpa.p, T(d.kappa), A.vt.p,
+                           d.fn ? fvals.p : (T *)nullptr);
       }
       lognormal_modes lm{d.n_modes, {0}, {0}, {0}};
       for (int m = 0; m < 4; ++m) { lm.mean_rd[m] = d.mean_rd[m]; lm.sdev[m] = d.sdev[m]; lm.n_stp[m] = d.n_stp[m]; }
       const T *fv = nullptr;
       if (d.fn) {                                                                        // host evaluation of the user functor (init_n.ipp:56-84)
-        std::vector<T> h(n_new);
-        HIPCHK(hipMemcpyAsync(h.data(), A.rd3.p + n_old, n_new * sizeof(T), hipMemcpyDeviceToHost, st));
+        // The host evaluates n(ln rd) -- and, since round 4, the dry volume rd3 = exp(3 ln rd) that the reference takes ln rd back from
+        // (init_dry_sd_conc.ipp:26-34, init_n.ipp:62-66): with the host's exp and log on both sides of that round trip the argument of
+        // the user's function, hence the integer multiplicity, is the reference's bit for bit (the device's exp differs from the
+        // host's in the last place now and then, which used to move n by one for < 0.1 % of the super-droplets)
+        std::vector<T> h(n_new), r3(n_new);
+        HIPCHK(hipMemcpyAsync(h.data(), fvals.p, n_new * sizeof(T), hipMemcpyDeviceToHost, st));      // (the drawn ln rd)
         sync();
-        for (size_t i = 0; i < n_new; ++i) { const T lnrd = T(std::log(h[i]) / 3.); h[i] = T(d.fn(lnrd, d.user)); }
-        fvals.alloc(n_new);
+        for (size_t i = 0; i < n_new; ++i) {
+          r3[i] = T(std::exp(3 * h[i]));
+          const T lnrd = T(std::log(r3[i]) / 3.);
+          h[i] = T(d.fn(lnrd, d.user));
+        }
+        HIPCHK(hipMemcpyAsync(A.rd3.p + n_old, r3.data(), n_new * sizeof(T), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(fvals.p, h.data(), n_new * sizeof(T), hipMemcpyHostToDevice, st));
         sync();
         fv = fvals.p;

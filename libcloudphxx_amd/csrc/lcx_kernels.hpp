@@ -2177,7 +2177,7 @@ __global__ void k_cell_max(size_t n_cell, const uint32_t *cell_start, const uint
 // ============================================================================================
 template <class T>
 __global__ void k_init_dry(size_t n_new, size_t n_old, n_t per_cell, T log_rd_min, T log_rd_max, u01_src<T> rs,
-                           uint32_t *ijk, T *rd3, T *kpa, T kappa, T *vt)
+                           uint32_t *ijk, T *rd3, T *kpa, T kappa, T *vt, T *lnrd_out = nullptr /* the drawn ln(rd) itself, for the host (see init_SD_with_distros) */)
 {
   const size_t gI = gid(); if (gI >= n_new) return;
   const size_t c = gI / per_cell;                                            // init_ijk.ipp:36-52 (cell-major)
@@ -2186,6 +2186,7 @@ __global__ void k_init_dry(size_t n_new, size_t n_old, n_t per_cell, T log_rd_mi
   const T lnrd = log_rd_min + T(T(gI - ptr) + u) * (log_rd_max - log_rd_min) / T(per_cell);   // init_dry_sd_conc.ipp:26-34
   ijk[n_old + gI] = uint32_t(c);
   rd3[n_old + gI] = exp(3 * lnrd);
+  if (lnrd_out) lnrd_out[gI] = lnrd;
   kpa[n_old + gI] = kappa;
   vt[n_old + gI] = T(-1);                                                    // resize fills vt with `invalid`
 }
