@@ -1121,7 +1121,8 @@ struct Particles : IParticles {
     if (carry_scatter) finish_deferred_sort(true);           // the in-cell ranking, behind the kernel that scattered
     {
       Range r(this, "cond_cellfinish");
-      launch_cellfinish(step, sstp_cond, fast, cond_in_storage_order ? sid() : (const uint32_t *)nullptr);
+      // (a kernel that carried the scatter has left each droplet's change at the droplet's place in the sorted order: no gather)
+      launch_cellfinish(step, sstp_cond, fast, cond_in_storage_order && !carry_scatter ? sid() : (const uint32_t *)nullptr);
       cond_in_storage_order = false;
     }
   }

@@ -1029,10 +1029,12 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
   // coalesced.  A droplet's answer does not depend on who computes it, and the sums per cell keep their order.
   const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
   uint32_t id, c;
+  size_t m3_pos = pos;
   if (a.storage_ijk) {
     id = uint32_t(pos); c = a.storage_ijk[pos];
     if (c == DEAD_CELL) return;
-    if (a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; }
+    // (the droplet's change goes where the droplet goes in the sorted order: the per-cell finish then reads one stretch, see there)
+    if (a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; m3_pos = q; }
   }
   else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
   T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id];
@@ -1053,7 +1055,7 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
     delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
   }
-  a.m3_after[pos] = delta;
+  a.m3_after[m3_pos] = delta;
 }
 
 // Growth-rate evaluations per droplet (an offline count over 2.1e6 droplets of the oracle's state on the bench's fields): 3 for 72 % of the
@@ -1156,6 +1158,37 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // more than the emptier waves did.
 // G lanes per cell: 1 = the ordered walk (strict arithmetic: the reference's summation order); 8 = fast arithmetic, every lane
 // sums each 8th value of the staged segment and a fixed 3-step shuffle tree joins them (deterministic, different rounding)
+//
+// Round 4: the fast arithmetic's sums of the droplets' CHANGES (delta mode) are taken in FIXED POINT.  The cell's addends are scaled by
+// an exact power of two chosen from the largest of them and their number (2^k with count x max|x| < 2^61 / 2^k: both independent of the
+// addends' order), rounded to integers once -- to 2^-50 of the largest addend or better -- and summed in 64-bit integer arithmetic:
+// integer addition is associative, so the sum does not depend on the ORDER of the addends.  That is what lets the storage-order condensation kernel leave a droplet's
+// change at the position where the re-sort's scatter puts the droplet (its ARRIVAL rank inside the cell -- the order in which the
+// move's histogram atomics happened to be served, different from run to run) and the finish read one contiguous stretch instead of
+// gathering 8 bytes per droplet through sorted_id: the same bits whichever way the addends come (the gathered form, the positional
+// form, the crowded cells' wave form), run after run.
+__device__ __forceinline__ int fx_shift(double amax, uint32_t cnt)
+{ int e; (void)frexp(amax, &e); return 61 - e - (32 - __clz(int(cnt | 1u))); }      // (amax < 2^e, cnt < 2^(32 - clz): cnt x amax x 2^k < 2^61)
+__device__ __forceinline__ long long to_fx(double x, int k) { return __double2ll_rn(ldexp(x, k)); }
+// one lane's share (every G-th value of the cell's segment): the largest magnitude, then the fixed-point sum
+template <class T, int G>
+__device__ __forceinline__ double seg_amax(const T *lds, const T *glob, const uint32_t *gather, bool staged, uint32_t base, uint32_t s, uint32_t e)
+{
+  double m = 0;
+  if (staged) for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(lds[q - base])));
+  else if (gather) for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(glob[gather[q]])));
+  else for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(glob[q])));
+  return m;
+}
+template <class T, int G>
+__device__ __forceinline__ long long seg_sum_fx(const T *lds, const T *glob, const uint32_t *gather, bool staged, uint32_t base, uint32_t s, uint32_t e, int k)
+{
+  long long acc = 0;
+  if (staged) for (uint32_t q = s; q < e; q += G) acc += to_fx(double(lds[q - base]), k);
+  else if (gather) for (uint32_t q = s; q < e; q += G) acc += to_fx(double(glob[gather[q]]), k);
+  else for (uint32_t q = s; q < e; q += G) acc += to_fx(double(glob[q]), k);
+  return acc;
+}
 template <class T, int G>
 __global__ void __launch_bounds__(BS)
 k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m3_before, const T *m3_after,
@@ -1177,6 +1210,8 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
   const uint32_t s = mine ? cs[cl] : 0u, e = mine ? cs[cl + 1] : 0u;
   const bool has = e > s;
   T after = 0, before = 0;
+  long long after_fx = 0;
+  int fxk = 0;
   // the workgroup's cells are taken in runs that fit the LDS stage (normally one run; crowded neighbourhoods split instead of
   // falling back to uncoalesced global reads); a single cell above CF_CAP is summed from global memory
   for (int cb = 0; cb < nc;) {
@@ -1198,7 +1233,14 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     }
     else if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_after[q];
     __syncthreads();
-    if (in_run) after = (gather && !staged) ? seg_sum_gather<T, G>(m3_after, gather, s + sub, e) : seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
+    if (delta) {
+      // (every lane of the workgroup takes part in the shuffles; lanes outside the run carry zeros)
+      double amax = in_run ? seg_amax<T, G>(lds, m3_after, gather, staged, base, s + sub, e) : 0.;
+#pragma unroll
+      for (int d = G / 2; d > 0; d >>= 1) amax = fmax(amax, __shfl_xor(amax, d));
+      if (in_run) { fxk = fx_shift(amax, e - s); after_fx = amax > 0 ? seg_sum_fx<T, G>(lds, m3_after, gather, staged, base, s + sub, e, fxk) : 0ll; }
+    }
+    else if (in_run) after = (gather && !staged) ? seg_sum_gather<T, G>(m3_after, gather, s + sub, e) : seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
     if (step == 0 && !delta) {
       __syncthreads();
       if (staged) for (uint32_t q = base + threadIdx.x; q < end; q += BS) lds[q - base] = m3_before[q];
@@ -1210,9 +1252,10 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
   }
   if (G > 1) {
 #pragma unroll
-    for (int d = G / 2; d > 0; d >>= 1) { after = after + __shfl_xor(after, d); before = before + __shfl_xor(before, d); }
+    for (int d = G / 2; d > 0; d >>= 1) { after = after + __shfl_xor(after, d); before = before + __shfl_xor(before, d); after_fx += __shfl_xor(after_fx, d); }
   }
   if (!mine || sub != 0) return;
+  if (delta) after = T(ldexp(double(after_fx), -fxk));
   cellfinish_apply(c, has, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);
 }
 // Fast arithmetic, crowded cells (hundreds of SDs per cell): ONE WAVE per cell sums the segment with coalesced loads and a
@@ -1230,9 +1273,22 @@ k_cond_cellfinish_wave(size_t n_cell, const uint32_t *cell_start, const T *m3_be
   if (delta) { step = 0; sstp = 1; }
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T after = 0, before = 0;
-  for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[gather ? gather[q] : q]; if (step == 0 && !delta) before = before + m3_before[q]; }
+  if (delta) {                          // (fixed point: see k_cond_cellfinish)
+    double amax = 0;
+    for (uint32_t q = s + lane_id(); q < e; q += WAVE) amax = fmax(amax, fabs(double(m3_after[gather ? gather[q] : q])));
 #pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) { after = after + __shfl_down(after, d); before = before + __shfl_down(before, d); }
+    for (int d = WAVE / 2; d > 0; d >>= 1) amax = fmax(amax, __shfl_xor(amax, d));
+    const int fxk = fx_shift(amax, e - s);
+    long long acc = 0;
+    if (amax > 0) for (uint32_t q = s + lane_id(); q < e; q += WAVE) acc += to_fx(double(m3_after[gather ? gather[q] : q]), fxk);
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    after = T(ldexp(double(acc), -fxk));
+  } else {
+    for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[gather ? gather[q] : q]; if (step == 0) before = before + m3_before[q]; }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) { after = after + __shfl_down(after, d); before = before + __shfl_down(before, d); }
+  }
   if (lane_id() == 0) cellfinish_apply(c, e > s, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);
 }
 
