@@ -399,9 +399,10 @@ def main():
         return prt, keep, arrays, devices, time.perf_counter() - t0
 
     state, fallback_reason = None, None
-    if native_multi and not idle and len(set(slab_dev)) > 1:
-        # several real devices in one process, never run on this hardware before this bench: a cross-device wait that never returns
-        # must not hold the launcher for its whole time-out -- give up loudly after 30 minutes (a default run takes about one)
+    if (native_multi and not idle and len(set(slab_dev)) > 1) or world > 1:
+        # several real devices (in one process, or one rank each), never run on this hardware before this bench: a cross-device wait
+        # or a point-to-point operation that never returns must not hold the launcher for its whole time-out -- give up loudly after
+        # 30 minutes (a default run takes about one)
         import threading
 
         def _give_up():
