@@ -2801,7 +2801,7 @@ __global__ void k_math_probe(int which, double *v, size_t n)
   if (i >= n) return;
   const double x = v[i];
   v[i] = which == 0 ? cbrt_seeded(x) : which == 1 ? exp_reduced(x) : which == 2 ? cbrt(x) : which == 4 ? rcp_refined(x) : which == 5 ? log_lean(x) :
-         which == 6 ? rcp_newton1(x) : which == 7 ? cbrt1p<true>(x) : which == 8 ? exp_kelvin(x) : exp(x);
+         which == 6 ? rcp_newton1(x) : which == 7 ? cbrt1p<true>(x) : which == 8 ? exp_kelvin(x) : which == 9 ? exp_lib(x) : exp(x);
 }
 
 } // namespace lcx

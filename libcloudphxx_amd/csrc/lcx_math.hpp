@@ -394,6 +394,54 @@ template <class T> LCX_HD T S_cr(T rd3, T kappa, T Tk)
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet
 // (the reference recomputes it in every drw2_dt call); each hoisted quantity is the same
 // expression, so the values entering the formulas are bit-identical.
+// The device library's exp(double), operation for operation (range reduction by ln 2 in two parts, the degree-11 Horner scheme, its two
+// closing steps, ldexp, the overflow / underflow selects -- read off the library's code for gfx950), with its coefficients in CONSTANT
+// memory: a literal 64-bit coefficient costs two v_mov_b32 per use (an fp64 instruction takes no 64-bit literal), 29 moves in front of
+// every inlined copy of the strict growth rate and two dozen vector registers held through it; through the scalar cache they arrive as
+// SGPR operands.  The same bits as exp() for every argument (tests/test_hip_parity.py::test_fast_math_accuracy, math probe 9 against 3).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__ unsigned long long lcx_explib_c[13] = {
+  0x3ff71547652b82feull, 0xbfe62e42fefa39efull, 0xbc7abc9e3b39803full, 0x3e5ade156a5dcb37ull, 0x3e928af3fca7ab0cull, 0x3ec71dee623fde64ull,
+  0x3efa01997c89e6b0ull, 0x3f2a01a014761f6eull, 0x3f56c16c1852b7b0ull, 0x3f81111111122322ull, 0x3fa55555555502a1ull, 0x3fc5555555555511ull,
+  0x3fe000000000000bull};
+#endif
+LCX_HD double exp_lib(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double *c = reinterpret_cast<const double *>(lcx_explib_c);
+  const double dn = __builtin_rint(x * c[0]);
+  double f = __builtin_fma(c[1], dn, x);
+  f = __builtin_fma(c[2], dn, f);
+  double p = __builtin_fma(c[3], f, c[4]);
+  p = __builtin_fma(f, p, c[5]);
+  p = __builtin_fma(f, p, c[6]);
+  p = __builtin_fma(f, p, c[7]);
+  p = __builtin_fma(f, p, c[8]);
+  p = __builtin_fma(f, p, c[9]);
+  p = __builtin_fma(f, p, c[10]);
+  p = __builtin_fma(f, p, c[11]);
+  p = __builtin_fma(f, p, c[12]);
+  p = __builtin_fma(f, p, 1.0);
+  p = __builtin_fma(f, p, 1.0);
+  double z = __builtin_ldexp(p, int(dn));
+  if (x > 1024.0) z = __builtin_inf();
+  if (x < -1075.0) z = 0.0;
+  return z;
+#else
+  return exp(x);
+#endif
+}
+LCX_HD float exp_lib(float x) { return exp(x); }
+// The library's pow as a REAL call (strict arithmetic only): Re^0.077 sits in a branch that only drops above ~50 um take, and the
+// library routine is ~220 instructions and two dozen 64-bit literals in each of the twenty places where the strict growth rate is
+// inlined -- half of the kernel's code.  Out of line it is there once; the same routine, the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) inline double pow_outlined(double x, double y) { return pow(x, y); }
+__device__ __attribute__((noinline)) inline float pow_outlined(float x, float y) { return pow(x, y); }
+#else
+inline double pow_outlined(double x, double y) { return pow(x, y); }
+inline float pow_outlined(float x, float y) { return pow(x, y); }
+#endif
 template <class T> struct cond_fun {
   T rw2_old, dt, rd3, kpa;
   T vt, rhod, eta;
@@ -405,7 +453,7 @@ template <class T> struct cond_fun {
   LCX_HD T Nu(T X, T Re) const
   {                                                                // ventil.hpp:30-44
     // max(1, pow(Re, .077)) == 1 for Re <= 1 (pow is monotone, pow(1,.)=1; NaN for Re<0 loses in std::max)
-    const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+    const T m = (Re > T(1)) ? mx(T(1), T(pow_outlined(Re, T(.077)))) : T(1);
     return T(1) + T(cbrt(T(1) + Re * X)) * m;
   }
   LCX_HD T drw2_dt(T rw2) const
@@ -420,7 +468,7 @@ template <class T> struct cond_fun {
     const T D = c::D_0 * beta(dv_(lambda_D, rw)) * (Nu(Sc, Re) / 2);
     const T K = c::K_0 * beta(dv_(lambda_K, rw)) * (Nu(Pr, Re) / 2);
     const T aw = dv_(rw3 - rd3, rw3 - rd3 * (T(1) - kpa));                                             // a_w
-    const T klv = exp(dv_(A, rw));
+    const T klv = exp_lib(dv_(A, rw));
     return T(2) * dv_(dv_(T(1) - dv_(aw * klv, RH_eff), c::rho_w),
                       dv_(dv_(T(1), D), rho_v) + dv_(dv_(dv_(lv, K), RH_eff), Tk) * lv_term);
   }
