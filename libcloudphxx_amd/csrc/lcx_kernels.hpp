@@ -1045,7 +1045,7 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
                "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
   if (!UNI) asm volatile("" : "+v"(kpa));
   T delta = 0;
-  if (rw2_old > 0) {
+  if (!(rw2_old <= 0)) {                // (cond_common.ipp:197-199; a NaN goes through the solver and poisons its cell as in the reference)
     cond_fun_fast<T, OPT> ff;
     ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
     T r;
@@ -1170,14 +1170,16 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 __device__ __forceinline__ int fx_shift(double amax, uint32_t cnt)
 { int e; (void)frexp(amax, &e); return 61 - e - (32 - __clz(int(cnt | 1u))); }      // (amax < 2^e, cnt < 2^(32 - clz): cnt x amax x 2^k < 2^61)
 __device__ __forceinline__ long long to_fx(double x, int k) { return __double2ll_rn(ldexp(x, k)); }
+// the larger magnitude; a NaN (or an infinity) among the addends stays and makes the cell's sum NaN as the floating-point sum would be
+__device__ __forceinline__ double nanmax(double a, double b) { return (b > a || b != b) ? b : a; }
 // one lane's share (every G-th value of the cell's segment): the largest magnitude, then the fixed-point sum
 template <class T, int G>
 __device__ __forceinline__ double seg_amax(const T *lds, const T *glob, const uint32_t *gather, bool staged, uint32_t base, uint32_t s, uint32_t e)
 {
   double m = 0;
-  if (staged) for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(lds[q - base])));
-  else if (gather) for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(glob[gather[q]])));
-  else for (uint32_t q = s; q < e; q += G) m = fmax(m, fabs(double(glob[q])));
+  if (staged) for (uint32_t q = s; q < e; q += G) m = nanmax(m, fabs(double(lds[q - base])));
+  else if (gather) for (uint32_t q = s; q < e; q += G) m = nanmax(m, fabs(double(glob[gather[q]])));
+  else for (uint32_t q = s; q < e; q += G) m = nanmax(m, fabs(double(glob[q])));
   return m;
 }
 template <class T, int G>
@@ -1212,6 +1214,7 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
   T after = 0, before = 0;
   long long after_fx = 0;
   int fxk = 0;
+  bool bad_fx = false;
   // the workgroup's cells are taken in runs that fit the LDS stage (normally one run; crowded neighbourhoods split instead of
   // falling back to uncoalesced global reads); a single cell above CF_CAP is summed from global memory
   for (int cb = 0; cb < nc;) {
@@ -1237,8 +1240,12 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
       // (every lane of the workgroup takes part in the shuffles; lanes outside the run carry zeros)
       double amax = in_run ? seg_amax<T, G>(lds, m3_after, gather, staged, base, s + sub, e) : 0.;
 #pragma unroll
-      for (int d = G / 2; d > 0; d >>= 1) amax = fmax(amax, __shfl_xor(amax, d));
-      if (in_run) { fxk = fx_shift(amax, e - s); after_fx = amax > 0 ? seg_sum_fx<T, G>(lds, m3_after, gather, staged, base, s + sub, e, fxk) : 0ll; }
+      for (int d = G / 2; d > 0; d >>= 1) amax = nanmax(amax, __shfl_xor(amax, d));
+      if (in_run) {
+        bad_fx = !(amax < 1e300);                    // (NaN or infinite addends: the sum is NaN)
+        fxk = fx_shift(amax, e - s);
+        after_fx = (amax > 0 && !bad_fx) ? seg_sum_fx<T, G>(lds, m3_after, gather, staged, base, s + sub, e, fxk) : 0ll;
+      }
     }
     else if (in_run) after = (gather && !staged) ? seg_sum_gather<T, G>(m3_after, gather, s + sub, e) : seg_sum<T, G>(lds, m3_after, staged, base, s + sub, e);
     if (step == 0 && !delta) {
@@ -1255,7 +1262,7 @@ k_cond_cellfinish(size_t n_cell, int cfc, const uint32_t *cell_start, const T *m
     for (int d = G / 2; d > 0; d >>= 1) { after = after + __shfl_xor(after, d); before = before + __shfl_xor(before, d); after_fx += __shfl_xor(after_fx, d); }
   }
   if (!mine || sub != 0) return;
-  if (delta) after = T(ldexp(double(after_fx), -fxk));
+  if (delta) after = bad_fx ? T(NAN) : T(ldexp(double(after_fx), -fxk));
   cellfinish_apply(c, has, after, before, dv, rhod, rv, th, Tk, rw_mom3, step, sstp, ndims);
 }
 // Fast arithmetic, crowded cells (hundreds of SDs per cell): ONE WAVE per cell sums the segment with coalesced loads and a
@@ -1275,15 +1282,16 @@ k_cond_cellfinish_wave(size_t n_cell, const uint32_t *cell_start, const T *m3_be
   T after = 0, before = 0;
   if (delta) {                          // (fixed point: see k_cond_cellfinish)
     double amax = 0;
-    for (uint32_t q = s + lane_id(); q < e; q += WAVE) amax = fmax(amax, fabs(double(m3_after[gather ? gather[q] : q])));
+    for (uint32_t q = s + lane_id(); q < e; q += WAVE) amax = nanmax(amax, fabs(double(m3_after[gather ? gather[q] : q])));
 #pragma unroll
-    for (int d = WAVE / 2; d > 0; d >>= 1) amax = fmax(amax, __shfl_xor(amax, d));
+    for (int d = WAVE / 2; d > 0; d >>= 1) amax = nanmax(amax, __shfl_xor(amax, d));
+    const bool bad = !(amax < 1e300);
     const int fxk = fx_shift(amax, e - s);
     long long acc = 0;
-    if (amax > 0) for (uint32_t q = s + lane_id(); q < e; q += WAVE) acc += to_fx(double(m3_after[gather ? gather[q] : q]), fxk);
+    if (amax > 0 && !bad) for (uint32_t q = s + lane_id(); q < e; q += WAVE) acc += to_fx(double(m3_after[gather ? gather[q] : q]), fxk);
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d);
-    after = T(ldexp(double(acc), -fxk));
+    after = bad ? T(NAN) : T(ldexp(double(acc), -fxk));
   } else {
     for (uint32_t q = s + lane_id(); q < e; q += WAVE) { after = after + m3_after[gather ? gather[q] : q]; if (step == 0) before = before + m3_before[q]; }
 #pragma unroll

@@ -299,3 +299,26 @@ def test_production_storage_order_holds_the_oracles_droplets(strict_fp):
     # the device's own order is a valid cell-sorted order of its renumbered storage
     sid, sijk, ijk = hip.state_u64("sorted_id"), hip.state_u64("sorted_ijk"), hip.state_u64("ijk")
     assert np.array_equal(ijk[sid], sijk) and np.all(np.diff(sijk.astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("strict_fp", [True, False])
+def test_a_nan_wet_radius_poisons_its_cell_and_nothing_else(strict_fp):
+    """The per-cell sums of fast arithmetic are taken in fixed point (order-independent, lcx_kernels.hpp k_cond_cellfinish): a NaN among
+    a cell's addends must still make that cell's th and rv NaN, as the floating-point sums of the strict arithmetic and of the
+    reference do -- and leave every other cell alone"""
+    oi = h.box_opts(4, 3, 5, 32, strict_fp=strict_fp, coal_switch=False)
+    th, rv, rhod, C = h.box_fields(oi)
+    hip = h.hip_particles(oi)
+    hip.init(th, rv, rhod, **C)
+    rw2 = hip.get_attr("rw2")
+    ijk = hip.state_u64("ijk")
+    victim = 7 * 32 + 3
+    rw2[victim] = np.nan
+    hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), hip.state_real("vt"), hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+    thh, rvh = th.copy(), rv.copy()
+    hip.step_sync(opts, thh, rvh, rhod, **C)
+    bad = np.isnan(thh.ravel())
+    assert bad.sum() == 1 and bad[int(ijk[victim])] and np.isnan(rvh.ravel()[int(ijk[victim])])
+    assert np.isfinite(rvh.ravel()[~bad]).all()
