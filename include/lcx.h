@@ -284,6 +284,9 @@ int lcx_rng_replay_pending(lcx_particles *, size_t *n_arrays);
  * 2: the tags by storage index at coalescence time, 3: the cell index by storage index at coalescence time (0xFFFFFFFF: a dead slot).
  * out == NULL queries the length. */
 int lcx_rng_dump(lcx_particles *, int call, int which, double *out, size_t cap, size_t *n);
+/* overwrite ONE per-super-droplet attribute in storage order, the whole storage extent (test hook; "tag" only, needs LCX_DBG_TAG: a test
+ * that follows droplets across the slabs of a decomposed domain gives them tags that are unique over all slabs) */
+int lcx_set_state_real(lcx_particles *, const char *name, const double *data, size_t n);
 /* run single housekeeping stages (for stage-level parity tests) */
 int lcx_stage(lcx_particles *, const char *stage, const lcx_opts_t *opts);
 /* per-stage device time of the last step in ms: fills names/values up to cap, returns count in *n */

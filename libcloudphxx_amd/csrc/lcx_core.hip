@@ -119,6 +119,7 @@ struct IParticles {
   virtual void rng_replay_push(int kind, const double *data, size_t n) = 0;
   virtual size_t rng_replay_pending() = 0;
   virtual void rng_dump(int call, int which, double *out, size_t cap, size_t *n) = 0;
+  virtual void set_state_real(const char *name, const double *data, size_t n) = 0;
   virtual void stage(const char *name, const lcx_opts_t *opts) = 0;
   virtual void timings(const char **names, double *ms, size_t cap, size_t *n) = 0;
   virtual void set_profiling(int on) = 0;
@@ -671,6 +672,13 @@ struct Particles : IParticles {
     hipLaunchKernelGGL(k_rng_record<T>, dim3(nblk(std::max(npart, nphys))), dim3(BS), 0, st, npart, nphys, last_shuffle_rs, ru, A.ext[ix_tag].p, ijk.p,
                        r->u01.p, r->un.p, r->tag.p, r->ijk.p);
     rng_recs.push_back(std::move(r));
+  }
+  void set_state_real(const char *name, const double *data, size_t n) override
+  {
+    if (std::string(name) != "tag" || ix_tag < 0) throw lcx_error("libcloudph++: lcx_set_state_real sets \"tag\" only (opts_init.dbg_flags & LCX_DBG_TAG)");
+    if (n != nphys) throw lcx_error("libcloudph++: lcx_set_state_real: one value per storage slot (" + std::to_string(nphys) + ")");
+    std::vector<T> h(data, data + n);
+    h2d(A.ext[ix_tag].p, h.data(), n * sizeof(T));
   }
   void rng_dump(int call, int which, double *out, size_t capn, size_t *n) override
   {
@@ -2520,6 +2528,7 @@ int lcx_set_particles(lcx_particles *h, size_t n, const unsigned long long *mult
 int lcx_rng_replay_push(lcx_particles *h, int kind, const double *data, size_t n) { LCX_TRY(H->rng_replay_push(kind, data, n)) }
 int lcx_rng_replay_pending(lcx_particles *h, size_t *n) { LCX_TRY(*n = H->rng_replay_pending()) }
 int lcx_rng_dump(lcx_particles *h, int call, int which, double *out, size_t cap, size_t *n) { LCX_TRY(H->rng_dump(call, which, out, cap, n)) }
+int lcx_set_state_real(lcx_particles *h, const char *name, const double *data, size_t n) { LCX_TRY(H->set_state_real(name, data, n)) }
 int lcx_stage(lcx_particles *h, const char *stage, const lcx_opts_t *o) { LCX_TRY(H->stage(stage, o)) }
 int lcx_timings(lcx_particles *h, const char **names, double *ms, size_t cap, size_t *n) { LCX_TRY(H->timings(names, ms, cap, n)) }
 int lcx_set_profiling(lcx_particles *h, int on) { LCX_TRY(H->set_profiling(on)) }

@@ -330,6 +330,7 @@ struct MultiParticles : IParticles {
   void rng_replay_push(int, const double *, size_t) override { per_slab(); }
   size_t rng_replay_pending() override { size_t n = 0; for (auto &s : slab) n += s->rng_replay_pending(); return n; }
   void rng_dump(int, int, double *, size_t, size_t *) override { per_slab(); }
+  void set_state_real(const char *, const double *, size_t) override { per_slab(); }
   void stage(const char *, const lcx_opts_t *) override { per_slab(); }
   void migrate_counts(size_t *, size_t *) override { per_slab(); }
   size_t migrate_record_bytes() override { return slab[0]->migrate_record_bytes(); }

@@ -596,7 +596,7 @@ class particles_t:
         self._chk(self._f("rng_replay_push")(self._h, C.c_int(kind), a.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(a.size)))
 
     def set_state_real(self, name, data):
-        """(the oracle only, orc_set_state_real: a test hook of tests/test_hip_reverse_replay.py)"""
+        """test hook of tests/test_hip_reverse_replay.py (the product sets "tag" only; the oracle also rw2, th, rv)"""
         a = np.ascontiguousarray(data, dtype=np.float64)
         self._chk(self._f("set_state_real")(self._h, name.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), C.c_size_t(a.size)))
 

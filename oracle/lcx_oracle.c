@@ -2203,7 +2203,7 @@ int orc_set_state_real(orc_particles *s, const char *name, const double *data, s
   const int cell = !strcmp(name, "th") || !strcmp(name, "rv");      /* (the cell fields that condensation has just updated) */
   if (n != (cell ? s->n_cell : s->n_part)) FAIL("oracle: set_state_real: %zu values for '%s'", n, name);
   double *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt :
-                !strcmp(name, "th") ? s->th : !strcmp(name, "rv") ? s->rv : NULL;
+                !strcmp(name, "th") ? s->th : !strcmp(name, "rv") ? s->rv : !strcmp(name, "tag") ? s->tag : NULL;
   if (!dst) FAIL("oracle: set_state_real: unknown attribute '%s'", name);
   memcpy(dst, data, n * sizeof(double));
   return 0;

@@ -278,6 +278,10 @@ class LocalRing:
             p.init(self.slab(th, r), self.slab(rv, r), self.slab(rhod, r), **kw)
 
     def step(self, opts, th, rv, rhod, Cx=None, Cy=None, Cz=None):
+        self.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        self.step_async(opts)
+
+    def step_sync(self, opts, th, rv, rhod, Cx=None, Cy=None, Cz=None):
         for r, p in enumerate(self.prts):
             a = [self.slab(th, r), self.slab(rv, r), self.slab(rhod, r),
                  None if Cx is None else self.slab(Cx, r, 1), None if Cy is None else self.slab(Cy, r), None if Cz is None else self.slab(Cz, r)]
@@ -301,6 +305,9 @@ class LocalRing:
             for r, p in enumerate(self.prts):
                 p.courant_halo_unpack(which, 0, bufs[(r - 1) % n][2])     # left halo <- left neighbour's right-edge planes
                 p.courant_halo_unpack(which, 1, bufs[(r + 1) % n][0])     # right halo <- right neighbour's left-edge planes
+
+    def step_async(self, opts):
+        n = self.size
         for p in self.prts:
             p.step_async(opts)
         packs = []

@@ -197,3 +197,91 @@ def test_reverse_replay_with_crowded_cells_and_substeps():
         assert np.array_equal(d["tag"], o["tag"]) and np.array_equal(d["n"], o["n"]) and np.array_equal(d["ijk"], o["ijk"]), it
         np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14)
         np.testing.assert_allclose(d["rw2"], o["rw2"], rtol=1e-13)
+
+
+@pytest.mark.parametrize("size,reorder_every", [(3, 0), (2, 3)])
+def test_reverse_replay_on_the_slabs_of_the_multi_device_object(size, reorder_every, monkeypatch):
+    """The same on a decomposed domain: the native multi-device object (all slabs on the one GPU), production path -- fast
+    arithmetic, the slabs' re-sort left to the next condensation kernel (round 4), immigrants taking over the emigrants' storage slots,
+    storage re-ordering -- against a ring of oracles, each fed the random stream that ITS slab's coalescence consumed on the device.
+    Tags are unique over all slabs (lcx_set_state_real), so a droplet is followed across the slab faces: after every step every slab
+    holds the same tags, multiplicities and cells as its oracle, rd3 to 1e-14, rw2 and positions to 1e-13."""
+    monkeypatch.setenv("LCX_MULTI_DEVICE_MAP", ",".join(["0"] * size))
+    nx, ny, nz, sd_conc, steps = 4 * size, 4, 6, 48, 8
+    oi = colliding_box(nx, ny, nz, sd_conc, dt=4.)
+    oi.reorder_every = reorder_every
+    oi.n_sd_max = int(sd_conc * nx * ny * nz * 1.6) + 64 * size
+    th, rv, rhod, C = h.box_fields(oi)
+    orc = h.LocalRing(oi, size, h.oracle_particles, h.host_alloc)
+    oi.dev_count = size
+    mul = lgrngn.factory(lgrngn.backend_t.multi_HIP, oi)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    mul.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    so = lgrngn.opts_t()
+    so.coal = so.adve = so.sedi = False
+    for _ in range(6):                                         # (spin-up on the oracles, see the single-device test)
+        orc.step(so, th, rv, rhod, **C)
+    slabs = [mul.slab(r) for r in range(size)]
+    for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
+        ph.opts_init = po.opts_init
+        h.copy_state(po, ph)
+        tags = 1e7 * r + np.arange(po.n_part, dtype=np.float64)          # unique over the slabs
+        po.set_state_real("tag", tags)
+        ph.set_state_real("tag", tags)
+    opts = lgrngn.opts_t()
+    fo, fh = [th.copy(), rv.copy()], [th.copy(), rv.copy()]
+    crossed = 0
+    mul.set_profiling(True)
+    for it in range(steps):
+        orc.step_sync(opts, fo[0], fo[1], rhod, **C)
+        mul.step_sync(opts, fh[0], fh[1], rhod, **C)
+        tags_o = []
+        for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
+            # condensation at its own bars, then the oracle slab goes on from the device's wet radii, th and rv (see the module's head)
+            d = device_by_tag(ph)
+            t_o = po.state_real("tag")
+            order = np.argsort(t_o, kind="stable")
+            assert np.array_equal(d["tag"], t_o[order]), (it, r)
+            rw2_o = po.state_real("rw2")
+            err = np.abs(d["rw2"] / rw2_o[order] - 1)
+            assert err.max() < 1e-4, (it, r, err.max())
+            rw2_new = np.empty_like(rw2_o)
+            rw2_new[order] = d["rw2"]
+            po.set_state_real("rw2", rw2_new)
+            sl = slice(orc.bfr[r], orc.bfr[r] + orc.nxl[r])
+            np.testing.assert_allclose(fh[0][sl], fo[0][sl], rtol=2e-6)
+            po.set_state_real("th", fh[0][sl].ravel())
+            po.set_state_real("rv", fh[1][sl].ravel())
+            tags_o.append(t_o)
+        fo[0][...] = fh[0]
+        fo[1][...] = fh[1]
+        mul.step_async(opts)
+        for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
+            u01 = ph.rng_dump(0, 0)
+            un_dev, tag_dev, ijk_dev = ph.rng_dump(0, 1), ph.rng_dump(0, 2), ph.rng_dump(0, 3)
+            alive = ijk_dev != DEAD
+            assert int(alive.sum()) == u01.size == tags_o[r].size, (it, r)
+            order = np.argsort(tag_dev[alive], kind="stable")
+            tags_sorted, keys_sorted = tag_dev[alive][order], un_dev[alive][order]
+            pos = np.searchsorted(tags_sorted, tags_o[r])
+            assert np.array_equal(tags_sorted[pos], tags_o[r]), (it, r)
+            po.rng_replay_push(1, keys_sorted[pos])
+            po.rng_replay_push(0, u01)
+        orc.step_async(opts)
+        for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
+            assert po.rng_replay_pending() == 0
+            assert ph.n_part == po.n_part, (it, r)
+            d, o = device_by_tag(ph), oracle_by_tag(po)
+            assert np.array_equal(d["tag"], o["tag"]), (it, r)
+            assert np.array_equal(d["n"], o["n"]) and np.array_equal(d["ijk"], o["ijk"]), (it, r)
+            np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14)
+            np.testing.assert_allclose(d["rw2"], o["rw2"], rtol=1e-13)
+            for a in ("x", "y", "z"):
+                np.testing.assert_allclose(d[a], o[a], rtol=1e-13, atol=1e-9, err_msg="%s, step %d, slab %d" % (a, it, r))
+            crossed += int(((d["tag"] // 1e7).astype(int) != r).sum())
+    assert crossed > 0                                         # droplets did change slabs
+    # the path under test: without a storage re-ordering in the run no slab re-sorted inside its exchange (the re-sort rode on the
+    # condensation kernel); with one every third step the overlapped interior re-sort ran in those steps
+    stages = mul.timings()
+    assert ("exchange_sort_interior" in stages) == (reorder_every > 0), sorted(stages)
+    assert "exchange_unpack" in stages and "cond" in stages
