@@ -92,8 +92,9 @@ def run(mode, rank, world, port, res, transport):
             np.save(res % rank, np.stack([before, after]))
             ok = np.array_equal(before, after) and prt.n_part == n_before and prt.bytes_moved > 0 and 1 <= prt.second_rounds <= 2
             sys.exit(0 if ok else 3)
-        nx, ny, nz = (8, 3, 4) if mode == "steps" else (7, 0, 5)
-        oi = box(nx, ny, nz, 24, 44 + rank, coal_switch=(mode == "steps"))
+        full = mode in ("steps", "fsteps")               # ("fsteps": fast arithmetic -- the slabs leave their re-sort to the next condensation kernel)
+        nx, ny, nz = (8, 3, 4) if full else (7, 0, 5)
+        oi = box(nx, ny, nz, 24, 44 + rank, coal_switch=full, strict_fp=(mode != "fsteps"))
         th, rv, rhod, C = h.box_fields(oi)
         if mode == "uneven":
             C["Cx"] = 0.95 * np.ones_like(C["Cx"])
@@ -101,9 +102,9 @@ def run(mode, rank, world, port, res, transport):
         prt = multi.particles_multi_t(oi, np.float64, device=dev, transport=transport, global_arrays=True, self_ring=self_ring)
         prt.init(th, rv, rhod, **C)
         opts = lgrngn.opts_t()
-        opts.coal = mode == "steps" and not self_ring
+        opts.coal = full and not self_ring
         n_tot0 = None
-        for it in range(3 if mode == "steps" else 5):
+        for it in range(3 if full else 5):
             prt.step_sync(opts, th, rv, rhod, **C)       # (global arrays: every rank writes its planes of its own copy)
             prt.step_async(opts)
         st = slab_state(prt.prt)

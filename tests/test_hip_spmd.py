@@ -61,7 +61,7 @@ def test_spmd_hip_engine_ring_round_trip_bit_identical(world, tmp_path):
         assert np.array_equal(d[0], d[1]) and d[0][0].sum() > 0
 
 
-@pytest.mark.parametrize("mode,world", [("steps", 2), ("steps", 4), ("uneven", 3)])
+@pytest.mark.parametrize("mode,world", [("steps", 2), ("steps", 4), ("fsteps", 2), ("fsteps", 3), ("uneven", 3)])
 def test_spmd_hip_engine_equals_the_native_multi_device_object(mode, world, tmp_path, monkeypatch):
     """three full steps (cond + coal + adve + sedi, Philox streams, production storage order) by `world` ranks = the slabs of ONE
     multi-device object over `world` slabs on the same device, bit for bit: same kernels, same message layout, same unpack order --
@@ -71,8 +71,9 @@ def test_spmd_hip_engine_equals_the_native_multi_device_object(mode, world, tmp_
     import _spmd_worker as w
     res = str(tmp_path / "s%d.npz")
     launch(mode, world, res)
-    nx, ny, nz = (8, 3, 4) if mode == "steps" else (7, 0, 5)
-    oi = w.box(nx, ny, nz, 24, 44, coal_switch=(mode == "steps"))
+    full = mode in ("steps", "fsteps")        # ("fsteps": fast arithmetic, the slabs' re-sort riding on the next condensation kernel)
+    nx, ny, nz = (8, 3, 4) if full else (7, 0, 5)
+    oi = w.box(nx, ny, nz, 24, 44, coal_switch=full, strict_fp=(mode != "fsteps"))
     th, rv, rhod, C = h.box_fields(oi)
     if mode == "uneven":
         C["Cx"] = 0.95 * np.ones_like(C["Cx"])
@@ -81,9 +82,9 @@ def test_spmd_hip_engine_equals_the_native_multi_device_object(mode, world, tmp_
     mul = lgrngn.factory(lgrngn.backend_t.multi_CUDA, oi)
     mul.init(th, rv, rhod, **C)
     opts = lgrngn.opts_t()
-    opts.coal = mode == "steps"
+    opts.coal = full
     n0 = mul.n_part
-    for it in range(3 if mode == "steps" else 5):
+    for it in range(3 if full else 5):
         mul.step_sync(opts, th, rv, rhod, **C)
         mul.step_async(opts)
     per = nx // world
