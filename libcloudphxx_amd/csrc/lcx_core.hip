@@ -995,7 +995,9 @@ struct Particles : IParticles {
     npart = nphys - dead;
     // default period: 64 steps; 32 for a slab with neighbours, whose storage the immigrants and emigrants disorder faster (8 slabs of C3,
     // ms per step of all slabs: 64: 20.2, 32: 19.3, 16: 19.4, 8: 19.6; a single device: 64 and 32 alike)
-    const int every_ = o.reorder_every > 0 ? o.reorder_every : (distmem() ? 32 : 64);
+    // (crowded cells, 512 per cell on C5: the pairs of coalescence are gathered from anywhere in a cell's 4 KB per attribute, and from
+    // further away the longer the storage has drifted from the cell order -- 66 steps of C5: period 64 79.8 ms per step, 32: 78.0, 16: 77.7)
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : (distmem() ? 32 : (ncell && npart / ncell >= 256 ? 16 : 64));
     const bool reorder_due = compact_now || (!strict_order && steps_since_reorder + 1 >= every_);     // (the re-ordering wants the plain order)
     // (strict arithmetic sums a cell's droplets in the reference's order, ascending id: k_cond_cellfinish<T, 1> walks the sorted order
     // as it finds it, so the cells must not be left in the shuffled order there -- the in-cell ranking by id stays, coalescence
