@@ -513,7 +513,7 @@ def main():
             launches = args.steps * args.sstp_cond
             avg_ms = stage_ms["cond"] / launches
             ach = cond_bytes_per_sd * n_local / (avg_ms * 1e-3) / 1e9
-            kname = "k_cond" if args.strict_fp else "k_cond_lean" if args.cond_solver == "lean" else "k_cond_fast_fold + k_cond_fast (first pass + straggler pass)"
+            kname = "k_cond" if args.strict_fp else "k_cond_lean" if args.cond_solver == "lean" else "k_cond_lean<.., SOLVER = TOMS748>"
             roof = {"bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_sd": cond_bytes_per_sd, "algorithmic_bytes": cond_bytes_per_sd * n_local}
@@ -708,7 +708,7 @@ def main():
                 # arithmetic -- held to SURVEY 8a's bars in every test, where the lean solver is held to its own (tests/_harness.py)
                 out["cond_solver_toms748"] = run_leg({"cond_solver": 1}, args.leg_steps)
                 out["cond_solver_toms748"]["fp_mode"] = "fast arithmetic, the reference's TOMS748 iterates (opts_init.cond_solver = 1)"
-                out["cond_solver_toms748"]["roofline"]["kernel"] = "k_cond_fast_fold + k_cond_fast"
+                out["cond_solver_toms748"]["roofline"]["kernel"] = "k_cond_lean<.., SOLVER = TOMS748>"
             if not args.no_host_leg:
                 # what an unchanged icicle / UWLCM gets: the Eulerian arrays in HOST memory (numpy arrays through arrinfo_t), every option
                 # as in the headline -- sync_in / sync_out include the PCIe transfers and the host-side row copies

@@ -112,8 +112,9 @@ typedef struct {
                          *    tolerance 2^-15 (csrc/lcx_math.hpp advance_rw2_lean_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within
                          *    that tolerance of the reference's answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5
                          *    from the root it brackets;
-                         * 1: the reference's TOMS748 iterates in the fast arithmetic (round 2's kernels: 1.6x the time of 0), for runs
-                         *    that are to follow the reference's answers as closely as its own builds follow each other */
+                         * 1: the reference's TOMS748 iterates in the fast arithmetic (the same storage-order kernel with TOMS748 in it: 2x the
+                         *    kernel time of 0, 1.33x the step), for runs that are to follow the reference's answers as closely as its own
+                         *    builds follow each other: held to SURVEY 8a's bars and the reference's refdata tolerances in the tests */
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers
                          * line-coalesced in long runs: 18.1 instead of 21.5 ms per step after 400 steps of the 128^3 box).
                          * N > 0: every N steps, and whenever dead super-droplets are compacted away anyway (the same one pass over
@@ -128,7 +129,7 @@ typedef struct {
    * options an object is created with, read once, and the library reads no environment variable but LCX_DATA_DIR (where the collision
    * efficiency tables live) and LCX_MULTI_DEVICE_MAP (slab -> device map of a multi-device object). */
   unsigned dbg_flags;   /* LCX_DBG_* bits below */
-  int dbg_cond_budget;  /* cond_solver = 1: iteration budget of the first condensation pass (stragglers go to a dense second launch);
+  int dbg_cond_budget;  /* cond_solver = 1 with LCX_DBG_COND_TOMS_TWO_PASS: iteration budget of the first condensation pass (stragglers go to a dense second launch);
                          * 0: the library's choice (6 from 2^25 super-droplets, else one pass), > 0: that budget, < 0: one pass */
   int dbg_pack_delay_us;/* multi-device tests: slabs with an odd first plane send their messages so many microseconds late */
 } lcx_opts_init_t;
@@ -139,7 +140,7 @@ enum lcx_dbg {
   LCX_DBG_EAGER_COMPACT = 1 << 2,      /* compact dead super-droplets away in every step (the reference's remove_n0) */
   LCX_DBG_SHUFFLE_PHILOX = 1 << 3,     /* shuffle keys drawn from Philox, ranked on 64 bits (round 2's form) */
   LCX_DBG_NO_DEFERRED_SORT = 1 << 4,   /* the end-of-step re-sort finished at once instead of riding on the next condensation kernel */
-  LCX_DBG_COND_NO_FOLD = 1 << 5,       /* cond_solver = 1: k_cond_fast instead of k_cond_fast_fold */
+  LCX_DBG_COND_NO_FOLD = 1 << 5,       /* cond_solver = 1 with LCX_DBG_COND_TOMS_TWO_PASS: k_cond_fast instead of k_cond_fast_fold */
   LCX_DBG_COND_SORTED_ORDER = 1 << 6,  /* k_cond_lean over the sorted order (gathers) instead of the storage order */
   LCX_DBG_NO_OVERLAP = 1 << 7,         /* exchange: no re-sort of the interior while the messages travel */
   LCX_DBG_MULTI_NO_PEER = 1 << 8,      /* multi-device object: treat the devices as unable to map each other's memory (staged copies) */
@@ -151,7 +152,9 @@ enum lcx_dbg {
   LCX_DBG_HOST_SYNC_LOOP = 1 << 12,    /* host arrays in sync_in / sync_out through the plain host loop (the form rounds 1-3 had) */
   LCX_DBG_EXCH_SORT_NOW = 1 << 14,     /* a slab with neighbours re-sorts inside its exchange (interior while the messages travel, boundary behind
                                         * them) even when the next condensation kernel could carry the scatter */
-  LCX_DBG_COND_LEAN_R3 = 1 << 13       /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
+  LCX_DBG_COND_LEAN_R3 = 1 << 13,      /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
+  LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
+                                        * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };
 
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */

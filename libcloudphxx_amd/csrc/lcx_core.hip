@@ -1063,7 +1063,8 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
   }
   bool lean_storage_cond() const
-  { return !o.strict_fp && !no_cond_pre && cond_storage_order && o.cond_solver != 1 && !o.exact_sstp_cond; }
+  { return !o.strict_fp && !no_cond_pre && cond_storage_order && !cond_toms_two_pass() && !o.exact_sstp_cond; }
+  bool cond_toms_two_pass() const { return o.cond_solver == 1 && dbg(LCX_DBG_COND_TOMS_TWO_PASS); }
   void cond_substep(double RH_max, int step, bool turb_cond = false)
   {
     const bool carry_scatter = sort_deferred && lean_storage_cond() && !turb_cond && npart;
@@ -1090,10 +1091,10 @@ struct Particles : IParticles {
                      xcd_group(npart, ncell),
                      turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
       const dim3 gr(nblk(npart)), bl(BS);
-      // fast arithmetic: the lean bracketed secant (k_cond_lean); opts_init.cond_solver = 1 keeps round 2's kernels
-      // -- TOMS748 iterates in fast arithmetic, iteration budget + straggler launch, fold
+      // fast arithmetic: k_cond_lean with the lean bracketed secant, or (opts_init.cond_solver = 1) with TOMS748 -- the reference's
+      // iterates in fast arithmetic; round 2's kernels for that (iteration budget + straggler launch, fold) behind a switch
       const bool cond_toms = o.cond_solver == 1;
-      if (fast && !cond_toms) {
+      if (fast && !cond_toms_two_pass()) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
         cond_in_storage_order = cond_storage_order;
         if (cond_in_storage_order) {
@@ -1101,10 +1102,13 @@ struct Particles : IParticles {
           if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
           // (one hygroscopicity in the whole run: a scalar instead of 8 B per droplet, see kpa_uniform)
           const dim3 gs(nblk(nphys));
-          if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, true>), gs, bl, 0, st, nphys, a, T(0));
+          if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
+          else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 7, false, 2>), gs, bl, 0, st, nphys, a, T(0));
+          else if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, 1>), gs, bl, 0, st, nphys, a, T(0));
           else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), gs, bl, 0, st, nphys, a, kpa_value);
           else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gs, bl, 0, st, nphys, a, T(0));
         }
+        else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 7, false, 2>), gr, bl, 0, st, npart, a, T(0));
         else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gr, bl, 0, st, npart, a, T(0));
       }
       else if (fast) {

@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // (advance_rw2_lean_with) instead of TOMS748 -- no iteration budget, no second launch, no fold: the iteration counts are short and even.
 // Round 4.  The solver's bookkeeping pared down (lcx_math.hpp, lean2_*: the same operations on the droplet's numbers, straight-line
 // loop body) and the growth rate's helper functions without the instructions that are identities here (OPT bit 2): 776 -> 671 vector
-// instructions per wave in the spin-up steps that rounds 1-3 profiled (637 in the settled box), the same rw2 bit for bit (R3 keeps
+// instructions per wave in the spin-up steps that rounds 1-3 profiled (637 in the settled box), the same rw2 bit for bit (SOLVER = 1 keeps
 // round 3's form for the test that shows it); the launch 3.43 -> 3.0 ms.  At that point the kernel is no longer bound by its vector
 // ALU alone: 0.83 busy, and 10.4 GB of traffic (its own 56 B per droplet + the carried scatter's 20) in 2.9 ms is 3.6 of the 4.85 TB/s
 // that a copy reaches on the same box.  UNI: a run with ONE hygroscopicity (one dry distribution, no user-set particles) passes it as
@@ -1021,7 +1021,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 //  * Two passes: every droplet's loop stopped after ONE evaluation, the 9 % that have not converged listed with the loop's state
 //    (seven reals, one atomic per wave) and taken up where they stand by a dense second launch -- the same bits; the first pass 637 -> 590
 //    instructions per wave and not a microsecond faster (2.98 against 3.00 ms: the memory side), the second pass 0.75 ms of gathers.
-template <class T, int OPT = 7, bool UNI = false, bool R3 = false>
+// SOLVER: 0 the lean solver in round 4's form, 1 in round 3's (the same bits, kept for the test that shows it), 2 TOMS748 -- the
+// reference's iterates on this kernel's growth-rate arithmetic (opts_init.cond_solver = 1), in the same storage-order walk
+template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0>
 __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
@@ -1049,7 +1051,8 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     cond_fun_fast<T, OPT> ff;
     ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
     T r;
-    if constexpr (R3) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    if constexpr (SOLVER == 2) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    else if constexpr (SOLVER == 1) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     a.rw2[id] = r;
     // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)

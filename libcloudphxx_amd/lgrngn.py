@@ -104,6 +104,7 @@ class dbg(enum.IntFlag):
     HOST_SYNC_LOOP = 1 << 12
     COND_LEAN_R3 = 1 << 13
     EXCH_SORT_NOW = 1 << 14
+    COND_TOMS_TWO_PASS = 1 << 15
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -14,13 +14,18 @@ pytestmark = pytest.mark.gpu
 ROWS = [r for r in pins._rows() if r["sstp_cond"] in ("1", "3", "8", "32") and r["RH_formula"] in ("pv_cc", "rv_tet")]
 
 
-@pytest.mark.parametrize("strict_fp", [True, False])
+@pytest.mark.parametrize("mode", ["strict", "fast", "toms"])
 @pytest.mark.parametrize("row", ROWS, ids=lambda r: "%s-%s-sstp%s" % ("constp" if r["constp"] == "True" else "varp", r["RH_formula"], r["sstp_cond"]))
-def test_cond_substepping_refdata_hip(row, strict_fp):
+def test_cond_substepping_refdata_hip(row, mode):
     """tests/python/physics/refdata/lgrngn_cond_substepping_refdata.csv through the GPU.  The run needs the CPU random
-    stream to reproduce the sampled aerosol (1000 SDs in two modes): the dry radii of both distros are replayed."""
+    stream to reproduce the sampled aerosol (1000 SDs in two modes): the dry radii of both distros are replayed.
+    Three arithmetic modes: strict (the API default), fast (the lean solver: the bench headline) and toms (fast arithmetic with the
+    reference's TOMS748 iterates, opts_init.cond_solver = 1) -- the last held to the reference's own tolerances like the first."""
+    strict_fp = mode != "fast"
+
     def make(oi):
-        oi.strict_fp = strict_fp
+        oi.strict_fp = mode == "strict"
+        oi.cond_solver = int(mode == "toms")
         orc = h.oracle_particles(oi)
         # fraction of sd_conc per distro is decided inside init; query the oracle for the split by running its init
         th, rv, rhod = np.array([305.]), np.array([0.0085]), np.array([1.1])
