@@ -153,6 +153,8 @@ enum lcx_dbg {
   LCX_DBG_EXCH_SORT_NOW = 1 << 14,     /* a slab with neighbours re-sorts inside its exchange (interior while the messages travel, boundary behind
                                         * them) even when the next condensation kernel could carry the scatter */
   LCX_DBG_COND_LEAN_R3 = 1 << 13,      /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
+  LCX_DBG_FINISH_STAGED = 1 << 16,     /* fast arithmetic: the per-cell finish through its LDS stage (k_cond_cellfinish) also where the changes lie in
+                                        * the sorted order and k_cond_cellfinish_direct would read them straight from memory */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };

@@ -1154,6 +1154,9 @@ struct Particles : IParticles {
     if (!o.strict_fp && ncell >= 4096 && npart / ncell >= 192)
       hipLaunchKernelGGL(k_cond_cellfinish_wave<T>, dim3(nblk(ncell, BS / WAVE)), dim3(BS), 0, st, ncell, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,
                          rv.p, th.p, Tk.p, rw_mom3.p, step, sstp, n_dims, dl, gather);
+    else if (!o.strict_fp && delta && !gather && !dbg(LCX_DBG_FINISH_STAGED))
+      hipLaunchKernelGGL(k_cond_cellfinish_direct<T>, dim3(nblk(ncell * 8)), dim3(BS), 0, st, ncell, cell_start.p, m3_after.p, dv.p, rhod.p, rv.p, th.p, Tk.p,
+                         rw_mom3.p, n_dims);
     else if (!o.strict_fp) {
       const int cfc = std::min(cf_cells(), BS / 8);
       hipLaunchKernelGGL((k_cond_cellfinish<T, 8>), dim3(nblk(ncell, cfc)), dim3(BS), 0, st, ncell, cfc, cell_start.p, m3_before.p, m3_after.p, dv.p, rhod.p,

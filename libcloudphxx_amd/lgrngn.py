@@ -105,6 +105,7 @@ class dbg(enum.IntFlag):
     COND_LEAN_R3 = 1 << 13
     EXCH_SORT_NOW = 1 << 14
     COND_TOMS_TWO_PASS = 1 << 15
+    FINISH_STAGED = 1 << 16
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -874,6 +874,31 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("sd_conc,steps", [(64, 6), (100, 4), (400, 3)])
+def test_per_cell_finish_without_its_lds_stage_gives_the_same_bits(sd_conc, steps):
+    """k_cond_cellfinish_direct (round 4: the changes lie in the sorted order, eight lanes per cell read them straight from memory, the
+    first 64 of a cell stay in registers between the two passes) against the staged k_cond_cellfinish (dbg_flags & FINISH_STAGED): the
+    per-cell sums are integer sums, so th and rv -- and with them everything that follows -- are the same bits.  Full steps, ordinary
+    cells, cells just above the registers' 64 and crowded ones (the loop that re-reads what lies beyond)"""
+    oi = h.box_opts(6, 5, 7, sd_conc, sstp_cond=2, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for staged in (False, True):
+        oi.dbg_flags = int(lgrngn.dbg.FINISH_STAGED) if staged else 0
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(steps):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n")))
+    for a_, b_ in zip(res[0], res[1]):
+        assert np.array_equal(a_, b_)
+    assert np.abs(res[0][2] - rv).max() > 0
+
+
 @pytest.mark.parametrize("sd_conc,steps", [(64, 6), (400, 3)])
 def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monkeypatch, sd_conc, steps):
     """k_cond_lean takes the droplets in STORAGE order (coalesced attribute reads and writes; the per-cell finish gathers the droplets'
