@@ -118,7 +118,7 @@ typedef struct {
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers
                          * line-coalesced in long runs: 18.1 instead of 21.5 ms per step after 400 steps of the 128^3 box).
                          * N > 0: every N steps, and whenever dead super-droplets are compacted away anyway (the same one pass over
-                         * the attributes, gathered in sorted order instead of storage order); 0 (default): N = 64, or 32 for a slab that has
+                         * the attributes, gathered in sorted order instead of storage order); 0 (default): N = 64, or 16 for a slab that has
                          * neighbours (one extra pass of ~3.4 ms per 64 steps of ~15 ms);
                          * -1: never -- stable compaction, storage order == the reference's id order at all times.
                          * A re-ordering renumbers the ids: SDs keep their relative order inside a cell, the relative order of SDs of

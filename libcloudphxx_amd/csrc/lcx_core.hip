@@ -801,7 +801,9 @@ struct Particles : IParticles {
   {
     const uint32_t meta[2] = {big_n, big_mx};
     const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
-    if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    // (the device generator's salted bijection keys: 32 bits order a cell)
+    if (shuffle && !rs.un && (rs.s1 | rs.s2)) hipLaunchKernelGGL((k_cellsort_wave<uint32_t, true>), dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    else if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
     else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
     if (meta[1] > uint32_t(CELLSORT_WAVE_MAX)) {
       const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
@@ -966,6 +968,7 @@ struct Particles : IParticles {
     sort_from_hist(false);
   }
   // post_copy when k_move has already produced ijk / histogram / ranks / the dead count
+  static constexpr int SLAB_REORDER_EVERY = 16;      // (see post_copy_after_fused_move)
   bool listed_from_hist = false, meta_known_valid = false; uint32_t meta_known_v[2] = {0, 0};
   void list_big_from_hist()
   {   // (big_meta was cleared behind the previous sort's scan)
@@ -993,11 +996,13 @@ struct Particles : IParticles {
     if (compact_now && strict_order) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
     npart = nphys - dead;
-    // default period: 64 steps; 32 for a slab with neighbours, whose storage the immigrants and emigrants disorder faster (8 slabs of C3,
-    // ms per step of all slabs: 64: 20.2, 32: 19.3, 16: 19.4, 8: 19.6; a single device: 64 and 32 alike)
+    // default period: 64 steps; 16 for a slab with neighbours, whose storage the immigrants and emigrants disorder faster -- a third of a
+    // 16-plane slab's droplets are replaced within 32 steps at |C| = 0.15, and the newcomers sit wherever a slot was free: coalescence
+    // 130 -> 233 us, the move 213 -> 317, condensation 339 -> 413 between two re-orderings of 0.85 ms (profiles/r04x_*; ms per step of the
+    // slab with its exchange, period 8: 1.400, 12: 1.388, 16: 1.367, 24: 1.385, 32: 1.408; a single device: 64 and 32 alike)
     // (crowded cells, 512 per cell on C5: the pairs of coalescence are gathered from anywhere in a cell's 4 KB per attribute, and from
     // further away the longer the storage has drifted from the cell order -- 66 steps of C5: period 64 79.8 ms per step, 32: 78.0, 16: 77.7)
-    const int every_ = o.reorder_every > 0 ? o.reorder_every : (distmem() ? 32 : (ncell && npart / ncell >= 256 ? 16 : 64));
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : (distmem() ? SLAB_REORDER_EVERY : (ncell && npart / ncell >= 256 ? 16 : 64));
     const bool reorder_due = compact_now || (!strict_order && steps_since_reorder + 1 >= every_);     // (the re-ordering wants the plain order)
     // (strict arithmetic sums a cell's droplets in the reference's order, ascending id: k_cond_cellfinish<T, 1> walks the sorted order
     // as it finds it, so the cells must not be left in the shuffled order there -- the in-cell ranking by id stays, coalescence
@@ -2185,7 +2190,7 @@ struct Particles : IParticles {
   // the unpack.  The overlapped form stays for the steps that re-order the storage, for strict arithmetic and for the other solvers.
   bool sort_will_be_deferred() const
   {
-    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : SLAB_REORDER_EVERY;
     const bool reorder_sched = !strict_order() && steps_since_reorder + 1 >= every_;
     return defer_sort_ok && lean_storage_cond() && !reorder_sched && replay.empty() && !dbg(LCX_DBG_EXCH_SORT_NOW);
   }
@@ -2203,7 +2208,7 @@ struct Particles : IParticles {
     ov_c_lo = uint32_t(size_t(bnd_planes()) * plane_cells()); ov_c_hi = uint32_t(ncell - size_t(bnd_planes()) * plane_cells());
     // (the storage re-ordering wants the plain order: its period is known ahead; a compaction that turns out to be due is not -- rare,
     // exch_finish re-ranks then)
-    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : SLAB_REORDER_EVERY;
     const bool reorder_sched = !strict_order() && steps_since_reorder + 1 >= every_;
     overlap_preshuffle = !strict_order() && !o.strict_fp && last_async_coal && o.coal_switch && !reorder_sched;
     // crowded interior cells from the stayers' histogram, which is final there (big_meta was cleared behind the previous sort)
@@ -2341,7 +2346,7 @@ struct Particles : IParticles {
     if (compact_now && strict) { post_copy(opts, true); return; }
     Range r(this, "post_copy");
     if (big_n) sort_listed_cells(overlap_preshuffle, overlap_rs);
-    const int every_ = o.reorder_every > 0 ? o.reorder_every : 32;
+    const int every_ = o.reorder_every > 0 ? o.reorder_every : SLAB_REORDER_EVERY;
     if (compact_now || (!strict && ++steps_since_reorder >= every_)) {
       if (sorted_shuffled) { order_cells(false); shuffle_fresh = false; }      // (a compaction that was not foreseen: the re-ordering wants ascending ids)
       reorder_storage();

@@ -558,11 +558,14 @@ __device__ __forceinline__ void wave_bitonic(KEY *a, uint32_t cnt, uint32_t P, u
 // for the bitonic network of 512..1024 keys (C5: 18.5 -> see DESIGN.md); keys are unique, so the order does not depend on the
 // arrival order of the atomics.  A degenerate un (a replayed constant array) only makes the in-bucket loop long, never wrong.
 constexpr int CSW_BUCKETS = 512;
-template <class KEY>
+// U32 (round 4): the device generator's shuffle keys are a bijection of the ids (rng_src), so 32 bits order a cell by themselves -- half the
+// LDS of the 64-bit (un << 32) | id form and one-word compares, the same order; the ids wait in registers (C5: 7.4 -> see DESIGN.md)
+template <class KEY, bool U32 = false>
 __global__ void __launch_bounds__(BS)
 k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r)
 {
-  constexpr int shuffle = sizeof(KEY) == 8;
+  constexpr int shuffle = sizeof(KEY) == 8 || U32;
+  static_assert(!U32 || sizeof(KEY) == 4, "the 32-bit shuffle keys");
   constexpr int PER = CELLSORT_WAVE_MAX / WAVE;
   __shared__ KEY lds[BS / WAVE][CELLSORT_WAVE_MAX];
   __shared__ uint32_t bkt[shuffle ? BS / WAVE : 1][shuffle ? CSW_BUCKETS : 1];
@@ -577,16 +580,22 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
       uint32_t *cb = bkt[wave_id()];
       uint16_t *ix = idx[wave_id()];
       constexpr int CPL = CSW_BUCKETS / WAVE;                // counters per lane in the scan
-      constexpr int SH = 64 - 9;
+      constexpr int SH = int(sizeof(KEY)) * 8 - 9;
       static_assert(CSW_BUCKETS == 512, "the bucket is the key's top 9 bits");
 #pragma unroll
       for (int j = 0; j < CPL; ++j) cb[lane + j * WAVE] = 0u;
       wave_sync();
       uint32_t slot[PER];
+      uint32_t idr[U32 ? PER : 1];
 #pragma unroll
       for (int k = 0; k < PER; ++k) {
         const uint32_t i = lane + k * WAVE;
-        if (i < cnt) { const KEY key = KEY(sort_key(sorted_id[start + i], shuffle, r)); a[i] = key; slot[k] = atomicAdd(&cb[uint32_t(key >> SH)], 1u); }
+        if (i < cnt) {
+          const uint32_t id = sorted_id[start + i];
+          KEY key;
+          if constexpr (U32) { key = shuffle_un(id, r.s1, r.s2); idr[k] = id; } else key = KEY(sort_key(id, shuffle, r));
+          a[i] = key; slot[k] = atomicAdd(&cb[uint32_t(key >> SH)], 1u);
+        }
       }
       wave_sync();
       uint32_t loc[CPL], sum = 0;
@@ -614,7 +623,7 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
           const uint32_t bk = uint32_t(key >> SH), s = cb[bk], e = bk + 1 < uint32_t(CSW_BUCKETS) ? cb[bk + 1] : cnt;
           uint32_t rank = s;
           for (uint32_t q = s; q < e; ++q) rank += a[ix[q]] < key;
-          sorted_id[start + rank] = uint32_t(key);
+          if constexpr (U32) sorted_id[start + rank] = idr[k]; else sorted_id[start + rank] = uint32_t(key);
         }
       }
       wave_sync();
@@ -1322,14 +1331,25 @@ k_cond_cellfinish_wave(size_t n_cell, const uint32_t *cell_start, const T *m3_be
   const uint32_t s = cell_start[c], e = cell_start[c + 1];
   T after = 0, before = 0;
   if (delta) {                          // (fixed point: see k_cond_cellfinish)
+    // (the first 512 values of the cell wait in registers between the two passes, as in k_cond_cellfinish_direct)
+    constexpr int PER = 8;
+    double v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const uint32_t q = s + lane_id() + uint32_t(k) * WAVE; v[k] = q < e ? double(m3_after[gather ? gather[q] : q]) : 0.; }
     double amax = 0;
-    for (uint32_t q = s + lane_id(); q < e; q += WAVE) amax = nanmax(amax, fabs(double(m3_after[gather ? gather[q] : q])));
+#pragma unroll
+    for (int k = 0; k < PER; ++k) amax = nanmax(amax, fabs(v[k]));
+    for (uint32_t q = s + lane_id() + uint32_t(PER) * WAVE; q < e; q += WAVE) amax = nanmax(amax, fabs(double(m3_after[gather ? gather[q] : q])));
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) amax = nanmax(amax, __shfl_xor(amax, d));
     const bool bad = !(amax < 1e300);
     const int fxk = fx_shift(amax, e - s);
     long long acc = 0;
-    if (amax > 0 && !bad) for (uint32_t q = s + lane_id(); q < e; q += WAVE) acc += to_fx(double(m3_after[gather ? gather[q] : q]), fxk);
+    if (amax > 0 && !bad) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) acc += to_fx(v[k], fxk);
+      for (uint32_t q = s + lane_id() + uint32_t(PER) * WAVE; q < e; q += WAVE) acc += to_fx(double(m3_after[gather ? gather[q] : q]), fxk);
+    }
 #pragma unroll
     for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d);
     after = bad ? T(NAN) : T(ldexp(double(acc), -fxk));
