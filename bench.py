@@ -188,6 +188,9 @@ def main():
     ap.add_argument("--cond-solver", choices=["lean", "toms748"], default="lean",
                     help="fast arithmetic only (opts_init.cond_solver): the lean bracketed secant, or the reference's TOMS748 iterates in "
                          "fast arithmetic (round 2's kernels)")
+    ap.add_argument("--stream-ordered", type=int, default=0, choices=[0, 1],
+                    help="opts_init.stream_ordered: with device arrays step_sync returns once its work is queued on the object's stream "
+                         "(the host queues step_async while condensation runs) instead of waiting for th and rv as the reference's does")
     ap.add_argument("--reorder-every", type=int, default=0,
                     help="opts_init.reorder_every: physical re-ordering of the super-droplet storage into the cell order every so "
                          "many steps (0 = the library default, every 64 steps -- 32 for slabs with neighbours -- and with every compaction; -1 = never, the reference's "
@@ -295,6 +298,7 @@ def main():
     oi.strict_fp = args.strict_fp
     oi.cond_solver = 1 if args.cond_solver == "toms748" else 0
     oi.reorder_every = args.reorder_every
+    oi.stream_ordered = bool(args.stream_ordered)
     for name in filter(None, args.dbg.split(",")):
         if name.strip().startswith("budget="):
             oi.dbg_cond_budget = int(name.split("=")[1])

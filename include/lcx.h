@@ -124,6 +124,11 @@ typedef struct {
                          * A re-ordering renumbers the ids: SDs keep their relative order inside a cell, the relative order of SDs of
                          * different cells and the id -> random-number association change (statistically equivalent).  An object
                          * that was ever fed a replayed random stream (lcx_rng_replay_push, i.e. a parity run) behaves like -1. */
+  int stream_ordered;   /* 0 (default): step_sync / step_cond return when th and rv have been written, as the reference's do.
+                         * 1: with DEVICE arrays (lcx_arrinfo_t.on_device) they return once the work is queued on the object's stream, like any
+                         *    GPU library call: th and rv are valid for work ordered behind lcx_stream() (an event wait on the caller's stream),
+                         *    the host does not wait -- it is already queueing step_async while condensation runs.  Calls that involve host
+                         *    arrays, and everything that hands data to the host (diag, outbuf, get_attr ...), synchronise as before. */
   /* --- test / measurement switches (no reference counterpart; all 0 in production).  They used to be LCX_* environment variables read
    * here and there in the library; a stray variable in a user's environment silently changed the kernel path.  Now they are part of the
    * options an object is created with, read once, and the library reads no environment variable but LCX_DATA_DIR (where the collision

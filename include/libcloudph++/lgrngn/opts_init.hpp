@@ -68,5 +68,6 @@ namespace libcloudphxx { namespace lgrngn {
     int n_x_bfr = 0, bcond_lft = 0, bcond_rgt = 0;
     unsigned dbg_flags = 0;    // test / measurement switches (lcx.h, enum lcx_dbg): all off in production
     int reorder_every = 0;     // storage re-ordering into the cell-sorted order: every N steps and with every compaction (0: N = 64), -1 never (lcx.h)
+    bool stream_ordered = false; // device arrays: step_sync returns once its work is queued on the object's stream (lcx.h)
   };
 } }

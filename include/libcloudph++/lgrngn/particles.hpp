@@ -140,7 +140,7 @@ namespace libcloudphxx { namespace lgrngn {
       c.dev_count = o.dev_count; c.dev_id = o.dev_id; c.rd_min = o.rd_min; c.rd_max = o.rd_max;
       c.no_ccn_at_init = o.no_ccn_at_init; c.open_side_walls = o.open_side_walls; c.periodic_topbot_walls = o.periodic_topbot_walls;
       c.src_type = int(o.src_type); c.th_dry = o.th_dry; c.const_p = o.const_p; c.diag_incloud_time = o.diag_incloud_time;
-      c.n_x_tot = n_x_tot; c.strict_fp = o.strict_fp; c.cond_solver = o.cond_solver; c.reorder_every = o.reorder_every;
+      c.n_x_tot = n_x_tot; c.strict_fp = o.strict_fp; c.cond_solver = o.cond_solver; c.reorder_every = o.reorder_every; c.stream_ordered = o.stream_ordered;
       c.dbg_flags = o.dbg_flags;
       c.n_x_bfr = o.n_x_bfr; c.bcond_lft = o.bcond_lft; c.bcond_rgt = o.bcond_rgt;
       // std::map iterates in (kappa, rd_insol) order, which is the order the library expects

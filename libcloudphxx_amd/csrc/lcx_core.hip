@@ -1785,8 +1785,10 @@ struct Particles : IParticles {
       { Range r(this, "sync_out"); sync_out_arr(th, th_, ncell); sync_out_arr(rv, rv_, ncell); flush_sync_jobs(); }
     }
     late_courants();               // (host rows and copies while the kernels queued above run)
+    // opts_init.stream_ordered: nothing of this call touches host memory -- the results are ordered on the stream, the host goes on
+    const bool no_wait = o.stream_ordered && out_jobs.empty() && !hstage_busy && (is_null(th_) || th_->on_device) && (is_null(rv_) || rv_->on_device);
     finish_sync_out();
-    sync();
+    if (!no_wait) sync();
     should_now_run_async = true;
     selected_before_counting = false;
   }

@@ -126,6 +126,7 @@ struct MultiParticles : IParticles {
         o.rng_seed = oi.rng_seed + i;
       }
       o.n_x_tot = oi.nx; o.n_x_bfr = bfr; o.dev_id = dev[i]; o.dev_count = D;
+      o.stream_ordered = 0;                     // (the slabs of this object are driven from worker threads that join per call)
       nx_loc[i] = o.nx; n_x_bfr[i] = bfr;
       HIPCHK(hipSetDevice(dev[i]));
       slab[i].reset(new Particles<T>(o));

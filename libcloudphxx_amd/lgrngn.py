@@ -162,7 +162,7 @@ class _opts_init_c(C.Structure):
         ("dry_distros", C.POINTER(_distro_c)), ("n_dry_distros", C.c_int),
         ("dry_sizes", C.POINTER(_dry_size_c)), ("n_dry_sizes", C.c_int),
         ("n_x_tot", C.c_int), ("n_x_bfr", C.c_int), ("bcond_lft", C.c_int), ("bcond_rgt", C.c_int),
-        ("strict_fp", C.c_int), ("cond_solver", C.c_int), ("reorder_every", C.c_int),
+        ("strict_fp", C.c_int), ("cond_solver", C.c_int), ("reorder_every", C.c_int), ("stream_ordered", C.c_int),
         ("dbg_flags", C.c_uint), ("dbg_cond_budget", C.c_int), ("dbg_pack_delay_us", C.c_int),
     ]
 
@@ -270,6 +270,7 @@ class opts_init_t:
         self.strict_fp = True
         self.cond_solver = 0          # fast arithmetic only: 0 lean bracketed secant, 1 the reference's TOMS748 iterates (include/lcx.h)
         self.reorder_every = 0
+        self.stream_ordered = False   # device arrays: step_sync returns once its work is queued on lcx_stream (include/lcx.h)
         # test / measurement switches (include/lcx.h, enum lcx_dbg): all off in production
         self.dbg_flags = 0
         self.dbg_cond_budget = 0

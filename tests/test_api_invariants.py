@@ -498,6 +498,39 @@ def test_host_arrays_through_the_staged_rows_equal_the_plain_host_loop(layout):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+def test_stream_ordered_step_sync_gives_the_same_run():
+    """opts_init.stream_ordered (extension): with DEVICE arrays step_sync returns once its work is queued on the object's stream -- the
+    caller orders its own stream behind lcx_stream() instead of the host waiting.  Same run bit for bit as the waiting form: th and rv
+    read after a device synchronisation, the droplets through get_attr (which synchronises by itself); a call with HOST arrays waits
+    whatever the option says."""
+    import torch
+    oi = h.box_opts(16, 12, 20, 16, strict_fp=False)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = []
+    for so in (False, True):
+        oi.stream_ordered = so
+        t = {k: torch.tensor(v, device="cuda") for k, v in dict(th=th, rv=rv, rhod=rhod, **C).items()}
+        torch.cuda.synchronize()
+        d = {k: lgrngn.DeviceArray(v.data_ptr(), v.shape) for k, v in t.items()}
+        pr = h.hip_particles(oi)
+        pr.init(d["th"], d["rv"], d["rhod"], Cx=d["Cx"], Cy=d["Cy"], Cz=d["Cz"])
+        opts = lgrngn.opts_t()
+        for _ in range(4):
+            pr.step_sync(opts, d["th"], d["rv"], d["rhod"], Cx=d["Cx"], Cy=d["Cy"], Cz=d["Cz"])
+            pr.step_async(opts)
+        torch.cuda.synchronize()
+        res.append((t["th"].cpu().numpy(), t["rv"].cpu().numpy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.state_u64("n")))
+        if so:                                       # host arrays through the same object: the call waits, the arrays are written on return
+            th_h, rv_h = res[-1][0].copy(), res[-1][1].copy()
+            pr.step_sync(opts, th_h, rv_h, rhod, **C)
+            assert not np.array_equal(th_h, res[-1][0])
+            pr.step_async(opts)
+    assert not np.array_equal(res[0][0], th)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("make,alloc", [pytest.param(h.oracle_particles, h.host_alloc, id="oracle"),
                                         pytest.param(h.hip_particles, h.dev_alloc, id="hip", marks=pytest.mark.gpu)])
 def test_slabs_indexing_the_global_arrays(make, alloc):
