@@ -160,6 +160,9 @@ enum lcx_dbg {
   LCX_DBG_COND_LEAN_R3 = 1 << 13,      /* k_cond_lean with round 3's form of the solver's bookkeeping and helper functions (the same rw2 bit for bit) */
   LCX_DBG_FINISH_STAGED = 1 << 16,     /* fast arithmetic: the per-cell finish through its LDS stage (k_cond_cellfinish) also where the changes lie in
                                         * the sorted order and k_cond_cellfinish_direct would read them straight from memory */
+  LCX_DBG_NO_RANK_OVERLAP = 1 << 17,   /* the in-cell ranking of a carried re-sort on the object's one stream, not next to the per-cell finish and
+                                        * the terminal velocities on a stream of its own */
+  LCX_DBG_RANK_BY_COUNTING = 1 << 18,  /* the in-cell shuffled order ranked by counting smaller keys (k_cellrank<uint32_t, true>) instead of by buckets */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };
@@ -273,7 +276,9 @@ int lcx_get_state_u64(lcx_particles *, const char *name, unsigned long long *out
  * reals) return the STORAGE as it is -- its whole extent, dead slots (n == 0) included, nothing compacted or sorted on the way: reading
  * them does not disturb a production run, whereas every other particle-state getter first puts the storage into the reference's order.
  * "raw_collided" (u64, one value): living super-droplets that carry coalescence's invalid terminal velocity, i.e. the number of pairs that
- * collided in the last lcx_step_async (bench.py's coal-stress workload reports it). */
+ * collided in the last lcx_step_async (bench.py's coal-stress workload reports it).  "raw_sorted_id" (u64): the cell-sorted order as the
+ * last sort left it -- after a step_sync with condensation, the shuffled order that the step's coalescence will pair up (an error while
+ * the re-sort is still deferred). */
 int lcx_get_state_real(lcx_particles *, const char *name, double *out, size_t cap, size_t *n);
 /* overwrite particle state (all arrays of length n; x/y/z may be NULL for absent dimensions);
  * lets a test start the device from an oracle state */

@@ -194,8 +194,15 @@ struct Particles : IParticles {
   // planes) below a fixed headroom, instead of moving the interior's entries once that number is known: sort_base = headroom - shift.
   size_t sort_base = 0, sort_headroom = 0;
   DevBuf<uint32_t> sorted_alt;          // (exchange only) the in-cell ranking's output while `rank` still holds the boundary SDs' arrival ranks
-  uint32_t *sid() const { return sorted_id.p + sort_base; }
-  uint32_t *sijk() const { return sorted_ijk.p + sort_base; }
+  // The in-cell ranking of a carried re-sort runs on a stream of its own (st_rank) next to what follows the condensation kernel on `st`:
+  // the per-cell finish, sync_out and, across the step boundary, the terminal velocities.  Those are bound by memory, the ranking by
+  // integer instructions and LDS, and none of them reads the sorted order.  Whoever does -- every user of sid() / sijk() / rnk(), the
+  // scan that rewrites cell_start, a host synchronisation -- makes `st` wait for the ranking first (join_rank): ordered by construction.
+  hipStream_t st_rank = nullptr; hipEvent_t ev_fork = nullptr, ev_rank = nullptr; mutable bool rank_pending = false;
+  void join_rank() const { if (rank_pending) { rank_pending = false; HIPCHK(hipStreamWaitEvent(st, ev_rank, 0)); } }
+  uint32_t *sid() const { join_rank(); return sorted_id.p + sort_base; }
+  uint32_t *sijk() const { join_rank(); return sorted_ijk.p + sort_base; }
+  uint32_t *rnk() const { join_rank(); return rank.p; }
   DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig;
   const bool use_wave_flags = !dbg(LCX_DBG_NO_WAVE_FLAGS);
   void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
@@ -307,6 +314,7 @@ struct Particles : IParticles {
   }
   ~Particles() override
   {
+    if (st_rank) { (void)hipStreamSynchronize(st_rank); (void)hipStreamDestroy(st_rank); (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_rank); }
     if (st) (void)hipStreamSynchronize(st);
     for (auto &e : prof_events) { (void)hipEventDestroy(e.second.first); (void)hipEventDestroy(e.second.second); }
     for (hipEvent_t e : prof_pool) (void)hipEventDestroy(e);
@@ -346,7 +354,9 @@ struct Particles : IParticles {
     for (int e = 0; e < n_ext; ++e) s.ext[e] = a.ext[e].p;
     return s;
   }
-  void sync() { HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
+  void sync() { join_rank(); HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
+  // the end of step_cond: th and rv are written on `st`; a ranking on st_rank goes on while the host queues step_async
+  void sync_results_only() { HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
 
   // ---- profiling ranges (hipEvents on OUR stream) ----
   // profiling: 0 off; 1 every stage; 2 the condensation kernel's stage only -- two event records per step instead of fifty: every record
@@ -394,6 +404,7 @@ struct Particles : IParticles {
   void exclusive_scan(const uint32_t *in, uint32_t *out, size_t m, uint32_t *out_last, uint32_t *zero_in = nullptr, uint32_t *zero_words = nullptr,
                       int n_zero_words = 0, uint32_t *total_slot = nullptr)
   {
+    join_rank();                       // (cell_start, which a ranking on st_rank may still be reading)
     uint32_t *total = total_slot ? total_slot : scan_total.p;
     const size_t tiles = (m + SCAN_TILE - 1) / SCAN_TILE;
     if (tiles == 0) { if (out_last) HIPCHK(hipMemsetAsync(out_last, 0, sizeof(uint32_t), st)); HIPCHK(hipMemsetAsync(total, 0, sizeof(uint32_t), st)); return; }
@@ -723,7 +734,7 @@ struct Particles : IParticles {
     if (do_hist) HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
     if (nphys)
       hipLaunchKernelGGL(k_ijk_hist<T>, dim3(nblk(nphys)), dim3(BS), 0, st, size_t(0), nphys, g, A.n.p, A.x.p, A.y.p, A.z.p, ijk.p,
-                         do_hist ? cell_cnt.p : nullptr, rank.p, do_ijk);
+                         do_hist ? cell_cnt.p : nullptr, rnk(), do_ijk);
   }
   void hskpng_ijk() { Range r(this, "hskpng_ijk"); ijk_and_hist(2, false); sorted = false; sort_deferred = false; }   // (a sort left undone is void)
   // finish a sort given cell_cnt/rank: scan -> scatter -> per-cell order
@@ -749,7 +760,7 @@ struct Particles : IParticles {
       return;
     }
     if (nphys)
-      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid(), sijk());
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rnk(), cell_start.p, sid(), sijk());
     order_cells(shuffle);
   }
   // scattered == false: nobody has carried the scatter
@@ -759,7 +770,7 @@ struct Particles : IParticles {
     sort_deferred = false;
     Range r(this, "post_copy");
     if (!scattered && nphys)
-      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid(), sijk());
+      hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rnk(), cell_start.p, sid(), sijk());
     order_cells(deferred_shuffle, &deferred_rs);
     shuffle_fresh = deferred_shuffle;
   }
@@ -782,9 +793,10 @@ struct Particles : IParticles {
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
-        if (shuffle && !rs.un && !crowded && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
-        else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
-        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rank.p + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        if (shuffle && !rs.un && !crowded && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING)) hipLaunchKernelGGL(k_cellrank_bkt<>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, rank_range{nullptr, nullptr, nullptr});
+        else if (shuffle && !rs.un && !crowded && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
+        else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
           uint32_t m2[2];
@@ -960,7 +972,7 @@ struct Particles : IParticles {
     if (dead && (force_compact || eager_compact || dead * 32 > nphys)) {
       if (!B.n.p) alloc_attrs(B);
       HIPCHK(hipMemsetAsync(cell_cnt.p, 0, ncell * sizeof(uint32_t), st));
-      hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, nphys, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rank.p);
+      hipLaunchKernelGGL(k_compact<T>, dim3(unsigned(tiles)), dim3(BS), 0, st, nphys, aset(A), aset(B), tile_sums.p, g, ijk.p, cell_cnt.p, rnk());
       swap_attr_sets();
       nphys = alive;
     } else ijk_and_hist(1, true);                    // re-index in place (dead SDs get DEAD_CELL)
@@ -1023,7 +1035,7 @@ struct Particles : IParticles {
     if (!npart) return;
     Range r(this, "reorder_storage");
     if (!B.n.p) alloc_attrs(B);
-    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rank.p);
+    hipLaunchKernelGGL(k_reorder<T>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sid(), sijk(), aset(A), aset(B), g, rnk());
     swap_attr_sets();
     ijk.swap(rank);
     hipLaunchKernelGGL(k_iota, dim3(nblk(npart)), dim3(BS), 0, st, sid(), npart);
@@ -1104,7 +1116,7 @@ struct Particles : IParticles {
         cond_in_storage_order = cond_storage_order;
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
-          if (carry_scatter) { a.sc_rank = rank.p; a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
+          if (carry_scatter) { a.sc_rank = rnk(); a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
           // (one hygroscopicity in the whole run: a scalar instead of 8 B per droplet, see kpa_uniform)
           const dim3 gs(nblk(nphys));
           if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
@@ -1124,7 +1136,7 @@ struct Particles : IParticles {
         // opts_init.dbg_cond_budget: test / measurement switch (the parity tests force the two-pass form at their small sizes with it)
         const int budget = o.dbg_cond_budget > 0 ? o.dbg_cond_budget : o.dbg_cond_budget < 0 ? 0 : (npart >= (size_t(1) << 25) ? 6 : 0);
         // (`rank` is free between the sorts; part s holds at most the positions of the workgroups b with b % DEFER_SHARDS == s)
-        cond_defer df{rank.p, defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
+        cond_defer df{rnk(), defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
         const bool fold = !dbg(LCX_DBG_COND_NO_FOLD);                             // (test / measurement switch)
         if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 3>), gr, bl, 0, st, npart, a, df);
@@ -1137,7 +1149,22 @@ struct Particles : IParticles {
       else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
       else hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a);
     }
-    if (carry_scatter) finish_deferred_sort(true);           // the in-cell ranking, behind the kernel that scattered
+    if (carry_scatter) {                                      // the in-cell ranking, behind the kernel that scattered
+      // (on its own stream when the list of crowded cells is on the host already, i.e. nothing in it waits for the device)
+      if (!dbg(LCX_DBG_NO_RANK_OVERLAP) && meta_version == cells_version) {
+        if (!st_rank) {
+          HIPCHK(hipStreamCreateWithFlags(&st_rank, hipStreamNonBlocking));
+          HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_rank, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(st_rank, ev_fork, 0));
+        std::swap(st, st_rank);
+        finish_deferred_sort(true);
+        HIPCHK(hipEventRecord(ev_rank, st));
+        std::swap(st, st_rank);
+        rank_pending = true;
+      } else finish_deferred_sort(true);
+    }
     {
       Range r(this, "cond_cellfinish");
       // (a kernel that carried the scatter has left each droplet's change at the droplet's place in the sorted order: no gather)
@@ -1327,7 +1354,7 @@ struct Particles : IParticles {
     a.puddle_partial = want_puddle ? puddle_partial.p : nullptr;
     a.mig = mig.p; a.wg_mig = (do_bcnd && distmem()) ? wg_mig.p : nullptr;
     // (no memsets: every lane stores its migrant flag, and the histogram and the dead count are cleared behind each sort's scan)
-    a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rank.p; a.dead_count = d_dead_p();
+    a.reindex = reindex; a.ijk_out = ijk.p; a.cnt = cell_cnt.p; a.rank = rnk(); a.dead_count = d_dead_p();
     a.check_n = !coal_marks_dead || zero_n_unmarked;
     if (reindex) zero_n_unmarked = false;
     const bool pc = adve_scheme == LCX_ADVE_PRED_CORR, tb = a.up != nullptr;
@@ -1788,7 +1815,7 @@ struct Particles : IParticles {
     // opts_init.stream_ordered: nothing of this call touches host memory -- the results are ordered on the stream, the host goes on
     const bool no_wait = o.stream_ordered && out_jobs.empty() && !hstage_busy && (is_null(th_) || th_->on_device) && (is_null(rv_) || rv_->on_device);
     finish_sync_out();
-    if (!no_wait) sync();
+    if (!no_wait) sync_results_only();
     should_now_run_async = true;
     selected_before_counting = false;
   }
@@ -1975,6 +2002,10 @@ struct Particles : IParticles {
     }
     else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
+    else if (s == "raw_sorted_id") {               // the cell-sorted order as the last sort left it (the shuffled order of the next coalescence, mostly)
+      if (sort_deferred || !sorted) throw lcx_error("raw_sorted_id: the re-sort of the last step has not been finished yet");
+      auto h = d2h(sid(), npart); v.assign(h.begin(), h.end());
+    }
     else if (s == "n") { auto h = d2h(A.n.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "ijk") { auto h = d2h(ijk.p, npart); v.assign(h.begin(), h.end()); }
     else if (s == "sorted_id") {
@@ -2119,7 +2150,7 @@ struct Particles : IParticles {
     const n_t *nb = (const n_t *)buf; const T *rb = (const T *)((const n_t *)buf + cnt);
     hipLaunchKernelGGL(k_unpack<T>, dim3(nblk(cnt)), dim3(BS), 0, st, cnt, nphys, aset(A), g, nb, rb, T(o.x0), T(o.x1), T(5e-4),
                        mig_ids[0].p, uint32_t(free_n[0]), mig_ids[1].p, uint32_t(free_n[1]), uint32_t(free_used),
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p);
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rnk());
     free_used += reuse; reused_total += reuse;
     nphys += cnt - reuse;
     sync();
@@ -2178,6 +2209,7 @@ struct Particles : IParticles {
     // headroom in front of the sorted order (see sort_base): as many entries as a message can bring.  `rank` and `ijk` trade places
     // with the sorted arrays now and then (order_cells, reorder_storage), so all of them get it; nothing is stored in them yet
     sort_headroom = inbox_cap_rec;
+    sync();
     for (DevBuf<uint32_t> *b : {&ijk, &sorted_id, &sorted_ijk, &rank, &sorted_alt}) { b->release(); b->alloc(cap + sort_headroom); }
     sync();
   }
@@ -2221,9 +2253,10 @@ struct Particles : IParticles {
     // step's counters
     exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, nullptr, nullptr, 0, scan_total.p + 3);      // (scan_total[0..1]: the emigrant counts)
     ++cells_version;
+    join_rank();
     uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
     if (use_wave_flags && !wave_flag.p) wave_flag.alloc_zero(cap / WAVE + 64, st);
-    hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
+    hipLaunchKernelGGL(k_scatter_sorted, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, rnk(), cell_start.p, sid_h, sijk_h,
                        sort_part{ov_c_lo, ov_c_hi, 1, nullptr, nullptr}, use_wave_flags ? wave_flag.p : (uint8_t *)nullptr);
     overlap_rs = rng_src{nullptr, 0, 0, 0u, 0u};
     if (overlap_preshuffle) overlap_rs = rand_un(nphys);
@@ -2232,6 +2265,7 @@ struct Particles : IParticles {
   size_t bnd_pop_hint = 0;
   void rank_boundary(unsigned blocks)
   {
+    join_rank();
     uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom, *alt_h = sorted_alt.p + sort_headroom;
     const uint32_t *shift = xcnt.p + 17;
     launch_cellrank_range(overlap_preshuffle, overlap_rs, sijk_h, sid_h, alt_h, rank_range{xcnt.p + 19 /* = 0 */, cell_start.p + ov_c_lo, shift}, blocks);
@@ -2240,7 +2274,8 @@ struct Particles : IParticles {
   void launch_cellrank_range(bool shuffle, const rng_src &rs, const uint32_t *sijk_p, const uint32_t *in, uint32_t *out, const rank_range &rg, unsigned blocks)
   {
     const int crowded = 0;       // (cells above CELLRANK_MAX keep their arrival order here and are sorted from the list, as everywhere)
-    if (shuffle && !rs.un && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
+    if (shuffle && !rs.un && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING)) hipLaunchKernelGGL(k_cellrank_bkt<>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, rg);
+    else if (shuffle && !rs.un && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
     else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
     else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(blocks), dim3(BS), 0, st, size_t(0), sijk_p, cell_start.p, in, out, rs, crowded, rg);
   }
@@ -2276,7 +2311,7 @@ struct Particles : IParticles {
     if (ov && retry) hipLaunchKernelGGL(k_csr_to_counts, dim3(nblk(ncell)), dim3(BS), 0, st, cell_start.p, cell_cnt.p, ncell);
     hipLaunchKernelGGL(k_unpack_dev<T>, dim3(nblk(2 * inbox_cap_rec)), dim3(BS), 0, st, in_l, in_r, have_l, have_r,
                        nphys, cap, aset(A), g, T(o.x0), T(o.x1), T(5e-4), mig_ids[0].p, mig_ids[1].p, n_free,
-                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rank.p, xcnt.p + 16, int(ov), ov_c_lo, ov_c_hi, big_meta_p(), xcnt.p + 22, int(retry),
+                       ijk.p, fused_pending ? cell_cnt.p : nullptr, rnk(), xcnt.p + 16, int(ov), ov_c_lo, ov_c_hi, big_meta_p(), xcnt.p + 22, int(retry),
                        (ov && use_wave_flags) ? wave_flag.p : (uint8_t *)nullptr);
     if (ov) {
       const uint32_t *shift = xcnt.p + 17, *extent = xcnt.p + 18;
@@ -2286,12 +2321,13 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell - ov_c_hi)), dim3(BS), 0, st, ncell, (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p,
                          big_meta_p(), big_meta_p() + 1, (const uint32_t *)cell_cnt.p, ov_c_hi);
       exclusive_scan(cell_cnt.p, cell_start.p, ncell, cell_start.p + ncell, cell_cnt.p, nullptr, 0, scan_total.p + 3);
+      join_rank();
       uint32_t *sid_h = sorted_id.p + sort_headroom, *sijk_h = sorted_ijk.p + sort_headroom;
       if (use_wave_flags)
-        hipLaunchKernelGGL(k_scatter_flagged, dim3(nblk((ext_max + 16 * WAVE - 1) / (16 * WAVE), BS / WAVE)), dim3(BS), 0, st, ext_max, wave_flag.p, ijk.p, rank.p,
+        hipLaunchKernelGGL(k_scatter_flagged, dim3(nblk((ext_max + 16 * WAVE - 1) / (16 * WAVE), BS / WAVE)), dim3(BS), 0, st, ext_max, wave_flag.p, ijk.p, rnk(),
                            cell_start.p, sid_h, sijk_h, sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
       else
-        hipLaunchKernelGGL(k_scatter_outside4, dim3(nblk((ext_max + 3) / 4)), dim3(BS), 0, st, ext_max, ijk.p, rank.p, cell_start.p, sid_h, sijk_h,
+        hipLaunchKernelGGL(k_scatter_outside4, dim3(nblk((ext_max + 3) / 4)), dim3(BS), 0, st, ext_max, ijk.p, rnk(), cell_start.p, sid_h, sijk_h,
                            sort_part{ov_c_lo, ov_c_hi, 2, extent, shift});
       rank_boundary(bnd_blocks);
     }

@@ -503,6 +503,109 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
   }
   out[s + rank] = id;
 }
+// Round 4: the shuffled order on the device generator's 32-bit keys, ranked by BUCKETS instead of by counting.  A key's bucket is its
+// expected rank in its cell, (key x count) >> 32 -- the keys are uniform, so a bucket holds one key on average.  The buckets of a cell are
+// as many as its droplets and lie where the cell's positions lie, so ONE prefix sum over the workgroup's staged range turns the bucket
+// counts into final positions: a key goes to (first position of its bucket) + (keys of its bucket that are smaller), the latter found by
+// comparing with the one to four keys that share the bucket instead of with all 64 of the cell.  ~110 vector instructions per wave
+// where the counting form (k_cellrank) has 285, five barriers where it has two -- which is why round 3 dropped it when the kernel ran
+// alone and was bound by its waits; now it runs next to the per-cell finish and the terminal velocities (Particles::st_rank), whose waves
+// fill the barriers, and the vector ALU is what the three share.  Same order as k_cellrank<uint32_t, true> (the keys are unique).
+// A workgroup whose first or last cell reaches beyond the speculative window, or whose staged range exceeds the stage, ranks by counting.
+template <bool DUMMY = true>
+__global__ void __launch_bounds__(BS)
+k_cellrank_bkt(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r,
+               rank_range rg = rank_range{nullptr, nullptr, nullptr})
+{
+  using KEY = uint32_t;
+  constexpr int CAP = cr_cap<KEY>;
+  static_assert(CAP == 4 * BS, "four counters per lane in the scan");
+  __shared__ KEY lds[CAP];                 // the keys grouped by bucket (counting fallback: by position)
+  __shared__ uint32_t bkt[CAP];            // bucket counts, then their exclusive prefix sums
+  __shared__ uint32_t bounds[4];
+  __shared__ uint32_t wsum[BS / WAVE];
+  size_t r_lo = 0;
+  if (rg.lo) { r_lo = *rg.lo; n = *rg.hi; }
+  if (rg.shift) { const uint32_t sh = *rg.shift; in -= sh; out -= sh; sorted_ijk -= sh; }
+  const size_t p0 = r_lo + size_t(blockIdx.x) * BS;
+  if (p0 >= n) return;
+  const size_t plast = (p0 + BS < n ? p0 + BS : n) - 1;
+  const size_t p = p0 + threadIdx.x;
+  const bool active = p < n;
+  uint32_t c = 0, s = 0, e = 0, id = 0;
+  constexpr int SPEC = BS / 2;             // (see k_cellrank)
+  const size_t pe = threadIdx.x < SPEC ? p0 - SPEC + threadIdx.x : p0 + BS + (threadIdx.x - SPEC);
+  const bool have_e = (threadIdx.x < SPEC ? p0 >= r_lo + (size_t(SPEC) - threadIdx.x) : true) && pe < n;
+  uint32_t id_e = 0;
+  if (have_e) id_e = in[pe];
+  if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
+#pragma unroll
+  for (int k = 0; k < CAP / BS; ++k) bkt[threadIdx.x + k * BS] = 0u;
+  const KEY mine = active ? shuffle_un(id, r.s1, r.s2) : KEY(0);
+  const KEY key_e = have_e ? shuffle_un(id_e, r.s1, r.s2) : KEY(0);
+  if (threadIdx.x == 0) { bounds[0] = s; bounds[2] = e; }
+  if (p == plast) { bounds[1] = e; bounds[3] = s; }
+  __syncthreads();
+  const uint32_t lo = bounds[0], hi = bounds[1], e_first = bounds[2], s_last = bounds[3];
+  const uint32_t m = hi - lo;
+  const uint32_t cnt = e - s;
+  const bool by_buckets = m <= uint32_t(CAP) && size_t(lo) + SPEC >= p0 && size_t(hi) <= p0 + BS + SPEC;
+  if (by_buckets) {
+    uint32_t bi = 0, slot = 0, bi_e = 0, slot_e = 0;
+    const bool ins_e = have_e && pe >= lo && pe < hi;
+    if (active) { bi = (s - lo) + __umulhi(mine, cnt); slot = atomicAdd(&bkt[bi], 1u); }
+    if (ins_e) {
+      const uint32_t se = pe < p0 ? lo : s_last, ee = pe < p0 ? e_first : hi;
+      bi_e = (se - lo) + __umulhi(key_e, ee - se); slot_e = atomicAdd(&bkt[bi_e], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum of the m counters, four per lane
+    uint32_t v[4], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = bkt[4 * threadIdx.x + k]; tsum += v[k]; }     // (counters behind m are zero)
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane_id()) >= d) incl += t; }
+    if (lane_id() == WAVE - 1) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t run = incl - tsum;
+#pragma unroll
+    for (int w = 0; w < BS / WAVE; ++w) if (w < int(wave_id())) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bkt[4 * threadIdx.x + k] = run; run += v[k]; }
+    __syncthreads();
+    if (active) lds[bkt[bi] + slot] = mine;
+    if (ins_e) lds[bkt[bi_e] + slot_e] = key_e;
+    __syncthreads();
+    if (!active) return;
+    if (cnt > uint32_t(cellrank_max<KEY>)) { out[p] = id; return; }      // listed by k_list_big_cells, sorted by a bitonic network
+    const uint32_t b0 = bkt[bi], b1 = bi + 1 < m ? bkt[bi + 1] : m;
+    uint32_t rank = b0;
+    for (uint32_t q = b0; q < b1; ++q) rank += lds[q] < mine;
+    out[lo + rank] = id;
+    return;
+  }
+  // counting, as k_cellrank
+  const bool staged = m <= uint32_t(CAP);
+  if (staged) {
+    if (active) lds[p - lo] = mine;
+    if (have_e && pe >= lo && pe < hi) lds[pe - lo] = key_e;
+    if (p0 >= r_lo + size_t(SPEC))
+      for (size_t q = size_t(lo) + threadIdx.x; q < p0 - SPEC; q += BS) lds[q - lo] = shuffle_un(in[q], r.s1, r.s2);
+    for (size_t q = p0 + BS + SPEC + threadIdx.x; q < hi; q += BS) lds[q - lo] = shuffle_un(in[q], r.s1, r.s2);
+  }
+  __syncthreads();
+  if (!active) return;
+  if (cnt > uint32_t(cellrank_max<KEY>)) { out[p] = id; return; }
+  uint32_t rank = 0;
+  if (staged) {
+    const KEY *seg = lds + (s - lo);
+    for (uint32_t q = 0; q < cnt; ++q) rank += seg[q] < mine;
+  } else {
+    for (uint32_t q = s; q < e; ++q) rank += shuffle_un(in[q], r.s1, r.s2) < mine;
+  }
+  out[s + rank] = id;
+}
 // the cells with more than `thr` SDs: wave-aggregated append (one atomic per wave of 64 cells, not one per cell -- with
 // 512 SDs in every cell a per-cell atomicAdd on one counter cost more than the sort itself)
 // counts != nullptr: straight from the cell histogram (before the scan: the fused move has just produced it), else from the CSR offsets

@@ -106,6 +106,8 @@ class dbg(enum.IntFlag):
     EXCH_SORT_NOW = 1 << 14
     COND_TOMS_TWO_PASS = 1 << 15
     FINISH_STAGED = 1 << 16
+    NO_RANK_OVERLAP = 1 << 17
+    RANK_BY_COUNTING = 1 << 18
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -100,7 +100,7 @@ def test_migration_carries_perparticle_state():
         orc.step(opts, *a, **C)
         hip.step(opts, *b, **C)
         np.testing.assert_allclose(b[0], a[0], rtol=1e-7)
-        np.testing.assert_allclose(b[1], a[1], rtol=1e-6)
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-7)
         for r, (po, ph) in enumerate(zip(orc.prts, hip.prts)):
             assert ph.n_part == po.n_part, (it, r)
             for nm in ("n", "ijk", "sorted_id"):

@@ -67,7 +67,7 @@ def test_multi_device_object_matches_oracle_ring(dims, size, monkeypatch):
         for r, (po, ph) in enumerate(zip(orc.prts, slabs)):
             np.testing.assert_allclose(ph.get_attr("rw2"), po.get_attr("rw2"), rtol=2e-4)
         np.testing.assert_allclose(thm, tho, rtol=1e-7)          # each slab wrote its planes of the global arrays
-        np.testing.assert_allclose(rvm, rvo, rtol=1e-6)
+        np.testing.assert_allclose(rvm, rvo, rtol=1e-7)
     assert mul.n_part == sum(p.n_part for p in orc.prts)
     # outbuf() is the global field (particles_multi_gpu_diag.ipp:274-307)
     mul.diag_all(); mul.diag_sd_conc()

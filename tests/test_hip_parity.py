@@ -285,7 +285,7 @@ def test_perparticle_cond_step(mode, strict_fp):
         np.testing.assert_allclose(rh, ro, rtol=2e-4)
         assert np.median(np.abs(rh / ro - 1)) < 2e-9      # no state copy between the steps here: 12 substeps of drift
         np.testing.assert_allclose(thh, tho, rtol=1e-7)
-        np.testing.assert_allclose(rvh, rvo, rtol=1e-6)
+        np.testing.assert_allclose(rvh, rvo, rtol=1e-7)
         for nm in ("sstp_tmp_rv", "sstp_tmp_th", "sstp_tmp_rh"):
             np.testing.assert_allclose(hip.state_real(nm), orc.state_real(nm), rtol=1e-6, err_msg=nm)
         if mode == "adaptive_act":
@@ -872,6 +872,37 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
         res.append((hip.get_attr("rw2"), thh, rvh))
     assert np.array_equal(res[0][0], res[1][0])
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize("sd_conc,dims", [(3, (9, 7, 11)), (64, (6, 5, 7)), (100, (6, 5, 7)), (150, (5, 4, 6)), (230, (4, 4, 5)), (64, (40, 0, 30))])
+@pytest.mark.parametrize("flags", [0, "NO_RANK_OVERLAP", "NO_DEFERRED_SORT"])
+def test_in_cell_order_by_buckets_is_the_order_by_counting(sd_conc, dims, flags):
+    """k_cellrank_bkt (round 4: a key's bucket is its expected rank in its cell, one prefix sum over the workgroup's staged range, compares
+    within the bucket only) against k_cellrank<uint32_t, true> (dbg_flags & RANK_BY_COUNTING: every key compared with every key of its cell):
+    the keys are unique, so both give THE order -- sorted_id after every step's coalescence and everything that follows from it, bit for bit.
+    Few droplets per cell (hundreds of cells per workgroup), the production 64, cells that straddle workgroups with more than the
+    speculative window covers (150, 230: the counting fallback inside the kernel), a 2-D box; with the ranking on its side stream (the
+    default), on the object's one stream, and without the deferred re-sort."""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, sd_conc, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for counting in (False, True):
+        oi.dbg_flags = int((lgrngn.dbg[flags] if flags else 0) | (lgrngn.dbg.RANK_BY_COUNTING if counting else 0))
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        out = []
+        for _ in range(4):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            out.append(hip.state_u64("raw_sorted_id"))          # (the order the step's coalescence will pair up)
+            hip.step_async(opts)
+        res.append(out + [hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.get_attr("x")])
+    assert not np.array_equal(res[0][1], res[0][2])            # (a fresh shuffle every step)
+    for a_, b_ in zip(res[0], res[1]):
+        assert np.array_equal(a_, b_)
 
 
 @pytest.mark.parametrize("sd_conc,steps", [(64, 6), (100, 4), (400, 3)])
