@@ -638,6 +638,9 @@ def main():
             # `cond` from the timed region; the other stages from args.stage_steps extra steps (scaled to the same per-step unit)
             "stage_ms_per_step": {k: (v / args.steps if k != "rendezvous_hidden_share" else v) for k, v in stage_ms.items()},
             "stage_pass_steps": 0 if args.no_stage_timers else args.stage_steps,
+            # (the stage pass times the stages ONE AFTER THE OTHER.  In the timed region the in-cell ranking -- most of post_copy -- runs on a
+            # stream of its own next to cond_cellfinish, sync_out, hskpng_Tpr and hskpng_vterm_all, so the stages add up to more than ms_per_step)
+            "stage_note": "stages timed serially by the stage pass; in the timed region post_copy's in-cell ranking overlaps cond_cellfinish .. hskpng_vterm_all",
             "stage_roofline": stage_roof,
         }
         if spmd or native_multi:

@@ -306,6 +306,8 @@ int lcx_set_state_real(lcx_particles *, const char *name, const double *data, si
 int lcx_stage(lcx_particles *, const char *stage, const lcx_opts_t *opts);
 /* per-stage device time of the last step in ms: fills names/values up to cap, returns count in *n */
 int lcx_timings(lcx_particles *, const char **names, double *ms, size_t cap, size_t *n);
+/* on: 0 off; 1 every stage (the stages then run one after the other: the in-cell ranking, which otherwise runs on a stream of its own
+ * next to the per-cell finish and the terminal velocities, stays on the object's stream); 2 the condensation kernel's stage only */
 int lcx_set_profiling(lcx_particles *, int on);
 
 /* ---- 1-D domain decomposition (replaces impl_multi_gpu/..._step_async_and_copy.ipp:28-206 and

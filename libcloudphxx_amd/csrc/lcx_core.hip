@@ -1151,7 +1151,8 @@ struct Particles : IParticles {
     }
     if (carry_scatter) {                                      // the in-cell ranking, behind the kernel that scattered
       // (on its own stream when the list of crowded cells is on the host already, i.e. nothing in it waits for the device)
-      if (!dbg(LCX_DBG_NO_RANK_OVERLAP) && meta_version == cells_version) {
+      // (not while every stage is being timed, lcx_set_profiling(1): the stage table is of stages that run one after the other)
+      if (!dbg(LCX_DBG_NO_RANK_OVERLAP) && profiling != 1 && meta_version == cells_version) {
         if (!st_rank) {
           HIPCHK(hipStreamCreateWithFlags(&st_rank, hipStreamNonBlocking));
           HIPCHK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_rank, hipEventDisableTiming));
