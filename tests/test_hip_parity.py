@@ -905,6 +905,37 @@ def test_in_cell_order_by_buckets_is_the_order_by_counting(sd_conc, dims, flags)
         assert np.array_equal(a_, b_)
 
 
+def test_in_cell_order_by_buckets_with_a_few_crowded_cells():
+    """The bucket ranking in a box whose MEAN occupancy keeps it on (64 per cell) while single cells are crowded: 184 droplets in one cell
+    (more than the speculative window of a neighbouring workgroup covers: that workgroup ranks by counting inside the same kernel) and
+    394 in another (above k_cellrank's limit: listed, sorted by one wave) -- the same order as ranking everything by counting."""
+    oi = h.box_opts(6, 5, 7, 64, strict_fp=False)
+    fields = h.box_fields(oi)
+    res = []
+    for counting in (False, True):
+        oi.dbg_flags = int(lgrngn.dbg.RANK_BY_COUNTING) if counting else 0
+        hip = h.hip_particles(oi)
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        x, y, z = hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z")
+        for sl, cell in ((slice(1000, 1120), (1, 1, 1)), (slice(5000, 5330), (3, 2, 4))):
+            x[sl], y[sl], z[sl] = (cell[0] + .5) * oi.dx, (cell[1] + .5) * oi.dy, (cell[2] + .5) * oi.dz
+        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), hip.get_attr("rw2"), hip.get_attr("kappa"), hip.state_real("vt"), x, y, z)
+        opts = lgrngn.opts_t()
+        opts.adve = opts.sedi = False                      # (the crowd stays together)
+        thh, rvh = th.copy(), rv.copy()
+        out = []
+        for _ in range(3):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            out.append(hip.state_u64("raw_sorted_id"))
+            hip.step_async(opts)
+        cnt = np.diff(hip.state_u64("cell_start").astype(np.int64))
+        assert cnt.max() > 300 and ((cnt > 150) & (cnt <= 256)).any()
+        res.append(out + [hip.get_attr("rw2"), hip.state_u64("n")])
+    for a_, b_ in zip(res[0], res[1]):
+        assert np.array_equal(a_, b_)
+
+
 @pytest.mark.parametrize("sd_conc,steps", [(64, 6), (100, 4), (400, 3)])
 def test_per_cell_finish_without_its_lds_stage_gives_the_same_bits(sd_conc, steps):
     """k_cond_cellfinish_direct (round 4: the changes lie in the sorted order, eight lanes per cell read them straight from memory, the
