@@ -507,8 +507,8 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
 // expected rank in its cell, (key x count) >> 32 -- the keys are uniform, so a bucket holds one key on average.  The buckets of a cell are
 // as many as its droplets and lie where the cell's positions lie, so ONE prefix sum over the workgroup's staged range turns the bucket
 // counts into final positions: a key goes to (first position of its bucket) + (keys of its bucket that are smaller), the latter found by
-// comparing with the one to four keys that share the bucket instead of with all 64 of the cell.  ~110 vector instructions per wave
-// where the counting form (k_cellrank) has 285, five barriers where it has two -- which is why round 3 dropped it when the kernel ran
+// comparing with the one to four keys that share the bucket instead of with all 64 of the cell.  210 vector instructions per wave
+// where the counting form (k_cellrank) has 285 (83 -> 50 LDS instructions), five barriers where it has two -- which is why round 3 dropped it when the kernel ran
 // alone and was bound by its waits; now it runs next to the per-cell finish and the terminal velocities (Particles::st_rank), whose waves
 // fill the barriers, and the vector ALU is what the three share.  Same order as k_cellrank<uint32_t, true> (the keys are unique).
 // A workgroup whose first or last cell reaches beyond the speculative window, or whose staged range exceeds the stage, ranks by counting.

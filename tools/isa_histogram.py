@@ -21,7 +21,7 @@ with tempfile.TemporaryDirectory() as d:
     s = open(os.path.join(d, "lcx_core-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 names = sorted(set(m.group(1) for m in re.finditer(r"^(_Z\S+):\s", s, re.M)))
 demangled = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
-pick = [(n, dm) for n, dm in zip(names, demangled) if pat in dm and "double" in dm]
+pick = [(n, dm) for n, dm in zip(names, demangled) if pat in dm and ("double" in dm or "<double" not in pat and "float" not in dm)]
 pick.sort(key=lambda nd: 0 if "k_cond_fast_fold<double, 3>" in nd[1] else 1 if "<double, 3, false>" in nd[1] else 1 if "k_cond_lean<double, 7, true, 0>" in nd[1] else 2)   # the production kernel first
 if not pick:
     sys.exit("no kernel matches " + pat)
