@@ -66,12 +66,24 @@ def oracle_by_tag(orc):
     return out
 
 
-def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1):
+def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1, rebase=True):
     """one full step of both; returns (collisions in the oracle, device storage extent before the step's end)"""
     orc.step_sync(opts, fo[0], fo[1], rhod, **C)
     hip.step_sync(opts, fh[0], fh[1], rhod, **C)
     tag_o = orc.state_real("tag")                       # the oracle's ids at coalescence time (it compacts at the END of step_async)
-    if opts.cond:
+    if opts.cond and not rebase:
+        # opts_init.cond_solver = 1: the device follows the reference's TOMS748 iterates -- nothing is re-based, the two runs are FREE;
+        # th and rv at the strict bars, the wet radii identical but where an ulp moved a stopping decision (a handful of droplets)
+        np.testing.assert_allclose(fh[0], fo[0], rtol=h.cond_bars(True)[0])
+        np.testing.assert_allclose(fh[1], fo[1], rtol=h.cond_bars(True)[1])
+        d = device_by_tag(hip)
+        order = np.argsort(tag_o, kind="stable")
+        assert np.array_equal(d["tag"], tag_o[order])
+        err = np.abs(d["rw2"] / orc.state_real("rw2")[order] - 1)
+        # (this spectrum's drops are all but insoluble, kappa = 1e-10, and as large dry as wet: rw^3 - rd^3 cancels to eight digits, and
+        # the fast arithmetic forms it with one rounding where the strict order has two -- 1e-7 here, 1e-14 on an aerosol's droplets)
+        assert err.max() < 1e-4 and np.quantile(err, .999) < 1e-6 and np.median(err) < 1e-7, (err.max(), np.quantile(err, .999), np.median(err))
+    elif opts.cond:
         # This box holds 1 g of liquid water per m^3.  The root finder's tolerance on rw2 (2^-14 relative, config.hpp:39 through
         # toms748.hpp:267-282: both the reference's midpoint and the lean solver's root lie within it of each other) is 1.5 x 2^-14 of
         # a droplet's mass; were every droplet of a cell off to the same side, rv would differ by that share of the cell's liquid
@@ -172,6 +184,46 @@ def test_production_coalescence_on_the_devices_own_stream_matches_the_oracle(con
         prt.diag_all(); prt.diag_sd_conc()
     assert np.array_equal(hip.outbuf_array(), orc.outbuf_array())
     print("collisions %d (multiple %d), super-droplets %d -> %d, re-orderings %d" % (collisions, multi, n0, orc.n_part, reorderings))
+
+
+def test_free_run_with_the_references_iterates_stays_on_the_oracle():
+    """The same colliding box with opts_init.cond_solver = 1 (TOMS748's iterates in fast arithmetic, in the storage-order kernel) and
+    NOTHING re-based: twelve full steps -- condensation, coalescence on the device's own stream, sedimentation, advection, lazy
+    compaction, storage re-ordering -- of two free runs.  Multiplicities, cells and tags stay exact; the wet radii stay identical but
+    for the few droplets where an ulp moved a stopping decision of the root finder (every one within its tolerance); th, rv at the
+    strict bars.  What the lean solver's test has to re-base, this mode does not."""
+    nx, ny, nz, sd_conc, steps = 6, 5, 7, 64, 12
+    oi = colliding_box(nx, ny, nz, sd_conc, dt=5., cond_solver=1)
+    fields = h.box_fields(oi)
+    th, rv, rhod, C = fields
+    orc = h.oracle_particles(oi)
+    hip = h.hip_particles(oi)
+    orc.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    hip.init(th.copy(), rv.copy(), rhod.copy(), **C)
+    so = lgrngn.opts_t()
+    so.coal = so.adve = so.sedi = False
+    for _ in range(8):
+        orc.step_sync(so, th, rv, rhod, **C)
+        orc.step_async(so)
+    h.copy_state(orc, hip)
+    opts = lgrngn.opts_t()
+    fo, fh = [th.copy(), rv.copy()], [th.copy(), rv.copy()]
+    n0, collisions = orc.n_part, 0
+    for it in range(steps):
+        ncol, _ = reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, rebase=False)
+        collisions += ncol
+        assert hip.n_part == orc.n_part, it
+        d, o = device_by_tag(hip), oracle_by_tag(orc)
+        assert np.array_equal(d["tag"], o["tag"]), it
+        assert np.array_equal(d["n"], o["n"]), (it, int((d["n"] != o["n"]).sum()))
+        assert np.array_equal(d["ijk"], o["ijk"]), it
+        err = np.abs(d["rw2"] / o["rw2"] - 1)
+        assert err.max() < 1e-4 and np.quantile(err, .999) < 1e-6, (it, err.max(), np.quantile(err, .999))
+        np.testing.assert_allclose(d["rd3"], o["rd3"], rtol=1e-14)
+        for a in ("x", "y"):
+            np.testing.assert_allclose(d[a], o[a], rtol=1e-13, atol=1e-10, err_msg="%s, step %d" % (a, it))
+        np.testing.assert_allclose(d["z"], o["z"], rtol=1e-13, atol=2e-3)      # (dt * vt of a drop whose rw2 differs by 1e-5 ... 1e-4, twelve steps)
+    assert collisions > 50 and orc.n_part < n0
 
 
 def test_reverse_replay_with_crowded_cells_and_substeps():
