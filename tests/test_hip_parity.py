@@ -874,7 +874,8 @@ def test_folded_condensation_kernel_is_bit_identical_to_the_plain_one(monkeypatc
     assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
 
 
-@pytest.mark.parametrize("sd_conc,dims", [(3, (9, 7, 11)), (64, (6, 5, 7)), (100, (6, 5, 7)), (150, (5, 4, 6)), (230, (4, 4, 5)), (64, (40, 0, 30))])
+@pytest.mark.parametrize("sd_conc,dims", [(1, (20, 18, 22)), (3, (9, 7, 11)), (64, (6, 5, 7)), (100, (6, 5, 7)), (127, (4, 4, 4)), (128, (4, 4, 4)),
+                                          (150, (5, 4, 6)), (230, (4, 4, 5)), (64, (40, 0, 30))])
 @pytest.mark.parametrize("flags", [0, "NO_RANK_OVERLAP", "NO_DEFERRED_SORT"])
 def test_in_cell_order_by_buckets_is_the_order_by_counting(sd_conc, dims, flags):
     """k_cellrank_bkt (round 4: a key's bucket is its expected rank in its cell, one prefix sum over the workgroup's staged range, compares
