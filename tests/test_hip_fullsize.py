@@ -99,3 +99,46 @@ def test_full_step_properties(big):
     for a in ("x", "y", "z"):
         v = pr.get_attr(a)
         assert v.min() >= 0 and v.max() < N * oi.dx
+
+
+def test_production_shuffled_order_at_full_size():
+    """The PRODUCTION path at BASELINE size (what bench.py times: fast arithmetic, the re-sort's scatter carried by the condensation
+    kernel, the in-cell ranking by buckets on its side stream, Philox + bijection keys): after each step_sync the sorted order is read as
+    it is ("raw_sorted_id"), and the shuffle keys that the step's coalescence then consumed are read back (lcx_rng_dump).  Properties that
+    do not depend on the size: the order is a permutation of the living super-droplets, grouped by ascending cell, the CSR offsets are the
+    cells' histogram, and inside every cell the keys ASCEND STRICTLY -- i.e. the order is the reference's shuffle-sort of these keys
+    (hskpng_sort.ipp:28-47), for all 1.3e8 of them; the keys of consecutive steps differ (a fresh shuffle per step)."""
+    oi = bench.make_opts_init(N, N, N, SD, 40., 1, 1, 44)
+    oi.strict_fp = False
+    oi.dbg_flags = int(lgrngn.dbg.TAG)                          # (lcx_rng_dump records what coalescence consumes)
+    th, rv, rhod, Cx, Cy, Cz = bench.make_fields(N, N, N, 0, N, np, np.float64)
+    pr = lgrngn.factory(lgrngn.backend_t.HIP, oi)
+    pr.init(th, rv, rhod, Cx=Cx, Cy=Cy, Cz=Cz)
+    opts = lgrngn.opts_t()
+    dead = 0xFFFFFFFF
+    last_keys = None
+    for it in range(4):
+        pr.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        order = pr.state_u64("raw_sorted_id").astype(np.int64)
+        ijk = pr.state_u64("raw_ijk")
+        alive = ijk != dead
+        n = pr.n_part
+        assert order.size == n == int(alive.sum())
+        seen = np.zeros(ijk.size, dtype=bool)
+        seen[order] = True
+        assert seen.sum() == n and not seen[~alive].any()          # every living super-droplet exactly once, no dead one
+        cells = ijk[order].astype(np.int64)
+        d = np.diff(cells)
+        assert d.min() >= 0                                        # grouped by ascending cell
+        cs = np.concatenate([[0], np.cumsum(np.bincount(cells, minlength=N ** 3))])
+        pr.step_async(opts)
+        keys = pr.rng_dump(0, 1).astype(np.int64)                  # un by storage id, as this step's coalescence drew them
+        k = keys[order]
+        if it == 0:                                                # (the sort behind init ranks by id; this step's coalescence shuffles for itself)
+            assert np.all(np.diff(order)[d == 0] > 0)
+        else:                                                      # (from then on the re-sort at the end of a step ranks by the NEXT coalescence's keys)
+            assert np.all(np.diff(k)[d == 0] > 0)                  # strictly ascending keys inside every cell
+        assert np.unique(np.diff(cs)).size > 1 or it == 0          # (cells differ in occupancy once droplets have moved)
+        if last_keys is not None and last_keys.size == keys.size:
+            assert (last_keys != keys).mean() > 0.99               # a fresh shuffle every step
+        last_keys = keys
