@@ -135,7 +135,9 @@ typedef struct {
    * efficiency tables live) and LCX_MULTI_DEVICE_MAP (slab -> device map of a multi-device object). */
   unsigned dbg_flags;   /* LCX_DBG_* bits below */
   int dbg_cond_budget;  /* cond_solver = 1 with LCX_DBG_COND_TOMS_TWO_PASS: iteration budget of the first condensation pass (stragglers go to a dense second launch);
-                         * 0: the library's choice (6 from 2^25 super-droplets, else one pass), > 0: that budget, < 0: one pass */
+                         * 0: the library's choice (6 from 2^25 super-droplets, else one pass), > 0: that budget, < 0: one pass.
+                         * The lean solver's folded kernel (k_cond_lean_fold): > 0 = slots of its LDS stage in use (at most 128; a test makes it
+                         * small so that unconverged droplets stay in their own lanes) */
   int dbg_pack_delay_us;/* multi-device tests: slabs with an odd first plane send their messages so many microseconds late */
 } lcx_opts_init_t;
 
@@ -163,6 +165,8 @@ enum lcx_dbg {
   LCX_DBG_NO_RANK_OVERLAP = 1 << 17,   /* the in-cell ranking of a carried re-sort on the object's one stream, not next to the per-cell finish and
                                         * the terminal velocities on a stream of its own */
   LCX_DBG_RANK_BY_COUNTING = 1 << 18,  /* the in-cell shuffled order ranked by counting smaller keys (k_cellrank<uint32_t, true>) instead of by buckets */
+  LCX_DBG_COND_FOLD = 1 << 19,         /* the lean solver's kernel with its workgroup folded behind the solver's first loop trip (k_cond_lean_fold: the
+                                          unconverged droplets handed to the workgroup's lowest lanes through LDS; the same rw2 bit for bit, not faster) */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };

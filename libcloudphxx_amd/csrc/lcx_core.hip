@@ -320,10 +320,11 @@ struct Particles : IParticles {
     for (hipEvent_t e : prof_pool) (void)hipEventDestroy(e);
     if (st) (void)hipStreamDestroy(st);
     if (pinned) (void)hipHostFree(pinned);
+    // (the copy stream reads the staging areas: it is drained before they are freed)
+    if (st_copy) { (void)hipStreamSynchronize(st_copy); (void)hipStreamDestroy(st_copy); }
     for (HostStage *h : {&hstage_in, &hstage_out}) if (h->p) (void)hipHostFree(h->p);
     for (hipEvent_t e : out_events) (void)hipEventDestroy(e);
     if (ev_copy) (void)hipEventDestroy(ev_copy);
-    if (st_copy) { (void)hipStreamSynchronize(st_copy); (void)hipStreamDestroy(st_copy); }
   }
   // small device -> host read-back through page-locked memory (a pageable destination makes the copy synchronous and slow)
   template <class S> void read_back(S *dst, const S *src, size_t n)
@@ -468,9 +469,8 @@ struct Particles : IParticles {
       // this step's condensation for the Courant numbers), and a device-to-device copy on the object's stream, behind an event, puts
       // it into the library's array (flush_host_in).  Nothing waits here: the staging area is not the caller's memory, and the
       // caller's array has been read completely when this returns
-      const size_t off = hstage_in.used;           // (stage_reserve may start over)
       T *stg = stage_reserve(hstage_in, n);
-      const size_t at = stg - (T *)hstage_in.p; (void)off;
+      const size_t at = stg - (T *)hstage_in.p;      // (stage_reserve may have started over)
       host_copy_rows(true, stg, (T *)a->data, n, n1, n2, s0, s1, s2, ioff, wrap);
       need_copy_stream();
       HIPCHK(hipMemcpyAsync(dstage.p + at, stg, n * sizeof(T), hipMemcpyHostToDevice, st_copy));
@@ -514,7 +514,8 @@ struct Particles : IParticles {
   T *stage_reserve(HostStage &h, size_t n)
   {
     if (h.used + n > h.cap / sizeof(T)) {
-      if (h.used) { flush_host_in(); sync(); h.used = 0; }         // (more fields than planned for: wait, start over)
+      // (more fields than planned for: wait, drain what the area still holds for the caller, start over)
+      if (h.used) { flush_host_in(); sync(); if (&h == &hstage_out) finish_sync_out(); h.used = 0; }
       if (n > h.cap / sizeof(T)) {
         const size_t want = std::max(n, &h == &hstage_in ? 4 * ncell + n_cx + n_cy + n_cz : 2 * ncell) * sizeof(T);
         if (h.p) HIPCHK(hipHostFree(h.p));
@@ -537,8 +538,10 @@ struct Particles : IParticles {
   void host_copy_rows(bool in, T *dense, T *user, size_t n, int n1, int n2, long s0, long s1, long s2, long ioff, long wrap)
   {
     const int nd = n_dims;
-    const size_t inner = nd >= 2 ? size_t(n2) : 1, rows = nd == 0 ? 1 : n / inner;
-    const long s_in = nd == 3 ? s2 : nd == 2 ? s1 : 1;
+    // (a 1-D domain without wrap is ONE row of n elements at stride s0, not n rows of one element)
+    const bool one_row = nd == 1 && !wrap;
+    const size_t inner = nd >= 2 ? size_t(n2) : one_row ? n : 1, rows = nd == 0 ? 1 : n / inner;
+    const long s_in = nd == 3 ? s2 : nd == 2 ? s1 : one_row ? s0 : 1;
     auto work = [=](size_t r0, size_t r1) {
       for (size_t r = r0; r < r1; ++r) {
         long i = nd == 3 ? long(r / size_t(n1)) : long(r);
@@ -578,6 +581,9 @@ struct Particles : IParticles {
     courants_late = false;
     sync_in_arr(late_c[0], courant_x, n_cx, 1, 0, 0, halo); sync_in_arr(late_c[1], courant_y, n_cy, 0, 1, 0, halo);
     sync_in_arr(late_c[2], courant_z, n_cz, 0, 0, 1, halo);
+    // a Courant array of the same call that lives on the DEVICE has only been listed (add_job): step_cond's flush_sync_jobs ran before
+    // this -- launch it here, or step_async advects with the previous step's numbers for that direction
+    flush_sync_jobs();
     flush_host_in();                                     // (whatever is queued on the object's stream from here on sees them)
   }
   static bool on_host(const lcx_arrinfo_t *a) { return !is_null(a) && !a->on_device; }
@@ -587,7 +593,9 @@ struct Particles : IParticles {
     // (pred_corr looks at the Courant numbers inside sync_in: no deferral then)
     courants_late = (on_host(cx) || on_host(cy) || on_host(cz)) && !dbg(LCX_DBG_HOST_SYNC_LOOP) && o.adve_scheme != LCX_ADVE_PRED_CORR && opts.cond;
     late_c[0] = cx; late_c[1] = cy; late_c[2] = cz;
-    try { sync_in(th_, rv_, rhod_, cx, cy, cz, diss); step_cond(opts, th_, rv_); } catch (...) { courants_late = false; throw; }
+    // (a failed call leaves no job behind that holds a caller pointer: the next call would read or write through it)
+    try { sync_in(th_, rv_, rhod_, cx, cy, cz, diss); step_cond(opts, th_, rv_); }
+    catch (...) { courants_late = false; out_jobs.clear(); host_in_jobs.clear(); jobs_in.n_jobs = jobs_out.n_jobs = 0; throw; }
   }
   void sync_out_arr(DevBuf<T> &from, const lcx_arrinfo_t *a, size_t n)
   {
@@ -1106,7 +1114,8 @@ struct Particles : IParticles {
       cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
                      lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, step == 0, ncell,
                      xcd_group(npart, ncell),
-                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                     turb_cond ? A.ext[ix_ssp].p : nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     unsigned(o.dbg_cond_budget > 0 ? std::min(o.dbg_cond_budget, FOLD_CAP) : FOLD_CAP)};
       const dim3 gr(nblk(npart)), bl(BS);
       // fast arithmetic: k_cond_lean with the lean bracketed secant, or (opts_init.cond_solver = 1) with TOMS748 -- the reference's
       // iterates in fast arithmetic; round 2's kernels for that (iteration budget + straggler launch, fold) behind a switch
@@ -1122,6 +1131,11 @@ struct Particles : IParticles {
           if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 7, false, 2>), gs, bl, 0, st, nphys, a, T(0));
           else if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, 1>), gs, bl, 0, st, nphys, a, T(0));
+          // (round 5, measured and kept behind a switch: the workgroup folded behind the solver's first loop trip -- the same bits, 6 % fewer
+          // vector instructions per wave at a higher lane use, and not faster: the chip runs this kernel at its package power cap, where
+          // what a launch costs is the lanes that compute, not the instructions that issue; see k_cond_lean_fold)
+          else if (dbg(LCX_DBG_COND_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true>), gs, bl, 0, st, nphys, a, kpa_value);
+          else if (dbg(LCX_DBG_COND_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false>), gs, bl, 0, st, nphys, a, T(0));
           else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), gs, bl, 0, st, nphys, a, kpa_value);
           else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gs, bl, 0, st, nphys, a, T(0));
         }
@@ -1159,10 +1173,13 @@ struct Particles : IParticles {
         }
         HIPCHK(hipEventRecord(ev_fork, st));
         HIPCHK(hipStreamWaitEvent(st_rank, ev_fork, 0));
-        std::swap(st, st_rank);
-        finish_deferred_sort(true);
-        HIPCHK(hipEventRecord(ev_rank, st));
-        std::swap(st, st_rank);
+        {
+          // (swapped back whatever happens inside: an exception between the two swaps would leave every later launch, and the stream
+          // that lcx_stream() hands out, on the side stream for the object's lifetime)
+          struct SwapBack { hipStream_t &a, &b; SwapBack(hipStream_t &a_, hipStream_t &b_) : a(a_), b(b_) { std::swap(a, b); } ~SwapBack() { std::swap(a, b); } } guard(st, st_rank);
+          finish_deferred_sort(true);
+          HIPCHK(hipEventRecord(ev_rank, st));
+        }
         rank_pending = true;
       } else finish_deferred_sort(true);
     }

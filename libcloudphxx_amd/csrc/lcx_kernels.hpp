@@ -17,7 +17,9 @@ namespace lcx {
 constexpr int BS = 256;                 // 4 waves per workgroup
 constexpr int WAVE = 64;
 
-__device__ __forceinline__ size_t gid() { return size_t(blockIdx.x) * blockDim.x + threadIdx.x; }
+// (BS, not blockDim.x: every kernel that calls gid() / gid_xcd() is launched with BS threads, and the run-time value is a vector load from
+// the dispatch packet with a full memory round trip ahead of the kernel's first own load -- one dependent level per wave, round 5)
+__device__ __forceinline__ size_t gid() { return size_t(blockIdx.x) * BS + threadIdx.x; }
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8; every XCD has its own 4 MiB L2).  gid_xcd hands each
 // XCD runs of XCD_GROUP consecutive workgroups of the walk instead of every 8th one, so that the gathers of neighbouring cells
 // (droplets that changed cell since the storage was last put in cell order sit in the neighbours' ranges) meet in ONE L2.
@@ -34,7 +36,7 @@ __device__ __forceinline__ size_t gid_xcd(unsigned group)
   const unsigned W = 8u * group;
   const unsigned b = blockIdx.x, w = b / W;
   const unsigned t = (w + 1) * W <= gridDim.x ? w * W + (b % 8u) * group + (b % W) / 8u : b;      // (the ragged tail keeps its order)
-  return size_t(t) * blockDim.x + threadIdx.x;
+  return size_t(t) * BS + threadIdx.x;
 }
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ unsigned wave_id() { return threadIdx.x / WAVE; }
@@ -95,7 +97,7 @@ __global__ void k_sync_multi(sync_jobs<T> J)
 {
   int j = 0;
   while (j + 1 < J.n_jobs && blockIdx.x >= J.first_block[j + 1]) ++j;
-  const size_t c = size_t(blockIdx.x - J.first_block[j]) * blockDim.x + threadIdx.x;
+  const size_t c = size_t(blockIdx.x - J.first_block[j]) * BS + threadIdx.x;
   if (c >= J.n[j]) return;
   const int n1 = J.n1[j], n2 = J.n2[j];
   long i = J.ndims == 0 ? 0 : J.ndims == 1 ? long(c) : J.ndims == 2 ? long(c / n2) : long(c / (size_t(n2) * n1));
@@ -949,6 +951,7 @@ struct cond_args {
   // the scatter of the re-sort that the end of the previous step left undone (k_scatter_sorted's two loads and two stores per droplet),
   // carried by the storage-order condensation kernel, whose memory pipes idle while its vector ALU is the bottleneck; else sc_rank == nullptr
   const uint32_t *sc_rank, *sc_cell_start; uint32_t *sc_sorted_id, *sc_sorted_ijk;
+  unsigned fold_cap;      // k_cond_lean_fold: slots of its LDS stage in use (<= FOLD_CAP; smaller only in tests, opts_init.dbg_cond_budget)
 };
 template <class T>
 __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
@@ -1144,17 +1147,39 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
   const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
   uint32_t id, c;
   size_t m3_pos = pos;
+  T rw2_old, rd3, vt, kpa = kpa_uniform;
+  n_t n_raw;
+  cond_cell_fast<T> cc;
   if (a.storage_ijk) {
-    id = uint32_t(pos); c = a.storage_ijk[pos];
+    // Round 5: TWO dependent memory levels instead of four.  Left to itself the compiler walked  blockDim (a vector load from the
+    // dispatch packet) -> ijk -> rank, cell_start -> the scatter's stores -> the droplet's attributes and the cell's constants, each
+    // behind a full wait: four round trips of a wave's life before its first fp64 instruction.  Everything the storage slot indexes
+    // is issued in ONE batch (a dead slot's attributes are read for nothing: fewer than 1 in 32), everything the cell indexes in a
+    // second; the empty asm statements are compiler barriers for memory operations -- loads are neither sunk nor hoisted across them.
+    id = uint32_t(pos);
+    c = a.storage_ijk[pos];
+    uint32_t rk = 0;
+    if (a.sc_rank) rk = a.sc_rank[pos];
+    rw2_old = a.rw2[pos]; rd3 = a.rd3[pos]; vt = a.vt[pos];
+    if (!UNI) kpa = a.kpa[pos];
+    n_raw = a.n[pos];
+    asm volatile("" ::: "memory");
     if (c == DEAD_CELL) return;
+    uint32_t cs = 0;
+    if (a.sc_rank) cs = a.sc_cell_start[c];
+    cc = a.pre[c];
+    asm volatile("" ::: "memory");
     // (the droplet's change goes where the droplet goes in the sorted order: the per-cell finish then reads one stretch, see there)
-    if (a.sc_rank) { const size_t q = size_t(a.sc_cell_start[c]) + a.sc_rank[pos]; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; m3_pos = q; }
+    if (a.sc_rank) { const size_t q = size_t(cs) + rk; a.sc_sorted_id[q] = id; a.sc_sorted_ijk[q] = c; m3_pos = q; }
   }
-  else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
-  T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id];
-  T kpa = UNI ? kpa_uniform : a.kpa[id];
-  T nn = T(a.n[id]);
-  cond_cell_fast<T> cc = a.pre[c];
+  else {
+    id = a.sorted_id[pos]; c = a.sorted_ijk[pos];
+    rw2_old = a.rw2[id]; rd3 = a.rd3[id]; vt = a.vt[id];
+    if (!UNI) kpa = a.kpa[id];
+    n_raw = a.n[id];
+    cc = a.pre[c];
+  }
+  T nn = T(n_raw);
   asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
                "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
   if (!UNI) asm volatile("" : "+v"(kpa));
@@ -1171,6 +1196,113 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
   }
   a.m3_after[m3_pos] = delta;
+}
+
+// Round 5, measured and kept behind opts_init.dbg_flags & COND_FOLD: the lean kernel with its workgroup FOLDED behind the solver's first
+// loop trip.  Evaluations per droplet (below): 1 for the 7 % that take an early out, 3 for 72 % (near end, far end, the first secant point,
+// which already confirms itself), 4...8 for the 21 % whose first secant point does not -- but a wave runs until its slowest droplet is
+// done: 5.2.  Every lane runs the uniform part (head + ONE loop trip); the droplets that have not converged hand the loop's state
+// where it stands (lean_state, the clamps, the droplet's constants: 13 reals + 3 words) through LDS to the lowest lanes of the
+// workgroup, three of the four waves leave, and one (now and then two) runs the remaining trips densely.  The same operations on every
+// droplet's numbers in the same order as k_cond_lean<T, 7, UNI, 0>: the same rw2 and the same change of n rw^3 bit for bit (lean2_loop
+// is resumable, see lcx_math.hpp; tests/test_hip_parity.py).  Droplets beyond the stage's capacity carry on in their own lanes.
+// Counters of the settled box (profiles/r05*_pmc_fold.txt): 638 -> 601 vector instructions per wave, fp64 FMAs 205 -> 172, lane use
+// 0.66 -> 0.76, vector ALU 0.90 -> 0.85 busy -- and 2.86-2.92 ms against 2.81-2.88 for the plain kernel on the same box.  Like
+// round 4's second-pass experiment it removes issued instructions whose lanes were mostly masked off, and those were not what the
+// launch costs: the package sits at 1.31 kW of its 1.40 kW cap through the whole step and the shader clock at 2.19 GHz instead of 2.40
+// (profiles/r05*_power.txt) -- the launch is priced in lanes that compute (energy), not in instructions that issue.  Storage order only.
+constexpr int FOLD_CAP = 128;
+template <class T, bool UNI>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_cond_lean_fold(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
+{
+  __shared__ T xs[13][FOLD_CAP];
+  __shared__ uint32_t xw[3][FOLD_CAP];
+  __shared__ uint32_t wcnt[BS / WAVE];
+  const size_t pos = gid_xcd(a.xcd_group);
+  bool live = pos < n_part;
+  uint32_t id = uint32_t(pos), c = DEAD_CELL, m3_pos = uint32_t(pos);
+  T rw2_old = 0, nn = 0, r = 0, rd2 = 0;
+  cond_fun_fast<T, 7> ff;
+  lean_state<T> s;
+  bool need = false;
+  if (live) {
+    // (the two load levels of k_cond_lean, see there)
+    c = a.storage_ijk[pos];
+    uint32_t rk = 0;
+    if (a.sc_rank) rk = a.sc_rank[pos];
+    rw2_old = a.rw2[pos];
+    T rd3 = a.rd3[pos], vt = a.vt[pos], kpa = kpa_uniform;
+    if (!UNI) kpa = a.kpa[pos];
+    const n_t n_raw = a.n[pos];
+    asm volatile("" ::: "memory");
+    live = c != DEAD_CELL;
+    if (live) {
+      uint32_t cs = 0;
+      if (a.sc_rank) cs = a.sc_cell_start[c];
+      cond_cell_fast<T> cc = a.pre[c];
+      asm volatile("" ::: "memory");
+      if (a.sc_rank) { m3_pos = cs + rk; a.sc_sorted_id[m3_pos] = id; a.sc_sorted_ijk[m3_pos] = c; }
+      nn = T(n_raw);
+      asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+                   "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+      if (!UNI) asm volatile("" : "+v"(kpa));
+      T delta = 0;
+      if (!(rw2_old <= 0)) {
+        ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+        if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2)) {
+          need = !lean2_loop(ff, a.eps, 1u, s, r);
+          if (!need) r = lean2_tail(s, r, rd2);
+        }
+        if (!need) {
+          a.rw2[id] = r;
+          delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+        }
+      }
+      if (!need) a.m3_after[m3_pos] = delta;
+    }
+  }
+  // ---- the fold: unconverged droplets -> lanes 0 .. total-1 of the workgroup
+  const unsigned long long bal = __ballot(need);
+  if (lane_id() == 0) wcnt[wave_id()] = uint32_t(__popcll(bal));
+  __syncthreads();
+  uint32_t first = 0, total = 0;
+#pragma unroll
+  for (unsigned w = 0; w < BS / WAVE; ++w) { const uint32_t n_w = wcnt[w]; if (w < wave_id()) first += n_w; total += n_w; }
+  if (total == 0) return;
+  const uint32_t slot = first + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)));
+  const uint32_t cap = a.fold_cap;                            // (FOLD_CAP; a test makes it small so that droplets stay behind)
+  const bool moved = need && slot < cap;
+  if (moved) {
+    xw[0][slot] = id; xw[1][slot] = c; xw[2][slot] = m3_pos;
+    xs[0][slot] = s.x0; xs[1][slot] = s.f0; xs[2][slot] = s.x1; xs[3][slot] = s.f1; xs[4][slot] = s.c; xs[5][slot] = s.a; xs[6][slot] = s.b;
+    xs[7][slot] = rd2; xs[8][slot] = rw2_old; xs[9][slot] = ff.rd3; xs[10][slot] = ff.rd3_1mk; xs[11][slot] = ff.c_Re; xs[12][slot] = nn;
+  }
+  __syncthreads();
+  bool run = need && !moved;                                  // (beyond the stage's capacity: carries on where it is)
+  const uint32_t t = threadIdx.x;
+  if (t < (total < cap ? total : cap)) {
+    id = xw[0][t]; c = xw[1][t]; m3_pos = xw[2][t];
+    s.x0 = xs[0][t]; s.f0 = xs[1][t]; s.x1 = xs[2][t]; s.f1 = xs[3][t]; s.c = xs[4][t]; s.a = xs[5][t]; s.b = xs[6][t];
+    rd2 = xs[7][t]; rw2_old = xs[8][t]; nn = xs[12][t];
+    // (the droplet's own products arrive as they were formed: the same bits as setup_cell's)
+    ff.rd3 = xs[9][t]; ff.rd3_1mk = xs[10][t]; ff.c_Re = xs[11][t];
+    r = s.c;
+    run = true;
+  }
+  if (!run) return;
+  {
+    // the cell's constants are read again by whoever goes on (also by a droplet that stays in its lane): nothing of them lives across
+    // the barriers, so that the kernel keeps the 80 vector registers of six waves per SIMD
+    const cond_cell_fast<T> cc = a.pre[c];
+    ff.rw2_old = rw2_old; ff.dt = a.dt_sub;
+    ff.Sc = cc.Sc; ff.Pr = cc.Pr; ff.lambda_D = cc.lambda_D; ff.lambda_K = cc.lambda_K; ff.A = cc.A; ff.RH_eff = cc.RH_eff;
+    ff.c1 = cc.c1; ff.c2_rho = cc.c2_rho; ff.RH_rho_w = cc.RH_rho_w;
+  }
+  if (!run) return;
+  lean2_loop(ff, a.eps, a.n_iter - 1u, s, r);
+  r = lean2_tail(s, r, rd2);
+  a.rw2[id] = r;
+  a.m3_after[m3_pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
 }
 
 // Growth-rate evaluations per droplet (an offline count over 2.1e6 droplets of the oracle's state on the bench's fields): 3 for 72 % of the
@@ -2741,7 +2873,7 @@ k_pack_dev(const uint32_t *counts, unsigned half, pack_side<T> L, pack_side<T> R
   const pack_side<T> &P = side ? R : L;
   if (!P.inbox) return;
   const uint32_t count = counts[side];
-  const size_t i = size_t(blockIdx.x - (side ? half : 0u)) * blockDim.x + threadIdx.x;
+  const size_t i = size_t(blockIdx.x - (side ? half : 0u)) * BS + threadIdx.x;
   if (i == 0) { uint32_t *h = reinterpret_cast<uint32_t *>(P.inbox); h[0] = count; h[1] = count > P.cap_rec ? 1u : 0u; h[2] = P.next_cap; }
   if (count > P.cap_rec || i >= count) return;        // overflow: nothing is shipped, the hosts of both slabs raise
   const int n_attr = 4 + g.ndims + s.n_ext;

@@ -108,6 +108,7 @@ class dbg(enum.IntFlag):
     FINISH_STAGED = 1 << 16
     NO_RANK_OVERLAP = 1 << 17
     RANK_BY_COUNTING = 1 << 18
+    COND_FOLD = 1 << 19
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -499,6 +499,42 @@ def test_host_arrays_through_the_staged_rows_equal_the_plain_host_loop(layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("host_dirs", ["z", "xy", "x"])
+def test_courant_arrays_partly_on_the_host_partly_on_the_device(host_dirs):
+    """A combined step_sync whose Courant arrays live on BOTH sides: the host ones are gathered while condensation runs
+    (late_courants), and the device ones of the same call must be launched there too -- they were only listed, after step_cond's one
+    launch of the listed jobs had gone, so that step_async advected with the PREVIOUS step's numbers for those directions.  The Courant
+    numbers change from step to step here; the run must equal the all-host run bit for bit."""
+    import torch
+    oi = h.box_opts(12, 10, 14, 8, coal_switch=False, strict_fp=False)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = []
+    for mixed in (False, True):
+        pr = h.hip_particles(oi)
+        a_th, a_rv = th.copy(), rv.copy()
+        pr.init(a_th, a_rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        opts.coal = False
+        keep = []
+        for step in range(4):
+            Cs = {k: np.ascontiguousarray(v * (1.0 - 0.4 * step)) for k, v in C.items()}
+            args = dict(Cs)
+            if mixed:
+                for k in list(args):
+                    if k[1] not in host_dirs:
+                        t = torch.tensor(args[k], device="cuda")
+                        keep.append(t)
+                        args[k] = lgrngn.DeviceArray(t.data_ptr(), t.shape)
+                torch.cuda.synchronize()
+            pr.step_sync(opts, a_th, a_rv, rhod, **args)
+            pr.step_async(opts)
+        res.append((a_th.copy(), pr.get_attr("x"), pr.get_attr("y"), pr.get_attr("z"), pr.state_real("courant_x"), pr.state_real("courant_y"),
+                    pr.state_real("courant_z")))
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_stream_ordered_step_sync_gives_the_same_run():
     """opts_init.stream_ordered (extension): with DEVICE arrays step_sync returns once its work is queued on the object's stream -- the
     caller orders its own stream behind lcx_stream() instead of the host waiting.  Same run bit for bit as the waiting form: th and rv
