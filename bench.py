@@ -230,6 +230,11 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "host"], default=None,
                     help="one object per rank: how the migrants travel -- device buffers over RCCL (default with one GPU per rank), or "
                          "staged through the host over gloo (default when the ranks share a GPU)")
+    ap.add_argument("--processes", default="all", choices=["cond", "cond+coal", "cond+coal+adve", "all"],
+                    help="which processes a step runs (opts_t.cond / coal / adve / sedi), as the reference's timing sweep does "
+                         "(models/kinematic_2D/tests/paper_GMD_2015/fig_b/calc.cpp:49: a / ac / acc / accs): substeps timed in isolation; "
+                         "the headline and every leg of the default line run all of them")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the coal_stress and c5 legs of the default line")
     ap.add_argument("--dbg", default="",
                     help="comma-separated names of opts_init.dbg_flags bits (libcloudphxx_amd.lgrngn.dbg: test / measurement switches, "
                          "e.g. NO_DEFERRED_SORT,COND_SORTED_ORDER,MULTI_SERIALIZE); the library reads no such switch from the environment")
@@ -448,6 +453,10 @@ def main():
         for d in devices:
             torch.cuda.synchronize(d)
     opts = lgrngn.opts_t()
+    opts.cond = True
+    opts.coal = args.processes in ("cond+coal", "cond+coal+adve", "all")
+    opts.adve = args.processes in ("cond+coal+adve", "all")
+    opts.sedi = args.processes == "all"
 
     def barrier():
         sync_all()
@@ -545,6 +554,11 @@ def main():
                         src = "profiles/" + os.path.basename(tf)
                         roof["traffic"] = t["hbm_bytes"]
                         roof["traffic_source"] = src
+                        # what the launch MOVES per super-droplet by the counters (the run's single hygroscopicity is a scalar: 8 of the
+                        # 56 algorithmic bytes are not read) -- `frac_with_carried` prices 76 algorithmic bytes, not these
+                        roof["bytes_moved_per_sd"] = t["hbm_bytes"] / n_local
+                        roof["achieved_on_bytes_moved"] = t["hbm_bytes"] / (avg_ms * 1e-3) / 1e9
+                        roof["frac_on_bytes_moved"] = roof["achieved_on_bytes_moved"] / HBM_PEAK_GBS
                         if "hbm_bytes_low" in t:
                             # FETCH_SIZE counts requests, not bytes: 128-B requests (coalesced reads) and 64-B ones (sparse gathers) look
                             # alike.  `traffic` prices every read request at 128 B (an upper bound), `traffic_low` at 64 B (a lower one);
@@ -627,8 +641,9 @@ def main():
             "vs_baseline": None,
             "dtype": args.real,
             "data": "synthetic",
-            "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, cond+coal+adve+sedi+bcnd, sstp %d/%d, kernel %s, vt beard77fast"
-                                   % (nx_tot, ny, nz, args.sd_conc, args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
+            "config": {"workload": "3-D box %dx%dx%d cells x %d SD/cell, %s, sstp %d/%d, kernel %s, vt beard77fast"
+                                   % (nx_tot, ny, nz, args.sd_conc, "cond+coal+adve+sedi+bcnd" if args.processes == "all" else args.processes + " only",
+                                      args.sstp_cond, args.sstp_coal, lgrngn.kernel_t(oi.kernel).name),
                        "super_droplets": int(sd_total / args.steps), "decomposition": "x-slabs:%d%s" % (world_out, decomposition_note), "cond_mode": args.cond_mode,
                        "fp_mode": "strict IEEE order, TOMS748 iterates" if args.strict_fp else
                                   "fp64, growth rate as one rational expression + FMA; " + ("lean bracketed secant to the reference's tolerance 2^-15" if args.cond_solver == "lean"
@@ -666,7 +681,7 @@ def main():
             gc.collect()
             torch.cuda.synchronize()
 
-            def run_leg(change, steps, host_arrays=False):
+            def run_leg(change, steps, host_arrays=False, collisions=False):
                 keep = {k: getattr(oi, k) for k in change}
                 for k, v in change.items():
                     setattr(oi, k, v)
@@ -699,11 +714,24 @@ def main():
                     torch.cuda.synchronize()
                     st_ = pr.timings()
                     ach_ = cond_bytes_per_sd * (done / steps) / (cond_ms_ * 1e-3) / 1e9 if cond_ms_ else None
+                    n_end = pr.n_part
+                    pairs_ = int(pr.state_u64("raw_collided")[0]) if collisions else None
                     res = {"value": done / dt_, "unit": "super-droplets/s", "ms_per_step": dt_ / steps * 1e3, "steps": steps,
                            "roofline": {"bound": "hbm", "achieved": ach_, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": ach_ / HBM_PEAK_GBS if ach_ else None, "avg_launch_ms": cond_ms_,
                                         "algorithmic_bytes_per_sd": cond_bytes_per_sd},
                            "stage_ms_per_step": {k: v / stage_steps_ for k, v in st_.items()}}
+                    if collisions:
+                        # pairs that collided in the last step (the living super-droplets that carry coalescence's invalid terminal velocity);
+                        # a collided pair writes back N + 3R bytes (n of the one, rw2, rd3, vt of the other)
+                        n_sd_ = done / steps
+                        res["collided_pairs_per_step"] = pairs_
+                        res["share_of_candidate_pairs"] = pairs_ / max(n_sd_ / 2., 1.)
+                        res["coal_ms"] = res["stage_ms_per_step"].get("coal")
+                        res["coal_bytes_per_sd"] = stage_bytes["coal"] + (8 + 3 * R) * pairs_ / max(n_sd_, 1.)
+                        res["coal_GBs"] = (res["coal_bytes_per_sd"] * n_sd_ / (res["coal_ms"] * 1e-3) / 1e9) if res["coal_ms"] else None
+                        res["cond_ms"] = cond_ms_
+                        res["super_droplets"] = int(n_sd_)
                     del pr, f, arrs
                     gc.collect()
                     torch.cuda.synchronize()
@@ -712,28 +740,47 @@ def main():
                     for k, v in keep.items():
                         setattr(oi, k, v)
 
-            if not args.strict_fp and not args.no_strict_leg:
-                # the API default (opts_init.strict_fp = 1; both host mirrors): IEEE operation order in the condensation kernel and the
-                # reference's ordered per-cell sums -- what a driver that changes no option gets
-                out["strict_fp"] = run_leg({"strict_fp": True}, args.strict_leg_steps)
-                out["strict_fp"]["fp_mode"] = "strict IEEE order (opts_init.strict_fp = 1, the API default)"
-                out["strict_fp"]["roofline"]["kernel"] = "k_cond"
             if not args.strict_fp and args.cond_solver == "lean" and not args.no_toms_leg:
-                # the reference-faithful fast mode: TOMS748's iterates (the reference's answer is the midpoint of ITS last bracket) in fast
-                # arithmetic -- held to SURVEY 8a's bars in every test, where the lean solver is held to its own (tests/_harness.py)
-                out["cond_solver_toms748"] = run_leg({"cond_solver": 1}, args.leg_steps)
-                out["cond_solver_toms748"]["fp_mode"] = "fast arithmetic, the reference's TOMS748 iterates (opts_init.cond_solver = 1)"
-                out["cond_solver_toms748"]["roofline"]["kernel"] = "k_cond_lean<.., SOLVER = TOMS748>"
+                # THE API DEFAULT since round 5 (both host mirrors, lcx_opts_init_default): fast arithmetic with the reference's TOMS748
+                # iterates (the reference's answer is the midpoint of ITS last bracket) -- held to SURVEY 8a's bars in every test, where
+                # the headline's lean solver is held to its own (tests/_harness.py).  What a driver that changes no option gets.
+                out["api_default"] = run_leg({"strict_fp": False, "cond_solver": 1}, args.leg_steps)
+                out["api_default"]["fp_mode"] = "fast arithmetic, the reference's TOMS748 iterates (opts_init.strict_fp = 0, cond_solver = 1: the API default)"
+                out["api_default"]["roofline"]["kernel"] = "k_cond_lean<.., SOLVER = TOMS748>"
             if not args.no_host_leg:
-                # what an unchanged icicle / UWLCM gets: the Eulerian arrays in HOST memory (numpy arrays through arrinfo_t), every option
-                # as in the headline -- sync_in / sync_out include the PCIe transfers and the host-side row copies
-                out["host_arrays"] = run_leg({}, args.leg_steps, host_arrays=True)
-                out["host_arrays"]["arrays"] = "th, rv, rhod, Cx, Cy, Cz as host (numpy) arrays: %.1f MB in, %.1f MB out per step" % (
+                # what an unchanged icicle / UWLCM gets: the Eulerian arrays in HOST memory (numpy arrays through arrinfo_t) -- sync_in /
+                # sync_out include the PCIe transfers and the host-side row copies.  Once with every option as in the headline, once with
+                # the API's default arithmetic: the caller that changes nothing at all
+                arrays_note = "th, rv, rhod, Cx, Cy, Cz as host (numpy) arrays: %.1f MB in, %.1f MB out per step" % (
                     (3 * nx_tot * ny * nz + (nx_tot + 1) * ny * nz + nx_tot * (ny + 1) * nz + nx_tot * ny * (nz + 1)) * R / 1e6, 2 * nx_tot * ny * nz * R / 1e6)
+                out["host_arrays"] = run_leg({}, args.leg_steps, host_arrays=True)
+                out["host_arrays"]["arrays"] = arrays_note
                 out["host_arrays"]["extra_ms_per_step"] = out["host_arrays"]["ms_per_step"] - out["ms_per_step"]
-                if not args.strict_fp and not args.no_strict_leg:
-                    # ... and with the API's default arithmetic as well: the caller that changes nothing at all
-                    out["host_arrays_strict_fp"] = run_leg({"strict_fp": True}, args.leg_steps, host_arrays=True)
+                if not args.strict_fp and args.cond_solver == "lean" and not args.no_toms_leg:
+                    out["api_default_host_arrays"] = run_leg({"strict_fp": False, "cond_solver": 1}, args.leg_steps, host_arrays=True)
+                    out["api_default_host_arrays"]["arrays"] = arrays_note
+            if not args.strict_fp and not args.no_strict_leg:
+                # the opt-in parity mode (opts_init.strict_fp = 1, the API default of rounds 1-4): IEEE operation order in the condensation
+                # kernel and the reference's ordered per-cell sums
+                out["strict_fp"] = run_leg({"strict_fp": True}, args.strict_leg_steps)
+                out["strict_fp"]["fp_mode"] = "strict IEEE order (opts_init.strict_fp = 1, opt-in)"
+                out["strict_fp"]["roofline"]["kernel"] = "k_cond"
+            default_box = args.sd_conc == 64 and args.workload == "stratocumulus" and args.processes == "all" and args.real == "f64"
+            if default_box and not args.no_extra_legs:
+                # A coalescence that COLLIDES (the stratocumulus box's candidate pairs all but never do): the Golovin test's
+                # spectrum under hall_davis_no_waals, everything else as the headline -- SURVEY 8(d), C5 variant (ii)
+                out["coal_stress"] = run_leg({"dry_distros": {(1e-10, 0.): lgrngn.expvolume(30.084e-6, 2 ** 23)},
+                                              "kernel": lgrngn.kernel_t.hall_davis_no_waals}, args.leg_steps, collisions=True)
+                out["coal_stress"]["spectrum"] = ("n(ln r) = 3 n0 (r/r0)^3 exp(-(r/r0)^3), r0 = 30.084 um, n0 = 2^23 m^-3, kappa = 1e-10 "
+                                                 "(ref tests/python/physics/coalescence_golovin.py:31-44), kernel hall_davis_no_waals")
+                # BASELINE configs[4] (C5): the headline spectrum x 512 per cell, 1.07e9 super-droplets on the one device (~210 GB);
+                # 17 steps behind 3 of warm-up: one storage re-ordering (every 16 steps where cells are crowded) falls into them
+                free_b, _tot_b = torch.cuda.mem_get_info()
+                if free_b > 230e9 * (nx_tot * ny * nz) / 128. ** 3:
+                    out["c5"] = run_leg({"sd_conc": 512, "n_sd_max": int(nx_tot * ny * nz * 512 * 1.15) + 1024}, 17)
+                    out["c5"]["workload"] = "3-D box %dx%dx%d cells x 512 SD/cell (BASELINE configs[4]), headline options" % (nx_tot, ny, nz)
+                else:
+                    out["c5"] = {"skipped": "%.0f GB of device memory free, the configuration needs ~210" % (free_b / 1e9)}
         if world_out == 1 and not args.no_cpu_baseline and not args.self_ring:
             out["cpu_baseline"] = cpu_baseline(args)
         sys.stdout.flush()
@@ -741,8 +788,12 @@ def main():
     if world > 1:
         dist.all_reduce(torch.zeros(1))
         if probe_state["hung"]:                              # (an abandoned RCCL operation: do not wait for its communicator)
+            # the line above is a measurement over the HOST transport of a node whose RCCL ring hung: it is printed, and the process says
+            # that something was wrong (ADVICE r03 / VERDICT r04: not exit code 0)
+            print("bench.py rank %d: exiting with code 4 -- the RCCL ring probe hung, the result line is the host-staged transport's" % rank,
+                  file=sys.stderr, flush=True)
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(4)
         dist.destroy_process_group()
 
 

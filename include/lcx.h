@@ -105,16 +105,19 @@ typedef struct {
   int n_x_tot;          /* total nx of the decomposed domain (ctor arg n_x_tot, particles.hpp:233) */
   int n_x_bfr;          /* x-planes owned by ranks to the left (distmem_opts.hpp:27) */
   int bcond_lft, bcond_rgt; /* 0 sharedmem, 1 distmem, 3 open  (src/detail/bcond.hpp) */
-  int strict_fp;        /* 1: IEEE order-preserving arithmetic, the reference's TOMS748 iterates (parity mode, default);
-                         * 0: fast arithmetic -- growth rate collected into one rational expression + FMA, refined reciprocals, and the
-                         *    condensation equation solved by cond_solver below */
-  int cond_solver;      /* fast arithmetic only.  0 (default): a lean bracketed secant on the reference's bracket, to the reference's
-                         *    tolerance 2^-15 (csrc/lcx_math.hpp advance_rw2_lean_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within
-                         *    that tolerance of the reference's answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5
-                         *    from the root it brackets;
-                         * 1: the reference's TOMS748 iterates in the fast arithmetic (the same storage-order kernel with TOMS748 in it: 2x the
-                         *    kernel time of 0, 1.33x the step), for runs that are to follow the reference's answers as closely as its own
-                         *    builds follow each other: held to SURVEY 8a's bars and the reference's refdata tolerances in the tests */
+  int strict_fp;        /* 0 (default since round 5): fast arithmetic -- growth rate collected into one rational expression + FMA, refined
+                         *    reciprocals, the way the reference's own Release build is compiled (-Ofast), and the condensation equation
+                         *    solved by cond_solver below;
+                         * 1: IEEE order-preserving arithmetic, the reference's TOMS748 iterates and its ordered per-cell sums (the parity
+                         *    mode that the tests pin; 2x the step time of the default) */
+  int cond_solver;      /* fast arithmetic only.
+                         * 1 (default since round 5): the reference's TOMS748 iterates in the fast arithmetic (the storage-order kernel with
+                         *    TOMS748 in it): the reference's answers as closely as its own builds follow each other -- held to SURVEY 8a's
+                         *    bars and to the reference's refdata tolerances, like strict_fp = 1, in every test;
+                         * 0: a lean bracketed secant on the reference's bracket, to the reference's tolerance 2^-15 (csrc/lcx_math.hpp
+                         *    advance_rw2_lean2_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within that tolerance of the reference's
+                         *    answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5 from the root it brackets; half the
+                         *    kernel time of 1, what bench.py's headline runs */
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers
                          * line-coalesced in long runs: 18.1 instead of 21.5 ms per step after 400 steps of the 128^3 box).
                          * N > 0: every N steps, and whenever dead super-droplets are compacted away anyway (the same one pass over

@@ -60,8 +60,8 @@ namespace libcloudphxx { namespace lgrngn {
     real_t rlx_sd_per_bin = 0, rlx_timescale = 1;
     int supstp_rlx = 1;
     // --- extensions of this backend (no reference counterpart, see include/lcx.h) ---
-    bool strict_fp = true;     // false: contracted one-division form of the condensational growth rate
-    int cond_solver = 0;       // fast arithmetic only: 0 lean bracketed secant (default), 1 the reference's TOMS748 iterates (lcx.h)
+    bool strict_fp = false;    // false (default since round 5): contracted one-division form of the condensational growth rate; true: IEEE operator order
+    int cond_solver = 1;       // fast arithmetic only: 1 the reference's TOMS748 iterates (default since round 5), 0 lean bracketed secant (lcx.h)
     // a slab of a 1-D decomposed domain (what detail::distmem_opts derives from the MPI rank inside the reference, distmem_opts.hpp:20-52):
     // x-planes owned by the ranks to the left, and the kind of the two x-faces (0 this process owns the whole domain, 1 neighbour
     // slab: leaving SDs are listed for lcx_migrate_pack, 3 open wall)

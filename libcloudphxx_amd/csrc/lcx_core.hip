@@ -2507,7 +2507,7 @@ void lcx_opts_init_default(lcx_opts_init_t *o)
   o->RH_max = .95; o->rng_seed = 44; o->rng_seed_init = 44;
   o->sstp_cond_adapt_drw2_eps = 1e-4; o->sstp_cond_adapt_drw2_max = 4; o->rc2_T = 10;
   o->adve_scheme = LCX_ADVE_IMPLICIT; o->RH_formula = LCX_RH_PV_CC;
-  o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 1;
+  o->dev_id = -1; o->rd_min = -1; o->rd_max = -1; o->th_dry = 1; o->strict_fp = 0; o->cond_solver = 1;   /* (round 5: the API default, see lcx.h) */
 }
 void lcx_opts_default(lcx_opts_t *o)
 {

@@ -807,13 +807,21 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
 // (80 KB of code): 16.3 ms against 8.6 -- the call ABI's register shuffling costs far more than the instruction cache gains.
 // cond_common.ipp:197-337 up to and including the first two root-finder steps.  Returns true when `result` is final.
 template <class T, class F>
-LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, toms_carry<T> &k, T &result)
+LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, toms_carry<T> &k, T &result,
+                                  T *rd2_lazy = nullptr)
 {
   const T drw2 = dt * f.drw2_dt(rw2_old);
   if (drw2 == 0) { result = rw2_old; return true; }
-  T rd;
-  if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
-  const T rd2 = rd * rd;
+  // rd2_lazy (fast arithmetic, a caller that runs head and tail on the same lane): the squared dry radius only ever clamps, and a droplet
+  // that grows from a wet radius above its dry one has neither clamp bind -- it skips the cube root (see lean2_head; the same bits);
+  // *rd2_lazy = 0 then stands for "below everything" in the tail as well
+  T rd2 = T(0);
+  if (!(rd2_lazy && fastdiv<F>::value != 0 && drw2 > 0 && rw2_old * rw2_old * rw2_old > rd3 * rd3 * T(1.000001))) {
+    T rd;
+    if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
+    rd2 = rd * rd;
+  }
+  if (rd2_lazy) *rd2_lazy = rd2;
   const T a_un = rw2_old + mn(T(0), cond_mlt * drw2);
   const T a = mx(rd2, a_un),
           b = rw2_old + mx(T(0), cond_mlt * drw2);
@@ -845,12 +853,16 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
   return true;
 }
 template <class T, class F>
-LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k, unsigned *iters_left = nullptr)
+LCX_HD T advance_rw2_tail_with(const F &f, T rd3, T eps, const toms_carry<T> &k, unsigned *iters_left = nullptr, const T *rd2_known = nullptr)
 {
   T rw2_new = toms748_tail(f, k, eps, iters_left);
-  T rd;
-  if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
-  const T rd2 = rd * rd;
+  T rd2;
+  if (rd2_known) rd2 = *rd2_known;                  // (the head's, see rd2_lazy there)
+  else {
+    T rd;
+    if constexpr (fastdiv<F>::value != 0) rd = cbrt_seeded(T(rd3 * T(0x1p90))) * T(0x1p-30); else rd = cbrt(rd3);   // exact scaling into the seeded domain
+    rd2 = rd * rd;
+  }
   if (rw2_new < rd2) rw2_new = rd2;
   return rw2_new;
 }
@@ -861,9 +873,9 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
 {                                                                  // cond_common.ipp:197-337
   toms_carry<T> k;
   k.count = n_iter;
-  T r;
-  if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r)) { if (iters_left) *iters_left = k.count; return r; }
-  return advance_rw2_tail_with(f, rd3, eps, k, iters_left);
+  T r, rd2;
+  if (advance_rw2_head_with(f, rw2_old, rd3, dt, eps, cond_mlt, n_iter, k, r, &rd2)) { if (iters_left) *iters_left = k.count; return r; }
+  return advance_rw2_tail_with(f, rd3, eps, k, iters_left, &rd2);
 }
 // ---- Fast arithmetic's own root finder (opts_init.strict_fp == 0).  TOMS748 was written to spend few FUNCTION EVALUATIONS; here an
 // evaluation is ~75 fp64 operations and the algorithm's own interpolation (a cubic through four points: six reciprocals and thirty

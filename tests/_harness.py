@@ -13,6 +13,35 @@ import numpy as np
 
 from libcloudphxx_amd import lgrngn
 
+# The tests were written against the PARITY mode -- IEEE operation order, the reference's TOMS748 iterates, its ordered per-cell
+# sums: opts_init.strict_fp = 1, the API default of rounds 1-4 -- and they keep pinning it: every opts_init_t() made under the test
+# suite (this module is imported by every test module and by the worker scripts) starts from strict_fp = True, cond_solver = 0, and a
+# test that wants another arithmetic says so (strict_fp = False, cond_solver = 1: the ARITH parameter of the condensation tests).  The
+# API default since round 5 -- fast arithmetic with the reference's iterates -- is tested as such by tests/test_abi.py and
+# tests/test_hip_parity.py::test_the_api_default_mode_keeps_the_strict_bars (API_DEFAULTS below).
+_opts_init_ctor = lgrngn.opts_init_t.__init__
+API_DEFAULTS = {}
+
+
+def _parity_mode_opts_init(self, *a, **k):
+    _opts_init_ctor(self, *a, **k)
+    if not API_DEFAULTS:
+        API_DEFAULTS.update(strict_fp=self.strict_fp, cond_solver=self.cond_solver)
+    self.strict_fp = True
+    self.cond_solver = 0
+
+
+lgrngn.opts_init_t.__init__ = _parity_mode_opts_init
+
+
+def api_default_opts(oi):
+    """puts the two arithmetic options of an opts_init_t back to what the mirror's constructor sets"""
+    if not API_DEFAULTS:
+        lgrngn.opts_init_t()
+    oi.strict_fp, oi.cond_solver = API_DEFAULTS["strict_fp"], API_DEFAULTS["cond_solver"]
+    return oi
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liblcx_oracle.so")

@@ -67,6 +67,28 @@ def test_multi_backend_without_gpu_fails_loudly():
             lgrngn.factory(b, oi)
 
 
+def test_api_default_arithmetic_is_the_same_in_every_mirror():
+    """Round 5: what a caller that sets nothing gets is fast arithmetic with the reference's TOMS748 iterates (strict_fp = 0,
+    cond_solver = 1) -- the C ABI's lcx_opts_init_default, the Python mirror's constructor and the C++ header mirror's member
+    initialisers say the same (the test suite itself pins the parity mode, tests/_harness.py)"""
+    import _harness as h
+    from libcloudphxx_amd import lgrngn, _lib
+    h.api_default_opts(lgrngn.opts_init_t())
+    assert h.API_DEFAULTS == {"strict_fp": False, "cond_solver": 1}
+    hdr = open(os.path.join(ROOT, "include", "libcloudph++", "lgrngn", "opts_init.hpp")).read()
+    assert re.search(r"bool strict_fp = false;", hdr) and re.search(r"int cond_solver = 1;", hdr)
+    c = lgrngn._opts_init_c()
+    f = _lib.load().lcx_opts_init_default
+    f.restype = None
+    f(ctypes.byref(c))
+    assert (c.strict_fp, c.cond_solver) == (0, 1)
+    # (the oracle is one arithmetic whatever the option says; its default follows the header it shares)
+    g = h.oracle_lib().orc_opts_init_default
+    g.restype = None
+    g(ctypes.byref(c))
+    assert (c.strict_fp, c.cond_solver) == (0, 1)
+
+
 def test_unavailable_backends_raise():
     from libcloudphxx_amd import lgrngn
     oi = lgrngn.opts_init_t()

@@ -68,8 +68,12 @@ def test_bench_prints_one_json_line_with_the_agreed_keys(extra):
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in c, k
         assert "strict_fp" in d and d["strict_fp"]["ms_per_step"] > 0
-        # the other legs: the reference-faithful fast solver, and the Eulerian arrays in host memory (what an unchanged caller passes)
-        assert d["cond_solver_toms748"]["ms_per_step"] > 0 and d["host_arrays"]["ms_per_step"] > 0 and d["host_arrays_strict_fp"]["ms_per_step"] > 0
+        # the other legs: the API's default arithmetic (round 5: fast, the reference's TOMS748 iterates) with device and with host arrays
+        # (what an unchanged caller passes), the headline with host arrays, a coalescence that collides, and 512 per cell (C5)
+        for leg in ("api_default", "api_default_host_arrays", "host_arrays", "coal_stress", "c5"):
+            assert d[leg]["ms_per_step"] > 0, leg
+        assert d["coal_stress"]["collided_pairs_per_step"] > 0 and d["coal_stress"]["coal_ms"] > 0
+        assert abs(d["c5"]["value"] * d["c5"]["ms_per_step"] * 1e-3 / (16 ** 3 * 512) - 1) < 0.05
 
 
 @pytest.mark.gpu

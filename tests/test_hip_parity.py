@@ -558,6 +558,27 @@ def test_full_steps_replay(dims, sstp, mode):
         h.copy_state(orc, hip)
 
 
+def test_the_api_default_mode_keeps_the_strict_bars():
+    """What a caller that sets NO arithmetic option gets since round 5 (both mirrors, lcx_opts_init_default): fast arithmetic with the
+    reference's TOMS748 iterates.  The suite pins the parity mode for every other test (tests/_harness.py); this one takes the
+    constructor's own values and holds three replayed full steps to the bars of the strict mode."""
+    oi = h.api_default_opts(h.box_opts(5, 4, 6, 64, sstp_cond=2))
+    assert (oi.strict_fp, oi.cond_solver) == (False, 1)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    opts = lgrngn.opts_t()
+    for it in range(3):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        assert hip.n_part == orc.n_part
+        exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
+        exact(hip.state_u64("n"), orc.state_u64("n"), "n")
+        np.testing.assert_allclose(thh, tho, rtol=h.cond_bars(True)[0])
+        np.testing.assert_allclose(rvh, rvo, rtol=h.cond_bars(True)[1])
+        err = np.abs(hip.get_attr("rw2") / orc.get_attr("rw2") - 1)
+        assert err.max() < 1e-4 and np.median(err) < h.cond_bars(True)[2], (err.max(), np.median(err))
+        h.copy_state(orc, hip)
+
+
 def test_incloud_time_matches_oracle():
     """opts_init.diag_incloud_time (update_incloud_time.ipp:36-66, the selector after collisions coal.ipp:17-31,505-525,
     diag_incloud_time_mom particles_diag.ipp:482-490): the attribute after replayed full steps and its moments"""
