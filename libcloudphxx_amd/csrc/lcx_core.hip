@@ -302,7 +302,7 @@ struct Particles : IParticles {
     ijk.alloc(cap); sorted_id.alloc(cap); sorted_ijk.alloc(cap); rank.alloc(cap);
     cell_cnt.alloc_zero(ncell, st); cell_start.alloc_zero(ncell + 1, st);
     tile_sums.alloc(2 * (std::max(cap, ncell) / SCAN_TILE + 2)); scan_total.alloc(4);   // (two halves for the two migrant lists)
-    big_list.alloc(std::min<size_t>(ncell, cap / CELLRANK_MAX + 1) + 1); step_cnt.alloc_zero(8, st);
+    big_list.alloc(ncell + 1); step_cnt.alloc_zero(8, st);        // (every cell can be listed: list_thr)
     m3_before.alloc(cap); m3_after.alloc(cap);
     if (oi.coal_switch) col.alloc(cap);
     for (DevBuf<T> *b : {&rhod, &th, &rv, &p, &Tk, &RH, &eta, &dv, &lambda_D, &lambda_K, &sstp_tmp_rv, &sstp_tmp_th, &sstp_tmp_rh, &rw_mom3, &count_mom})
@@ -749,6 +749,16 @@ struct Particles : IParticles {
   // meta_known: {number of cells above CELLRANK_MAX, largest occupancy} already on the host (listed from the histogram ahead of the
   // step's read-back), else order_cells lists them from the CSR offsets and pays a host round trip of its own
   uint32_t big_n = 0, big_mx = 0; uint64_t meta_version = ~0ull;
+  // Which cells are listed for the one-wave-per-cell sorts.  Where cells are crowded on average (above CELLRANK_MAX / 2 per cell: C5's 512)
+  // k_cellrank has nothing to rank -- round 4 ran it all the same, every workgroup voting "all crowded" and copying its ids to the
+  // other buffer: 20 B per super-droplet moved for nothing, a third of C5's re-sort.  Round 5: in such a box k_cellrank is not launched,
+  // one wave per cell orders EVERY cell's scattered ids in place without a list (sort_listed_cells), and only the cells beyond a wave's
+  // capacity are listed (threshold CELLSORT_WAVE_MAX) for the workgroup-wide sorts.  big_thr: the threshold the list in big_list was
+  // made with (a slab with neighbours keeps CELLRANK_MAX: its boundary ranges are ranked by k_cellrank)
+  uint32_t big_thr = uint32_t(CELLRANK_MAX);
+  uint32_t list_thr() const
+  { return (!distmem() && ncell && npart / ncell > size_t(CELLRANK_MAX) / 2) ? uint32_t(CELLSORT_WAVE_MAX) : uint32_t(CELLRANK_MAX); }
+  bool every_cell_by_a_wave() const { return big_thr == uint32_t(CELLSORT_WAVE_MAX); }
   // defer: the scan only -- the scatter and the in-cell ranking are left to the next step's condensation (finish_deferred_sort, or the
   // storage-order kernel that carries the scatter, cond_substep); the random keys of a shuffle are drawn NOW, at their place in the
   // generator's sequence
@@ -796,22 +806,24 @@ struct Particles : IParticles {
         // the list of cells too big for k_cellrank costs a host round trip unless it came with the step's read-back (sort_from_hist);
         // the in-cell shuffle of coalescence re-orders the SAME segments as the sort before it, so the list is kept until cell_start changes
         if (meta_version != cells_version) {
+          big_thr = list_thr();
           HIPCHK(hipMemsetAsync(big_meta_own_p(), 0, 2 * sizeof(uint32_t), st));
-          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, uint32_t(CELLRANK_MAX), big_list.p, big_meta_own_p(),
+          hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, cell_start.p, big_thr, big_list.p, big_meta_own_p(),
                              big_meta_own_p() + 1, (const uint32_t *)nullptr);
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
-        if (shuffle && !rs.un && !crowded && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING)) hipLaunchKernelGGL(k_cellrank_bkt<>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, rank_range{nullptr, nullptr, nullptr});
+        if (every_cell_by_a_wave()) ;           // every cell is sorted in place below: nothing to rank and no buffer swap
+        else if (shuffle && !rs.un && !crowded && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING)) hipLaunchKernelGGL(k_cellrank_bkt<>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, rank_range{nullptr, nullptr, nullptr});
         else if (shuffle && !rs.un && !crowded && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         else hipLaunchKernelGGL(k_cellrank<uint32_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
-        sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
+        if (!every_cell_by_a_wave()) sorted_id.swap(rank);        // `rank` is free after the scatter: it serves as the output buffer
         if (meta_version != cells_version) {
           uint32_t m2[2];
           read_back(m2, big_meta_own_p(), 2);
           big_n = m2[0]; big_mx = m2[1]; meta_version = cells_version;
         }
-        if (big_n) sort_listed_cells(shuffle, rs);
+        if (big_n || every_cell_by_a_wave()) sort_listed_cells(shuffle, rs);
       }
     }
     sorted = true; sorted_shuffled = shuffle; shuffle_fresh = false;
@@ -820,11 +832,20 @@ struct Particles : IParticles {
   void sort_listed_cells(bool shuffle, const rng_src &rs)
   {
     const uint32_t meta[2] = {big_n, big_mx};
-    const unsigned nbw = std::min<unsigned>((meta[0] + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
+    // every_cell_by_a_wave(): no list for the one-wave sorts -- every cell of the box in turn (the list then holds what is beyond a wave)
+    const uint32_t *lst = every_cell_by_a_wave() ? (const uint32_t *)nullptr : big_list.p;
+    const uint32_t n_w = every_cell_by_a_wave() ? uint32_t(ncell) : meta[0];
+    const unsigned nbw = std::min<unsigned>((n_w + BS / WAVE - 1) / (BS / WAVE), 256u * 32u);
     // (the device generator's salted bijection keys: 32 bits order a cell)
-    if (shuffle && !rs.un && (rs.s1 | rs.s2)) hipLaunchKernelGGL((k_cellsort_wave<uint32_t, true>), dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
-    else if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
-    else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
+    if (shuffle && !rs.un && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING))
+    {
+      hipLaunchKernelGGL(k_cellsort_wave_bkt<10>, dim3(nbw), dim3(BS), 0, st, lst, n_w, cell_start.p, sid(), rs, 1u);
+      hipLaunchKernelGGL((k_cellsort_wave_bkt<CELLSORT_WAVE_MAX / WAVE>), dim3(nbw), dim3(BS), 0, st, lst, n_w, cell_start.p, sid(), rs, 10u * WAVE);
+    }
+    else if (shuffle && !rs.un && (rs.s1 | rs.s2)) hipLaunchKernelGGL((k_cellsort_wave<uint32_t, true>), dim3(nbw), dim3(BS), 0, st, lst, n_w, cell_start.p, sid(), rs);
+    else if (shuffle) hipLaunchKernelGGL(k_cellsort_wave<uint64_t>, dim3(nbw), dim3(BS), 0, st, lst, n_w, cell_start.p, sid(), rs);
+    else         hipLaunchKernelGGL(k_cellsort_wave<uint32_t>, dim3(nbw), dim3(BS), 0, st, lst, n_w, cell_start.p, sid(), rs);
+    if (!meta[0]) return;
     if (meta[1] > uint32_t(CELLSORT_WAVE_MAX)) {
       const unsigned nbl = std::min<unsigned>(meta[0], 256u * 16u);
       if (shuffle) hipLaunchKernelGGL(k_cellsort_lds<uint64_t>, dim3(nbl), dim3(BS), 0, st, big_list.p, meta[0], cell_start.p, sid(), rs);
@@ -992,7 +1013,8 @@ struct Particles : IParticles {
   bool listed_from_hist = false, meta_known_valid = false; uint32_t meta_known_v[2] = {0, 0};
   void list_big_from_hist()
   {   // (big_meta was cleared behind the previous sort's scan)
-    hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, (const uint32_t *)nullptr, uint32_t(CELLRANK_MAX), big_list.p, big_meta_p(), big_meta_p() + 1,
+    big_thr = list_thr();
+    hipLaunchKernelGGL(k_list_big_cells, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, (const uint32_t *)nullptr, big_thr, big_list.p, big_meta_p(), big_meta_p() + 1,
                        (const uint32_t *)cell_cnt.p);
     listed_from_hist = true;
   }

@@ -679,8 +679,8 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
   const uint32_t lane = lane_id();
   auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
   for (uint32_t b = blockIdx.x * (BS / WAVE) + wave_id(); b < n_big; b += gridDim.x * (BS / WAVE)) {
-    const uint32_t c = big_list[b], start = cell_start[c], cnt = cell_start[c + 1] - start;
-    if (cnt > uint32_t(CELLSORT_WAVE_MAX)) continue;         // k_cellsort_lds / k_cellsort_big take it
+    const uint32_t c = big_list ? big_list[b] : b, start = cell_start[c], cnt = cell_start[c + 1] - start;      // (no list: every cell in turn)
+    if (cnt > uint32_t(CELLSORT_WAVE_MAX) || cnt < 2u) continue;         // k_cellsort_lds / k_cellsort_big take it
     if constexpr (shuffle) {
       uint32_t *cb = bkt[wave_id()];
       uint16_t *ix = idx[wave_id()];
@@ -740,6 +740,76 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
       for (uint32_t i = lane; i < cnt; i += WAVE) sorted_id[start + i] = uint32_t(a[i]);
       wave_sync();
     }
+  }
+}
+// Round 5: the crowded cells' shuffled order on the device generator's 32-bit keys (C5: every cell, 512 keys each), one wave per cell,
+// the scheme of k_cellrank_bkt inside a wave.  A key's bucket is HALF its expected rank in its cell, (key x count) >> 33: two keys per bucket
+// on average whatever the cell holds (k_cellsort_wave's 512 fixed buckets are one or two keys at 512 per cell and ten at 1024); the keys
+// are written GROUPED BY BUCKET behind one wave scan of the bucket counts, and a key's rank is the first position of its bucket + the
+// smaller keys inside it.  Against k_cellsort_wave<uint32_t, true>: no position-ordered copy of the keys and no index array in LDS (the
+// keys wait in registers, the bucket's members are read where they lie) -- eight LDS operations per key instead of fourteen, 6 KB of
+// LDS per wave instead of 8.  big_list == nullptr: every cell of [0, n_big) in turn (round 5: a box whose cells are crowded on average
+// is not listed at all -- the list cost C5 0.75 ms of single-address atomics, and round 4 copied every id through k_cellrank first).
+// Cells above CELLSORT_WAVE_MAX are left to k_cellsort_lds / k_cellsort_big as before.  The same order: the keys are unique.
+// PER: keys per lane at most -- the launch takes the cells of more than cnt_above and at most PER x 64 keys.  Ten serve C5's cells (512
+// +- 60) from 68 vector registers, six waves per SIMD; sixteen (a wave's capacity) need 116: the host launches both, the second finds
+// next to nothing to do.
+template <int PER>
+__global__ void __launch_bounds__(BS)
+k_cellsort_wave_bkt(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_start, uint32_t *sorted_id, rng_src r, uint32_t cnt_above)
+{
+  static_assert(PER * WAVE <= CELLSORT_WAVE_MAX, "a wave's stage");
+  constexpr int NB = CELLSORT_WAVE_MAX / 2;                // buckets at most
+  constexpr int CPL = NB / WAVE;                           // counters per lane in the scan
+  __shared__ uint32_t grp[BS / WAVE][CELLSORT_WAVE_MAX];   // the keys grouped by bucket
+  __shared__ uint32_t bkt[BS / WAVE][NB];                  // bucket counts, then their exclusive prefix sums
+  uint32_t *g = grp[wave_id()], *cb = bkt[wave_id()];
+  const uint32_t lane = lane_id();
+  auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+  for (uint32_t b = blockIdx.x * (BS / WAVE) + wave_id(); b < n_big; b += gridDim.x * (BS / WAVE)) {
+    const uint32_t c = big_list ? big_list[b] : b, start = cell_start[c], cnt = cell_start[c + 1] - start;
+    if (cnt <= cnt_above || cnt > uint32_t(PER * WAVE)) continue;
+    const uint32_t nb = (cnt + 1u) >> 1;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) cb[lane + j * WAVE] = 0u;
+    uint32_t key[PER], idr[PER], slot[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const uint32_t i = lane + k * WAVE; idr[k] = i < cnt ? sorted_id[start + i] : 0u; }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = lane + k * WAVE;
+      if (i < cnt) { key[k] = shuffle_un(idr[k], r.s1, r.s2); slot[k] = atomicAdd(&cb[__umulhi(key[k], cnt) >> 1], 1u); }
+    }
+    wave_sync();
+    uint32_t loc[CPL], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { loc[j] = cb[lane * CPL + j]; sum += loc[j]; }      // (counters behind nb are zero)
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane) >= d) incl += t; }
+    uint32_t run = incl - sum;
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { cb[lane * CPL + j] = run; run += loc[j]; }         // first position of every bucket
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = lane + k * WAVE;
+      if (i < cnt) { slot[k] += cb[__umulhi(key[k], cnt) >> 1]; g[slot[k]] = key[k]; }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t i = lane + k * WAVE;
+      if (i < cnt) {
+        const uint32_t bk = __umulhi(key[k], cnt) >> 1, s = cb[bk], e = bk + 1u < nb ? cb[bk + 1u] : cnt;
+        uint32_t rank = s;
+        for (uint32_t q = s; q < e; ++q) rank += g[q] < key[k];
+        sorted_id[start + rank] = idr[k];
+      }
+    }
+    wave_sync();
   }
 }
 // listed segments of up to CELLSORT_LDS_MAX keys: one workgroup per segment, bitonic network

@@ -66,7 +66,7 @@ def oracle_by_tag(orc):
     return out
 
 
-def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1, rebase=True):
+def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1, rebase=True, free_bars=(1e-4, 1e-6, 1e-7)):
     """one full step of both; returns (collisions in the oracle, device storage extent before the step's end)"""
     orc.step_sync(opts, fo[0], fo[1], rhod, **C)
     hip.step_sync(opts, fh[0], fh[1], rhod, **C)
@@ -82,7 +82,8 @@ def reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, sstp_coal=1, rebase=Tru
         err = np.abs(d["rw2"] / orc.state_real("rw2")[order] - 1)
         # (this spectrum's drops are all but insoluble, kappa = 1e-10, and as large dry as wet: rw^3 - rd^3 cancels to eight digits, and
         # the fast arithmetic forms it with one rounding where the strict order has two -- 1e-7 here, 1e-14 on an aerosol's droplets)
-        assert err.max() < 1e-4 and np.quantile(err, .999) < 1e-6 and np.median(err) < 1e-7, (err.max(), np.quantile(err, .999), np.median(err))
+        # free_bars: (every droplet, 99.9 % of them, the median)
+        assert err.max() < free_bars[0] and np.quantile(err, .999) < free_bars[1] and np.median(err) < free_bars[2], (err.max(), np.quantile(err, .999), np.median(err))
     elif opts.cond:
         # This box holds 1 g of liquid water per m^3.  The root finder's tolerance on rw2 (2^-14 relative, config.hpp:39 through
         # toms748.hpp:267-282: both the reference's midpoint and the lean solver's root lie within it of each other) is 1.5 x 2^-14 of
@@ -394,7 +395,13 @@ def test_reverse_replay_at_production_size(workload, cond_solver):
     assert orc.n_part == hip.n_part
     n0, collisions, reorderings, last_first_tag = orc.n_part, 0, 0, None
     for it in range(steps):
-        ncol, _ = reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, rebase=cond_solver == 0)
+        # (the free run's wet radii: an aerosol's droplets are identical to the oracle's -- median below 1e-10 -- but where an ulp of the
+        # fast arithmetic moved one of TOMS748's stopping decisions, and then by what one bisection of its last bracket is worth: 8e-6
+        # for one droplet in a thousand of this box, 3e-5 at most)
+        # ... and a FREE run carries a droplet's difference into its next step, where a droplet that is activating amplifies it (the
+        # growth of a droplet at its critical radius is unstable): up to 8e-3 for the worst few of 1.7e7 in the course of seven steps --
+        # the thousandth-worst stays at one bisection (1.3e-5), the median at 1e-11
+        ncol, _ = reverse_replay_step(orc, hip, opts, fo, fh, rhod, C, rebase=cond_solver == 0, free_bars=(5e-2, 5e-5, h.cond_bars(True)[2]))
         collisions += ncol
         assert hip.n_part == orc.n_part, it
         d, o = device_by_tag(hip), oracle_by_tag(orc)
@@ -409,7 +416,7 @@ def test_reverse_replay_at_production_size(workload, cond_solver):
                 np.testing.assert_allclose(d[a_], o[a_], rtol=1e-13, atol=1e-9, err_msg="%s, step %d" % (a_, it))
         else:
             err = np.abs(d["rw2"] / o["rw2"] - 1)
-            assert err.max() < 1e-4 and np.quantile(err, .999) < 1e-6, (it, err.max(), np.quantile(err, .999))
+            assert err.max() < 5e-2 and np.quantile(err, .999) < 1e-4 and np.median(err) < 1e-9, (it, err.max(), np.quantile(err, .999), np.median(err))
             for a_ in ("x", "y"):
                 np.testing.assert_allclose(d[a_], o[a_], rtol=1e-13, atol=1e-9, err_msg="%s, step %d" % (a_, it))
             np.testing.assert_allclose(d["z"], o["z"], rtol=1e-13, atol=2e-3)
