@@ -131,7 +131,12 @@ typedef struct {
                          * 1: with DEVICE arrays (lcx_arrinfo_t.on_device) they return once the work is queued on the object's stream, like any
                          *    GPU library call: th and rv are valid for work ordered behind lcx_stream() (an event wait on the caller's stream),
                          *    the host does not wait -- it is already queueing step_async while condensation runs.  Calls that involve host
-                         *    arrays, and everything that hands data to the host (diag, outbuf, get_attr ...), synchronise as before. */
+                         *    arrays, and everything that hands data to the host (diag, outbuf, get_attr ...), synchronise as before.
+                         *    THE OTHER DIRECTION IS THE CALLER'S TOO: the next step_sync reads the caller's device arrays (th, rv, rhod, the
+                         *    Courant numbers) on lcx_stream() with no host wait in between, so a caller that rewrites them on a stream of its
+                         *    own makes lcx_stream() wait for that work first (hipStreamWaitEvent(lcx_stream(h), its_event), or a device
+                         *    synchronisation) -- with stream_ordered = 0 the host waits at the end of step_cond and only the usual rule is
+                         *    left: what the caller queued on its streams before calling in must have been ordered by the caller. */
   /* --- test / measurement switches (no reference counterpart; all 0 in production).  They used to be LCX_* environment variables read
    * here and there in the library; a stray variable in a user's environment silently changed the kernel path.  Now they are part of the
    * options an object is created with, read once, and the library reads no environment variable but LCX_DATA_DIR (where the collision

@@ -1150,19 +1150,19 @@ struct Particles : IParticles {
           if (carry_scatter) { a.sc_rank = rnk(); a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
           // (one hygroscopicity in the whole run: a scalar instead of 8 B per droplet, see kpa_uniform)
           const dim3 gs(nblk(nphys));
-          if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
-          else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 7, false, 2>), gs, bl, 0, st, nphys, a, T(0));
-          else if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 3, false, 1>), gs, bl, 0, st, nphys, a, T(0));
+          if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
+          else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gs, bl, 0, st, nphys, a, T(0));
+          else if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 11, false, 1>), gs, bl, 0, st, nphys, a, T(0));
           // (round 5, measured and kept behind a switch: the workgroup folded behind the solver's first loop trip -- the same bits, 6 % fewer
           // vector instructions per wave at a higher lane use, and not faster: the chip runs this kernel at its package power cap, where
           // what a launch costs is the lanes that compute, not the instructions that issue; see k_cond_lean_fold)
           else if (dbg(LCX_DBG_COND_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (dbg(LCX_DBG_COND_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false>), gs, bl, 0, st, nphys, a, T(0));
-          else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 7, true>), gs, bl, 0, st, nphys, a, kpa_value);
-          else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gs, bl, 0, st, nphys, a, T(0));
+          else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value);
+          else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0));
         }
-        else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 7, false, 2>), gr, bl, 0, st, npart, a, T(0));
-        else hipLaunchKernelGGL((k_cond_lean<T, 7, false>), gr, bl, 0, st, npart, a, T(0));
+        else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0));
+        else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0));
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
@@ -1175,11 +1175,11 @@ struct Particles : IParticles {
         cond_defer df{rnk(), defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
         const bool fold = !dbg(LCX_DBG_COND_NO_FOLD);                             // (test / measurement switch)
-        if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 3>), gr, bl, 0, st, npart, a, df);
-        else hipLaunchKernelGGL((k_cond_fast<T, 3, false>), gr, bl, 0, st, npart, a, df);
+        if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 11>), gr, bl, 0, st, npart, a, df);
+        else hipLaunchKernelGGL((k_cond_fast<T, 11, false>), gr, bl, 0, st, npart, a, df);
         if (df.budget) {
           const unsigned per_shard = std::max(1u, std::min(nblk(npart / 8 + 1), 256u * 64u) / DEFER_SHARDS);
-          hipLaunchKernelGGL((k_cond_fast<T, 3, true>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, npart, a, df);
+          hipLaunchKernelGGL((k_cond_fast<T, 11, true>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, npart, a, df);
         }
       }
       else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);

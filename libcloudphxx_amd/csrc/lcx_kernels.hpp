@@ -1292,7 +1292,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
   bool live = pos < n_part;
   uint32_t id = uint32_t(pos), c = DEAD_CELL, m3_pos = uint32_t(pos);
   T rw2_old = 0, nn = 0, r = 0, rd2 = 0;
-  cond_fun_fast<T, 7> ff;
+  cond_fun_fast<T, 15> ff;
   lean_state<T> s;
   bool need = false;
   if (live) {
@@ -1367,6 +1367,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
     ff.rw2_old = rw2_old; ff.dt = a.dt_sub;
     ff.Sc = cc.Sc; ff.Pr = cc.Pr; ff.lambda_D = cc.lambda_D; ff.lambda_K = cc.lambda_K; ff.A = cc.A; ff.RH_eff = cc.RH_eff;
     ff.c1 = cc.c1; ff.c2_rho = cc.c2_rho; ff.RH_rho_w = cc.RH_rho_w;
+    if constexpr (decltype(ff)::trim) { ff.Sc = ff.c_Re * cc.Sc; ff.Pr = ff.c_Re * cc.Pr; }      // (setup_cell's products, see cond_fun_fast)
   }
   if (!run) return;
   lean2_loop(ff, a.eps, a.n_iter - 1u, s, r);

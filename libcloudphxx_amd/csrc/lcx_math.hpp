@@ -711,8 +711,15 @@ __device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10.
 // the series' range test as one v_max_f64.  (Measured and dropped: the Kelvin exponential without its range reduction where that is
 // the identity, A / r_w < 0.34 -- the same bits from five instructions fewer per evaluation, but the fallback's second code path costs
 // 23 VGPRs, 102 instead of 79: four waves per SIMD instead of six.)
+// Bit 3 (round 5, the production kernels): the same rational expression from six instructions fewer per evaluation, inside the mode's
+// few-ulp envelope but NOT the same bits as without it -- Re Sc and Re Pr from per-droplet products c_Re Sc, c_Re Pr (Sc, Pr then hold those
+// products); 1 + (1 + x p(x)) of the common branch as 2 + x p(x); the quotient's reciprocal with one Newton step instead of two
+// (v_rcp_f64 delivers 2^-25: <= 11 ulp after one step, lcx_math.hpp rcp_newton1 -- a relative 2e-15 of a growth rate that the root
+// finder resolves to 3e-5); and 2 dt folded into one factor of the root finder's function (dt then holds 2 dt inside operator()).
+// The launch is priced in lanes that compute (the package power cap, see k_cond_lean_fold): every fp64 operation less is time.
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
   static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
+  static constexpr bool trim = (OPT & 8) != 0 && sizeof(T) == 8;
   T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
   LCX_HD void setup(const cond_fun<T> &f)
   {
@@ -732,8 +739,10 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
     c_Re = vt * T(2) * cc.rhod / cc.eta;
     Sc = cc.Sc; Pr = cc.Pr; lambda_D = cc.lambda_D; lambda_K = cc.lambda_K; A = cc.A; RH_eff = cc.RH_eff;
     c1 = cc.c1; c2_rho = cc.c2_rho; RH_rho_w = cc.RH_rho_w;
+    if constexpr (trim) { Sc = c_Re * Sc; Pr = c_Re * Pr; }
   }
-  LCX_HD T drw2_dt(T rw2) const
+  LCX_HD T drw2_dt(T rw2) const { return T(2) * half_drw2_dt(rw2); }
+  LCX_HD T half_drw2_dt(T rw2) const         // r dr/dt
   {
 #pragma clang fp contract(fast)
     T irw;                            // one v_rsq + Newton step; rw = rw2 / sqrt(rw2) to ~1 ulp
@@ -754,7 +763,8 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       // latency of its dependent fp64 chains, and every branch (even one that the whole wave skips) ends a scheduling region.  Bigger
       // droplets repair Sh and Nu behind it in one rarely taken branch.  (cond on C3: 7.0 -> 6.7 ms with the two cube roots behind one
       // branch instead of two; -> see DESIGN.md for this form.)
-      const T xS = Re * Sc, xN = Re * Pr;
+      T xS, xN;
+      if constexpr (trim) { xS = rw * Sc; xN = rw * Pr; } else { xS = Re * Sc; xN = Re * Pr; }
 #if defined(__HIP_DEVICE_COMPILE__)
       const double *q = lcx_cbrt1p_c;                  // (coefficients through the scalar cache, see exp_kelvin)
       T cS = T(1) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
@@ -764,7 +774,14 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       T cN = T(1) + xN * (T(1. / 3) + xN * (T(-1. / 9) + xN * (T(5. / 81) + xN * (T(-10. / 243) + xN * T(22. / 729)))));
 #endif
       klv = exp_kelvin(A * irw);
-      Sh = T(1) + cS; Nu = T(1) + cN;
+      if constexpr (trim) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        Sh = T(2) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
+        Nu = T(2) + xN * (T(q[0]) + xN * (T(q[1]) + xN * (T(q[2]) + xN * (T(q[3]) + xN * T(q[4])))));
+#else
+        Sh = T(1) + cS; Nu = T(1) + cN;
+#endif
+      } else { Sh = T(1) + cS; Nu = T(1) + cN; }
       bool big;
       if constexpr ((OPT & 4) != 0) big = !(T(__builtin_fmax(fabs(xS), fabs(xN))) < T(0x1p-8)); else big = !(mx(fabs(xS), fabs(xN)) < T(0x1p-8));
       if (big) {
@@ -785,11 +802,14 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
     const T nDSh = nD * Sh, nKNu = nK * Nu;
     const T num = (da * RH_eff - na * klv) * (nDSh * nKNu);
     const T den = (da * RH_rho_w) * (c1 * dD * nKNu + c2_rho * dK * nDSh);
-    return T(2) * dvd<1>(num, den);
+    if constexpr (trim) return dvd<2>(num, den);
+    return dvd<1>(num, den);
   }
   LCX_HD T operator()(T rw2) const
   {
 #pragma clang fp contract(fast)
+    // (dt is uniform: 2 dt is formed once, in a scalar register pair; the fused operation written out, see na / da above)
+    if constexpr (trim) return T(fma(T(dt + dt), half_drw2_dt(rw2), rw2_old)) - rw2;
     return rw2_old + dt * drw2_dt(rw2) - rw2;
   }
 };

@@ -567,6 +567,48 @@ def test_stream_ordered_step_sync_gives_the_same_run():
         assert np.array_equal(a, b)
 
 
+@pytest.mark.gpu
+def test_stream_ordered_caller_rewrites_its_arrays_on_its_own_stream():
+    """The other direction of opts_init.stream_ordered's contract (include/lcx.h): between two steps the caller -- a
+    dynamical core that lives on the GPU -- rewrites th, rv and the Courant numbers on a stream of ITS OWN, behind the library's results
+    (its stream waits for lcx_stream), and makes lcx_stream() wait for that work before the next step_sync instead of synchronising the
+    device.  The run equals the one whose caller synchronises the device around every call."""
+    import torch
+    oi = h.box_opts(16, 12, 20, 16, strict_fp=False, stream_ordered=True)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = []
+    for events_only in (False, True):
+        t = {k: torch.tensor(v, device="cuda") for k, v in dict(th=th, rv=rv, rhod=rhod, **C).items()}
+        torch.cuda.synchronize()
+        d = {k: lgrngn.DeviceArray(v.data_ptr(), v.shape) for k, v in t.items()}
+        pr = h.hip_particles(oi)
+        pr.init(d["th"], d["rv"], d["rhod"], Cx=d["Cx"], Cy=d["Cy"], Cz=d["Cz"])
+        lib_stream = torch.cuda.ExternalStream(pr.stream())
+        mine = torch.cuda.Stream()
+        opts = lgrngn.opts_t()
+        for it in range(4):
+            pr.step_sync(opts, d["th"], d["rv"], d["rhod"], Cx=d["Cx"], Cy=d["Cy"], Cz=d["Cz"])
+            pr.step_async(opts)
+            if events_only:
+                mine.wait_stream(lib_stream)              # the caller's stream behind the library's results
+            else:
+                torch.cuda.synchronize()
+            with torch.cuda.stream(mine):                 # the "dynamical core": a big, slow rewrite of the fields on the caller's stream
+                for _ in range(20):
+                    t["th"].mul_(1.0 + 1e-6).add_(1e-5)
+                t["rv"].mul_(1.0 - 1e-5)
+                t["Cx"].mul_(0.97); t["Cz"].mul_(1.01)
+            if events_only:
+                lib_stream.wait_stream(mine)              # ... and the library's stream behind the rewrite: no host wait anywhere
+            else:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res.append((t["th"].cpu().numpy(), t["rv"].cpu().numpy(), pr.get_attr("rw2"), pr.get_attr("x"), pr.get_attr("z"), pr.state_u64("n")))
+    assert not np.array_equal(res[0][0], th)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("make,alloc", [pytest.param(h.oracle_particles, h.host_alloc, id="oracle"),
                                         pytest.param(h.hip_particles, h.dev_alloc, id="hip", marks=pytest.mark.gpu)])
 def test_slabs_indexing_the_global_arrays(make, alloc):

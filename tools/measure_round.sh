@@ -6,7 +6,7 @@ tag=${1:-r02}
 ulimit -c 0
 out=gpurun_out/meas_$tag
 mkdir -p $out
-B="python3 bench.py --no-cpu-baseline --no-strict-leg --no-toms-leg --no-host-leg"
+B="python3 bench.py --no-cpu-baseline --no-strict-leg --no-toms-leg --no-host-leg --no-extra-legs"
 # one slab of the strong-scaling split of C3 on a device of its own (what each GPU of an N-GPU run computes, without exchange)
 for nx in 64 32 16; do $B --nx $nx --steps 100 > $out/slab_nx$nx.json 2> $out/slab_nx$nx.err; done
 # the same slabs as ONE RANK of the one-object-per-rank path whose neighbours are the rank itself: the whole exchange (pack, RCCL send and

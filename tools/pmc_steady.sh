@@ -8,7 +8,7 @@ mkdir -p $out
 i=0
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $out/pmc_$i -- python3 bench.py --steps 2 --warmup 18 --no-cpu-baseline --no-strict-leg --no-toms-leg --no-host-leg --no-stage-timers $extra > $out/pmc_$i.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $out/pmc_$i -- python3 bench.py --steps 2 --warmup 18 --no-cpu-baseline --no-strict-leg --no-toms-leg --no-host-leg --no-extra-legs --no-stage-timers $extra > $out/pmc_$i.log 2>&1
 done
 python3 - $out <<'PY'
 import collections, csv, glob, sys
