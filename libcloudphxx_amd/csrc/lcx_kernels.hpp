@@ -1251,8 +1251,9 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
   }
   T nn = T(n_raw);
   asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
-               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w));
   if (!UNI) asm volatile("" : "+v"(kpa));
+  if constexpr (cond_fun_fast<T, OPT>::trim) asm volatile("" : "+v"(cc.two_rho_eta)); else asm volatile("" : "+v"(cc.rhod), "+v"(cc.eta));
   T delta = 0;
   if (!(rw2_old <= 0)) {                // (cond_common.ipp:197-199; a NaN goes through the solver and poisons its cell as in the reference)
     cond_fun_fast<T, OPT> ff;
@@ -1283,7 +1284,7 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
 // (profiles/r05*_power.txt) -- the launch is priced in lanes that compute (energy), not in instructions that issue.  Storage order only.
 constexpr int FOLD_CAP = 128;
 template <class T, bool UNI>
-__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6))) k_cond_lean_fold(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
+__global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
 {
   __shared__ T xs[13][FOLD_CAP];
   __shared__ uint32_t xw[3][FOLD_CAP];
@@ -1314,8 +1315,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6, 6)))
       if (a.sc_rank) { m3_pos = cs + rk; a.sc_sorted_id[m3_pos] = id; a.sc_sorted_ijk[m3_pos] = c; }
       nn = T(n_raw);
       asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
-                   "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w), "+v"(cc.rhod), "+v"(cc.eta));
+                   "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w));
       if (!UNI) asm volatile("" : "+v"(kpa));
+      asm volatile("" : "+v"(cc.two_rho_eta));
       T delta = 0;
       if (!(rw2_old <= 0)) {
         ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);

@@ -692,7 +692,8 @@ LCX_HD float pow_core(float x, float y) { return pow(x, y); }
 //   r dr/dt = (da RH - na klv) nD Sh nK Nu / ( da RH rho_w (c1 dD nK Nu + c2 dK nD Sh) )
 // with beta(Kn) = n/d, a_w = na/da, c1 = 2/(D_0 rho_v), c2 = 2 l_v (l_v/(R_v T) - 1)/(K_0 RH T).
 // droplet-independent part of the collected growth rate's set-up
-template <class T> struct cond_cell_fast { T Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w, rhod, eta, pad_; };
+// (two_rho_eta = 2 rhod / eta: the cell's part of the Reynolds number, for the production kernels' form of the growth rate -- OPT bit 3)
+template <class T> struct cond_cell_fast { T Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w, rhod, eta, two_rho_eta; };
 // cbrt(1 + x): for |x| below 2^-8 (Re Sc of droplets up to ~8 um) the Taylor series to x^5 (next term 0.023 x^6 < 1e-16)
 template <bool SERIES, class T> LCX_HD T cbrt1p(T x)
 {
@@ -715,7 +716,8 @@ __device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10.
 // few-ulp envelope but NOT the same bits as without it -- Re Sc and Re Pr from per-droplet products c_Re Sc, c_Re Pr (Sc, Pr then hold those
 // products); 1 + (1 + x p(x)) of the common branch as 2 + x p(x); the quotient's reciprocal with one Newton step instead of two
 // (v_rcp_f64 delivers 2^-25: <= 11 ulp after one step, lcx_math.hpp rcp_newton1 -- a relative 2e-15 of a growth rate that the root
-// finder resolves to 3e-5); and 2 dt folded into one factor of the root finder's function (dt then holds 2 dt inside operator()).
+// finder resolves to 3e-5); 2 dt folded into one factor of the root finder's function; and the Reynolds number's 2 rhod / eta taken per
+// cell (one product per droplet instead of an IEEE division).
 // The launch is priced in lanes that compute (the package power cap, see k_cond_lean_fold): every fp64 operation less is time.
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
   static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
@@ -736,7 +738,8 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
   LCX_HD void setup_cell(const cond_cell_fast<T> &cc, T rw2_old_, T dt_, T rd3_, T kpa, T vt)
   {
     rw2_old = rw2_old_; dt = dt_; rd3 = rd3_; rd3_1mk = rd3_ * (T(1) - kpa);
-    c_Re = vt * T(2) * cc.rhod / cc.eta;
+    // (bit 3: the cell's 2 rhod / eta comes with the cell's constants -- one product per droplet instead of an IEEE division)
+    if constexpr (trim) c_Re = vt * cc.two_rho_eta; else c_Re = vt * T(2) * cc.rhod / cc.eta;
     Sc = cc.Sc; Pr = cc.Pr; lambda_D = cc.lambda_D; lambda_K = cc.lambda_K; A = cc.A; RH_eff = cc.RH_eff;
     c1 = cc.c1; c2_rho = cc.c2_rho; RH_rho_w = cc.RH_rho_w;
     if constexpr (trim) { Sc = c_Re * Sc; Pr = c_Re * Pr; }
@@ -1009,9 +1012,14 @@ LCX_HD bool lean2_loop(const F &f, T eps, unsigned budget, lean_state<T> &s, T &
   for (unsigned it = 0; it < budget; ++it) {
     const T fc = f(c);
     const bool opp = (fc < 0) != (f1 < 0);                          // the root is between the last two points
-    T m = T(1) - dvd<FD>(fc, f1);                                   // same side twice: Anderson-Bjorck scaling of the retained end
-    m = m > 0 ? m : T(0.5);
-    const T f0s = f0 * m;
+    // same side twice: Anderson-Bjorck scaling of the retained end.  Round 5: behind a branch again -- nine droplets in ten do not take
+    // it, and what a launch costs is the lanes that compute (the package's power cap), not the instructions that a wave issues
+    T f0s = f0;
+    if (!opp) {
+      T m = T(1) - dvd<FD>(fc, f1);
+      m = m > 0 ? m : T(0.5);
+      f0s = f0 * m;
+    }
     f0 = opp ? f1 : f0s;
     x0 = opp ? x1 : x0;
     x1 = c; f1 = fc;
@@ -1057,7 +1065,7 @@ LCX_HD cond_cell_fast<T> make_cond_cell_fast(T rhod, T rv, T Tk, T eta, T lambda
   cc.c1 = T(2) / (c::D_0 * rho_v);
   cc.c2_rho = T(2) * lv * lv_term / (c::K_0 * cc.RH_eff * Tk);
   cc.RH_rho_w = cc.RH_eff * c::rho_w;
-  cc.rhod = rhod; cc.eta = eta; cc.pad_ = T(0);
+  cc.rhod = rhod; cc.eta = eta; cc.two_rho_eta = T(2) * rhod / eta;
   return cc;
 }
 // builds the growth-rate functor (strict or collected form) and hands it to `body`
