@@ -760,14 +760,40 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
     // the third moment) would change the last bit of every evaluation
     const T na = T(fma(rw2, rw, -rd3)), da = T(fma(rw2, rw, -rd3_1mk));
     T Sh, Nu, klv;
-    if constexpr ((OPT & 2) != 0 && sizeof(T) == 8) {
+    if constexpr (trim) {
+      // Round 5, the production form: the series of the common droplet and the cube roots of the bigger one behind the two sides of ONE
+      // branch (round 2 computed the series for everybody and repaired Sh and Nu behind it: what a launch costs is the lanes that compute,
+      // and on drizzle -- bench.py's coal-stress leg -- every lane took both), and the cube roots without the handling of a negative or
+      // tiny argument unless a lane has one (1 + Re Sc >= 1 for every droplet whose terminal velocity is valid): the same bits as
+      // cbrt_signed_core there.
+#if defined(__HIP_DEVICE_COMPILE__)
+      const T xS = rw * Sc, xN = rw * Pr;                // (Sc, Pr hold c_Re Sc, c_Re Pr)
+      const double *q = lcx_cbrt1p_c;                  // (coefficients through the scalar cache, see exp_kelvin)
+      klv = exp_kelvin(A * irw);
+      if (T(__builtin_fmax(fabs(xS), fabs(xN))) < T(0x1p-8)) {
+        Sh = T(2) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
+        Nu = T(2) + xN * (T(q[0]) + xN * (T(q[1]) + xN * (T(q[2]) + xN * (T(q[3]) + xN * T(q[4])))));
+      } else {
+        const T aS = T(1) + xS, aN = T(1) + xN;
+        T cS, cN;
+        if (aS >= T(0.125) && aN >= T(0.125)) { cS = cbrt_seeded_core(aS); cN = cbrt_seeded_core(aN); }
+        else { cS = cbrt_signed_core(aS); cN = cbrt_signed_core(aN); }      // (a droplet whose vt is flagged invalid, -1: see below)
+        const T m = (Re > T(1)) ? mx(T(1), T(pow_core(Re, T(.077)))) : T(1);
+        Sh = T(1) + cS * m; Nu = T(1) + cN * m;
+      }
+#else
+      const T m = (Re > T(1)) ? mx(T(1), T(pow(Re, T(.077)))) : T(1);
+      Sh = T(1) + cbrt1p<false>(Re * (Sc / c_Re)) * m;
+      Nu = T(1) + cbrt1p<false>(Re * (Pr / c_Re)) * m;
+      klv = exp_reduced(A * irw);
+#endif
+    } else if constexpr ((OPT & 2) != 0 && sizeof(T) == 8) {
       // ONE straight-line block for the common droplet (Re Sc < 2^-8: below ~8 um): the two cube-root series, the Knudsen terms and the
       // Kelvin exponential are independent chains that the scheduler interleaves -- at four waves per SIMD the kernel runs at the
       // latency of its dependent fp64 chains, and every branch (even one that the whole wave skips) ends a scheduling region.  Bigger
       // droplets repair Sh and Nu behind it in one rarely taken branch.  (cond on C3: 7.0 -> 6.7 ms with the two cube roots behind one
       // branch instead of two; -> see DESIGN.md for this form.)
-      T xS, xN;
-      if constexpr (trim) { xS = rw * Sc; xN = rw * Pr; } else { xS = Re * Sc; xN = Re * Pr; }
+      const T xS = Re * Sc, xN = Re * Pr;
 #if defined(__HIP_DEVICE_COMPILE__)
       const double *q = lcx_cbrt1p_c;                  // (coefficients through the scalar cache, see exp_kelvin)
       T cS = T(1) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
@@ -777,14 +803,7 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       T cN = T(1) + xN * (T(1. / 3) + xN * (T(-1. / 9) + xN * (T(5. / 81) + xN * (T(-10. / 243) + xN * T(22. / 729)))));
 #endif
       klv = exp_kelvin(A * irw);
-      if constexpr (trim) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        Sh = T(2) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
-        Nu = T(2) + xN * (T(q[0]) + xN * (T(q[1]) + xN * (T(q[2]) + xN * (T(q[3]) + xN * T(q[4])))));
-#else
-        Sh = T(1) + cS; Nu = T(1) + cN;
-#endif
-      } else { Sh = T(1) + cS; Nu = T(1) + cN; }
+      Sh = T(1) + cS; Nu = T(1) + cN;
       bool big;
       if constexpr ((OPT & 4) != 0) big = !(T(__builtin_fmax(fabs(xS), fabs(xN))) < T(0x1p-8)); else big = !(mx(fabs(xS), fabs(xN)) < T(0x1p-8));
       if (big) {

@@ -1,7 +1,7 @@
 /*
  * lcx_oracle.c -- TEST INFRASTRUCTURE.  CPU oracle for the lgrngn hot path.
  *
- * A serial, plain-C (double precision) restatement of what the reference's serial backend
+ * A serial, plain-C restatement of what the reference's serial backend
  * (thrust::cpp) does on particles_t::init / step_sync / step_async / diag_*, following the
  * reference's control flow and evaluation order file by file (citations at each function,
  * paths relative to the reference checkout).  It exports the same entry points as the product
@@ -54,80 +54,89 @@ static uint32_t mt_next(mt19937_t *g)
   y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
   return y;
 }
-/* uniform_real_distribution<double>(0,1) == generate_canonical<double,53>: two 32-bit draws */
-static double rng_u01(mt19937_t *g)
+/* uniform_real_distribution<real>(0,1) == generate_canonical<real,53>: two 32-bit draws */
+static dbl rng_u01_dbl(mt19937_t *g)
 {
-  const double x0 = (double)mt_next(g);
-  const double x1 = (double)mt_next(g);
-  double r = (x0 + x1 * 4294967296.0) / 18446744073709551616.0;
-  if (r >= 1.0) r = nextafter(1.0, 0.0);
+  const dbl x0 = (dbl)mt_next(g);
+  const dbl x1 = (dbl)mt_next(g);
+  dbl r = (x0 + x1 * (dbl)4294967296.0) / (dbl)18446744073709551616.0;
+  if (r >= (dbl)1.0) r = nextafter((dbl)1.0, (dbl)0.0);
+  return r;
+}
+/* (the float flavour takes the double draw -- the SAME stream as the double flavour, so that one replay serves both -- and keeps the
+ * distribution's promise u < 1 in its own type; the reference's float run draws generate_canonical<float, 24> from one 32-bit word
+ * instead: no reference-held data pins either) */
+static real rng_u01(mt19937_t *g)
+{
+  real r = (real)rng_u01_dbl(g);
+  if (r >= 1) r = nextafter((real)1, (real)0);
   return r;
 }
 /* uniform_int_distribution<unsigned>(0,UINT_MAX): one draw; fnctr_un returns it through real_t */
-static double rng_un(mt19937_t *g) { return (double)mt_next(g); }
+static dbl rng_un_dbl(mt19937_t *g) { return (dbl)mt_next(g); }      /* (through double in every flavour: a float would lose eight of the 32 bits) */
 
-/* std::normal_distribution<double>(0,1) of libstdc++ (bits/random.tcc): Marsaglia polar method; every second call returns
+/* std::normal_distribution<real>(0,1) of libstdc++ (bits/random.tcc): Marsaglia polar method; every second call returns
  * the value saved by the previous one.  The distribution object is a member of the reference's rng (urand.hpp:30,43), so
  * the saved value survives from one generate_normal_n call to the next. */
-typedef struct { int saved_available; double saved; } normal_state;
-static double rng_normal(mt19937_t *g, normal_state *ns)
+typedef struct { int saved_available; dbl saved; } normal_state;
+static real rng_normal(mt19937_t *g, normal_state *ns)
 {
-  if (ns->saved_available) { ns->saved_available = 0; return ns->saved; }
-  double x, y, r2;
+  if (ns->saved_available) { ns->saved_available = 0; return (real)ns->saved; }
+  dbl x, y, r2;
   do {
-    x = 2.0 * rng_u01(g) - 1.0;
-    y = 2.0 * rng_u01(g) - 1.0;
+    x = (dbl)2.0 * rng_u01_dbl(g) - (dbl)1.0;
+    y = (dbl)2.0 * rng_u01_dbl(g) - (dbl)1.0;
     r2 = x * x + y * y;
-  } while (r2 > 1.0 || r2 == 0.0);
-  const double mult = sqrt(-2 * log(r2) / r2);
+  } while (r2 > (dbl)1.0 || r2 == (dbl)0.0);
+  const dbl mult = sqrt(-2 * log(r2) / r2);
   ns->saved = x * mult;
   ns->saved_available = 1;
-  return y * mult;
+  return (real)(y * mult);
 }
 
 /* ---------------- state (src/impl/particles_impl.ipp:26-325) ---------------- */
-typedef struct { double *q; sz len, pos; } fifo_arr;
+typedef struct { real *q; sz len, pos; } fifo_arr;
 
 struct orc_particles {
   lcx_opts_init_t o;
   lcx_distro_t *distros; lcx_dry_size_t *sizes;
-  double *kernel_parameters; sz n_kernel_parameters; double kernel_r_max; int n_user_params; int n_size_keys;
-  double *w_LS, *aerosol_conc_factor;
+  real *kernel_parameters; sz n_kernel_parameters; real kernel_r_max; int n_user_params; int n_size_keys;
+  real *w_LS, *aerosol_conc_factor;
   int n_dims; sz n_cell, n_part, n_part_old, n_part_to_init, cap;
   int init_called, should_now_run_async, should_now_run_cond, selected_before_counting, var_rho, sorted;
   int sstp_cond, sstp_coal, allow_sstp_cond, pure_const_multi, increase_sstp_coal;
-  double dt; int adve_scheme; int halo;      /* halo: x-planes of Courant halo on each side (2 with pred_corr, particles_impl.ipp:361) */
+  real dt; int adve_scheme; int halo;      /* halo: x-planes of Courant halo on each side (2 with pred_corr, particles_impl.ipp:361) */
   mt19937_t rng; normal_state rng_ns;
   /* SGS turbulence (turb_adve / turb_cond): cell field diss_rate (holds TKE after hskpng_tke), SGS mixing length profile,
    * per-particle velocity perturbations and supersaturation perturbation (particles_impl.ipp:141-144,461-473) */
-  double *diss_rate, *SGS_mix_len, *tau_cell;
+  real *diss_rate, *SGS_mix_len, *tau_cell;
   /* test hooks of the "reverse replay" (tests/test_hip_reverse_replay.py; no reference counterpart): LCX_DBG_TAG gives every super-droplet
    * a persistent tag that is compacted and migrates with it like any attribute, and orc_rng_replay_push queues random arrays that the
    * next hskpng_shuffle_and_sort / coal consume INSTEAD of drawing from the engine -- so that this restatement can be run on the
    * device generator's stream while the device stays on its production path */
-  double *tag;
-  struct { int kind; double *v; sz n; } rq[64]; int rq_head, rq_tail;
-  double *ict;     /* opts_init.diag_incloud_time: time each SD has been activated (particles_impl.ipp:93,475-476) */
-  double *up, *vp, *wp, *ssp, *dot_ssp;
+  real *tag;
+  struct { int kind; dbl *v; sz n; } rq[64]; int rq_head, rq_tail;      /* (dbl: the un of a shuffle are 32-bit integers passed as doubles) */
+  real *ict;     /* opts_init.diag_incloud_time: time each SD has been activated (particles_impl.ipp:93,475-476) */
+  real *up, *vp, *wp, *ssp, *dot_ssp;
   /* particle attributes */
-  n_t *n; double *rd3, *rw2, *kpa, *x, *y, *z, *vt;
+  n_t *n; real *rd3, *rw2, *kpa, *x, *y, *z, *vt;
   sz *ijk, *sorted_id, *sorted_ijk;
-  double *n_filtered, *tmp_part, *col, *mom_vals;
+  real *n_filtered, *tmp_part, *col, *mom_vals;
   /* cell fields */
-  double *rhod, *th, *rv, *p, *T, *RH, *eta, *dv, *lambda_D, *lambda_K;
-  double *sstp_tmp_rv, *sstp_tmp_th, *sstp_tmp_rh, *drw_mom3, *rw_mom3, *scl;
+  real *rhod, *th, *rv, *p, *T, *RH, *eta, *dv, *lambda_D, *lambda_K;
+  real *sstp_tmp_rv, *sstp_tmp_th, *sstp_tmp_rh, *drw_mom3, *rw_mom3, *scl;
   /* per-particle substepping (exact_sstp_cond): the reference re-uses sstp_tmp_{rv,th,rh,p} as n_part-long attributes
    * (particles_impl.ipp:452-459); rc2 only with sstp_cond_act > 1 (:488-491) */
   int exact, use_rc2, sstp_cond_act;
-  double *pp_rv, *pp_th, *pp_rh, *pp_p, *rc2;
-  double *dlt_rv, *dlt_th, *dlt_rh, *dlt_p, *rwX, *drwX, *Tp; unsigned *pp_sstp;
-  double *courant_x, *courant_y, *courant_z; sz n_cx, n_cy, n_cz;
-  sz *count_ijk, *off; n_t *count_num; double *count_mom; sz count_n;
-  double vt_0[10000]; double vt0_ln_r_min, vt0_ln_r_max;
-  double log_rd_min, log_rd_max, multiplier;
-  double puddle[LCX_OUT_COUNT];
-  double *outbuf;
-  double eps_tol;
+  real *pp_rv, *pp_th, *pp_rh, *pp_p, *rc2;
+  real *dlt_rv, *dlt_th, *dlt_rh, *dlt_p, *rwX, *drwX, *Tp; unsigned *pp_sstp;
+  real *courant_x, *courant_y, *courant_z; sz n_cx, n_cy, n_cz;
+  sz *count_ijk, *off; n_t *count_num; real *count_mom; sz count_n;
+  real vt_0[10000]; real vt0_ln_r_min, vt0_ln_r_max;
+  real log_rd_min, log_rd_max, multiplier;
+  real puddle[LCX_OUT_COUNT];
+  real *outbuf;
+  real eps_tol;
   /* distmem */
   sz *lft_id, *rgt_id; sz lft_count, rgt_count;
   /* message buffers of the device-driven exchange protocol (orc_exch_*, the CPU twin of include/lcx.h lcx_exch_*) */
@@ -147,22 +156,22 @@ const char *orc_last_error(void) { return orc_err; }
 void orc_set_real_bytes(int bytes) { orc_real_bytes_v = bytes == 4 ? 4u : 8u; }
 #ifdef _OPENMP
 #include <omp.h>
-const char *orc_version(void) { return "lcx-oracle 1 (double, OpenMP elementwise loops)"; }
+const char *orc_version(void) { return "lcx-oracle 1 (OpenMP elementwise loops)"; }
 int orc_num_threads(void) { return omp_get_max_threads(); }
 void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 #else
 void orc_set_num_threads(int n) { (void)n; }
-const char *orc_version(void) { return "lcx-oracle 1 (double, serial)"; }
+const char *orc_version(void) { return "lcx-oracle 1 (serial)"; }
 int orc_num_threads(void) { return 1; }
 #endif
 /* Stage timers of the oracle itself (ORC_TIMERS=1 in the environment; orc_timers_dump prints and clears them): used once to see
  * which stages of the OpenMP build were still serial (bench.py's cpu_baseline leg). */
 #include <time.h>
 enum { TM_SORT, TM_COND, TM_MOMS, TM_TPR, TM_VTERM, TM_COAL, TM_MOVE, TM_POST, TM_OTHER, TM_N };
-static double tm_acc[TM_N];
+static real tm_acc[TM_N];
 static int tm_on = -1;
-static double tm_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
-#define TMR(k, stmt) do { if (tm_on < 0) tm_on = getenv("ORC_TIMERS") != NULL; if (tm_on) { const double t0_ = tm_now(); stmt; tm_acc[k] += tm_now() - t0_; } else { stmt; } } while (0)
+static real tm_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+#define TMR(k, stmt) do { if (tm_on < 0) tm_on = getenv("ORC_TIMERS") != NULL; if (tm_on) { const real t0_ = tm_now(); stmt; tm_acc[k] += tm_now() - t0_; } else { stmt; } } while (0)
 void orc_timers_dump(void)
 {
   static const char *nm[TM_N] = {"sort", "cond", "th_rv", "Tpr", "vterm", "coal", "adve+sedi+bcnd", "post_copy", "other"};
@@ -190,9 +199,10 @@ static int distmem(const orc_particles *s) { return s->o.bcond_lft == 1 || s->o.
 
 int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
 {
-  if (real_kind != 8) FAIL("oracle: only real_kind=8 (double) is supported");
+  if (real_kind != (int)sizeof(real)) FAIL("oracle: this flavour computes in a real_t of %d bytes (liblcx_oracle.so: double, liblcx_oracle_f32.so: float)", (int)sizeof(real));
   if (oi->chem_switch || oi->ice_switch || oi->rlx_switch || oi->src_type)
     FAIL("libcloudph++: option outside the accelerated hot path (chem/ice/src/rlx)");
+  if (sizeof(real) == 4 && oi->sstp_cond_act > 1) FAIL("oracle (float flavour): sstp_cond_act > 1 needs the critical radius in double (orc_physics.h)");
   orc_particles *s = NEW(orc_particles, 1);
   s->o = *oi;
   s->distros = NEW(lcx_distro_t, oi->n_dry_distros);
@@ -203,12 +213,12 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   for (int d = 0; d < oi->n_dry_sizes; ++d)        /* dry_sizes.size() of the reference = number of (kappa, rd_insol) keys */
     if (d == 0 || oi->dry_sizes[d].kappa != oi->dry_sizes[d - 1].kappa || oi->dry_sizes[d].rd_insol != oi->dry_sizes[d - 1].rd_insol) s->n_size_keys++;
   s->n_kernel_parameters = oi->n_kernel_parameters;
-  s->kernel_parameters = NEW(double, oi->n_kernel_parameters);
-  if (oi->n_kernel_parameters) memcpy(s->kernel_parameters, oi->kernel_parameters, sizeof(double) * oi->n_kernel_parameters);
-  s->w_LS = NEW(double, oi->n_w_LS);
-  if (oi->n_w_LS) memcpy(s->w_LS, oi->w_LS, sizeof(double) * oi->n_w_LS);
-  s->aerosol_conc_factor = NEW(double, oi->n_aerosol_conc_factor);
-  if (oi->n_aerosol_conc_factor) memcpy(s->aerosol_conc_factor, oi->aerosol_conc_factor, sizeof(double) * oi->n_aerosol_conc_factor);
+  s->kernel_parameters = NEW(real, oi->n_kernel_parameters);
+  for (int i = 0; i < oi->n_kernel_parameters; ++i) s->kernel_parameters[i] = (real)oi->kernel_parameters[i];
+  s->w_LS = NEW(real, oi->n_w_LS);
+  for (int i = 0; i < oi->n_w_LS; ++i) s->w_LS[i] = (real)oi->w_LS[i];
+  s->aerosol_conc_factor = NEW(real, oi->n_aerosol_conc_factor);
+  for (int i = 0; i < oi->n_aerosol_conc_factor; ++i) s->aerosol_conc_factor[i] = (real)oi->aerosol_conc_factor[i];
   /* particles_impl.ipp:327-345 */
   s->n_dims = oi->nx / m1(oi->nx) + oi->ny / m1(oi->ny) + oi->nz / m1(oi->nz);
   s->n_cell = (sz)m1(oi->nx) * m1(oi->ny) * m1(oi->nz);
@@ -226,34 +236,34 @@ int orc_create(const lcx_opts_init_t *oi, int real_kind, orc_particles **out)
   s->vt0_ln_r_min = log(5e-7); s->vt0_ln_r_max = log(3e-3); /* config.hpp:36-38 */
   s->cap = (sz)oi->n_sd_max;
   sz c = s->cap, nc = s->n_cell;
-  s->n = NEW(n_t, c); s->rd3 = NEW(double, c); s->rw2 = NEW(double, c); s->kpa = NEW(double, c);
-  s->x = NEW(double, c); s->y = NEW(double, c); s->z = NEW(double, c); s->vt = NEW(double, c);
+  s->n = NEW(n_t, c); s->rd3 = NEW(real, c); s->rw2 = NEW(real, c); s->kpa = NEW(real, c);
+  s->x = NEW(real, c); s->y = NEW(real, c); s->z = NEW(real, c); s->vt = NEW(real, c);
   s->ijk = NEW(sz, c); s->sorted_id = NEW(sz, c); s->sorted_ijk = NEW(sz, c);
-  s->n_filtered = NEW(double, c); s->tmp_part = NEW(double, c); s->col = NEW(double, c); s->mom_vals = NEW(double, c);
+  s->n_filtered = NEW(real, c); s->tmp_part = NEW(real, c); s->col = NEW(real, c); s->mom_vals = NEW(real, c);
   s->lft_id = NEW(sz, c); s->rgt_id = NEW(sz, c);
-  s->rhod = NEW(double, nc); s->th = NEW(double, nc); s->rv = NEW(double, nc); s->p = NEW(double, nc);
-  s->T = NEW(double, nc); s->RH = NEW(double, nc); s->eta = NEW(double, nc); s->dv = NEW(double, nc);
-  s->lambda_D = NEW(double, nc); s->lambda_K = NEW(double, nc);
-  s->sstp_tmp_rv = NEW(double, nc); s->sstp_tmp_th = NEW(double, nc); s->sstp_tmp_rh = NEW(double, nc);
-  s->drw_mom3 = NEW(double, nc); s->rw_mom3 = NEW(double, nc); s->scl = NEW(double, nc);
+  s->rhod = NEW(real, nc); s->th = NEW(real, nc); s->rv = NEW(real, nc); s->p = NEW(real, nc);
+  s->T = NEW(real, nc); s->RH = NEW(real, nc); s->eta = NEW(real, nc); s->dv = NEW(real, nc);
+  s->lambda_D = NEW(real, nc); s->lambda_K = NEW(real, nc);
+  s->sstp_tmp_rv = NEW(real, nc); s->sstp_tmp_th = NEW(real, nc); s->sstp_tmp_rh = NEW(real, nc);
+  s->drw_mom3 = NEW(real, nc); s->rw_mom3 = NEW(real, nc); s->scl = NEW(real, nc);
   if (s->exact) {
-    s->pp_rv = NEW(double, c); s->pp_th = NEW(double, c); s->pp_rh = NEW(double, c); s->pp_p = NEW(double, c);
-    s->dlt_rv = NEW(double, c); s->dlt_th = NEW(double, c); s->dlt_rh = NEW(double, c); s->dlt_p = NEW(double, c);
-    s->rwX = NEW(double, c); s->drwX = NEW(double, c); s->Tp = NEW(double, c); s->pp_sstp = NEW(unsigned, c);
+    s->pp_rv = NEW(real, c); s->pp_th = NEW(real, c); s->pp_rh = NEW(real, c); s->pp_p = NEW(real, c);
+    s->dlt_rv = NEW(real, c); s->dlt_th = NEW(real, c); s->dlt_rh = NEW(real, c); s->dlt_p = NEW(real, c);
+    s->rwX = NEW(real, c); s->drwX = NEW(real, c); s->Tp = NEW(real, c); s->pp_sstp = NEW(unsigned, c);
   }
-  if (s->use_rc2) s->rc2 = NEW(double, c);
-  if (oi->diag_incloud_time) s->ict = NEW(double, c);                    /* init_incloud_time.ipp:14-17: zero */
-  if (oi->dbg_flags & LCX_DBG_TAG) s->tag = NEW(double, c);
-  if (oi->turb_coal_switch && !(oi->turb_adve_switch || oi->turb_cond_switch)) s->diss_rate = NEW(double, nc);
+  if (s->use_rc2) s->rc2 = NEW(real, c);
+  if (oi->diag_incloud_time) s->ict = NEW(real, c);                    /* init_incloud_time.ipp:14-17: zero */
+  if (oi->dbg_flags & LCX_DBG_TAG) s->tag = NEW(real, c);
+  if (oi->turb_coal_switch && !(oi->turb_adve_switch || oi->turb_cond_switch)) s->diss_rate = NEW(real, nc);
   if (oi->turb_adve_switch || oi->turb_cond_switch) {
-    s->diss_rate = NEW(double, nc); s->tau_cell = NEW(double, nc);
-    s->SGS_mix_len = NEW(double, oi->n_SGS_mix_len);
-    if (oi->n_SGS_mix_len) memcpy(s->SGS_mix_len, oi->SGS_mix_len, sizeof(double) * oi->n_SGS_mix_len);
-    s->up = NEW(double, c); s->vp = NEW(double, c); s->wp = NEW(double, c);       /* resized with the initial value 0 */
-    if (oi->turb_cond_switch) { s->ssp = NEW(double, c); s->dot_ssp = NEW(double, c); }
+    s->diss_rate = NEW(real, nc); s->tau_cell = NEW(real, nc);
+    s->SGS_mix_len = NEW(real, oi->n_SGS_mix_len);
+    for (int i = 0; i < oi->n_SGS_mix_len; ++i) s->SGS_mix_len[i] = (real)oi->SGS_mix_len[i];
+    s->up = NEW(real, c); s->vp = NEW(real, c); s->wp = NEW(real, c);       /* resized with the initial value 0 */
+    if (oi->turb_cond_switch) { s->ssp = NEW(real, c); s->dot_ssp = NEW(real, c); }
   }
-  s->count_ijk = NEW(sz, nc); s->off = NEW(sz, nc + 1); s->count_num = NEW(n_t, nc); s->count_mom = NEW(double, nc);
-  s->outbuf = NEW(double, nc);
+  s->count_ijk = NEW(sz, nc); s->off = NEW(sz, nc + 1); s->count_num = NEW(n_t, nc); s->count_mom = NEW(real, nc);
+  s->outbuf = NEW(real, nc);
   *out = s;
   return 0;
 }
@@ -298,22 +308,22 @@ static ptrdiff_t l2e_halo(const orc_particles *s, const lcx_arrinfo_t *a, sz c, 
 }
 static ptrdiff_t l2e(const orc_particles *s, const lcx_arrinfo_t *a, sz c, int ex, int ey, int ez) { return l2e_halo(s, a, c, ex, ey, ez, 0); }
 static int arr_null(const lcx_arrinfo_t *a) { return !a || !a->data || !a->strides; }
-static void sync_in_arr(const orc_particles *s, const lcx_arrinfo_t *a, double *to, sz n, int ex, int ey, int ez)
+static void sync_in_arr(const orc_particles *s, const lcx_arrinfo_t *a, real *to, sz n, int ex, int ey, int ez)
 {
   if (arr_null(a)) return;
-  const double *d = (const double *)a->data;
+  const real *d = (const real *)a->data;
   for (sz c = 0; c < n; ++c) to[c] = d[l2e(s, a, c, ex, ey, ez)];
 }
-static void sync_in_courant(const orc_particles *s, const lcx_arrinfo_t *a, double *to, sz n, int ex, int ey, int ez)
+static void sync_in_courant(const orc_particles *s, const lcx_arrinfo_t *a, real *to, sz n, int ex, int ey, int ez)
 {
   if (arr_null(a)) return;
-  const double *d = (const double *)a->data;
+  const real *d = (const real *)a->data;
   for (sz c = 0; c < n; ++c) to[c] = d[l2e_halo(s, a, c, ex, ey, ez, s->halo)];
 }
-static void sync_out_arr(const orc_particles *s, const double *from, const lcx_arrinfo_t *a, sz n)
+static void sync_out_arr(const orc_particles *s, const real *from, const lcx_arrinfo_t *a, sz n)
 {
   if (arr_null(a)) return;
-  double *d = (double *)a->data;
+  real *d = (real *)a->data;
   for (sz c = 0; c < n; ++c) d[l2e(s, a, c, 0, 0, 0)] = from[c];
 }
 
@@ -340,7 +350,7 @@ static void hskpng_mfp(orc_particles *s)
     s->lambda_K[c] = lambda_K_of(s->T[c], s->p[c]);
   }
 }
-/* hskpng_ijk.ipp:159-200, :33-82 : size_t(double(x)/double(dx)), z fastest */
+/* hskpng_ijk.ipp:159-200, :33-82 : size_t(real(x)/real(dx)), z fastest */
 static void hskpng_ijk(orc_particles *s)
 {
   const lcx_opts_init_t *o = &s->o;
@@ -474,11 +484,11 @@ static void stable_sort_by_key(sz *key, sz *val, sz n, sz nkeys)
   free(k2); free(v2);
 }
 /* next queued random array of the given kind (orc_rng_replay_push), or NULL when the queue is empty: the engine draws then */
-static double *replay_pop(orc_particles *s, int kind, sz n)
+static dbl *replay_pop(orc_particles *s, int kind, sz n)
 {
   if (s->rq_head == s->rq_tail) return NULL;
   if (s->rq[s->rq_head].kind != kind || s->rq[s->rq_head].n < n) { fprintf(stderr, "oracle: rng replay queue does not match the request (kind %d, %zu values)\n", kind, (size_t)n); abort(); }
-  double *v = s->rq[s->rq_head].v;
+  dbl *v = s->rq[s->rq_head].v;
   s->rq_head = (s->rq_head + 1) % 64;
   return v;
 }
@@ -495,9 +505,9 @@ static void hskpng_sort_helper(orc_particles *s, int shuffle)
 #else
     sz *un = NEW(sz, n);
 #endif
-    double *rq = replay_pop(s, 1, n);
+    dbl *rq = replay_pop(s, 1, n);
     if (rq) { for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rq[p]; free(rq); }
-    else for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un(&s->rng);
+    else for (sz p = 0; p < n; ++p) un[p] = (sz)(unsigned int)rng_un_dbl(&s->rng);
     stable_sort_by_key(un, s->sorted_id, n, 0);
     OMP_FOR
     for (sz p = 0; p < n; ++p) s->sorted_ijk[p] = s->ijk[s->sorted_id[p]];
@@ -535,16 +545,16 @@ static void hskpng_count(orc_particles *s)
   count_runs(s);
 }
 /* hskpng_vterm.ipp:15-33,185-342 */
-static int vt0_bin(const orc_particles *s, double rw2)
+static int vt0_bin(const orc_particles *s, real rw2)
 {
   const int n_bin = 10000;
-  const double dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
-  const double lnr = .5 * log(rw2);
+  const real dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
+  const real lnr = .5 * log(rw2);
   return lnr <= s->vt0_ln_r_min ? 0 : lnr >= s->vt0_ln_r_max ? n_bin - 1 : (int)((lnr - s->vt0_ln_r_min) / dlnr);
 }
-static double vt_of(const orc_particles *s, double rw2, sz c)
+static real vt_of(const orc_particles *s, real rw2, sz c)
 {
-  const double r = sqrt(rw2);
+  const real r = sqrt(rw2);
   switch (s->o.terminal_velocity) {
     case LCX_VT_BEARD76: return vt_beard76(r, s->T[c], s->p[c], s->rhod[c], s->eta[c]);
     case LCX_VT_BEARD77: return vt_beard77_fact(r, s->p[c], s->rhod[c], s->eta[c]) * vt_beard77_v0(r);
@@ -567,14 +577,14 @@ static void init_vterm(orc_particles *s)
 {
   if (s->o.terminal_velocity != LCX_VT_BEARD77FAST) return;
   const int n_bin = 10000;
-  const double dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
+  const real dlnr = (s->vt0_ln_r_max - s->vt0_ln_r_min) / n_bin;
   for (int it = 0; it < n_bin; ++it) s->vt_0[it] = vt_beard77_v0(exp(s->vt0_ln_r_min + (it + 0.5) * dlnr));
 }
 /* hskpng_remove.ipp:20-76 (stable), hskpng_resize.ipp:7-32 */
-static int mig_attrs(orc_particles *s, double **a);
+static int mig_attrs(orc_particles *s, real **a);
 static int hskpng_remove_n0(orc_particles *s)
 {
-  double *attrs[24]; const int na = mig_attrs(s, attrs);       /* every registered attribute (distmem_real_vctrs) + n */
+  real *attrs[24]; const int na = mig_attrs(s, attrs);       /* every registered attribute (distmem_real_vctrs) + n */
 #ifdef _OPENMP
   {
     const sz n = s->n_part;
@@ -584,14 +594,14 @@ static int hskpng_remove_n0(orc_particles *s)
     for (sz p = 0; p < n; ++p) keep[p] = s->n[p] != 0;
     const sz m = par_select(keep, n, idx);
     if (m != n) {
-      double *tmp = (double *)scr_get(SCR_TMP, m * sizeof(double));
+      real *tmp = (real *)scr_get(SCR_TMP, m * sizeof(real));
       for (int a = 0; a < na; ++a) {
         OMP_FOR
         for (sz i = 0; i < m; ++i) tmp[i] = attrs[a][idx[i]];
         OMP_FOR
         for (sz i = 0; i < m; ++i) attrs[a][i] = tmp[i];
       }
-      n_t *tn = (n_t *)tmp;                              /* (n_t and double are both 8 bytes) */
+      n_t *tn = (n_t *)tmp;                              /* (n_t and real are both 8 bytes) */
       OMP_FOR
       for (sz i = 0; i < m; ++i) tn[i] = s->n[idx[i]];
       OMP_FOR
@@ -619,35 +629,35 @@ static void moms_all(orc_particles *s)
 {
   hskpng_sort(s);
   OMP_FOR
-  for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = (double)s->n[p];
+  for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = (real)s->n[p];
   s->selected_before_counting = 1;
 }
-static void moms_rng(orc_particles *s, double mn, double mx, const double *vec, int cons)
+static void moms_rng(orc_particles *s, real mn, real mx, const real *vec, int cons)
 {
   hskpng_sort(s);
   for (sz p = 0; p < s->n_part; ++p) {
-    const double y = cons ? s->n_filtered[p] : (double)s->n[p];
+    const real y = cons ? s->n_filtered[p] : (real)s->n[p];
     s->n_filtered[p] = (vec[p] >= mn && vec[p] < mx) ? y : 0;
   }
   s->selected_before_counting = 1;
 }
-static void moms_gt0(orc_particles *s, const double *vec, int cons)
+static void moms_gt0(orc_particles *s, const real *vec, int cons)
 {
   hskpng_sort(s);
   for (sz p = 0; p < s->n_part; ++p) {
-    const double y = cons ? s->n_filtered[p] : (double)s->n[p];
+    const real y = cons ? s->n_filtered[p] : (real)s->n[p];
     s->n_filtered[p] = y * (vec[p] > 0);
   }
   s->selected_before_counting = 1;
 }
-static double moment_counter(double n, double x, double xp)
+static real moment_counter(real n, real x, real xp)
 {
-  return x >= 0 ? n * pow(x, xp) : n * pow(x, (double)(int)xp);
+  return x >= 0 ? n * pow(x, xp) : n * pow(x, (real)(int)xp);
 }
-static void moms_calc(orc_particles *s, const double *vec, double power, int specific)
+static void moms_calc(orc_particles *s, const real *vec, real power, int specific)
 {
   sz cn = 0;
-  double *vals = s->mom_vals;            /* not tmp_part: diag_precip_rate passes that one as vec */
+  real *vals = s->mom_vals;            /* not tmp_part: diag_precip_rate passes that one as vec */
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) { const sz id = s->sorted_id[p]; vals[p] = moment_counter(s->n_filtered[id], vec[id], power); }
 #ifdef _OPENMP
@@ -656,14 +666,14 @@ static void moms_calc(orc_particles *s, const double *vec, double power, int spe
     cn = par_runs(s->sorted_ijk, s->n_part, start);
     OMP_FOR
     for (sz i = 0; i < cn; ++i) {
-      double acc = vals[start[i]];
+      real acc = vals[start[i]];
       for (sz p = start[i] + 1; p < start[i + 1]; ++p) acc = acc + vals[p];
       s->count_ijk[i] = s->sorted_ijk[start[i]]; s->count_mom[i] = acc;
     }
   }
 #else
   for (sz p = 0; p < s->n_part; ++p) {
-    const double v = vals[p];
+    const real v = vals[p];
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
     else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
   }
@@ -690,16 +700,16 @@ static void sstp_save(orc_particles *s)
     }
     return;
   }
-  memcpy(s->sstp_tmp_rv, s->rv, s->n_cell * sizeof(double));
-  memcpy(s->sstp_tmp_th, s->th, s->n_cell * sizeof(double));
-  memcpy(s->sstp_tmp_rh, s->rhod, s->n_cell * sizeof(double));
+  memcpy(s->sstp_tmp_rv, s->rv, s->n_cell * sizeof(real));
+  memcpy(s->sstp_tmp_th, s->th, s->n_cell * sizeof(real));
+  memcpy(s->sstp_tmp_rh, s->rhod, s->n_cell * sizeof(real));
 }
 /* sstp_percell_step.ipp:7-48 */
 static void sstp_percell_step(orc_particles *s, int step)
 {
   if (s->sstp_cond == 1) return;
-  double *scl[3] = {s->rv, s->th, s->rhod}, *tmp[3] = {s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh};
-  const double sstp = s->sstp_cond;
+  real *scl[3] = {s->rv, s->th, s->rhod}, *tmp[3] = {s->sstp_tmp_rv, s->sstp_tmp_th, s->sstp_tmp_rh};
+  const real sstp = s->sstp_cond;
   for (int ix = 0; ix < (s->var_rho ? 3 : 2); ++ix)
     for (sz c = 0; c < s->n_cell; ++c) {
       if (step == 0) {
@@ -719,7 +729,7 @@ static void save_liq_before(orc_particles *s)
   for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = -s->count_mom[i];
 }
 /* percell/particles_impl_cond.ipp:13-139 */
-static void cond(orc_particles *s, double dt, double RH_max, int step, int turb_cond)
+static void cond(orc_particles *s, real dt, real RH_max, int step, int turb_cond)
 {
   hskpng_sort(s);
   if (step == 0) { if (s->count_n != s->n_cell) for (sz c = 0; c < s->n_cell; ++c) s->rw_mom3[c] = 0.; }
@@ -746,7 +756,7 @@ static void cond(orc_particles *s, double dt, double RH_max, int step, int turb_
 /* particles_impl_update_th_rv.ipp:74-191 */
 static void update_th_rv(orc_particles *s)
 {
-  const double mlt = rho_w * (4. / 3) * ORC_PI;
+  const real mlt = rho_w * (4. / 3) * ORC_PI;
   OMP_FOR
   for (sz c = 0; c < s->n_cell; ++c) s->drw_mom3[c] = s->drw_mom3[c] * mlt;
   OMP_FOR
@@ -783,37 +793,37 @@ static void apply_noncond_perparticle_sstp_delta(orc_particles *s)
     if (s->o.const_p) s->pp_p[p] = s->pp_p[p] + s->dlt_p[p] / s->sstp_cond;
   }
 }
-static double rw2torw3(double rw2) { return rw2 * sqrt(rw2); }       /* cond_common.ipp:57-67 */
+static real rw2torw3(real rw2) { return rw2 * sqrt(rw2); }       /* cond_common.ipp:57-67 */
 /* cond_common.ipp:24-41 */
-static double rw3diff2drv(const orc_particles *s, double rw3diff, double rhod, n_t n, double dv)
+static real rw3diff2drv(const orc_particles *s, real rw3diff, real rhod, n_t n, real dv)
 {
-  const double mlt = -rho_w * (4. / 3) * ORC_PI;
-  if (s->n_dims > 0) return mlt * rw3diff * (double)n / rhod / dv;
-  return mlt * rw3diff * (double)n;
+  const real mlt = -rho_w * (4. / 3) * ORC_PI;
+  if (s->n_dims > 0) return mlt * rw3diff * (real)n / rhod / dv;
+  return mlt * rw3diff * (real)n;
 }
-static double pp_T(const orc_particles *s, double th, double rhod, double p)
+static real pp_T(const orc_particles *s, real th, real rhod, real p)
 { return s->o.th_dry ? theta_dry_T(th, rhod) : th * theta_std_exner(p); }     /* hskpng_Tpr.ipp:26-46 */
 /* cond_perparticle_advance_rw2.ipp:30-125 + perparticle_advance_rw2.ipp:8-43 */
-static void cond_perparticle_advance_rw2(orc_particles *s, double RH_max, int turb_cond)
+static void cond_perparticle_advance_rw2(orc_particles *s, real RH_max, int turb_cond)
 {
   for (sz p = 0; p < s->n_part; ++p) s->Tp[p] = pp_T(s, s->pp_th[p], s->pp_rh[p], s->pp_p[p]);
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
-    const double pr = s->o.const_p ? s->pp_p[p] : theta_dry_p(s->pp_rh[p], s->pp_rv[p], s->Tp[p]);
-    const double RH = RH_of(s->o.RH_formula, pr, s->pp_rv[p], s->Tp[p]) + (turb_cond ? s->ssp[p] : 0.);   /* RH_sgs, :8-22 */
+    const real pr = s->o.const_p ? s->pp_p[p] : theta_dry_p(s->pp_rh[p], s->pp_rv[p], s->Tp[p]);
+    const real RH = RH_of(s->o.RH_formula, pr, s->pp_rv[p], s->Tp[p]) + (turb_cond ? s->ssp[p] : 0.);   /* RH_sgs, :8-22 */
     cond_ctx cc = {s->rw2[p], s->dt / s->sstp_cond, s->pp_rh[p], s->pp_rv[p], s->Tp[p], pr, RH, visc(s->Tp[p]),
                    s->rd3[p], s->kpa[p], s->vt[p], RH_max, s->lambda_D[c], s->lambda_K[c]};
     s->rw2[p] = advance_rw2(&cc, s->eps_tol, 2., 100);
   }
 }
 /* update_th_rv.ipp:243-283: per-cell sum (sorted order) of a per-particle change, added to every particle of the cell */
-static void update_pstate(orc_particles *s, double *pstate, const double *pdstate)
+static void update_pstate(orc_particles *s, real *pstate, const real *pdstate)
 {
-  double *dstate = s->scl;
+  real *dstate = s->scl;
   for (sz c = 0; c < s->n_cell; ++c) dstate[c] = 0.;
   sz nseg = 0;
   for (sz q = 0; q < s->n_part; ++q) {                     /* thrust::reduce_by_key over the sorted order */
-    const double v = pdstate[s->sorted_id[q]];
+    const real v = pdstate[s->sorted_id[q]];
     if (q == 0 || s->sorted_ijk[q] != s->sorted_ijk[q - 1]) { s->count_ijk[nseg] = s->sorted_ijk[q]; s->count_mom[nseg] = v; ++nseg; }
     else s->count_mom[nseg - 1] = s->count_mom[nseg - 1] + v;
   }
@@ -824,7 +834,7 @@ static void update_pstate(orc_particles *s, double *pstate, const double *pdstat
 /* apply_perparticle_drw3_to_perparticle_rv_and_th.ipp:13-60 */
 static void apply_perparticle_drw3_to_perparticle_rv_and_th(orc_particles *s)
 {
-  double *drw3 = s->drwX;
+  real *drw3 = s->drwX;
   for (sz p = 0; p < s->n_part; ++p) drw3[p] = rw3diff2drv(s, drw3[p], s->pp_rh[p], s->n[p], s->dv[s->ijk[p]]);
   if (s->o.sstp_cond_mix) update_pstate(s, s->pp_rv, drw3);
   else for (sz p = 0; p < s->n_part; ++p) s->pp_rv[p] = drw3[p] + s->pp_rv[p];
@@ -840,33 +850,33 @@ static void calc_liq_content_change(orc_particles *s)
   for (sz i = 0; i < s->count_n; ++i) s->drw_mom3[s->count_ijk[i]] = s->count_mom[i] + s->drw_mom3[s->count_ijk[i]];
 }
 /* perparticle_nomixing_adaptive_sstp_cond.ipp:56-265, one super-droplet */
-static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max, int turb_cond)
+static void adaptive_sstp_cond_one(orc_particles *s, sz p, real RH_max, int turb_cond)
 {
   const lcx_opts_init_t *o = &s->o;
   const sz c = s->ijk[p];
-  const double dlt_rv = s->dlt_rv[p], dlt_th = s->dlt_th[p], dlt_rhod = s->dlt_rh[p], dlt_p = s->dlt_p[p];
+  const real dlt_rv = s->dlt_rv[p], dlt_th = s->dlt_th[p], dlt_rhod = s->dlt_rh[p], dlt_p = s->dlt_p[p];
   const n_t n = s->n[p];
-  const double dv = s->dv[c], lambda_D = s->lambda_D[c], lambda_K = s->lambda_K[c], rd3 = s->rd3[p], kpa = s->kpa[p], vt = s->vt[p];
+  const real dv = s->dv[c], lambda_D = s->lambda_D[c], lambda_K = s->lambda_K[c], rd3 = s->rd3[p], kpa = s->kpa[p], vt = s->vt[p];
   const int sstp_cond_max = s->sstp_cond, sstp_cond_act = s->sstp_cond_act;
   unsigned sstp_cond;
-  double t_rv = s->pp_rv[p], t_th = s->pp_th[p], t_rh = s->pp_rh[p], t_p = o->const_p ? s->pp_p[p] : 0., rw2 = s->rw2[p];
-  double drw2 = 0, Tp = 0, RH = 0, delta_fraction_applied = 0;
-  const double dot_ssp = turb_cond ? s->dot_ssp[p] : 0.;                       /* :66,74 */
-  double ssp = turb_cond ? s->ssp[p] : 0.;
-#define APPLY_DELTA(mult) do { const double m_ = (mult); t_rv += dlt_rv * m_; t_th += dlt_th * m_; t_rh += dlt_rhod * m_; \
+  real t_rv = s->pp_rv[p], t_th = s->pp_th[p], t_rh = s->pp_rh[p], t_p = o->const_p ? s->pp_p[p] : 0., rw2 = s->rw2[p];
+  real drw2 = 0, Tp = 0, RH = 0, delta_fraction_applied = 0;
+  const real dot_ssp = turb_cond ? s->dot_ssp[p] : 0.;                       /* :66,74 */
+  real ssp = turb_cond ? s->ssp[p] : 0.;
+#define APPLY_DELTA(mult) do { const real m_ = (mult); t_rv += dlt_rv * m_; t_th += dlt_th * m_; t_rh += dlt_rhod * m_; \
                                if (o->const_p) { t_p += dlt_p * m_; } if (turb_cond) { ssp += dot_ssp * s->dt * m_; } } while (0)
 #define CALC_STATE() do { Tp = pp_T(s, t_th, t_rh, t_p); if (!o->const_p) t_p = theta_dry_p(t_rh, t_rv, Tp); \
                           RH = RH_of(o->RH_formula, t_p, t_rv, Tp) + (turb_cond ? ssp : 0.); } while (0)
   int first_cond_step_done_in_adaptation = sstp_cond_max == 1 ? 1 : 0;
   {
-    double drw2_new = 0;
+    real drw2_new = 0;
     sstp_cond = (unsigned)sstp_cond_max;
     for (int sstp_cond_try = 1; sstp_cond_try <= sstp_cond_max; sstp_cond_try *= 2) {
       delta_fraction_applied = sstp_cond_try == 1 ? 1 : -1. / sstp_cond_try;
       APPLY_DELTA(delta_fraction_applied);
       CALC_STATE();
       cond_ctx cc = {rw2, s->dt / sstp_cond_try, t_rh, t_rv, Tp, t_p, RH, visc(Tp), rd3, kpa, vt, RH_max, lambda_D, lambda_K};
-      const double d = advance_rw2_apply(&cc, s->eps_tol, 2., 100, 0);
+      const real d = advance_rw2_apply(&cc, s->eps_tol, 2., 100, 0);
       if (sstp_cond_try == 1) drw2 = d; else drw2_new = d;
       if (sstp_cond_try > 1) {
         if ((fabs(drw2_new * 2 - drw2) <= o->sstp_cond_adapt_drw2_eps * rw2) && (fabs(drw2) < o->sstp_cond_adapt_drw2_max * rw2)) {
@@ -879,7 +889,7 @@ static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max, int tu
       }
     }
     if (sstp_cond_act > 1) {
-      const double rc2 = s->rc2[p];
+      const real rc2 = s->rc2[p];
       if ((rw2 < rc2 && (rw2 + sstp_cond * drw2) > rc2) || (rw2 > rc2 && (rw2 + sstp_cond * drw2) < rc2)) {
         sstp_cond = (unsigned)sstp_cond_act;
         first_cond_step_done_in_adaptation = 0;
@@ -889,7 +899,7 @@ static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max, int tu
       APPLY_DELTA(sstp_cond_max == 1 ? -delta_fraction_applied : delta_fraction_applied);
   }
   delta_fraction_applied = 1. / sstp_cond;
-  double rw3 = drw2, drw3;          /* `real_t &rw3 = drw2`: drw2 is only needed at the start of the first step */
+  real rw3 = drw2, drw3;          /* `real_t &rw3 = drw2`: drw2 is only needed at the start of the first step */
   for (unsigned step = 0; step < sstp_cond; ++step) {
     drw3 = step > 0 ? -rw3 : -rw2torw3(rw2);
     if (first_cond_step_done_in_adaptation && step == 0) rw2 += rw3;      /* rw3 aliases drw2 here */
@@ -915,7 +925,7 @@ static void adaptive_sstp_cond_one(orc_particles *s, sz p, double RH_max, int tu
   s->rw2[p] = rw2;
 }
 /* particles_step.ipp:199-236 */
-static void cond_perparticle(orc_particles *s, double RH_max, int turb_cond)
+static void cond_perparticle(orc_particles *s, real RH_max, int turb_cond)
 {
   if (!s->o.sstp_cond_mix) save_liq_before(s);
   calculate_noncond_perparticle_sstp_delta(s);
@@ -948,28 +958,28 @@ static void hskpng_tke(orc_particles *s)
 {                                                   /* diss_rate := TKE = ((L eps) / C_E)^(2/3), L = SGS_mix_len[k] */
   const sz nz = m1(s->o.nz);
   for (sz c = 0; c < s->n_cell; ++c) {
-    const double ret = cbrt((s->SGS_mix_len[c % nz] * s->diss_rate[c]) / 0.845);
+    const real ret = cbrt((s->SGS_mix_len[c % nz] * s->diss_rate[c]) / 0.845);
     s->diss_rate[c] = ret * ret;
   }
 }
-static void hskpng_turb_vel(orc_particles *s, double dt, int only_vertical)
+static void hskpng_turb_vel(orc_particles *s, real dt, int only_vertical)
 {
   const sz nz = m1(s->o.nz);
-  const double cube_root_of_two_pi = pow(2. * ORC_PI, 1. / 3.);
+  const real cube_root_of_two_pi = pow(2. * ORC_PI, 1. / 3.);
   for (sz c = 0; c < s->n_cell; ++c) s->tau_cell[c] = s->SGS_mix_len[c % nz] / cube_root_of_two_pi * sqrt(1.5 / s->diss_rate[c]);
-  double *vel[3] = {s->up, s->wp, s->vp};
+  real *vel[3] = {s->up, s->wp, s->vp};
   for (int i = only_vertical ? 1 : 0; i < (only_vertical ? 2 : s->n_dims); ++i) {
     for (sz p = 0; p < s->n_part; ++p) s->tmp_part[p] = rng_normal(&s->rng, &s->rng_ns);
     for (sz p = 0; p < s->n_part; ++p) {
       const sz c = s->ijk[p];
-      const double e = exp(-dt / s->tau_cell[c]);                              /* update_turb_vel */
+      const real e = exp(-dt / s->tau_cell[c]);                              /* update_turb_vel */
       vel[i][p] = vel[i][p] * e + sqrt((1. - e * e) * (2. / 3.) * s->diss_rate[c]) * s->tmp_part[p];
     }
   }
 }
 static void hskpng_turb_dot_ss(orc_particles *s)
 {
-  double *tau_rlx = s->scl;
+  real *tau_rlx = s->scl;
   moms_all(s);
   moms_calc(s, s->rw2, 1. / 2, 0);
   for (sz i = 0; i < s->count_n; ++i) tau_rlx[s->count_ijk[i]] = 1. / (2.8e-4 * (s->count_mom[i] / s->dv[s->count_ijk[i]]));   /* tau_relax */
@@ -977,7 +987,7 @@ static void hskpng_turb_dot_ss(orc_particles *s)
 }
 
 /* particles_impl_adjust_timesteps.ipp:13-24 */
-static int adjust_timesteps(orc_particles *s, double dt)
+static int adjust_timesteps(orc_particles *s, real dt)
 {
   if (dt > 0 && !s->o.variable_dt_switch) FAIL("libcloudph++: opts.dt specified, but opts_init.variable_dt_switch is false.");
   s->sstp_cond = dt > 0 && s->o.sstp_cond > 1 ? (int)ceil(s->o.sstp_cond * dt / s->o.dt) : s->o.sstp_cond;
@@ -993,9 +1003,9 @@ static sz kernel_vector_index(int i, int j, n_t nup)
 {                                                                                             /* kernel_utils.hpp:21-29 */
   return i >= j ? (sz)(0.5 * i * (i + 1) + j + nup) : (sz)(0.5 * j * (j + 1) + i + nup);
 }
-static double interpolated_efficiency(const orc_particles *s, double r1, double r2)
+static real interpolated_efficiency(const orc_particles *s, real r1, real r2)
 {                                                                                             /* kernel_interpolation.hpp:9-65 */
-  const double *kp = s->kernel_parameters; const n_t nup = s->n_user_params;
+  const real *kp = s->kernel_parameters; const n_t nup = s->n_user_params;
   r1 *= 1e6; r2 *= 1e6;
   if (r1 >= s->kernel_r_max) r1 = s->kernel_r_max - 1e-6;
   if (r2 >= s->kernel_r_max) r2 = s->kernel_r_max - 1e-6;
@@ -1008,11 +1018,11 @@ static double interpolated_efficiency(const orc_particles *s, double r1, double 
   iv[1] = kernel_vector_index(kernel_index(x[1]), kernel_index(x[2]), nup);
   iv[2] = kernel_vector_index(kernel_index(x[0]), kernel_index(x[3]), nup);
   iv[3] = kernel_vector_index(kernel_index(x[1]), kernel_index(x[3]), nup);
-  double w[4];
+  real w[4];
   w[0] = r1 - x[0]; w[1] = x[1] - r1; w[2] = r2 - x[2]; w[3] = x[3] - r2;
   return (kp[iv[0]] * w[1] * w[3] + kp[iv[1]] * w[0] * w[3] + kp[iv[2]] * w[1] * w[2] + kp[iv[3]] * w[0] * w[2]) / dx / dy;
 }
-static double k_geometric(n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb)
+static real k_geometric(n_t na, n_t nb, real rw2a, real rw2b, real vta, real vtb)
 {
   const n_t nmax = na < nb ? nb : na;
   return ORC_PI * nmax * fabs(vta - vtb) * (rw2a + rw2b + 2. * sqrt(rw2a * rw2b));
@@ -1020,58 +1030,58 @@ static double k_geometric(n_t na, n_t nb, double rw2a, double rw2b, double vta, 
 /* Onishi turbulent kernel without gravitational settling, 2 pi R^2 <|Wr|> g(R) (src/detail/kernel_onishi_nograv.hpp:29-153).
    The reference computes the Kolmogorov length as pow(nu^3/eps, real_t(1/4)) with an INTEGER 1/4 == 0, i.e. leta == 1:
    reproduced, the results are what the reference produces. */
-static double kernel_onishi_nograv(double r1, double r2, double Re_l, double eps, double dnu, double ratio_den)
+static real kernel_onishi_nograv(real r1, real r2, real Re_l, real eps, real dnu, real ratio_den)
 {
   if (eps < 1e-10) return 0.;
-  const double urms = sqrt(Re_l / sqrt(15. / dnu / eps));
-  const double CR = r1 + r2;
-  const double taup1 = ratio_den * 4. * r1 * r1 / 18. / dnu, taup2 = ratio_den * 4. * r2 * r2 / 18. / dnu;
-  const double leta = pow(dnu * dnu * dnu / eps, 0.);
-  const double tauk = leta * leta / dnu;
-  const double Te = Re_l * tauk / sqrt(15.);
-  const double theta1 = 2.5 * taup1 / Te, theta2 = 2.5 * taup2 / Te;
-  const double phi = dmax(theta2 / theta1, theta1 / theta2);
-  const double cw = 1. + 0.6 * exp(-pow(phi - 1., 1.5));
-  double gamma = 0.183 * urms * urms / (dnu * dnu / leta / leta);
+  const real urms = sqrt(Re_l / sqrt(15. / dnu / eps));
+  const real CR = r1 + r2;
+  const real taup1 = ratio_den * 4. * r1 * r1 / 18. / dnu, taup2 = ratio_den * 4. * r2 * r2 / 18. / dnu;
+  const real leta = pow(dnu * dnu * dnu / eps, 0.);
+  const real tauk = leta * leta / dnu;
+  const real Te = Re_l * tauk / sqrt(15.);
+  const real theta1 = 2.5 * taup1 / Te, theta2 = 2.5 * taup2 / Te;
+  const real phi = dmax(theta2 / theta1, theta1 / theta2);
+  const real cw = 1. + 0.6 * exp(-pow(phi - 1., 1.5));
+  real gamma = 0.183 * urms * urms / (dnu * dnu / leta / leta);
   gamma = phi * gamma;
-  const double WrS2 = (dnu * dnu * CR * CR) / (leta * leta * leta * leta) / 15.;
-  double WrA2 = urms * urms * gamma / (gamma - 1.)
+  const real WrS2 = (dnu * dnu * CR * CR) / (leta * leta * leta * leta) / 15.;
+  real WrA2 = urms * urms * gamma / (gamma - 1.)
     * ((theta1 + theta2) - 4. * theta1 * theta2 / (theta1 + theta2) * sqrt((1. + theta1 + theta2) / (1. + theta1) / (1. + theta2)))
     * (1. / (1. + theta1) / (1. + theta2) - 1. / (1. + gamma * theta1) / (1. + gamma * theta2));
   WrA2 = cw * WrA2;
   WrA2 = WrA2 / 3.;
-  const double Wr = sqrt(2. / ORC_PI * (WrA2 + WrS2));
-  const double A1 = 110.0, A2 = 0.38, A3 = 0.16;
-  double alpha = log10(0.26 * sqrt(Re_l)) / log10(2.0);
+  const real Wr = sqrt(2. / ORC_PI * (WrA2 + WrS2));
+  const real A1 = 110.0, A2 = 0.38, A3 = 0.16;
+  real alpha = log10(0.26 * sqrt(Re_l)) / log10(2.0);
   alpha = dmax(alpha, 1.e-20);
-  const double CA = 0.06 * pow(Re_l, 0.30), CB = 0.4;
-  const double StA = pow(A2 / A1 * Re_l, 0.25);
-  const double hlpr = cbrt(A2 / A3);
-  const double StB = hlpr * hlpr * cbrt(Re_l);
-  const double St1 = taup1 / tauk, St2 = taup2 / tauk;
-  double y11, y21, y12, y22;
+  const real CA = 0.06 * pow(Re_l, 0.30), CB = 0.4;
+  const real StA = pow(A2 / A1 * Re_l, 0.25);
+  const real hlpr = cbrt(A2 / A3);
+  const real StB = hlpr * hlpr * cbrt(Re_l);
+  const real St1 = taup1 / tauk, St2 = taup2 / tauk;
+  real y11, y21, y12, y22;
   if (St2 <= StA) { y11 = A1 * St1 * St1; y21 = 0.; } else { y11 = 0.; y21 = A2 * Re_l / (St1 * St1); }
-  const double y31 = A3 * sqrt(Re_l / St1);
+  const real y31 = A3 * sqrt(Re_l / St1);
   if (St1 <= StA) { y12 = A1 * St2 * St2; y22 = 0.; } else { y12 = 0.; y22 = A2 * Re_l / (St2 * St2); }
-  const double y32 = A3 * sqrt(Re_l / St2);
-  const double za1 = 0.5 * (1. - tanh((log10(St1) - log10(StA)) / CA));
-  const double zb1 = 0.5 * (1. + tanh((log10(St1) - log10(StB)) / CB));
-  const double za2 = 0.5 * (1. - tanh((log10(St2) - log10(StA)) / CA));
-  const double zb2 = 0.5 * (1. + tanh((log10(St2) - log10(StB)) / CB));
-  const double gR1 = y11 * pow(za1, alpha) + y21 * pow(1. - za1, alpha) + y31 * zb1 + 1.;
-  const double gR2 = y12 * pow(za2, alpha) + y22 * pow(1. - za2, alpha) + y32 * zb2 + 1.;
-  const double xai = dmax(taup2 / taup1, taup1 / taup2);
-  const double RG12 = 2.6 * exp(-xai) + 0.205 * exp(-0.0206 * xai) * 0.5 * (1.0 + tanh(xai - 3.0));
-  const double gR = 1. + RG12 * sqrt(gR1 - 1.) * sqrt(gR2 - 1.);
+  const real y32 = A3 * sqrt(Re_l / St2);
+  const real za1 = 0.5 * (1. - tanh((log10(St1) - log10(StA)) / CA));
+  const real zb1 = 0.5 * (1. + tanh((log10(St1) - log10(StB)) / CB));
+  const real za2 = 0.5 * (1. - tanh((log10(St2) - log10(StA)) / CA));
+  const real zb2 = 0.5 * (1. + tanh((log10(St2) - log10(StB)) / CB));
+  const real gR1 = y11 * pow(za1, alpha) + y21 * pow(1. - za1, alpha) + y31 * zb1 + 1.;
+  const real gR2 = y12 * pow(za2, alpha) + y22 * pow(1. - za2, alpha) + y32 * zb2 + 1.;
+  const real xai = dmax(taup2 / taup1, taup1 / taup2);
+  const real RG12 = 2.6 * exp(-xai) + 0.205 * exp(-0.0206 * xai) * 0.5 * (1.0 + tanh(xai - 3.0));
+  const real gR = 1. + RG12 * sqrt(gR1 - 1.) * sqrt(gR2 - 1.);
   return 2. * ORC_PI * CR * CR * Wr * gR;
 }
 /* Wang et al. (2009) turbulent enhancement of the collision efficiency (src/detail/wang_collision_enhancement.hpp:13-92);
    table values: the published Table 1 as the reference tabulates it, [ratio][eps class][collector radius] */
-static double wang_collision_enhancement(double r1, double r2, double eps)
+static real wang_collision_enhancement(real r1, real r2, real eps)
 {
-  static const double R0[7] = {10e-6, 20e-6, 30e-6, 40e-6, 50e-6, 60e-6, 100e-6};
-  static const double rat[11] = {0., .1, .2, .3, .4, .5, .6, .7, .8, .9, 1.};
-  static const double eta_e[11][2][7] = {
+  static const real R0[7] = {10e-6, 20e-6, 30e-6, 40e-6, 50e-6, 60e-6, 100e-6};
+  static const real rat[11] = {0., .1, .2, .3, .4, .5, .6, .7, .8, .9, 1.};
+  static const real eta_e[11][2][7] = {
     {{1.74, 1.74, 1.773, 1.49, 1.207, 1.207, 1.0}, {4.976, 4.976, 3.593, 2.519, 1.445, 1.445, 1.0}},
     {{1.46, 1.46, 1.421, 1.245, 1.069, 1.069, 1.0}, {2.984, 2.984, 2.181, 1.691, 1.201, 1.201, 1.0}},
     {{1.32, 1.32, 1.245, 1.123, 1.000, 1.000, 1.0}, {1.988, 1.988, 1.475, 1.313, 1.150, 1.150, 1.0}},
@@ -1083,29 +1093,29 @@ static double wang_collision_enhancement(double r1, double r2, double eps)
     {{1.223, 1.223, 1.117, 1.069, 1.021, 1.021, 1.0}, {1.716, 1.716, 1.345, 1.223, 1.100, 1.100, 1.0}},
     {{1.570, 1.570, 1.244, 1.166, 1.088, 1.088, 1.0}, {3.788, 3.788, 1.501, 1.311, 1.120, 1.120, 1.0}},
     {{20.3, 20.3, 14.6, 8.61, 2.60, 2.60, 1.0}, {36.52, 36.52, 19.16, 22.80, 26.0, 26.0, 1.0}}};
-  const double R = r1 > r2 ? r1 : r2, r = r1 > r2 ? r2 : r1;
+  const real R = r1 > r2 ? r1 : r2, r = r1 > r2 ? r2 : r1;
   if (R > 100e-6) return 1.;
   const int n_eps = eps <= 2.5e-2 ? 0 : 1;
   int n_R0, n_rat;
   for (n_R0 = 0; n_R0 < 7; ++n_R0) if (R0[n_R0] > R) break;
-  const double ratio = r / R;
+  const real ratio = r / R;
   for (n_rat = 1; n_rat < 11; ++n_rat) if (rat[n_rat] > ratio) break;
   if (n_R0 == 0) return eta_e[n_rat][n_eps][n_R0];
-  const double w0 = R - R0[n_R0 - 1], w1 = R0[n_R0] - R, w2 = ratio - rat[n_rat - 1], w3 = rat[n_rat] - ratio;
+  const real w0 = R - R0[n_R0 - 1], w1 = R0[n_R0] - R, w2 = ratio - rat[n_rat - 1], w3 = rat[n_rat] - ratio;
   return (eta_e[n_rat - 1][n_eps][n_R0 - 1] * w1 * w3 + eta_e[n_rat - 1][n_eps][n_R0] * w0 * w3 +
           eta_e[n_rat][n_eps][n_R0 - 1] * w1 * w2 + eta_e[n_rat][n_eps][n_R0] * w0 * w2)
          / (R0[n_R0] - R0[n_R0 - 1]) / (rat[n_rat] - rat[n_rat - 1]);
 }
 /* c = cell of the pair, diss = its TKE dissipation rate when opts.turb_coal, else 0 (coal.ipp:392-416,439-451) */
-static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, double rw2b, double vta, double vtb, sz c, double diss)
+static real kernel_calc(const orc_particles *s, n_t na, n_t nb, real rw2a, real rw2b, real vta, real vtb, sz c, real diss)
 {
   switch (s->o.kernel) {
     case LCX_KERNEL_ONISHI_HALL:
     case LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS: {                                   /* kernel_onishi::calc, kernels.hpp:209-250 */
-      const double rwa = sqrt(rw2a), rwb = sqrt(rw2b);
-      const double Re_l = s->kernel_parameters[0];
-      const double nograv = kernel_onishi_nograv(rwa, rwb, Re_l, diss, s->eta[c] / s->rhod[c], 1e3 / s->rhod[c]);
-      const double geometric = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+      const real rwa = sqrt(rw2a), rwb = sqrt(rw2b);
+      const real Re_l = s->kernel_parameters[0];
+      const real nograv = kernel_onishi_nograv(rwa, rwb, Re_l, diss, s->eta[c] / s->rhod[c], 1e3 / s->rhod[c]);
+      const real geometric = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
       /* the reference hands k_params[0] (Re_lambda) to the enhancement's dissipation-rate argument: reproduced */
       return interpolated_efficiency(s, rwa, rwb) * wang_collision_enhancement(rwa, rwb, Re_l) *
              sqrt(geometric * geometric + nograv * nograv);
@@ -1118,10 +1128,10 @@ static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, d
       if (s->n_user_params == 1) return k_geometric(na, nb, rw2a, rw2b, vta, vtb) * s->kernel_parameters[0];
       return k_geometric(na, nb, rw2a, rw2b, vta, vtb);
     case LCX_KERNEL_LONG: {
-      double res = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
-      const double r_L = dmax(sqrt(rw2a), sqrt(rw2b));
+      real res = k_geometric(na, nb, rw2a, rw2b, vta, vtb);
+      const real r_L = dmax(sqrt(rw2a), sqrt(rw2b));
       if (r_L < 50.e-6) {
-        const double r_s = dmin(sqrt(rw2a), sqrt(rw2b));
+        const real r_s = dmin(sqrt(rw2a), sqrt(rw2b));
         if (r_s <= 3e-6) res = 0.; else res *= 4.5e8 * r_L * r_L * (1. - 3e-6 / r_s);
       }
       return res;
@@ -1134,13 +1144,13 @@ static double kernel_calc(const orc_particles *s, n_t na, n_t nb, double rw2a, d
 static void collide(orc_particles *s, sz a, sz b, n_t col_no)
 {
   s->n[a] -= col_no * s->n[b];
-  const double rw_b = cbrt(col_no * s->rw2[a] * sqrt(s->rw2[a]) + s->rw2[b] * sqrt(s->rw2[b]));
+  const real rw_b = cbrt(col_no * s->rw2[a] * sqrt(s->rw2[a]) + s->rw2[b] * sqrt(s->rw2[b]));
   s->rw2[b] = rw_b * rw_b;
   s->rd3[b] = col_no * s->rd3[a] + s->rd3[b];
   s->vt[b] = -1.;
   if (s->use_rc2) s->rc2[b] = -1.;        /* invalidator, coal.ipp:33-44,527-545 */
 }
-static void coal(orc_particles *s, double dt, int turb_coal)
+static void coal(orc_particles *s, real dt, int turb_coal)
 {
   hskpng_sort_helper(s, 1);
   s->sorted = 1;
@@ -1150,13 +1160,13 @@ static void coal(orc_particles *s, double dt, int turb_coal)
   OMP_FOR
   for (sz i = 0; i < s->count_n; ++i) {
     const n_t n = s->count_num[i];
-    s->scl[s->count_ijk[i]] = n > 1 ? ((double)(n * (n - 1)) / 2) / (n / 2) : 0;      /* scale_factor, coal.ipp:99-107 */
+    s->scl[s->count_ijk[i]] = n > 1 ? ((real)(n * (n - 1)) / 2) / (n / 2) : 0;      /* scale_factor, coal.ipp:99-107 */
     s->off[s->count_ijk[i]] = (sz)n;
   }
   { sz acc = 0; for (sz c = 0; c < s->n_cell; ++c) { sz t = s->off[c]; s->off[c] = acc; acc += t; } }
-  double *u01 = s->col;
-  { double *rq = replay_pop(s, 0, s->n_part);
-    if (rq) { memcpy(u01, rq, s->n_part * sizeof(double)); free(rq); }
+  real *u01 = s->col;
+  { dbl *rq = replay_pop(s, 0, s->n_part);
+    if (rq) { for (sz p = 0; p < s->n_part; ++p) u01[p] = (real)rq[p]; free(rq); }
     else for (sz p = 0; p < s->n_part; ++p) u01[p] = rng_u01(&s->rng); }
   const sz n_pairs_end = s->n_part ? s->n_part - 1 : 0;
   OMP_FOR
@@ -1167,7 +1177,7 @@ static void coal(orc_particles *s, double dt, int turb_coal)
     const sz cix_b = (p + 1) - s->off[cb];
     if (cix_a != cix_b - 1) { s->col[p] = 0.; continue; }
     const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
-    const double prob = dt / s->dv[ca] * s->scl[ca] *
+    const real prob = dt / s->dv[ca] * s->scl[ca] *
       kernel_calc(s, s->n[a], s->n[b], s->rw2[a], s->rw2[b], s->vt[a], s->vt[b], ca, turb_coal ? s->diss_rate[ca] : 0.);
     n_t col_no = (n_t)prob;
     if (s->pure_const_multi && col_no >= 1) s->increase_sstp_coal = 1;
@@ -1182,14 +1192,14 @@ static void coal(orc_particles *s, double dt, int turb_coal)
       collide(s, b, a, col_no);
       s->col[p + 1] = -1.;
     }
-    s->col[p] = (double)col_no;
+    s->col[p] = (real)col_no;
   }
   if (s->o.n_dry_distros + s->n_size_keys > 1)             /* weighted_summator, coal.ipp:57-97,458-480 */
     for (sz p = 0; p + 1 < s->n_part; ++p) {
       if (s->col[p] <= 0) continue;
       const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
       const int na_ge_nb = s->col[p + 1] == -2.;
-      double rd3_old = na_ge_nb ? s->rd3[b] - s->col[p] * s->rd3[a] : s->rd3[a] - s->col[p] * s->rd3[b];
+      real rd3_old = na_ge_nb ? s->rd3[b] - s->col[p] * s->rd3[a] : s->rd3[a] - s->col[p] * s->rd3[b];
       for (int ci = 0; ci < s->col[p]; ++ci) {
         if (na_ge_nb) { s->kpa[b] = (s->kpa[a] * s->rd3[a] + s->kpa[b] * rd3_old) / (s->rd3[a] + rd3_old); rd3_old += s->rd3[a]; }
         else          { s->kpa[a] = (s->kpa[b] * s->rd3[b] + s->kpa[a] * rd3_old) / (s->rd3[b] + rd3_old); rd3_old += s->rd3[b]; }
@@ -1199,20 +1209,20 @@ static void coal(orc_particles *s, double dt, int turb_coal)
     for (sz p = 0; p + 1 < s->n_part; ++p) {
       if (s->col[p] <= 0) continue;
       const sz a = s->sorted_id[p], b = s->sorted_id[p + 1];
-      const double m = dmax(s->ict[a], s->ict[b]);
+      const real m = dmax(s->ict[a], s->ict[b]);
       if (s->col[p + 1] == -2.) s->ict[b] = m; else s->ict[a] = m;
     }
 }
 
-static int mig_attrs(orc_particles *s, double **a);
+static int mig_attrs(orc_particles *s, real **a);
 /* ---------------- advection, sedimentation, boundary (adve.ipp:28-304, sedi.ipp:13-25, subs.ipp:13-25, bcnd.ipp:99-368) -------- */
-static double adve_1d(int scheme, double x, sz fl, double C_l, double C_r, double dx)
+static real adve_1d(int scheme, real x, sz fl, real C_l, real C_r, real dx)
 {
   if (scheme == LCX_ADVE_IMPLICIT) return (x + dx * (C_l - fl * (C_r - C_l))) / (1 - (C_r - C_l));
   return 1 * x + (C_r - C_l) * (x - dx * fl) + dx * C_l;
 }
 /* Courant numbers at the faces of extended-grid cell ce (grid with nx + 2 halo planes), init_grid.ipp:57-158 */
-static void faces(const orc_particles *s, sz ce, double *Cxl, double *Cxr, double *Cyl, double *Cyr, double *Czl, double *Czr)
+static void faces(const orc_particles *s, sz ce, real *Cxl, real *Cxr, real *Cyl, real *Cyr, real *Czl, real *Czr)
 {
   const lcx_opts_init_t *o = &s->o;
   const sz nz = m1(o->nz), ny = m1(o->ny);
@@ -1224,24 +1234,24 @@ static void faces(const orc_particles *s, sz ce, double *Cxl, double *Cxr, doubl
     *Czl = s->courant_z[blw]; *Czr = s->courant_z[blw + 1];
   }
 }
-static sz cell_ext(const orc_particles *s, double x, double y, double z)
+static sz cell_ext(const orc_particles *s, real x, real y, real z)
 {                                                   /* hskpng_ijk in the coordinates that start at the halo's left edge */
   const lcx_opts_init_t *o = &s->o;
   const sz i = o->nx ? (sz)(x / o->dx) : 0, j = o->ny ? (sz)(y / o->dy) : 0, k = o->nz ? (sz)(z / o->dz) : 0;
   switch (s->n_dims) { case 1: return i; case 2: return i * o->nz + k; default: return i * ((sz)o->nz * o->ny) + j * o->nz + k; }
 }
-static double periodic(double x, double a, double b);
+static real periodic(real x, real a, real b);
 /* adve.ipp:184-304: predictor-corrector with nearest-neighbour interpolation */
 static void adve_pred_corr(orc_particles *s)
 {
   const lcx_opts_init_t *o = &s->o;
   const sz nz = m1(o->nz), ny = m1(o->ny);
-  const double shift = (double)s->halo * o->dx;
+  const real shift = (real)s->halo * o->dx;
   for (sz p = 0; p < s->n_part; ++p) {
-    double x = s->x[p] + shift, y = s->y[p], z = s->z[p];
-    double Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0;
+    real x = s->x[p] + shift, y = s->y[p], z = s->z[p];
+    real Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0;
     sz ce = cell_ext(s, x, y, z);
-    double x_old = x, y_old = y, z_old = z;
+    real x_old = x, y_old = y, z_old = z;
     faces(s, ce, &Cxl, &Cxr, &Cyl, &Cyr, &Czl, &Czr);             /* predictor: explicit Euler */
     {
       sz i, j = 0, k = 0;
@@ -1307,17 +1317,17 @@ static void adve(orc_particles *s)
     }
   }
 }
-static void sedi(orc_particles *s, double dt)
+static void sedi(orc_particles *s, real dt)
 {
   OMP_FOR
   for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->vt[p];
 }
-static void subs(orc_particles *s, double dt)
+static void subs(orc_particles *s, real dt)
 {
   const sz nz = m1(s->o.nz);
   for (sz p = 0; p < s->n_part; ++p) s->z[p] = s->z[p] - dt * s->w_LS[s->ijk[p] % nz];
 }
-static double periodic(double x, double a, double b) { return a + fmod((x - a) + 10 * (b - a), b - a); }
+static real periodic(real x, real a, real b) { return a + fmod((x - a) + 10 * (b - a), b - a); }
 static void bcnd(orc_particles *s)
 {
   if (s->n_dims == 0) return;
@@ -1340,9 +1350,9 @@ static void bcnd(orc_particles *s)
     if (!o->periodic_topbot_walls) {
       OMP_FOR
       for (sz p = 0; p < s->n_part; ++p) if (s->z[p] >= o->z1) s->n[p] = 0;
-      double liq_vol = 0, dry_vol = 0, liq_num = 0, prtcl_num = 0;
+      real liq_vol = 0, dry_vol = 0, liq_num = 0, prtcl_num = 0;
       OMP_FOR
-      for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = s->z[p] < o->z0 ? (double)s->n[p] : 0.;
+      for (sz p = 0; p < s->n_part; ++p) s->n_filtered[p] = s->z[p] < o->z0 ? (real)s->n[p] : 0.;
 #ifdef _OPENMP
       {                        /* the four sums over the SDs below the floor only, in index order: every other term is +0.0, which
                                   leaves a non-negative running sum as it is -- the same bits as the full serial loops below */
@@ -1401,7 +1411,7 @@ static void rcyc(orc_particles *s)
   while (n_splittable < N && key[N - 1 - n_splittable] != 1) ++n_splittable;
   if (n_splittable == 0) { hskpng_remove_n0(s); return; }
   if (n_splittable < n_flagged) n_flagged = n_splittable;
-  double *attrs[24]; const int na = mig_attrs(s, attrs);             /* distmem_real_vctrs: everything but n */
+  real *attrs[24]; const int na = mig_attrs(s, attrs);             /* distmem_real_vctrs: everything but n */
   for (int a = 0; a < na; ++a)
     for (sz t = 0; t < n_flagged; ++t) attrs[a][sid[t]] = attrs[a][sid[N - 1 - t]];
   for (sz t = 0; t < n_flagged; ++t) { const n_t big = s->n[sid[N - 1 - t]]; s->n[sid[t]] = big - big / 2; }
@@ -1418,26 +1428,26 @@ static int post_copy(orc_particles *s, const lcx_opts_t *opts)
 }
 
 /* ---------------- initialisation (particles_init.ipp:16-131 and src/impl/initialization/) ---------------- */
-static double eval_distro(const lcx_distro_t *d, double lnrd)
+static real eval_distro(const lcx_distro_t *d, real lnrd)
 {
   if (d->fn) return d->fn(lnrd, d->user);
-  double res = 0;                                   /* common/lognormal.hpp:25-37, sum of modes */
-  if (d->n_modes < 0) { const double q = pow(exp(lnrd), 3) / pow(d->mean_rd[0], 3); return d->n_stp[0] * 3. * q * exp(-q); }   /* lcx.h: exponential in volume */
+  real res = 0;                                   /* common/lognormal.hpp:25-37, sum of modes */
+  if (d->n_modes < 0) { const real q = pow(exp(lnrd), 3) / pow(d->mean_rd[0], 3); return d->n_stp[0] * 3. * q * exp(-q); }   /* lcx.h: exponential in volume */
   for (int m = 0; m < d->n_modes; ++m)
     res += d->n_stp[m] / sqrt(2 * ORC_PI) / log(d->sdev[m]) *
            exp(-pow((lnrd - log(d->mean_rd[m])), 2) / 2. / pow(log(d->sdev[m]), 2));
   return res;
 }
 /* init_dist_analysis.ipp:17-77 */
-static int init_dist_analysis_sd_conc(orc_particles *s, const lcx_distro_t *d, n_t sd_conc, double dt)
+static int init_dist_analysis_sd_conc(orc_particles *s, const lcx_distro_t *d, n_t sd_conc, real dt)
 {
   const lcx_opts_init_t *o = &s->o;
-  const double vol = s->n_dims == 0 ? s->dv[0] : (o->dx * o->dy * o->dz);
+  const real vol = s->n_dims == 0 ? s->dv[0] : (o->dx * o->dy * o->dz);
   if (o->rd_min >= 0 && o->rd_max >= 0) {
     s->multiplier = log(o->rd_max / o->rd_min) / sd_conc * dt * vol;
     s->log_rd_min = log(o->rd_min); s->log_rd_max = log(o->rd_max);
   } else if (o->rd_min < 0 && o->rd_max < 0) {
-    double rd_min = 1e-14, rd_max = 1e-3;            /* config.hpp:23-24 */
+    real rd_min = 1e-14, rd_max = 1e-3;            /* config.hpp:23-24 */
     int found = 0;
     while (!found) {
       s->multiplier = log(rd_max / rd_min) / sd_conc * dt * vol;
@@ -1458,7 +1468,7 @@ static int resize_npart(orc_particles *s)
 }
 /* init_SD_with_distros_finalize: init_kappa, init_wet (init_wet.ipp:17-78), init_xyz (init_xyz.ipp:40-74) for the SDs
  * [n_part_old, n_part) */
-static void init_finalize(orc_particles *s, double kappa)
+static void init_finalize(orc_particles *s, real kappa)
 {
   const lcx_opts_init_t *o = &s->o;
   OMP_FOR
@@ -1469,8 +1479,8 @@ static void init_finalize(orc_particles *s, double kappa)
     s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
   }
   const int nn[3] = {o->nx, o->ny, o->nz};
-  const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
-  double *v[3] = {s->x, s->y, s->z};
+  const real a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
+  real *v[3] = {s->x, s->y, s->z};
   const sz nz = m1(o->nz), ny = m1(o->ny);
   for (int ix = 0; ix < 3; ++ix) {
     if (nn[ix] == 0) continue;
@@ -1482,7 +1492,7 @@ static void init_finalize(orc_particles *s, double kappa)
       if (s->n_dims == 1) ii = c;
       else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
       else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
-      const double u = s->tmp_part[g];
+      const real u = s->tmp_part[g];
       v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
     }
   }
@@ -1493,12 +1503,12 @@ static void init_finalize(orc_particles *s, double kappa)
  * vendored and its version is not pinned by the reference: parity UNPINNED for this routine).  Restated from the
  * published algorithm (R. P. Brent, Algorithms for Minimization without Derivatives, 1973, ch. 5) in the form Boost
  * documents: golden ratio 0.3819660, tolerance 2^(1-bits) with bits = min(digits/2, requested). */
-typedef double (*orc_fn1)(double, void *);
-static double brent_find_minimum(orc_fn1 f, void *ctx, double min, double max, int bits, uintmax_t *max_iter, double *fmin)
+typedef real (*orc_fn1)(real, void *);
+static real brent_find_minimum(orc_fn1 f, void *ctx, real min, real max, int bits, uintmax_t *max_iter, real *fmin)
 {
   if (bits > 53 / 2) bits = 53 / 2;
-  const double tolerance = ldexp(1.0, 1 - bits), golden = 0.3819660f;
-  double x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
+  const real tolerance = ldexp(1.0, 1 - bits), golden = 0.3819660f;
+  real x, w, v, u, delta, delta2, fu, fv, fw, fx, mid, fract1, fract2;
   x = w = v = max;
   fw = fv = fx = f(x, ctx);
   delta2 = delta = 0;
@@ -1509,11 +1519,11 @@ static double brent_find_minimum(orc_fn1 f, void *ctx, double min, double max, i
     fract2 = 2 * fract1;
     if (fabs(x - mid) <= (fract2 - (max - min) / 2)) break;
     if (fabs(delta2) > fract1) {
-      double r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
+      real r = (x - w) * (fx - fv), q = (x - v) * (fx - fw), p = (x - v) * q - (x - w) * r;
       q = 2 * (q - r);
       if (q > 0) p = -p;
       q = fabs(q);
-      const double td = delta2;
+      const real td = delta2;
       delta2 = delta;
       if ((fabs(p) >= fabs(q * td / 2)) || (p <= q * (min - x)) || (p >= q * (max - x))) {
         delta2 = (x >= mid) ? min - x : max - x;
@@ -1542,8 +1552,8 @@ static double brent_find_minimum(orc_fn1 f, void *ctx, double min, double max, i
   *fmin = fx;
   return x;
 }
-typedef struct { const lcx_distro_t *d; double mul, add; } distro_ctx;
-static double distro_mul_add(double lnrd, void *vc) { const distro_ctx *c = (const distro_ctx *)vc; return eval_distro(c->d, lnrd) * c->mul + c->add; }
+typedef struct { const lcx_distro_t *d; real mul, add; } distro_ctx;
+static real distro_mul_add(real lnrd, void *vc) { const distro_ctx *c = (const distro_ctx *)vc; return eval_distro(c->d, lnrd) * c->mul + c->add; }
 /* init_dist_analysis.ipp:80-120 */
 static int init_dist_analysis_const_multi(orc_particles *s, const lcx_distro_t *d)
 {
@@ -1552,9 +1562,9 @@ static int init_dist_analysis_const_multi(orc_particles *s, const lcx_distro_t *
   else if (o->rd_min < 0 && o->rd_max < 0) {
     distro_ctx neg = {d, -1., 0.};
     uintmax_t n_iter = 100;
-    double fmin;
-    const double lnrd_max = brent_find_minimum(distro_mul_add, &neg, log(1e-14), log(1e-3), 200, &n_iter, &fmin);
-    const double bound = -fmin / 1e20;                         /* config.hpp:21 threshold */
+    real fmin;
+    const real lnrd_max = brent_find_minimum(distro_mul_add, &neg, log(1e-14), log(1e-3), 200, &n_iter, &fmin);
+    const real bound = -fmin / 1e20;                         /* config.hpp:21 threshold */
     distro_ctx lvl = {d, 1., -bound};
     n_iter = 100;
     s->log_rd_min = orc_toms748(distro_mul_add, &lvl, log(1e-14), lnrd_max, distro_mul_add(log(1e-14), &lvl), distro_mul_add(lnrd_max, &lvl),
@@ -1570,14 +1580,14 @@ static int init_dist_analysis_const_multi(orc_particles *s, const lcx_distro_t *
 static int init_const_multi_like(orc_particles *s, const lcx_distro_t *d, n_t const_multi)
 {
   const lcx_opts_init_t *o = &s->o;
-  const double bin = 1e-4, lo = s->log_rd_min, hi = s->log_rd_max;         /* config.hpp:20 bin_precision */
+  const real bin = 1e-4, lo = s->log_rd_min, hi = s->log_rd_max;         /* config.hpp:20 bin_precision */
   const int nb = (int)((hi - lo) / bin);
-  double integral = (eval_distro(d, lo) + eval_distro(d, hi)) / 2.;
+  real integral = (eval_distro(d, lo) + eval_distro(d, hi)) / 2.;
   for (int i = 1; i < nb; ++i) integral += eval_distro(d, lo + i * bin);
   integral = integral * bin;
   sz total = 0;
   for (sz c = 0; c < s->n_cell; ++c) {                                     /* init_count_num_hlpr + conc_to_number */
-    double conc = integral;
+    real conc = integral;
     conc = conc * s->dv[c];
     if (!o->aerosol_independent_of_rhod) conc = s->rhod[c] / rho_stp * conc;
     if (o->n_aerosol_conc_factor > 0) conc = conc * s->aerosol_conc_factor[c % o->nz];
@@ -1591,16 +1601,16 @@ static int init_const_multi_like(orc_particles *s, const lcx_distro_t *d, n_t co
   for (sz p = s->n_part_old; p < s->n_part; ++p) { s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
   { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < s->count_num[c]; ++q) s->ijk[w++] = c; }
   const sz ncdf = (sz)((hi - lo) / bin + 1);
-  double *cdf = NEW(double, ncdf);
+  real *cdf = NEW(real, ncdf);
   for (sz i = 0; i < ncdf; ++i) cdf[i] = eval_distro(d, lo + bin * i) * 1;
   for (sz i = 1; i < ncdf; ++i) cdf[i] = cdf[i - 1] + cdf[i];
-  { const double back = cdf[ncdf - 1]; for (sz i = 0; i < ncdf; ++i) cdf[i] = cdf[i] / back; }
+  { const real back = cdf[ncdf - 1]; for (sz i = 0; i < ncdf; ++i) cdf[i] = cdf[i] / back; }
   for (sz g = 0; g < total; ++g) s->tmp_part[g] = rng_u01(&s->rng);
   for (sz g = 0; g < total; ++g) {
-    const double u = s->tmp_part[g];
+    const real u = s->tmp_part[g];
     sz a = 0, b = ncdf;                                                    /* thrust::upper_bound: first index with cdf > u */
     while (a < b) { const sz m = a + (b - a) / 2; if (!(u < cdf[m])) a = m + 1; else b = m; }
-    const double lnrd = lo + (double)a * bin;
+    const real lnrd = lo + (real)a * bin;
     s->rd3[s->n_part_old + g] = exp(3 * lnrd);
   }
   free(cdf);
@@ -1610,7 +1620,7 @@ static int init_const_multi_like(orc_particles *s, const lcx_distro_t *d, n_t co
 static int init_SD_with_distros(orc_particles *s)
 {
   const lcx_opts_init_t *o = &s->o;
-  double tot_lnrd_rng = 0.;
+  real tot_lnrd_rng = 0.;
   if (o->sd_conc > 0)
     for (int d = 0; d < o->n_dry_distros; ++d) {
       if (init_dist_analysis_sd_conc(s, &s->distros[d], o->sd_conc, 1.)) return 1;
@@ -1622,7 +1632,7 @@ static int init_SD_with_distros(orc_particles *s)
     /* init_SD_with_distros_sd_conc.ipp:14-46 */
     if (init_dist_analysis_sd_conc(s, dd, o->sd_conc, 1.)) return 1;
     if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
-    const double fraction = (s->log_rd_max - s->log_rd_min) / tot_lnrd_rng;
+    const real fraction = (s->log_rd_max - s->log_rd_min) / tot_lnrd_rng;
     s->multiplier *= o->sd_conc / (n_t)(int)(fraction * o->sd_conc + 0.5);
     const n_t per_cell = (n_t)(fraction * o->sd_conc);               /* init_count_num.ipp:32-35 */
     for (sz c = 0; c < s->n_cell; ++c) s->count_num[c] = per_cell;
@@ -1641,15 +1651,15 @@ static int init_SD_with_distros(orc_particles *s)
     for (sz g = 0; g < s->n_part_to_init; ++g) {
       const sz c = s->ijk[s->n_part_old + g];
       const sz ptr = (sz)per_cell * c;
-      const double lnrd = s->log_rd_min + ((double)(g - ptr) + s->tmp_part[g]) * (s->log_rd_max - s->log_rd_min) / (double)s->count_num[c];
+      const real lnrd = s->log_rd_min + ((real)(g - ptr) + s->tmp_part[g]) * (s->log_rd_max - s->log_rd_min) / (real)s->count_num[c];
       s->rd3[s->n_part_old + g] = exp(3 * lnrd);
     }
     /* init_n.ipp:48-143 (a distribution given as a function pointer may be a Python callback: those stay on one thread) */
 #pragma omp parallel for schedule(static) if (dd->fn == NULL)
     for (sz g = 0; g < s->n_part_to_init; ++g) {
       const sz p = s->n_part_old + g, c = s->ijk[p];
-      const double lnrd = log(s->rd3[p]) / 3.;
-      double v = s->multiplier * eval_distro(dd, lnrd);
+      const real lnrd = log(s->rd3[p]) / 3.;
+      real v = s->multiplier * eval_distro(dd, lnrd);
       if (!o->aerosol_independent_of_rhod) v = v * s->rhod[c] / rho_stp;
       if (o->n_aerosol_conc_factor > 0) v = v * s->aerosol_conc_factor[c % o->nz];
       if (s->n_dims > 0) v = v * s->dv[c] / (o->dx * o->dy * o->dz);
@@ -1657,7 +1667,7 @@ static int init_SD_with_distros(orc_particles *s)
     }
     init_finalize(s, dd->kappa);
     if (o->sd_conc_large_tail) {                                            /* init_SD_with_distros_tail.ipp:14-40 */
-      const double log_rd_min_init = s->log_rd_max;
+      const real log_rd_min_init = s->log_rd_max;
       if (init_dist_analysis_const_multi(s, dd)) return 1;
       s->log_rd_min = log_rd_min_init;
       if (s->log_rd_min >= s->log_rd_max) FAIL("Distribution analysis error: rd_min(%g) >= rd_max(%g)", exp(s->log_rd_min), exp(s->log_rd_max));
@@ -1687,11 +1697,11 @@ static int init_SD_with_sizes(orc_particles *s)
     s->n_part += s->n_part_to_init;
     if (resize_npart(s)) return 1;
     { sz w = s->n_part_old; for (sz c = 0; c < s->n_cell; ++c) for (n_t q = 0; q < per_cell; ++q) s->ijk[w++] = c; }
-    const double rad3 = ds->radius * ds->radius * ds->radius;
+    const real rad3 = ds->radius * ds->radius * ds->radius;
     for (sz p = s->n_part_old; p < s->n_part; ++p) { s->rd3[p] = rad3; s->kpa[p] = ds->kappa; s->vt[p] = -1.; if (s->use_rc2) s->rc2[p] = -1.; }
     for (sz p = s->n_part_old; p < s->n_part; ++p) {
       const sz c = s->ijk[p];
-      double conc = ds->conc;
+      real conc = ds->conc;
       conc = conc * s->dv[c];
       if (!o->aerosol_independent_of_rhod) conc = s->rhod[c] / rho_stp * conc;
       if (o->n_aerosol_conc_factor > 0) conc = conc * s->aerosol_conc_factor[c % o->nz];
@@ -1702,8 +1712,8 @@ static int init_SD_with_sizes(orc_particles *s)
       s->rw2[p] = pow(rw3_eq(s->rd3[p], s->kpa[p], dmin(s->RH[c], o->RH_max), s->T[c]), 2. / 3);
     }
     const int nn[3] = {o->nx, o->ny, o->nz};
-    const double a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
-    double *v[3] = {s->x, s->y, s->z};
+    const real a[3] = {o->x0, o->y0, o->z0}, b[3] = {o->x1, o->y1, o->z1}, dd3[3] = {o->dx, o->dy, o->dz};
+    real *v[3] = {s->x, s->y, s->z};
     const sz nz = m1(o->nz), ny = m1(o->ny);
     for (int ix = 0; ix < 3; ++ix) {
       if (nn[ix] == 0) continue;
@@ -1714,7 +1724,7 @@ static int init_SD_with_sizes(orc_particles *s)
         if (s->n_dims == 1) ii = c;
         else if (s->n_dims == 2) ii = ix == 0 ? c / nz : c % nz;
         else ii = ix == 0 ? c / (nz * ny) : ix == 1 ? (c / nz) % ny : c % nz;
-        const double u = s->tmp_part[g];
+        const real u = s->tmp_part[g];
         v[ix][p] = u * dmin(b[ix], (ii + 1) * dd3[ix]) + (1. - u) * dmax(a[ix], ii * dd3[ix]);
       }
     }
@@ -1756,14 +1766,16 @@ static int init_kernel(orc_particles *s)
         if (s->n_user_params != 1) FAIL("libcloudph++: Please supply one kernel parameter: Taylor microscale Reynolds number.");
         if (!o->turb_coal_switch) FAIL("libcloudph++: To use the turbulent Onishis kernel, set turb_coal_switch=True");
       } else if (s->n_user_params != 0) FAIL("this kernel doesn't accept parameters");
-      sz n = 0; double r_max = 0;
+      sz n = 0; real r_max = 0;
       const int eff = o->kernel == LCX_KERNEL_ONISHI_HALL ? LCX_KERNEL_HALL :
                       o->kernel == LCX_KERNEL_ONISHI_HALL_DAVIS_NO_WAALS ? LCX_KERNEL_HALL_DAVIS_NO_WAALS : o->kernel;
-      const double *tab = orc_efficiency_table(eff, &n, &r_max);
+      dbl r_max_d = 0;
+      const dbl *tab = orc_efficiency_table(eff, &n, &r_max_d);      /* (the tables are data: doubles in every flavour) */
+      r_max = (real)r_max_d;
       if (!tab) FAIL("libcloudph++: kernel %d not available in this backend", o->kernel);
-      double *kp = NEW(double, n + s->n_user_params);                    /* user parameters first, then the efficiencies */
+      real *kp = NEW(real, n + s->n_user_params);                    /* user parameters first, then the efficiencies */
       for (int i = 0; i < s->n_user_params; ++i) kp[i] = s->kernel_parameters[i];
-      memcpy(kp + s->n_user_params, tab, n * sizeof(double));
+      for (sz i = 0; i < n; ++i) kp[s->n_user_params + i] = (real)tab[i];
       free(s->kernel_parameters);
       s->kernel_parameters = kp;
       s->n_kernel_parameters = n + s->n_user_params; s->kernel_r_max = r_max;
@@ -1830,7 +1842,7 @@ static void alloc_courants(orc_particles *s)
     case 1: s->n_cx = (sz)nxh + 1; break;
     default: break;
   }
-  s->courant_x = NEW(double, s->n_cx); s->courant_y = NEW(double, s->n_cy); s->courant_z = NEW(double, s->n_cz);
+  s->courant_x = NEW(real, s->n_cx); s->courant_y = NEW(real, s->n_cy); s->courant_z = NEW(real, s->n_cz);
 }
 int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv, const lcx_arrinfo_t *rhod,
              const lcx_arrinfo_t *p, const lcx_arrinfo_t *cx, const lcx_arrinfo_t *cy, const lcx_arrinfo_t *cz)
@@ -1858,7 +1870,7 @@ int orc_init(orc_particles *s, const lcx_arrinfo_t *th, const lcx_arrinfo_t *rv,
   sstp_save(s);
   hskpng_count(s);
   mt_seed(&s->rng, (uint32_t)s->o.rng_seed);
-  if (s->tag) for (sz p = 0; p < s->n_part; ++p) s->tag[p] = (double)p;
+  if (s->tag) for (sz p = 0; p < s->n_part; ++p) s->tag[p] = (real)p;
   return 0;
 }
 
@@ -1900,7 +1912,7 @@ int orc_step_cond(orc_particles *s, const lcx_opts_t *opts, const lcx_arrinfo_t 
   if (adjust_timesteps(s, opts->dt)) return 1;
   if (s->o.diag_incloud_time)                                  /* update_incloud_time.ipp:36-66: += dt while rw2 > rc2, else 0 */
     for (sz p = 0; p < s->n_part; ++p) {
-      const double rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
+      const real rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
       if (s->rw2[p] > rc2) s->ict[p] += s->dt; else s->ict[p] = 0;
     }
   if (opts->cond) {
@@ -1961,7 +1973,7 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
   if (opts->adve) TMR(TM_MOVE, adve(s));
   s->adve_scheme = s->o.adve_scheme;
   if (opts->turb_adve) {                                                      /* turb_adve.ipp:13-33: x, z, y get up, wp, vp */
-    double *pos[3] = {s->x, s->z, s->y}, *vel[3] = {s->up, s->wp, s->vp};
+    real *pos[3] = {s->x, s->z, s->y}, *vel[3] = {s->up, s->wp, s->vp};
     for (int i = 0; i < s->n_dims; ++i) for (sz p = 0; p < s->n_part; ++p) pos[i][p] = pos[i][p] + vel[i][p] * s->dt;
   }
   if (opts->sedi) TMR(TM_MOVE, sedi(s, s->dt));
@@ -1973,10 +1985,10 @@ int orc_step_async(orc_particles *s, const lcx_opts_t *opts)
 }
 
 /* ---------------- diagnostics (particles_diag.ipp, fill_outbuf.ipp) ---------------- */
-static void diag_cellfield(orc_particles *s, const double *f)
+static void diag_cellfield(orc_particles *s, const real *f)
 {
   hskpng_Tpr(s);
-  memcpy(s->count_mom, f, s->n_cell * sizeof(double));
+  memcpy(s->count_mom, f, s->n_cell * sizeof(real));
   s->count_n = s->n_cell;
   for (sz c = 0; c < s->n_cell; ++c) s->count_ijk[c] = c;
 }
@@ -1987,7 +1999,7 @@ int orc_diag_vel_div(orc_particles *s)
   const sz nz = m1(s->o.nz), ny = m1(s->o.ny);
   const sz plane = s->n_dims == 1 ? 1 : s->n_dims == 2 ? nz : nz * ny;
   for (sz c = 0; c < s->n_cell; ++c) {
-    double Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0, d = 0.;
+    real Cxl, Cxr, Cyl = 0, Cyr = 0, Czl = 0, Czr = 0, d = 0.;
     faces(s, c + (sz)s->halo * plane, &Cxl, &Cxr, &Cyl, &Cyr, &Czl, &Czr);
     if (s->n_dims == 3) d = d + (Cyr - Cyl) / s->o.dt;
     if (s->n_dims >= 2) d = d + (Czr - Czl) / s->o.dt;
@@ -2006,7 +2018,7 @@ int orc_diag_sd_conc(orc_particles *s)
   hskpng_sort(s);
   sz cn = 0;
   for (sz p = 0; p < s->n_part; ++p) {
-    const double v = s->n_filtered[s->sorted_id[p]] > 0. ? 1 : 0;
+    const real v = s->n_filtered[s->sorted_id[p]] > 0. ? 1 : 0;
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
     else s->count_mom[cn - 1] += v;
   }
@@ -2016,7 +2028,7 @@ int orc_diag_sd_conc(orc_particles *s)
 int orc_diag_all(orc_particles *s) { moms_all(s); return 0; }
 int orc_diag_water(orc_particles *s) { moms_gt0(s, s->rw2, 0); return 0; }
 int orc_diag_water_cons(orc_particles *s) { moms_gt0(s, s->rw2, 1); return 0; }                  /* particles_diag.ipp:346-349 */
-static int diag_sgs_mom(orc_particles *s, const double *v, int k)                                /* particles_diag.ipp:463-480 */
+static int diag_sgs_mom(orc_particles *s, const real *v, int k)                                /* particles_diag.ipp:463-480 */
 {
   if (!v) FAIL("libcloudph++: moment of an SGS velocity perturbation that this set-up does not carry (turb_adve_switch / turb_cond_switch, dimensions)");
   if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments");
@@ -2025,12 +2037,12 @@ static int diag_sgs_mom(orc_particles *s, const double *v, int k)               
 int orc_diag_up_mom(orc_particles *s, int k) { return diag_sgs_mom(s, s->o.turb_adve_switch && s->o.nx ? s->up : NULL, k); }
 int orc_diag_vp_mom(orc_particles *s, int k) { return diag_sgs_mom(s, s->o.turb_adve_switch && s->o.ny ? s->vp : NULL, k); }
 int orc_diag_wp_mom(orc_particles *s, int k) { return diag_sgs_mom(s, (s->o.turb_adve_switch && s->o.nz) || s->o.turb_cond_switch ? s->wp : NULL, k); }
-int orc_diag_dry_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 0); return 0; }
-int orc_diag_wet_rng(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 0); return 0; }
-int orc_diag_kappa_rng(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 0); return 0; }
-int orc_diag_dry_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 1); return 0; }
-int orc_diag_wet_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 1); return 0; }
-int orc_diag_kappa_rng_cons(orc_particles *s, double a, double b) { moms_rng(s, a, b, s->kpa, 1); return 0; }
+int orc_diag_dry_rng(orc_particles *s, dbl a, dbl b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 0); return 0; }
+int orc_diag_wet_rng(orc_particles *s, dbl a, dbl b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 0); return 0; }
+int orc_diag_kappa_rng(orc_particles *s, dbl a, dbl b) { moms_rng(s, a, b, s->kpa, 0); return 0; }
+int orc_diag_dry_rng_cons(orc_particles *s, dbl a, dbl b) { moms_rng(s, pow(a, 3), pow(b, 3), s->rd3, 1); return 0; }
+int orc_diag_wet_rng_cons(orc_particles *s, dbl a, dbl b) { moms_rng(s, pow(a, 2), pow(b, 2), s->rw2, 1); return 0; }
+int orc_diag_kappa_rng_cons(orc_particles *s, dbl a, dbl b) { moms_rng(s, a, b, s->kpa, 1); return 0; }
 #define NEED_SELECTION if (!s->selected_before_counting) FAIL("libcloudph++: please select super-droplets (diag_all / diag_*_rng) before counting moments")
 int orc_diag_dry_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rd3, k / 3., 1); return 0; }
 int orc_diag_wet_mom(orc_particles *s, int k) { NEED_SELECTION; moms_calc(s, s->rw2, k / 2., 1); return 0; }
@@ -2055,8 +2067,8 @@ int orc_diag_RH_ge_Sc(orc_particles *s)
   hskpng_sort(s);
   for (sz p = 0; p < s->n_part; ++p) {
     const sz c = s->ijk[p];
-    const double v = s->RH[c] - S_cr(s->rd3[p], s->kpa[p], s->T[c]);
-    s->n_filtered[p] = (double)s->n[p] * (v >= 0);
+    const real v = s->RH[c] - S_cr(s->rd3[p], s->kpa[p], s->T[c]);
+    s->n_filtered[p] = (real)s->n[p] * (v >= 0);
   }
   s->selected_before_counting = 1;
   return 0;
@@ -2065,30 +2077,30 @@ int orc_diag_rw_ge_rc(orc_particles *s)
 {
   hskpng_sort(s);
   for (sz p = 0; p < s->n_part; ++p) {
-    const double rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
-    s->n_filtered[p] = s->rw2[p] >= rc2 ? (double)s->n[p] : 0;
+    const real rc2 = pow(rw3_cr(s->rd3[p], s->kpa[p], s->T[s->ijk[p]]), 2. / 3);
+    s->n_filtered[p] = s->rw2[p] >= rc2 ? (real)s->n[p] : 0;
   }
   s->selected_before_counting = 1;
   return 0;
 }
 /* particles_diag.ipp:494-497, mass_dens.ipp:7-120 (the kernel width uses the number of SDs of the SD's cell) */
-int orc_diag_wet_mass_dens(orc_particles *s, double rad, double sig0)
+int orc_diag_wet_mass_dens(orc_particles *s, dbl rad, dbl sig0)
 {
   NEED_SELECTION;
   hskpng_sort(s);
   hskpng_count(s);
   for (sz c = 0; c < s->n_cell; ++c) s->scl[c] = 0.;
-  for (sz i = 0; i < s->count_n; ++i) s->scl[s->count_ijk[i]] = (double)s->count_num[i];
+  for (sz i = 0; i < s->count_n; ++i) s->scl[s->count_ijk[i]] = (real)s->count_num[i];
   sz cn = 0;
   for (sz q = 0; q < s->n_part; ++q) {
     const sz id = s->sorted_id[q], c = s->sorted_ijk[q];
-    const double x = s->rw2[id], sig = sig0 / pow(s->scl[c], 0.2);
-    const double v = s->n_filtered[id] / sig * pow(x, 3 * .5) * exp(-pow((log(pow(x, .5)) - log(rad)) / sig, 2) / 2.);
+    const real x = s->rw2[id], sig = sig0 / pow(s->scl[c], 0.2);
+    const real v = s->n_filtered[id] / sig * pow(x, 3 * .5) * exp(-pow((log(pow(x, .5)) - log(rad)) / sig, 2) / 2.);
     if (q == 0 || c != s->sorted_ijk[q - 1]) { s->count_ijk[cn] = c; s->count_mom[cn] = v; ++cn; }
     else s->count_mom[cn - 1] = s->count_mom[cn - 1] + v;
   }
   s->count_n = cn;
-  const double prefactor = 4. / 3. * rho_w * sqrt(ORC_PI / 2.);
+  const real prefactor = 4. / 3. * rho_w * sqrt(ORC_PI / 2.);
   for (sz i = 0; i < cn; ++i) s->count_mom[i] = prefactor * s->count_mom[i] / s->dv[s->count_ijk[i]];
   return 0;
 }
@@ -2098,7 +2110,7 @@ int orc_diag_max_rw(orc_particles *s)
   hskpng_sort(s);
   sz cn = 0;
   for (sz p = 0; p < s->n_part; ++p) {
-    const double v = sqrt(s->rw2[s->sorted_id[p]]);
+    const real v = sqrt(s->rw2[s->sorted_id[p]]);
     if (p == 0 || s->sorted_ijk[p] != s->sorted_ijk[p - 1]) { s->count_ijk[cn] = s->sorted_ijk[p]; s->count_mom[cn] = v; ++cn; }
     else if (s->count_mom[cn - 1] < v) s->count_mom[cn - 1] = v;
   }
@@ -2115,14 +2127,14 @@ int orc_outbuf(orc_particles *s, const void **data, size_t *n)
 }
 int orc_get_attr(orc_particles *s, const char *name, void *out, size_t cap, size_t *n)
 {
-  const double *v = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "kappa") ? s->kpa :
+  const real *v = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "kappa") ? s->kpa :
                     !strcmp(name, "x") ? s->x : !strcmp(name, "y") ? s->y : !strcmp(name, "z") ? s->z : NULL;
   if (!v) FAIL("Unknown attribute name passed to get_attr.");
   *n = s->n_part;
-  if (out) { if (cap < s->n_part) FAIL("get_attr: buffer too small"); memcpy(out, v, s->n_part * sizeof(double)); }
+  if (out) { if (cap < s->n_part) FAIL("get_attr: buffer too small"); memcpy(out, v, s->n_part * sizeof(real)); }
   return 0;
 }
-int orc_diag_puddle(orc_particles *s, double out[LCX_OUT_COUNT]) { memcpy(out, s->puddle, sizeof s->puddle); return 0; }
+int orc_diag_puddle(orc_particles *s, dbl out[LCX_OUT_COUNT]) { for (int i = 0; i < LCX_OUT_COUNT; ++i) out[i] = (dbl)s->puddle[i]; return 0; }
 
 /* ---------------- introspection hooks ---------------- */
 int orc_n_part(orc_particles *s, size_t *n) { *n = s->n_part; return 0; }
@@ -2141,9 +2153,9 @@ int orc_get_state_u64(orc_particles *s, const char *name, unsigned long long *ou
   if (out) { if (cap < len) FAIL("buffer too small"); for (sz i = 0; i < len; ++i) out[i] = v[i]; }
   return 0;
 }
-int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t cap, size_t *n)
+int orc_get_state_real(orc_particles *s, const char *name, dbl *out, size_t cap, size_t *n)
 {
-  struct { const char *nm; const double *v; sz len; } tab[] = {
+  struct { const char *nm; const real *v; sz len; } tab[] = {
     {"vt", s->vt, s->n_part}, {"T", s->T, s->n_cell}, {"p", s->p, s->n_cell}, {"RH", s->RH, s->n_cell},
     {"eta", s->eta, s->n_cell}, {"th", s->th, s->n_cell}, {"rv", s->rv, s->n_cell}, {"rhod", s->rhod, s->n_cell},
     {"dv", s->dv, s->n_cell}, {"lambda_D", s->lambda_D, s->n_cell}, {"lambda_K", s->lambda_K, s->n_cell},
@@ -2161,60 +2173,60 @@ int orc_get_state_real(orc_particles *s, const char *name, double *out, size_t c
   for (sz i = 0; i < sizeof tab / sizeof *tab; ++i)
     if (!strcmp(name, tab[i].nm)) {
       *n = tab[i].len;
-      if (out) { if (cap < tab[i].len) FAIL("buffer too small"); memcpy(out, tab[i].v, tab[i].len * sizeof(double)); }
+      if (out) { if (cap < tab[i].len) FAIL("buffer too small"); for (sz k = 0; k < tab[i].len; ++k) out[k] = (dbl)tab[i].v[k]; }
       return 0;
     }
   FAIL("unknown real state '%s'", name);
 }
-int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult, const double *rd3, const double *rw2,
-                      const double *kpa, const double *vt, const double *x, const double *y, const double *z)
+int orc_set_particles(orc_particles *s, size_t n, const unsigned long long *mult, const dbl *rd3, const dbl *rw2,
+                      const dbl *kpa, const dbl *vt, const dbl *x, const dbl *y, const dbl *z)
 {
   if (n > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, n);
   s->n_part = n;
-  memcpy(s->n, mult, n * sizeof(n_t)); memcpy(s->rd3, rd3, n * 8); memcpy(s->rw2, rw2, n * 8);
-  memcpy(s->kpa, kpa, n * 8); memcpy(s->vt, vt, n * 8);
-  if (x) memcpy(s->x, x, n * 8);
-  if (y) memcpy(s->y, y, n * 8);
-  if (z) memcpy(s->z, z, n * 8);
+  memcpy(s->n, mult, n * sizeof(n_t));
+  for (sz p = 0; p < n; ++p) { s->rd3[p] = (real)rd3[p]; s->rw2[p] = (real)rw2[p]; s->kpa[p] = (real)kpa[p]; s->vt[p] = (real)vt[p]; }
+  if (x) for (sz p = 0; p < n; ++p) s->x[p] = (real)x[p];
+  if (y) for (sz p = 0; p < n; ++p) s->y[p] = (real)y[p];
+  if (z) for (sz p = 0; p < n; ++p) s->z[p] = (real)z[p];
   hskpng_ijk(s);
   if (s->use_rc2) { for (sz p = 0; p < n; ++p) s->rc2[p] = -1.; hskpng_approximate_rc2_invalid(s); }
-  if (s->up) { memset(s->up, 0, n * 8); memset(s->vp, 0, n * 8); memset(s->wp, 0, n * 8); }
-  if (s->ssp) { memset(s->ssp, 0, n * 8); memset(s->dot_ssp, 0, n * 8); }
-  if (s->ict) memset(s->ict, 0, n * 8);
-  if (s->tag) for (sz p = 0; p < n; ++p) s->tag[p] = (double)p;
+  if (s->up) { memset(s->up, 0, n * sizeof(real)); memset(s->vp, 0, n * sizeof(real)); memset(s->wp, 0, n * sizeof(real)); }
+  if (s->ssp) { memset(s->ssp, 0, n * sizeof(real)); memset(s->dot_ssp, 0, n * sizeof(real)); }
+  if (s->ict) memset(s->ict, 0, n * sizeof(real));
+  if (s->tag) for (sz p = 0; p < n; ++p) s->tag[p] = (real)p;
   sstp_save(s);
   hskpng_count(s);
   return 0;
 }
 /* preview of the next random arrays WITHOUT advancing the engine: kinds[i] 0 = u01, 1 = un; lens[i] values each;
  * out receives the concatenation.  Used to replay the CPU stream on the device. */
-int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int ncalls, double *out)
+int orc_rng_preview(orc_particles *s, const int *kinds, const size_t *lens, int ncalls, dbl *out)
 {
   mt19937_t g = s->rng;
   normal_state ns = s->rng_ns;
   for (int c = 0; c < ncalls; ++c)
-    for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? rng_u01(&g) : kinds[c] == 1 ? rng_un(&g) : rng_normal(&g, &ns);
+    for (sz i = 0; i < lens[c]; ++i) *out++ = kinds[c] == 0 ? (dbl)rng_u01(&g) : kinds[c] == 1 ? rng_un_dbl(&g) : (dbl)rng_normal(&g, &ns);
   return 0;
 }
 /* test hook of the reverse replay: overwrite ONE particle attribute in place ("rw2": the wet radii after a condensation step, so that
  * the stages behind it are compared from identical inputs); nothing else is touched */
-int orc_set_state_real(orc_particles *s, const char *name, const double *data, size_t n)
+int orc_set_state_real(orc_particles *s, const char *name, const dbl *data, size_t n)
 {
   const int cell = !strcmp(name, "th") || !strcmp(name, "rv");      /* (the cell fields that condensation has just updated) */
   if (n != (cell ? s->n_cell : s->n_part)) FAIL("oracle: set_state_real: %zu values for '%s'", n, name);
-  double *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt :
+  real *dst = !strcmp(name, "rw2") ? s->rw2 : !strcmp(name, "rd3") ? s->rd3 : !strcmp(name, "vt") ? s->vt :
                 !strcmp(name, "th") ? s->th : !strcmp(name, "rv") ? s->rv : !strcmp(name, "tag") ? s->tag : NULL;
   if (!dst) FAIL("oracle: set_state_real: unknown attribute '%s'", name);
-  memcpy(dst, data, n * sizeof(double));
+  for (sz i = 0; i < n; ++i) dst[i] = (real)data[i];
   return 0;
 }
 /* queue a random array for the next consumer of its kind (0: the u01 of a coalescence call, 1: the un of a shuffle), see struct */
-int orc_rng_replay_push(orc_particles *s, int kind, const double *data, size_t n)
+int orc_rng_replay_push(orc_particles *s, int kind, const dbl *data, size_t n)
 {
   if ((s->rq_tail + 1) % 64 == s->rq_head) FAIL("oracle: rng replay queue is full");
   if (kind != 0 && kind != 1) FAIL("oracle: rng replay kind must be 0 (u01) or 1 (un)");
-  double *v = NEW(double, n);
-  memcpy(v, data, n * sizeof(double));
+  dbl *v = NEW(dbl, n);
+  memcpy(v, data, n * sizeof(dbl));
   s->rq[s->rq_tail].kind = kind; s->rq[s->rq_tail].v = v; s->rq[s->rq_tail].n = n;
   s->rq_tail = (s->rq_tail + 1) % 64;
   return 0;
@@ -2242,7 +2254,7 @@ int orc_stage(orc_particles *s, const char *st, const lcx_opts_t *opts)
 /* ---------------- 1-D decomposition helpers (pack.ipp:14-133, unpack.ipp:14-143) ---------------- */
 int orc_migrate_counts(orc_particles *s, size_t *l, size_t *r) { *l = s->lft_count; *r = s->rgt_count; return 0; }
 /* attributes that travel with a super-droplet: distmem_real_vctrs, particles_impl.ipp:440-491 */
-static int mig_attrs(orc_particles *s, double **a)
+static int mig_attrs(orc_particles *s, real **a)
 {
   int k = 0;
   a[k++] = s->rd3; a[k++] = s->rw2; a[k++] = s->kpa; a[k++] = s->vt;
@@ -2257,16 +2269,16 @@ static int mig_attrs(orc_particles *s, double **a)
   if (s->tag) a[k++] = s->tag;
   return k;
 }
-size_t orc_migrate_record_bytes(orc_particles *s) { double *a[24]; return 8 + 8 * (size_t)mig_attrs(s, a); }
-int orc_migrate_pack(orc_particles *s, int side, double x_rmt, void *buf, size_t cap_bytes)
+size_t orc_migrate_record_bytes(orc_particles *s) { real *a[24]; return sizeof(n_t) + sizeof(real) * (size_t)mig_attrs(s, a); }
+int orc_migrate_pack(orc_particles *s, int side, dbl x_rmt, void *buf, size_t cap_bytes)
 {
   const sz cnt = side == 0 ? s->lft_count : s->rgt_count;
   const sz *id = side == 0 ? s->lft_id : s->rgt_id;
   if (cap_bytes < cnt * orc_migrate_record_bytes(s)) FAIL("migrate_pack: buffer too small");
-  const double x_lcl = side == 0 ? s->o.x0 : s->o.x1;
+  const real x_lcl = side == 0 ? s->o.x0 : s->o.x1;
   for (sz i = 0; i < cnt; ++i) s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;   /* detail::remote, pack.ipp:14-26 */
-  n_t *nb = (n_t *)buf; double *rb = (double *)buf + cnt;
-  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  n_t *nb = (n_t *)buf; real *rb = (real *)(nb + cnt);
+  real *attrs[24]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) nb[i] = s->n[id[i]];
   for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) rb[(sz)a * cnt + i] = attrs[a][id[i]];
   return 0;
@@ -2276,12 +2288,12 @@ int orc_migrate_unpack(orc_particles *s, const void *buf, size_t cnt)
   if (cnt == 0) return 0;
   const sz old = s->n_part;
   if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
-  const n_t *nb = (const n_t *)buf; const double *rb = (const double *)buf + cnt;
-  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  const n_t *nb = (const n_t *)buf; const real *rb = (const real *)(nb + cnt);
+  real *attrs[24]; const int na = mig_attrs(s, attrs);
   for (sz i = 0; i < cnt; ++i) s->n[old + i] = nb[i];
   for (int a = 0; a < na; ++a) for (sz i = 0; i < cnt; ++i) attrs[a][old + i] = rb[(sz)a * cnt + i];
-  const double tol = 5e-4;                          /* config.hpp:31, tolerance_away_from_bcond */
-  for (sz i = old; i < old + cnt; ++i) { const double x = s->x[i]; s->x[i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x; }
+  const real tol = 5e-4;                          /* config.hpp:31, tolerance_away_from_bcond */
+  for (sz i = old; i < old + cnt; ++i) { const real x = s->x[i]; s->x[i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x; }
   s->n_part = old + cnt;
   return 0;
 }
@@ -2301,7 +2313,7 @@ int orc_migrate_finish(orc_particles *s, const lcx_opts_t *opts)
  * reference's attribute-major buffers it replaces). */
 #define XHDR 256
 #define XTILE 256
-static size_t x_rec_bytes(orc_particles *s) { double *a[24]; return 8 + 8 * (size_t)mig_attrs(s, a); }
+static size_t x_rec_bytes(orc_particles *s) { real *a[24]; return sizeof(n_t) + sizeof(real) * (size_t)mig_attrs(s, a); }
 static size_t x_msg_bytes(orc_particles *s, size_t n_rec) { return XHDR + ((n_rec + XTILE - 1) / XTILE) * XTILE * x_rec_bytes(s); }
 int orc_exch_enable(orc_particles *s, int nx_min, size_t *cap_rec)
 {
@@ -2314,23 +2326,23 @@ int orc_exch_enable(orc_particles *s, int nx_min, size_t *cap_rec)
 }
 int orc_exch_buffers(orc_particles *s, void *ptrs[4]) { for (int k = 0; k < 4; ++k) ptrs[k] = s->xbox[k]; return 0; }
 size_t orc_exch_message_bytes(orc_particles *s, size_t n_rec) { return x_msg_bytes(s, n_rec); }
-static void x_pack_side(orc_particles *s, unsigned char *msg, const sz *id, sz cnt, double x_rmt, double x_lcl, unsigned next_cap)
+static void x_pack_side(orc_particles *s, unsigned char *msg, const sz *id, sz cnt, real x_rmt, real x_lcl, unsigned next_cap)
 {
   unsigned *h = (unsigned *)msg;
   h[0] = (unsigned)cnt; h[1] = cnt > s->xcap; h[2] = next_cap;
   if (cnt > s->xcap) return;
-  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  real *attrs[24]; const int na = mig_attrs(s, attrs);
   const size_t tile_bytes = XTILE * x_rec_bytes(s);
   for (sz i = 0; i < cnt; ++i) {
     s->x[id[i]] = x_rmt + s->x[id[i]] - x_lcl;                       /* detail::remote, pack.ipp:14-26 */
     unsigned char *t = msg + XHDR + (i / XTILE) * tile_bytes;
     const sz j = i % XTILE;
     ((n_t *)t)[j] = s->n[id[i]];
-    for (int a = 0; a < na; ++a) ((double *)(t + XTILE * 8))[(sz)a * XTILE + j] = attrs[a][id[i]];
+    for (int a = 0; a < na; ++a) ((real *)(t + XTILE * sizeof(n_t)))[(sz)a * XTILE + j] = attrs[a][id[i]];
     s->n[id[i]] = 0;                                                   /* flag_lft / flag_rgt, unpack.ipp:118-141 */
   }
 }
-int orc_exch_pack(orc_particles *s, int has_lft, double lft_x1, int has_rgt, double rgt_x0, unsigned next_lft, unsigned next_rgt)
+int orc_exch_pack(orc_particles *s, int has_lft, dbl lft_x1, int has_rgt, dbl rgt_x0, unsigned next_lft, unsigned next_rgt)
 {
   if (has_lft) x_pack_side(s, s->xbox[0], s->lft_id, s->lft_count, lft_x1, s->o.x0, next_lft);
   if (has_rgt) x_pack_side(s, s->xbox[1], s->rgt_id, s->rgt_count, rgt_x0, s->o.x1, next_rgt);
@@ -2341,15 +2353,15 @@ static int x_unpack_side(orc_particles *s, const unsigned char *msg)
   const unsigned *h = (const unsigned *)msg;
   const sz cnt = h[1] ? 0 : h[0], old = s->n_part;
   if (old + cnt > s->cap) FAIL("n_sd_max (%llu) < n_part (%zu)", s->o.n_sd_max, old + cnt);
-  double *attrs[24]; const int na = mig_attrs(s, attrs);
+  real *attrs[24]; const int na = mig_attrs(s, attrs);
   const size_t tile_bytes = XTILE * x_rec_bytes(s);
-  const double tol = 5e-4;                                             /* config.hpp:31, tolerance_away_from_bcond */
+  const real tol = 5e-4;                                             /* config.hpp:31, tolerance_away_from_bcond */
   for (sz i = 0; i < cnt; ++i) {
     const unsigned char *t = msg + XHDR + (i / XTILE) * tile_bytes;
     const sz j = i % XTILE;
     s->n[old + i] = ((const n_t *)t)[j];
-    for (int a = 0; a < na; ++a) attrs[a][old + i] = ((const double *)(t + XTILE * 8))[(sz)a * XTILE + j];
-    const double x = s->x[old + i];
+    for (int a = 0; a < na; ++a) attrs[a][old + i] = ((const real *)(t + XTILE * sizeof(n_t)))[(sz)a * XTILE + j];
+    const real x = s->x[old + i];
     s->x[old + i] = x >= s->o.x1 ? x - tol : x < s->o.x0 ? x + tol : x;
   }
   s->n_part = old + cnt;
@@ -2381,7 +2393,7 @@ int orc_stream(orc_particles *s, void **stream) { (void)s; *stream = NULL; retur
 
 /* ---------------- Courant halo exchange of pred_corr (xchng_courants.ipp:15-160) ---------------- */
 /* element ranges inside the halo-extended arrays: [send to left, send to right, recv from left, recv from right] */
-static sz courant_halo_geom(orc_particles *s, int which, double **arr, sz off[4])
+static sz courant_halo_geom(orc_particles *s, int which, real **arr, sz off[4])
 {
   const lcx_opts_init_t *o = &s->o;
   if (!s->halo || s->n_dims == 0) return 0;
@@ -2396,25 +2408,34 @@ static sz courant_halo_geom(orc_particles *s, int which, double **arr, sz off[4]
   off[2] = 0; off[3] = n - cnt;
   return cnt;
 }
-size_t orc_courant_halo_count(orc_particles *s, int which) { double *a; sz off[4]; return courant_halo_geom(s, which, &a, off); }
+size_t orc_courant_halo_count(orc_particles *s, int which) { real *a; sz off[4]; return courant_halo_geom(s, which, &a, off); }
 int orc_courant_halo_pack(orc_particles *s, int which, int side, void *buf)
 {
-  double *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
-  if (cnt) memcpy(buf, a + off[side], cnt * sizeof(double));
+  real *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
+  if (cnt) memcpy(buf, a + off[side], cnt * sizeof(real));
   return 0;
 }
 int orc_courant_halo_unpack(orc_particles *s, int which, int side, const void *buf)
 {
-  double *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
-  if (cnt) memcpy(a + off[2 + side], buf, cnt * sizeof(double));
+  real *a; sz off[4]; const sz cnt = courant_halo_geom(s, which, &a, off);
+  if (cnt) memcpy(a + off[2 + side], buf, cnt * sizeof(real));
   return 0;
 }
 
 /* libcloudphxx.common of the reference's Python module (bindings/python/common.hpp:19-172, lib.cpp:55-66,129-144), scalar */
-int orc_common_eval(const char *name, const double *a, int n, double *out)
+static int orc_common_eval_real(const char *name, const real *a, int n, real *out);
+int orc_common_eval(const char *name, const dbl *a_, int n, dbl *out_)
+{
+  real a[16], out_v = 0, *out = &out_v;
+  for (int i = 0; i < n && i < 16; ++i) a[i] = (real)a_[i];
+  const int rc_ = orc_common_eval_real(name, a, n, out);
+  *out_ = (dbl)out_v;
+  return rc_;
+}
+static int orc_common_eval_real(const char *name, const real *a, int n, real *out)
 {
 #define IS(nm) (!strcmp(name, nm))
-  const double kap = R_d / c_pd;
+  const real kap = R_d / c_pd;
   if (IS("th_dry2std") && n == 2) *out = a[0] / pow(1 + a[1] * R_v / R_d, kap);                   /* theta_dry.hpp:101-113 */
   else if (IS("th_std2dry") && n == 2) *out = a[0] * pow(1 + a[1] * R_v / R_d, kap);              /* theta_dry.hpp:86-99 */
   else if (IS("exner") && n == 1) *out = theta_std_exner(a[0]);
@@ -2429,7 +2450,7 @@ int orc_common_eval(const char *name, const double *a, int n, double *out)
   else if (IS("rw3_cr") && n == 3) *out = rw3_cr(a[0], a[1], a[2]);
   else if (IS("S_cr") && n == 3) *out = S_cr(a[0], a[1], a[2]);
   else if (IS("p_hydro") && n == 5) {                                                             /* hydrostatic.hpp:24-38 */
-    const double R_moist = (R_d + a[2] * R_v) / (1 + a[2]);                                       /* moist_air.hpp:54-70 */
+    const real R_moist = (R_d + a[2] * R_v) / (1 + a[2]);                                       /* moist_air.hpp:54-70 */
     *out = p_1000 * pow(pow(a[4] / p_1000, kap) - kap * g_earth / a[1] / R_moist * (a[0] - a[3]), c_pd / R_d);
   }
   else if (IS("rhod") && n == 3) *out = (a[0] - p_v(a[0], a[2])) / (pow(a[0] / p_1000, kap) * R_d * a[1]);   /* theta_std.hpp:23-32 */

@@ -54,7 +54,8 @@ def oracle_lib():
         srcs = [os.path.join(ORACLE_DIR, f) for f in ("lcx_oracle.c", "orc_physics.h", "orc_tables.h")]
         fm = os.path.join(ORACLE_DIR, "liblcx_oracle_fastmath.so")
         omp = os.path.join(ORACLE_DIR, "liblcx_oracle_omp.so")
-        if (not os.path.exists(ORACLE_SO)) or (not os.path.exists(fm)) or (not os.path.exists(omp)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
+        f32 = os.path.join(ORACLE_DIR, "liblcx_oracle_f32.so")
+        if (not os.path.exists(ORACLE_SO)) or (not os.path.exists(fm)) or (not os.path.exists(omp)) or (not os.path.exists(f32)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
         os.environ.setdefault("LCX_DATA_DIR", os.path.join(ROOT, "libcloudphxx_amd", "data"))
         _oracle = ctypes.CDLL(ORACLE_SO)
@@ -110,6 +111,22 @@ def oracle_omp_lib():
         _oracle_omp.orc_num_threads.restype = ctypes.c_int
         _oracle_omp.orc_set_num_threads(ctypes.c_int(min(cpu_quota(), int(_oracle_omp.orc_num_threads()))))
     return _oracle_omp
+
+
+_oracle_f32 = None
+
+
+def oracle_f32_lib():
+    """the oracle's float flavour (oracle/Makefile: the same source with real = float)"""
+    global _oracle_f32
+    if _oracle_f32 is None:
+        oracle_lib()
+        _oracle_f32 = ctypes.CDLL(os.path.join(ORACLE_DIR, "liblcx_oracle_f32.so"))
+    return _oracle_f32
+
+
+def oracle_f32_particles(opts_init):
+    return lgrngn.particles_t(opts_init, np.float32, lib=oracle_f32_lib(), prefix="orc_")
 
 
 def oracle_omp_particles(opts_init):

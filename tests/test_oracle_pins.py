@@ -437,3 +437,46 @@ def test_icicle_t0_initial_spectra_oracle():
     pr = oracle_particles(oi)
     pr.init(th, rv, rhod)
     check_icicle_t0(icicle_t0_diagnose(pr, d), d)
+
+
+# ---- the oracle's float flavour (round 5; oracle/Makefile: the same source with real = float, <tgmath.h>, float literals)
+def test_icicle_t0_initial_spectra_oracle_float_flavour():
+    """the reference's t = 0 output came from ITS float build (fig_a/calc.cpp:36-39): the float flavour of the oracle is held to the same
+    statistics as the double one (five sampling standard deviations of 2.3e5 super-droplets, no common factor)"""
+    import _harness as h
+    oi, th, rv, rhod, d = icicle_t0_setup()
+    pr = h.oracle_f32_particles(oi)
+    pr.init(th.astype(np.float32), rv.astype(np.float32), rhod.astype(np.float32))
+    check_icicle_t0(icicle_t0_diagnose(pr, d), d)
+
+
+def test_float_flavour_of_the_oracle_tracks_the_double_one():
+    """the two flavours on one small box, three full steps each on its own (the double engine's draws serve both: one random stream):
+    the same cells throughout, th / rv / wet radii as far apart as 24-bit arithmetic and a root finder at float's tolerance 2^-7 put them"""
+    import _harness as h
+    from libcloudphxx_amd import lgrngn
+    oi = h.box_opts(4, 3, 5, 32)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = {}
+    for nm, mk, dt in (("f64", h.oracle_particles, np.float64), ("f32", h.oracle_f32_particles, np.float32)):
+        pr = mk(oi)
+        f = [a.astype(dt) for a in (th, rv, rhod)]
+        Cs = {k: v.astype(dt) for k, v in C.items()}
+        pr.init(f[0], f[1], f[2], **Cs)
+        assert pr.get_attr("rw2").dtype == dt
+        opts = lgrngn.opts_t()
+        opts.coal = False                    # (multiplicities differ by one here and there: rounded from float products)
+        for _ in range(3):
+            pr.step_sync(opts, f[0], f[1], f[2], **Cs)
+            pr.step_async(opts)
+        res[nm] = (f[0].astype(np.float64), f[1].astype(np.float64), pr.state_real("rw2"), pr.state_u64("ijk"), pr.state_real("x"))
+    a, b = res["f64"], res["f32"]
+    assert a[2].size == b[2].size
+    assert (a[3] != b[3]).mean() < 2e-3                   # (a droplet within 1e-7 of a cell face)
+    np.testing.assert_allclose(b[0], a[0], rtol=2e-5)
+    np.testing.assert_allclose(b[1], a[1], rtol=3e-4)
+    err = np.abs(b[2] / a[2] - 1)
+    assert np.median(err) < 2e-3 and err.max() < 0.1, (np.median(err), err.max())
+    np.testing.assert_allclose(b[4], a[4], rtol=0, atol=1e-3)
+    with pytest.raises(RuntimeError, match="real_t of 4 bytes"):
+        lgrngn.particles_t(oi, np.float64, lib=h.oracle_f32_lib(), prefix="orc_")
