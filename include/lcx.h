@@ -155,7 +155,8 @@ enum lcx_dbg {
   LCX_DBG_EAGER_COMPACT = 1 << 2,      /* compact dead super-droplets away in every step (the reference's remove_n0) */
   LCX_DBG_SHUFFLE_PHILOX = 1 << 3,     /* shuffle keys drawn from Philox, ranked on 64 bits (round 2's form) */
   LCX_DBG_NO_DEFERRED_SORT = 1 << 4,   /* the end-of-step re-sort finished at once instead of riding on the next condensation kernel */
-  LCX_DBG_COND_NO_FOLD = 1 << 5,       /* cond_solver = 1 with LCX_DBG_COND_TOMS_TWO_PASS: k_cond_fast instead of k_cond_fast_fold */
+  LCX_DBG_COND_NO_FOLD = 1 << 5,       /* cond_solver = 1: the plain storage-order kernel instead of the one folded behind TOMS748's head (k_cond_lean_fold<.., 2>,
+                                          the same bits); with LCX_DBG_COND_TOMS_TWO_PASS: k_cond_fast instead of k_cond_fast_fold */
   LCX_DBG_COND_SORTED_ORDER = 1 << 6,  /* k_cond_lean over the sorted order (gathers) instead of the storage order */
   LCX_DBG_NO_OVERLAP = 1 << 7,         /* exchange: no re-sort of the interior while the messages travel */
   LCX_DBG_MULTI_NO_PEER = 1 << 8,      /* multi-device object: treat the devices as unable to map each other's memory (staged copies) */

@@ -1150,7 +1150,11 @@ struct Particles : IParticles {
           if (carry_scatter) { a.sc_rank = rnk(); a.sc_cell_start = cell_start.p; a.sc_sorted_id = sid(); a.sc_sorted_ijk = sijk(); }
           // (one hygroscopicity in the whole run: a scalar instead of 8 B per droplet, see kpa_uniform)
           const dim3 gs(nblk(nphys));
-          if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
+          // (cond_solver = 1: the workgroup folded behind TOMS748's head -- this kernel is bound by instruction issue at half-empty
+          // waves, unlike the lean solver's; LCX_DBG_COND_NO_FOLD: the plain kernel, the same bits)
+          if (cond_toms && !dbg(LCX_DBG_COND_NO_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
+          else if (cond_toms && !dbg(LCX_DBG_COND_NO_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false, 2>), gs, bl, 0, st, nphys, a, T(0));
+          else if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gs, bl, 0, st, nphys, a, T(0));
           else if (dbg(LCX_DBG_COND_LEAN_R3)) hipLaunchKernelGGL((k_cond_lean<T, 11, false, 1>), gs, bl, 0, st, nphys, a, T(0));
           // (round 5, measured and kept behind a switch: the workgroup folded behind the solver's first loop trip -- the same bits, 6 % fewer

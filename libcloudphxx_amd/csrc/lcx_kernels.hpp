@@ -1283,11 +1283,18 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
 // launch costs: the package sits at 1.31 kW of its 1.40 kW cap through the whole step and the shader clock at 2.19 GHz instead of 2.40
 // (profiles/r05*_power.txt) -- the launch is priced in lanes that compute (energy), not in instructions that issue.  Storage order only.
 constexpr int FOLD_CAP = 128;
-template <class T, bool UNI>
+// SOLVER = 2 (round 5): the same fold for TOMS748 (opts_init.cond_solver = 1, the API default) -- behind the root finder's HEAD (the far
+// end, the secant and the first quadratic step: four evaluations that every droplet makes), where the 37 % of the droplets whose
+// bracket is not yet inside the tolerance enter its main loop: toms_carry + the clamp + the droplet's constants, 14 reals + 4 words.
+// Unlike the lean solver's, THIS kernel is bound by instruction issue, not by power (vector ALU 0.94 busy at a lane use of 0.50,
+// profiles/r05b_pmc_toms.txt: half of the lanes it issues for are idle, and idle lanes draw no power), so emptying three of four waves
+// ahead of the loop is time: see DESIGN.md section 4.  The same operations per droplet, the same bits as k_cond_lean<T, 15, UNI, 2>.
+template <class T, bool UNI, int SOLVER = 0>
 __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
 {
-  __shared__ T xs[13][FOLD_CAP];
-  __shared__ uint32_t xw[3][FOLD_CAP];
+  constexpr bool TOMS = SOLVER == 2;
+  __shared__ T xs[TOMS ? 14 : 13][FOLD_CAP];
+  __shared__ uint32_t xw[TOMS ? 4 : 3][FOLD_CAP];
   __shared__ uint32_t wcnt[BS / WAVE];
   const size_t pos = gid_xcd(a.xcd_group);
   bool live = pos < n_part;
@@ -1295,6 +1302,8 @@ __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<
   T rw2_old = 0, nn = 0, r = 0, rd2 = 0;
   cond_fun_fast<T, 15> ff;
   lean_state<T> s;
+  toms_carry<T> k;
+  k.count = a.n_iter;
   bool need = false;
   if (live) {
     // (the two load levels of k_cond_lean, see there)
@@ -1321,7 +1330,8 @@ __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<
       T delta = 0;
       if (!(rw2_old <= 0)) {
         ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
-        if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2)) {
+        if constexpr (TOMS) need = !advance_rw2_head_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, k, r, &rd2);
+        else if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2)) {
           need = !lean2_loop(ff, a.eps, 1u, s, r);
           if (!need) r = lean2_tail(s, r, rd2);
         }
@@ -1346,7 +1356,13 @@ __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<
   const bool moved = need && slot < cap;
   if (moved) {
     xw[0][slot] = id; xw[1][slot] = c; xw[2][slot] = m3_pos;
-    xs[0][slot] = s.x0; xs[1][slot] = s.f0; xs[2][slot] = s.x1; xs[3][slot] = s.f1; xs[4][slot] = s.c; xs[5][slot] = s.a; xs[6][slot] = s.b;
+    if constexpr (TOMS) {
+      xw[3][slot] = k.count;
+      xs[0][slot] = k.s.a; xs[1][slot] = k.s.b; xs[2][slot] = k.s.fa; xs[3][slot] = k.s.fb; xs[4][slot] = k.s.d; xs[5][slot] = k.s.fd;
+      xs[6][slot] = k.e; xs[13][slot] = k.fe;
+    } else {
+      xs[0][slot] = s.x0; xs[1][slot] = s.f0; xs[2][slot] = s.x1; xs[3][slot] = s.f1; xs[4][slot] = s.c; xs[5][slot] = s.a; xs[6][slot] = s.b;
+    }
     xs[7][slot] = rd2; xs[8][slot] = rw2_old; xs[9][slot] = ff.rd3; xs[10][slot] = ff.rd3_1mk; xs[11][slot] = ff.c_Re; xs[12][slot] = nn;
   }
   __syncthreads();
@@ -1354,11 +1370,17 @@ __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<
   const uint32_t t = threadIdx.x;
   if (t < (total < cap ? total : cap)) {
     id = xw[0][t]; c = xw[1][t]; m3_pos = xw[2][t];
-    s.x0 = xs[0][t]; s.f0 = xs[1][t]; s.x1 = xs[2][t]; s.f1 = xs[3][t]; s.c = xs[4][t]; s.a = xs[5][t]; s.b = xs[6][t];
+    if constexpr (TOMS) {
+      k.count = xw[3][t];
+      k.s.a = xs[0][t]; k.s.b = xs[1][t]; k.s.fa = xs[2][t]; k.s.fb = xs[3][t]; k.s.d = xs[4][t]; k.s.fd = xs[5][t];
+      k.e = xs[6][t]; k.fe = xs[13][t];
+    } else {
+      s.x0 = xs[0][t]; s.f0 = xs[1][t]; s.x1 = xs[2][t]; s.f1 = xs[3][t]; s.c = xs[4][t]; s.a = xs[5][t]; s.b = xs[6][t];
+    }
     rd2 = xs[7][t]; rw2_old = xs[8][t]; nn = xs[12][t];
     // (the droplet's own products arrive as they were formed: the same bits as setup_cell's)
     ff.rd3 = xs[9][t]; ff.rd3_1mk = xs[10][t]; ff.c_Re = xs[11][t];
-    r = s.c;
+    if constexpr (!TOMS) r = s.c;
     run = true;
   }
   if (!run) return;
@@ -1372,8 +1394,11 @@ __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<
     if constexpr (decltype(ff)::trim) { ff.Sc = ff.c_Re * cc.Sc; ff.Pr = ff.c_Re * cc.Pr; }      // (setup_cell's products, see cond_fun_fast)
   }
   if (!run) return;
-  lean2_loop(ff, a.eps, a.n_iter - 1u, s, r);
-  r = lean2_tail(s, r, rd2);
+  if constexpr (TOMS) r = advance_rw2_tail_with(ff, ff.rd3, a.eps, k, (unsigned *)nullptr, &rd2);
+  else {
+    lean2_loop(ff, a.eps, a.n_iter - 1u, s, r);
+    r = lean2_tail(s, r, rd2);
+  }
   a.rw2[id] = r;
   a.m3_after[m3_pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
 }

@@ -851,8 +851,11 @@ def test_toms748_in_the_storage_order_kernel_gives_round_2s_bits():
     oi = h.box_opts(16, 8, 8, 64, strict_fp=False, cond_solver=1)       # (one substep: the second would start from the first one's rounding)
     fields = h.box_fields(oi)
     res = []
-    for two_pass in (False, True):
-        oi.dbg_flags = int(lgrngn.dbg.COND_TOMS_TWO_PASS) if two_pass else 0
+    # round 5: the default is the kernel FOLDED behind TOMS748's head (k_cond_lean_fold<.., SOLVER = 2>); COND_NO_FOLD the plain
+    # storage-order kernel; a stage of 8 slots (dbg_cond_budget) leaves most of the droplets that enter the loop in their own lanes
+    for flags, budget in ((0, 0), (int(lgrngn.dbg.COND_TOMS_TWO_PASS), 0), (int(lgrngn.dbg.COND_NO_FOLD), 0), (0, 8), (int(lgrngn.dbg.KPA_ARRAY), 0)):
+        oi.dbg_flags = flags
+        oi.dbg_cond_budget = budget
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -867,6 +870,9 @@ def test_toms748_in_the_storage_order_kernel_gives_round_2s_bits():
     assert np.array_equal(res[0][0], res[1][0])
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-13)
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=1e-11)
+    for k in (2, 3, 4):                          # the storage-order kernel's forms among themselves: every bit
+        for a_, b_ in zip(res[0], res[k]):
+            assert np.array_equal(a_, b_), k
     assert np.abs(res[0][2] - rv).max() > 0
 
 
