@@ -719,6 +719,9 @@ __device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10.
 // finder resolves to 3e-5); 2 dt folded into one factor of the root finder's function; and the Reynolds number's 2 rhod / eta taken per
 // cell (one product per droplet instead of an IEEE division).
 // The launch is priced in lanes that compute (the package power cap, see k_cond_lean_fold): every fp64 operation less is time.
+// (Measured and dropped once more, round 5: the Kelvin exponential without its range reduction for A / r_w < 0.34 -- six instructions
+// that are the identity for every droplet above 3 nm -- with exp_kelvin as the fallback of the lanes outside: inlined, 78 -> 100 vector
+// registers; as an out-of-line call 82, five waves per SIMD and the call's register traffic: 3.16 ms against 2.77 on one box.)
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
   static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
   static constexpr bool trim = (OPT & 8) != 0 && sizeof(T) == 8;
