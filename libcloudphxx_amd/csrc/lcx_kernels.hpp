@@ -1289,6 +1289,8 @@ constexpr int FOLD_CAP = 128;
 // Unlike the lean solver's, THIS kernel is bound by instruction issue, not by power (vector ALU 0.94 busy at a lane use of 0.50,
 // profiles/r05b_pmc_toms.txt: half of the lanes it issues for are idle, and idle lanes draw no power), so emptying three of four waves
 // ahead of the loop is time: see DESIGN.md section 4.  The same operations per droplet, the same bits as k_cond_lean<T, 15, UNI, 2>.
+// (Measured and dropped: workgroups of 512 threads, so that the 190 droplets that enter the loop fill three dense waves of eight instead
+// of 2 x (64 + 31): 6.5 ms against 5.45 -- eight waves meeting at the fold's barriers cost more than the emptier waves did.)
 template <class T, bool UNI, int SOLVER = 0>
 __global__ void __launch_bounds__(BS) k_cond_lean_fold(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
 {
