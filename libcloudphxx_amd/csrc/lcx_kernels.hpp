@@ -2129,7 +2129,12 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // kernel (hall*, vohl*), random numbers from Philox, no per-particle rc2 / in-cloud time, used-up super-droplets marked in ijk
 // (Measured and dropped, round 3: the terminal velocities of hskpng_vterm_all computed HERE by the lane that owns the pair, from the wet
 // radii it has gathered anyway, and stored -- instead of the separate streaming pass (28 B per SD, 0.81 ms on C3).  Same values, but
-// k_coal 1.55 -> 2.56 ms and k_move +0.1: the scattered 8-byte stores of vt and the logarithm per droplet cost more than the pass.)
+// k_coal 1.55 -> 2.56 ms and k_move +0.1: the scattered 8-byte stores of vt and the logarithm per droplet cost more than the pass.
+// Round 5, once more without the scattered stores: k_coal evaluating the pair's velocities WITHOUT storing them (the droplet that grew
+// marked by a bit of ijk instead of the invalid flag) and k_move evaluating, storing and using every droplet's -- the same bits in every
+// attribute, no separate pass in the stretch where the in-cell ranking waits for the memory system; k_coal 1.44 -> 1.67 ms, k_move
+// 1.90 -> 2.53 (the table look-up and the logarithm per droplet in a pass that was bound by memory), the pass itself 0.66: the step
+// 8.11 -> 8.41 ms.  The pass stays.)
 template <class T, bool ONISHI, bool TAB = false>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
