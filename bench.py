@@ -548,7 +548,7 @@ def main():
                 import glob
                 for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1:]:
                     tj = json.load(open(tf))
-                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_lean") and "<double" in k_]
+                    both = [v for k_, v in tj.items() if k_.startswith("lcx::k_cond_lean<double")]
                     t = {k_: sum(v.get(k_, 0) for v in both) for k_ in set().union(*both) if isinstance(both[0].get(k_, 0), (int, float))} if both else None
                     if t:
                         src = "profiles/" + os.path.basename(tf)
