@@ -31,9 +31,10 @@ def test_hip_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
-def test_oracle_exports_the_same_surface():
-    from _harness import oracle_lib
-    lib = oracle_lib()
+@pytest.mark.parametrize("flavour", ["double", "float"])
+def test_oracle_exports_the_same_surface(flavour):
+    from _harness import oracle_lib, oracle_f32_lib
+    lib = oracle_lib() if flavour == "double" else oracle_f32_lib()       # (round 5: the same source with real = float)
     # the oracle mirrors the ABI (prefix orc_) for everything the tests drive through the shared harness
     skip = {"lcx_dev_alloc", "lcx_dev_free", "lcx_dev_copy", "lcx_dev_sync", "lcx_timings", "lcx_set_profiling",
             "lcx_rng_dump", "lcx_math_probe",                      # (lcx_rng_dump: the device generator's stream; the oracle CONSUMES it, orc_rng_replay_push)
