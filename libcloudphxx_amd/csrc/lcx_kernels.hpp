@@ -2134,7 +2134,12 @@ template <class T> struct u01_src { const T *arr; uint64_t call, seed; };
 // marked by a bit of ijk instead of the invalid flag) and k_move evaluating, storing and using every droplet's -- the same bits in every
 // attribute, no separate pass in the stretch where the in-cell ranking waits for the memory system; k_coal 1.44 -> 1.67 ms, k_move
 // 1.90 -> 2.53 (the table look-up and the logarithm per droplet in a pass that was bound by memory), the pass itself 0.66: the step
-// 8.11 -> 8.41 ms.  The pass stays.)
+// 8.11 -> 8.41 ms.  The pass stays.
+// Also round 5, for crowded cells (C5, 512 per cell, where a pair's members lie anywhere in 4 KB per attribute and this kernel takes
+// 14.7 ps per droplet against 10.4 at 64 per cell): one workgroup per cell, the cell's multiplicities, wet radii and velocities
+// gathered ONCE into LDS (24 B per droplet) and the pairs served from there -- the same droplets bit for bit, and 16.1 ms against
+// 14.2 on C5: the L1 already spares the L2 most of the repeated lines, and 2.1e6 workgroups that each wait at a barrier behind their
+// gathers are slower than the walk's independent lanes.)
 template <class T, bool ONISHI, bool TAB = false>
 __global__ void __launch_bounds__(BS)
 k_coal(size_t n_part, const uint32_t *sorted_id, const uint32_t *sorted_ijk, const uint32_t *cell_start,
