@@ -256,6 +256,40 @@ def test_cond_step_with_invalid_terminal_velocities(mode):
     np.testing.assert_allclose(rvh, rvo, rtol=1e-6 if mode == "strict" else 3e-6 if mode == "toms" else 2e-4)
 
 
+@pytest.mark.parametrize("mode", ARITH)
+def test_cond_step_with_near_dry_particles(mode):
+    """Particles of almost no hygroscopicity (kappa = 1e-10, the set-up of the reference's coalescence tests and of bench.py's coal-stress
+    leg) a relative 1e-9 ... 1e-3 above their dry radius: in subsaturated cells the bracket's lower end is clamped by the dry radius and
+    often already inside the root finder's tolerance -- the reference evaluates f at the dry radius (zero water activity: the particle
+    would grow there), sees the sign change and returns the bracket's midpoint (toms748.hpp:305-313); the lean solver answers that
+    midpoint without the evaluation since round 5 (lcx_math.hpp lean2_head).  In supersaturated cells the same particles take the
+    explicit-Euler jump of a bracket without a sign change.  All arithmetic modes against the oracle, two steps"""
+    kw, strict_fp = _arith(mode)
+    oi = h.box_opts(4, 4, 6, 64, sstp_cond=1, **kw)
+    fields = h.box_fields(oi)
+    orc, hip = h.make_pair(oi, fields)
+    g = orc.state_real
+    rd3 = g("rd3")
+    rng = np.random.default_rng(11)
+    rw2 = np.cbrt(rd3) ** 2 * (1. + 10. ** rng.uniform(-9, -3, size=rd3.shape))
+    rw2[::16] = np.cbrt(rd3[::16]) ** 2                           # (and some exactly on it)
+    args = (orc.state_u64("n"), rd3, rw2, np.full_like(rd3, 1e-10), g("vt"), g("x"), g("y"), g("z"))
+    orc.set_particles(*args)
+    hip.set_particles(*args)
+    opts = lgrngn.opts_t()
+    opts.coal = opts.adve = opts.sedi = False
+    for it in range(2):
+        (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        ro, rh = orc.get_attr("rw2"), hip.get_attr("rw2")
+        np.testing.assert_allclose(rh, ro, rtol=1e-4)
+        if it == 0:
+            stay = np.abs(ro / rw2 - 1.) < 2. ** -15
+            assert .02 < stay.mean() < .95, stay.mean()            # both kinds of cell are in the box (most of it is supersaturated)
+        np.testing.assert_allclose(thh, tho, rtol=2e-6)
+        np.testing.assert_allclose(rvh, rvo, rtol=2e-4)
+        h.copy_state(orc, hip)
+
+
 @pytest.mark.parametrize("strict_fp", [True, False])
 @pytest.mark.parametrize("mode", ["nomix", "mix", "adaptive", "adaptive_act"])
 def test_perparticle_cond_step(mode, strict_fp):

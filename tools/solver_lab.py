@@ -160,8 +160,9 @@ def check_derivative():
     print("derivative check: median rel diff %.2e, 99%% %.2e, max %.2e" % (np.median(rel), np.percentile(rel, 99), rel.max()))
 
 
-def solve_lean2():
-    """the product's round-4 solver (lcx_math.hpp advance_rw2_lean2_with)"""
+def solve_lean2(guard=False):
+    """the product's round-4 solver (lcx_math.hpp advance_rw2_lean2_with); guard: round 5's stopping rule (the iterate's convergence
+    believed only while |f| falls to at most half of the previous value on its side)"""
     fn = Fun()
     r = rw2_old.copy()
     all_i = np.nonzero(rw2_old > 0)[0]
@@ -191,6 +192,7 @@ def solve_lean2():
         k = np.nonzero(act)[0]
         fc = fn.f(idx[k], c[k])
         opp = (fc < 0) != (f1[k] < 0)
+        fs = np.where(opp, f0[k], f1[k])
         m = 1. - fc / f1[k]
         m = np.where(m > 0, m, .5)
         f0[k] = np.where(opp, f1[k], f0[k] * m)
@@ -198,7 +200,10 @@ def solve_lean2():
         x1[k] = c[k]; f1[k] = fc
         c_new = x1[k] - f1[k] * (x1[k] - x0[k]) / (f1[k] - f0[k])
         res[k] = c_new
-        done = (np.abs(c_new - c[k]) <= eps * np.minimum(np.abs(c_new), np.abs(c[k]))) | tol_reached(x0[k], x1[k])
+        conv = np.abs(c_new - c[k]) <= eps * np.minimum(np.abs(c_new), np.abs(c[k]))
+        if guard:
+            conv &= np.abs(fc) <= .5 * np.abs(fs)
+        done = conv | tol_reached(x0[k], x1[k])
         c[k] = c_new
         act[k[done]] = False
     bad = loop & ~((res > np.minimum(a, b)) & (res < np.maximum(a, b)))
@@ -406,7 +411,57 @@ def solve_lean4(overshoot=.5, max_unbr=100, first_push=None):
     return r, fn
 
 
-def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
+def safe_mask(idx, x_old, drw2, a, b, a_un):
+    """the far end's sign follows from monotone bounds (see classify_safe for the check of each rule)"""
+    irw = 1. / np.sqrt(x_old); rw3 = x_old * x_old * irw
+    na, da = rw3 - rd3[idx], rw3 - rd3_1mk[idx]
+    klv = np.exp(A[idx] * irw)
+    RHe = RH_eff[idx]
+    g0 = da * RHe - na * klv
+    g1 = da * RHe - na
+    base = (da > 0) & (c_Re[idx] >= 0) & (rd3_1mk[idx] < rd3[idx])
+    grows = drw2 > 0
+    # G1: F(b) < 2 F(a) from monotone bounds (a_w and beta Sh / r grow resp. fall with r, klv >= 1), AND f monotone on the bracket --
+    #     dt F' <= (b/a) drw2 [da klv A irw^3 / (2 g0) + (g1/g0) / a] < 1 (the Kelvin term's slope on the falling branch bounded by
+    #     its value at the near end, the transfer factor's by H / x)
+    U = b * drw2 * (.5 * da * klv * A[idx] * irw + g1) < g0 * x_old * x_old
+    G1 = grows & (g1 * b < 2. * g0 * a) & U
+    G2 = grows & (RHe <= 1.) & (b < 2. * a)
+    unc = a == a_un
+    E1 = ~grows & unc & (na > 0) & (3. * x_old * x_old * (da - na) > A[idx] * na * da)
+    sfr = (x_old - a) / x_old
+    # E3 (falling branch, evaporating): the Kelvin term's growth over the bracket bounded (Bernoulli), and f monotone:
+    #     dt F' <= |drw2| da klv' A irw'^3 / (2 |g0|) with the primed values at the far end <= 1.5 x the near end's for sfr <= 1/8
+    E3 = ~grows & unc & (sfr <= .125) & (na > 0) & (na * klv * sfr * (klv - 1.) < -g0) & (.75 * -drw2 * da * klv * A[idx] * irw < -g0 * x_old)
+    E4 = np.zeros_like(grows)
+    return base & (G1 | G2 | E1 | E3 | E4)
+
+
+def approx_dF(idx, x, Fv):
+    """the derivative the kernel can afford: ventilation factors held constant, single precision"""
+    f = np.float32
+    irw = 1. / np.sqrt(x); rw = x * irw; rw3 = x * rw
+    na, da = rw3 - rd3[idx], rw3 - rd3_1mk[idx]
+    klv = np.exp(A[idx] * irw)
+    g = da * RH_eff[idx] - na * klv
+    Re = c_Re[idx] * rw
+    m = np.where(Re > 1., np.maximum(1., np.abs(Re) ** .077), 1.)
+    Sh, Nu = 1. + np.cbrt(1. + Re * Sc[idx]) * m, 1. + np.cbrt(1. + Re * Pr[idx]) * m
+    KnD, KnK = (lam_D[idx] * irw).astype(f), (lam_K[idx] * irw).astype(f)
+    nD, dD = f(1) + KnD, f(1) + KnD * (f(1.71) + f(1.33) * KnD)
+    nK, dK = f(1) + KnK, f(1) + KnK * (f(1.71) + f(1.33) * KnK)
+    tD = (c1[idx]).astype(f) * dD / (nD * Sh.astype(f))
+    tK = (c2_rho[idx]).astype(f) * dK / (nK * Nu.astype(f))
+    i2x = (.5 / x).astype(f)
+    bD = KnD * ((f(1.71) + f(2.66) * KnD) / dD - f(1) / nD)
+    bK = KnK * ((f(1.71) + f(2.66) * KnK) / dK - f(1) / nK)
+    mix = i2x * (tD * bD + tK * bK) / (tD + tK)
+    dg = (1.5 * rw * (RH_eff[idx] - klv)).astype(f) + (na * klv * A[idx] * irw).astype(f) * i2x
+    rel = dg / g.astype(f) - (1.5 * rw / da).astype(f) + mix
+    return (Fv.astype(f) * rel).astype(np.float64)
+
+
+def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False, cheap_deriv=False, need_br=False, max_unbr=100):
     """lean4 with the reference's far-end rule kept where it can matter.  After the first evaluation (with derivative):
       SAFE   a growing droplet whose far end provably has the opposite sign -- F(b) < 2 F(a) follows from monotone bounds:
              (da RH - na) b < 2 (da RH - na klv) a  [beta(Kn), Sh, Nu and a_w grow with r at most like r; klv >= 1] -- takes the Newton
@@ -426,9 +481,14 @@ def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
     mid = ~early & (a == a_un) & tol_reached(a, b)
     r[all_i[mid]] = (a[mid] + b[mid]) / 2
     go = ~early & ~mid
-    idx = all_i[go]; a, b, drw2, rd2, dF = a[go], b[go], drw2[go], rd2[go], dF[go]
+    idx = all_i[go]; a, b, drw2, rd2, dF, a_un = a[go], b[go], drw2[go], rd2[go], dF[go], a_un[go]
     M = idx.size
     x_old = rw2_old[idx]
+    if cheap_deriv:
+        dFx = dF
+        dF = approx_dF(idx, x_old, drw2 / dt)
+        rel = np.abs(dt * dF - dt * dFx) / np.maximum(1., np.abs(dt * dFx))
+        print("      cheap derivative: |dt dF - exact| / max(1, |dt dF|): median %.1e  99%% %.1e  max %.1e" % (np.median(rel), np.percentile(rel, 99), rel.max()))
     grows = drw2 > 0
     far = np.where(grows, b, a)
     dirn = np.where(grows, 1., -1.)
@@ -442,6 +502,8 @@ def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
     g0 = da * RH_eff[idx] - na * klv
     g1 = da * RH_eff[idx] - na
     safe = grows & (g1 * b < 2. * g0 * a) & (da > 0) & ok if safe_bound else np.zeros(M, bool)
+    if safe_bound == "full":
+        safe = safe_mask(idx, x_old, drw2, a, b, a_un) & ok
     print("      safe (far end not evaluated): %.4f of the droplets that iterate; growing %.4f" % (safe.mean(), grows.mean()))
     x0, f0 = far.copy(), np.full(M, np.nan)
     x1, f1 = x_old.copy(), drw2.copy()
@@ -462,6 +524,7 @@ def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
     n_euler = int(same.sum())
     # dekker: remember the previous same-side point for a secant through the two latest iterates
     xp, fp_ = np.full(M, np.nan), np.full(M, np.nan)
+    trips = np.zeros(M, dtype=np.int64)
     for it in range(100):
         if not act.any():
             break
@@ -489,9 +552,12 @@ def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
             c_new = np.where(use, cs, c_new)
         res[k] = c_new
         done = (np.abs(c_new - c[k]) <= eps * np.minimum(np.abs(c_new), np.abs(c[k]))) | (br[k] & tol_reached(x0[k], x1[k]))
+        if need_br:
+            done &= br[k]
         unb = ~br[k]
+        trips[k[unb]] += 1
         cn = np.where(unb, c_new + overshoot * eps * np.abs(c_new) * dirn[k], c_new)
-        gofar = unb & ~(((cn - x1[k]) * dirn[k] > 0) & ((far[k] - cn) * dirn[k] > 0))
+        gofar = unb & (~(((cn - x1[k]) * dirn[k] > 0) & ((far[k] - cn) * dirn[k] > 0)) | (trips[k] >= max_unbr))
         cn = np.where(gofar, far[k], cn)
         at_far[k] = gofar
         c[k] = cn
@@ -503,3 +569,33 @@ def solve_lean5(overshoot=.5, safe_bound=True, newton_first=True, dekker=False):
     r[idx] = res
     print("      (explicit-Euler answers: %d, still active after 100: %d)" % (n_euler, act.sum()))
     return r, fn
+
+
+def classify_safe():
+    """which droplets' far-end sign follows from monotone bounds; checks the claim and that f is monotone on their brackets"""
+    fn = Fun()
+    all_i = np.nonzero(rw2_old > 0)[0]
+    x = rw2_old[all_i]
+    drw2 = dt * fn.F(all_i, x)
+    rd2 = np.cbrt(rd3[all_i]) ** 2
+    a_un = x + np.minimum(0., cond_mlt * drw2)
+    a = np.maximum(rd2, a_un)
+    b = x + np.maximum(0., cond_mlt * drw2)
+    early = (drw2 == 0) | (a == b) | ((a == a_un) & tol_reached(a, b))
+    safe = safe_mask(all_i, x, drw2, a, b, a_un) & ~early
+    print("iterating %d, safe %.4f" % ((~early).sum(), safe.sum() / (~early).sum()))
+    k = all_i[safe]
+    grows = drw2[safe] > 0
+    far = np.where(grows, b[safe], a[safe])
+    ff = fn.f(k, far)
+    wrong = (ff < 0) == (drw2[safe] < 0)
+    print("   far-end sign as claimed: %d violations of %d" % (wrong.sum(), k.size))
+    prev = drw2[safe].copy()
+    nonmono = np.zeros(k.size, bool)
+    for j in range(1, 33):
+        xx = x[safe] + (far - x[safe]) * (j / 32.)
+        cur = fn.f(k, xx)
+        nonmono |= np.where(grows, cur > prev, cur < prev) if False else ((cur - prev) * np.where(grows, 1., -1.) > 0)
+        prev = cur
+    print("   f not monotone along the bracket (33 samples): %d" % nonmono.sum())
+    return all_i, safe
