@@ -176,6 +176,8 @@ enum lcx_dbg {
   LCX_DBG_RANK_BY_COUNTING = 1 << 18,  /* the in-cell shuffled order ranked by counting smaller keys (k_cellrank<uint32_t, true>) instead of by buckets */
   LCX_DBG_COND_FOLD = 1 << 19,         /* the lean solver's kernel with its workgroup folded behind the solver's first loop trip (k_cond_lean_fold: the
                                           unconverged droplets handed to the workgroup's lowest lanes through LDS; the same rw2 bit for bit, not faster) */
+  LCX_DBG_COND_NO_LIST = 1 << 20,      /* cond_solver = 0: no list of droplets for the reference's iterates (brackets that may hold several roots, k_cond_lean /
+                                        * k_cond_lean_listed): the lean solver takes every droplet, as in rounds 3-4 */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };

@@ -203,7 +203,7 @@ struct Particles : IParticles {
   uint32_t *sid() const { join_rank(); return sorted_id.p + sort_base; }
   uint32_t *sijk() const { join_rank(); return sorted_ijk.p + sort_base; }
   uint32_t *rnk() const { join_rank(); return rank.p; }
-  DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig;
+  DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig, cond_listed;
   const bool use_wave_flags = !dbg(LCX_DBG_NO_WAVE_FLAGS);
   void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
   DevBuf<uint64_t> sort_scratch;
@@ -1123,8 +1123,9 @@ struct Particles : IParticles {
       // the substep's cell pass in one launch: mean free paths (substep 0, from the previous T and p as the reference's hskpng_mfp
       // ahead of the loop), hskpng_Tpr, and in fast arithmetic the droplet-independent set-up of the growth rate
       Range r(this, "hskpng_Tpr");
-      if (fast) { cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>)); defer_cnt.alloc(DEFER_SHARDS * DEFER_CNT_STRIDE); }
-      const int n_defer_words = DEFER_SHARDS * DEFER_CNT_STRIDE;
+      // (the last 16 words: the counter of k_cond_lean's list of droplets for the reference's iterates, see cond_list -- cleared with the rest)
+      if (fast) { cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>)); defer_cnt.alloc(DEFER_SHARDS * DEFER_CNT_STRIDE + 16); }
+      const int n_defer_words = DEFER_SHARDS * DEFER_CNT_STRIDE + 16;
       hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(std::max(nblk(ncell), nblk(size_t(n_defer_words)))), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p,
                          Tk.p, RH.p, eta.p, dv.p, lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
                          fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr,
@@ -1144,6 +1145,13 @@ struct Particles : IParticles {
       const bool cond_toms = o.cond_solver == 1;
       if (fast && !cond_toms_two_pass()) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
+        // the lean solver's list (cond_list): room for every droplet, 4 B each
+        cond_list lst{nullptr, nullptr};
+        bool listed = false;
+        if (!cond_toms && !dbg(LCX_DBG_COND_NO_LIST)) {
+          cond_listed.alloc(std::max<size_t>(cap, std::max<size_t>(nphys, npart)));
+          lst = cond_list{cond_listed.p, defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE};
+        }
         cond_in_storage_order = cond_storage_order;
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
@@ -1162,11 +1170,16 @@ struct Particles : IParticles {
           // what a launch costs is the lanes that compute, not the instructions that issue; see k_cond_lean_fold)
           else if (dbg(LCX_DBG_COND_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (dbg(LCX_DBG_COND_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false>), gs, bl, 0, st, nphys, a, T(0));
-          else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value);
-          else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0));
+          else if (kpa_uniform) { hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value, lst); listed = lst.ent != nullptr; }
+          else { hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0), lst); listed = lst.ent != nullptr; }
         }
         else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0));
-        else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0));
+        else { hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
+        // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell finish
+        if (listed) {
+          if (kpa_uniform && cond_in_storage_order) hipLaunchKernelGGL((k_cond_lean_listed<T, true>), dim3(2048), bl, 0, st, a, lst, kpa_value);
+          else hipLaunchKernelGGL((k_cond_lean_listed<T, false>), dim3(2048), bl, 0, st, a, lst, T(0));
+        }
       }
       else if (fast) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);

@@ -1208,8 +1208,14 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 //    instructions per wave and not a microsecond faster (2.98 against 3.00 ms: the memory side), the second pass 0.75 ms of gathers.
 // SOLVER: 0 the lean solver in round 4's form, 1 in round 3's (the same bits, kept for the test that shows it), 2 TOMS748 -- the
 // reference's iterates on this kernel's growth-rate arithmetic (opts_init.cond_solver = 1), in the same storage-order walk
+// Round 5 (late): droplets whose bracket may hold SEVERAL roots (lcx_math.hpp lean2_head, `suspicious`) are not solved here: they
+// are listed (one atomic per wave that has any: 0.1-0.3 % of the droplets of bench.py's boxes, a tenth of a box whose aerosol is just
+// activating) and k_cond_lean_listed takes them through TOMS748 -- the reference's iterates decide which root such a droplet ends on.
+// ent: the kernel's own index of the droplet (storage slot, or position in the sorted order), room for every one of them -- a list that
+// could overflow would make WHO is listed depend on the order in which the atomics are served; count: the entries
+struct cond_list { uint32_t *ent, *count; };
 template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0>
-__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0))
+__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0), cond_list lst = cond_list{nullptr, nullptr})
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
   // attributes and the change (m3_after, storage-indexed; the per-cell finish gathers it through sorted_id) are read and written
@@ -1255,18 +1261,52 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
   if (!UNI) asm volatile("" : "+v"(kpa));
   if constexpr (cond_fun_fast<T, OPT>::trim) asm volatile("" : "+v"(cc.two_rho_eta)); else asm volatile("" : "+v"(cc.rhod), "+v"(cc.eta));
   T delta = 0;
+  bool several = false;                 // (SOLVER 0 with a list: the bracket may hold several roots, see cond_list)
   if (!(rw2_old <= 0)) {                // (cond_common.ipp:197-199; a NaN goes through the solver and poisons its cell as in the reference)
     cond_fun_fast<T, OPT> ff;
     ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
     T r;
     if constexpr (SOLVER == 2) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     else if constexpr (SOLVER == 1) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-    else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-    a.rw2[id] = r;
-    // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
-    delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+    else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, &several, lst.ent != nullptr);
+    if (!several) {
+      a.rw2[id] = r;
+      // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
+      delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+    }
+  }
+  if constexpr (SOLVER == 0) {
+    const unsigned long long bal = __ballot(several);
+    if (bal) {
+      const int leader = __ffsll((long long)bal) - 1;
+      uint32_t base = 0;
+      if (int(lane_id()) == leader) base = atomicAdd(lst.count, uint32_t(__popcll(bal)));
+      base = __shfl(base, leader);
+      // (the kernel's own index of the droplet, from what is live anyway: the storage slot is `id`, the position in the sorted order `m3_pos`)
+      if (several) { lst.ent[base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)))] = a.storage_ijk ? id : uint32_t(m3_pos); return; }      // (its change: k_cond_lean_listed)
+    }
   }
   a.m3_after[m3_pos] = delta;
+}
+// the listed droplets of k_cond_lean through TOMS748 on the same growth-rate arithmetic (what k_cond_lean<T, 15, UNI, 2> computes for them,
+// bit for bit): a grid-stride walk over the list, a droplet per lane
+template <class T, bool UNI>
+__global__ void __launch_bounds__(BS) k_cond_lean_listed(cond_args<T> a, cond_list lst, T kpa_uniform)
+{
+  const uint32_t n = *lst.count;
+  for (size_t q = gid(); q < n; q += size_t(gridDim.x) * BS) {
+    const uint32_t pos = lst.ent[q];
+    uint32_t id, c, m3_pos = pos;
+    if (a.storage_ijk) { id = pos; c = a.storage_ijk[pos]; if (a.sc_rank) m3_pos = a.sc_cell_start[c] + a.sc_rank[pos]; }
+    else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
+    const T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id], kpa = UNI ? kpa_uniform : a.kpa[id], nn = T(a.n[id]);
+    const cond_cell_fast<T> cc = a.pre[c];
+    cond_fun_fast<T, 15> ff;
+    ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+    const T r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    a.rw2[id] = r;
+    a.m3_after[m3_pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+  }
 }
 
 // Round 5, measured and kept behind opts_init.dbg_flags & COND_FOLD: the lean kernel with its workgroup FOLDED behind the solver's first

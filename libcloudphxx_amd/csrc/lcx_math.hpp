@@ -991,8 +991,14 @@ LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond
 //   lean2_loop   up to `budget` evaluations; false: the budget ran out, s.c is the next point to evaluate
 //   lean2_tail   the two clamps
 template <class T> struct lean_state { T x0, f0, x1, f1, c, a, b; };      // (x1, f1): the latest point, (x0, f0): the retained end (opposite sign)
+// suspicious (optional): set when the bracket may hold SEVERAL roots -- the caller then hands the droplet to the reference's own iterates
+// (k_cond_lean) and the function returns at once.  Seen at production size only (tests/test_hip_reverse_replay.py, 2^24 droplets): a
+// droplet that can evaporate down to its dry core within the step (the bracket's lower end is the dry radius, far below: a 0.8 um
+// droplet on a 5 nm core) has a root where it has shrunk to half its radius AND roots next to the core, where the Kelvin term takes
+// over; the growing counterpart is a bracket that spans more than a factor of four in radius in supersaturated air.  Each solver's
+// iterates pick one root; TOMS748's choice is the reference's.  0.1-0.3 % of the droplets of bench.py's boxes.
 template <class T, class F>
-LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, lean_state<T> &s, T &r, T &rd2)
+LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, lean_state<T> &s, T &r, T &rd2, bool *suspicious = nullptr, bool ask = true)
 {
   constexpr int FD = fastdiv<F>::value;
   const T drw2 = dt * f.drw2_dt(rw2_old);
@@ -1019,6 +1025,11 @@ LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, le
   // bench.py's coal-stress box (kappa = 1e-10, the reference's coalescence tests' set-up): its condensation launch 5.85 -> 4.95 ms.
   if (tol_reached(eps, a, b) && (a == a_un || lean_clamped_sign_change(f))) { r = (a + b) / 2; return true; }
   const bool grows = drw2 > 0;
+  if (suspicious && ask) {      // (`ask`: a run-time switch beside the pointer -- a pointer that is selected at run time keeps the flag in memory)
+    const bool several = grows ? (f.RH_eff > T(1) && b > T(16) * rw2_old) : (a != a_un && rw2_old > T(16) * rd2);
+    *suspicious = several;
+    if (several) return true;
+  }
   const T f_far = f(grows ? b : a);
   const T fa = grows ? drw2 : f_far, fb = grows ? f_far : drw2;     // f(rw2_old) == drw2 (cond_common.ipp:296-305)
   bool final = true;
@@ -1085,11 +1096,11 @@ LCX_HD T lean2_tail(const lean_state<T> &s, T r, T rd2)
   return r;
 }
 template <class T, class F>
-LCX_HD T advance_rw2_lean2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
+LCX_HD T advance_rw2_lean2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, bool *suspicious = nullptr, bool ask = true)
 {
   lean_state<T> s;
   T r, rd2 = 0;
-  if (lean2_head(f, rw2_old, rd3, dt, eps, cond_mlt, s, r, rd2)) return r;
+  if (lean2_head(f, rw2_old, rd3, dt, eps, cond_mlt, s, r, rd2, suspicious, ask)) return r;
   lean2_loop(f, eps, n_iter, s, r);       // (a budget that runs out leaves the last iterate in r, as the plain loop does)
   return lean2_tail(s, r, rd2);
 }

@@ -109,6 +109,7 @@ class dbg(enum.IntFlag):
     NO_RANK_OVERLAP = 1 << 17
     RANK_BY_COUNTING = 1 << 18
     COND_FOLD = 1 << 19
+    COND_NO_LIST = 1 << 20
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

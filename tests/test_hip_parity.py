@@ -1068,9 +1068,11 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
     # (round 5: COND_FOLD is the kernel FOLDED behind the solver's first loop trip -- k_cond_lean_fold, the unconverged droplets of a
     # workgroup handed to its lowest lanes through LDS -- and a stage of 8 slots (dbg_cond_budget) leaves most of the unconverged
     # droplets in their own lanes: every droplet's numbers see the same operations in all of them)
-    FO = int(lgrngn.dbg.COND_FOLD)
+    # (late round 5: the production kernel hands the droplets whose bracket may hold several roots to TOMS748, cond_list; the variants
+    # compared HERE are kernels around the lean solver alone -- COND_NO_LIST in all of them; the list has its own test below)
+    FO, NL = int(lgrngn.dbg.COND_FOLD), int(lgrngn.dbg.COND_NO_LIST)
     for flags, budget in ((0, 0), (int(lgrngn.dbg.KPA_ARRAY), 0), (int(lgrngn.dbg.COND_LEAN_R3), 0), (FO, 0), (FO | int(lgrngn.dbg.KPA_ARRAY), 0), (FO, 8)):
-        oi.dbg_flags = flags
+        oi.dbg_flags = flags | NL
         oi.dbg_cond_budget = budget
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
@@ -1086,6 +1088,49 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
         for a_, b_ in zip(res[0][:4], res[k][:4]):
             assert np.array_equal(a_, b_), k
     assert np.abs(res[0][2] - rv).max() > 0
+
+
+def test_brackets_that_may_hold_several_roots_take_the_references_iterates():
+    """Late round 5.  A droplet that can evaporate down to its dry core within the step (a 0.8 um droplet on a 5 nm core in subsaturated
+    air: a root where it has shrunk to half its radius, and roots next to the core where the Kelvin term takes over), or whose bracket
+    spans more than a factor of four in radius in supersaturated air, has SEVERAL roots of the step's equation inside the reference's
+    bracket; which one TOMS748 returns is a property of its iterates (at 2^24 droplets the lean solver differed for up to 65 per step,
+    tests/test_hip_reverse_replay.py).  k_cond_lean lists such droplets (lcx_math.hpp lean2_head, `suspicious`) and
+    k_cond_lean_listed takes them through TOMS748 on the same growth-rate arithmetic.  One condensation step of a box that holds such
+    droplets, three ways: the production kernel, the same without the list (dbg COND_NO_LIST: the lean solver for everybody), and
+    cond_solver = 1 (TOMS748 for everybody) -- a droplet of the production run carries EITHER the lean solver's bits or TOMS748's, both
+    kinds occur, and every droplet whose lean answer is far from TOMS748's is among the listed."""
+    oi = h.box_opts(8, 8, 8, 64, sstp_cond=1, strict_fp=False)
+    th, rv, rhod, C = h.box_fields(oi)
+    res = {}
+    for name, flags, solver in (("prod", 0, 0), ("lean", int(lgrngn.dbg.COND_NO_LIST), 0), ("toms", 0, 1)):
+        oi.dbg_flags = flags
+        oi.cond_solver = solver
+        hip = h.hip_particles(oi)
+        hip.init(th, rv, rhod, **C)
+        g = hip.state_real
+        rw2, rd3 = g("rw2"), g("rd3")
+        rng = np.random.default_rng(9)
+        rd = np.cbrt(rd3)
+        big = rng.random(rw2.shape) < .3
+        rw2[big] = np.maximum(rd[big] * 1.05, rng.uniform(.2e-6, 1.5e-6, size=int(big.sum()))) ** 2      # droplets of 0.2 ... 1.5 um on whatever core they have
+        hip.set_particles(hip.state_u64("n"), rd3, rw2, g("kappa"), g("vt"), g("x"), g("y"), g("z"))
+        opts = lgrngn.opts_t()
+        opts.coal = opts.sedi = opts.adve = False
+        thh, rvh = th.copy(), rv.copy()
+        hip.step_sync(opts, thh, rvh, rhod, **C)
+        hip.step_async(opts)
+        res[name] = hip.get_attr("rw2")
+    prod, lean, toms = res["prod"], res["lean"], res["toms"]
+    from_lean, from_toms = prod == lean, prod == toms
+    assert (from_lean | from_toms).all(), int((~(from_lean | from_toms)).sum())
+    # (this box is made of such droplets -- fresh aerosol activating at RH 1.01, droplets of a micrometre on nanometre cores: most of it
+    # is listed; bench.py's boxes list 0.1-0.3 %)
+    assert (~from_lean).sum() > 100 and (~from_toms).sum() > 100, ((~from_lean).sum(), (~from_toms).sum())
+    far = np.abs(lean / toms - 1.) > 1e-4
+    assert from_toms[far].all(), int((~from_toms[far]).sum())
+    print("TOMS748's bits %d, the lean solver's %d (both: %d) of %d; lean solver far from TOMS748's root: %d, all of them listed" % (
+        from_toms.sum(), from_lean.sum(), (from_lean & from_toms).sum(), prod.size, far.sum()))
 
 
 @pytest.mark.parametrize("sd_conc,reorder_every,cond_every", [(64, 0, 1), (64, 3, 1), (300, 4, 1), (48, 5, 2)])
