@@ -116,7 +116,10 @@ typedef struct {
                          *    bars and to the reference's refdata tolerances, like strict_fp = 1, in every test;
                          * 0: a lean bracketed secant on the reference's bracket, to the reference's tolerance 2^-15 (csrc/lcx_math.hpp
                          *    advance_rw2_lean2_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within that tolerance of the reference's
-                         *    answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5 from the root it brackets; half the
+                         *    answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5 from the root it brackets.  A droplet
+                         *    whose bracket can hold SEVERAL roots (one that can evaporate down to its dry core within the step, a bracket
+                         *    across more than a factor of four in radius in supersaturated air: 0.1-0.3 % of a cloudy box) is solved with
+                         *    TOMS748 as under 1, so that WHICH root it ends on is the reference's choice (k_cond_lean_listed).  Half the
                          *    kernel time of 1, what bench.py's headline runs */
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers
                          * line-coalesced in long runs: 18.1 instead of 21.5 ms per step after 400 steps of the 128^3 box).
