@@ -18,6 +18,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <functional>
 
 #include "../../include/lcx.h"
 #include "lcx_kernels.hpp"
@@ -1145,11 +1146,11 @@ struct Particles : IParticles {
       const bool cond_toms = o.cond_solver == 1;
       if (fast && !cond_toms_two_pass()) {
         a.pre = reinterpret_cast<const cond_cell_fast<T> *>(cond_pre.p);
-        // the lean solver's list (cond_list): room for every droplet, 4 B each
+        // the lean solver's list (cond_list): room for every droplet, 8 B each
         cond_list lst{nullptr, nullptr};
         bool listed = false;
         if (!cond_toms && !dbg(LCX_DBG_COND_NO_LIST)) {
-          cond_listed.alloc(std::max<size_t>(cap, std::max<size_t>(nphys, npart)));
+          cond_listed.alloc(2 * std::max<size_t>(cap, std::max<size_t>(nphys, npart)));
           lst = cond_list{cond_listed.p, defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE};
         }
         cond_in_storage_order = cond_storage_order;
@@ -1175,10 +1176,15 @@ struct Particles : IParticles {
         }
         else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0));
         else { hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
-        // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell finish
+        // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell
+        // finish -- launched BEHIND the fork of the in-cell ranking below, so that its few thousand waves run next to the ranking's
         if (listed) {
-          if (kpa_uniform && cond_in_storage_order) hipLaunchKernelGGL((k_cond_lean_listed<T, true>), dim3(2048), bl, 0, st, a, lst, kpa_value);
-          else hipLaunchKernelGGL((k_cond_lean_listed<T, false>), dim3(2048), bl, 0, st, a, lst, T(0));
+          const bool uni = kpa_uniform && cond_in_storage_order;
+          const T kv = uni ? kpa_value : T(0);
+          launch_listed = [this, a, lst, uni, kv, bl]() {
+            if (uni) hipLaunchKernelGGL((k_cond_lean_listed<T, true>), dim3(2048), bl, 0, st, a, lst, kv);
+            else hipLaunchKernelGGL((k_cond_lean_listed<T, false>), dim3(2048), bl, 0, st, a, lst, kv);
+          };
         }
       }
       else if (fast) {
@@ -1222,6 +1228,7 @@ struct Particles : IParticles {
         rank_pending = true;
       } else finish_deferred_sort(true);
     }
+    if (launch_listed) { Range r(this, "cond"); launch_listed(); launch_listed = nullptr; }
     {
       Range r(this, "cond_cellfinish");
       // (a kernel that carried the scatter has left each droplet's change at the droplet's place in the sorted order: no gather)
@@ -1233,6 +1240,7 @@ struct Particles : IParticles {
   // nothing set by the caller (set_particles), so that coalescence never mixes two values -- the condensation kernel then takes it as
   // a scalar.  (LCX_DBG_KPA_ARRAY: the array is read all the same.)
   bool kpa_uniform = false; T kpa_value = T(0);
+  std::function<void()> launch_listed;       // (cond_substep: k_cond_lean_listed, queued behind the fork of the in-cell ranking)
   const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
   // per-cell sums of n rw^3 before / after the substep + update_th_rv.  Strict arithmetic: the ordered single-lane walk (the

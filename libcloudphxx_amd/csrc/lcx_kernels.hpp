@@ -1211,8 +1211,10 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // Round 5 (late): droplets whose bracket may hold SEVERAL roots (lcx_math.hpp lean2_head, `suspicious`) are not solved here: they
 // are listed (one atomic per wave that has any: 0.1-0.3 % of the droplets of bench.py's boxes, a tenth of a box whose aerosol is just
 // activating) and k_cond_lean_listed takes them through TOMS748 -- the reference's iterates decide which root such a droplet ends on.
-// ent: the kernel's own index of the droplet (storage slot, or position in the sorted order), room for every one of them -- a list that
-// could overflow would make WHO is listed depend on the order in which the atomics are served; count: the entries
+// ent: two words per entry -- the kernel's own index of the droplet (storage slot, or position in the sorted order) and the position of
+// its change (what the carried scatter made of its rank: the rank buffer itself is the in-cell ranking's OUTPUT, and that ranking runs
+// on its side stream next to k_cond_lean_listed); room for every droplet -- a list that could overflow would make WHO is listed depend
+// on the order in which the atomics are served; count: the entries
 struct cond_list { uint32_t *ent, *count; };
 template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0>
 __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0), cond_list lst = cond_list{nullptr, nullptr})
@@ -1283,7 +1285,11 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
       if (int(lane_id()) == leader) base = atomicAdd(lst.count, uint32_t(__popcll(bal)));
       base = __shfl(base, leader);
       // (the kernel's own index of the droplet, from what is live anyway: the storage slot is `id`, the position in the sorted order `m3_pos`)
-      if (several) { lst.ent[base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull)))] = a.storage_ijk ? id : uint32_t(m3_pos); return; }      // (its change: k_cond_lean_listed)
+      if (several) {
+        const size_t q = 2 * size_t(base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull))));
+        lst.ent[q] = a.storage_ijk ? id : uint32_t(m3_pos); lst.ent[q + 1] = uint32_t(m3_pos);
+        return;                                                  // (its change: k_cond_lean_listed)
+      }
     }
   }
   a.m3_after[m3_pos] = delta;
@@ -1295,9 +1301,9 @@ __global__ void __launch_bounds__(BS) k_cond_lean_listed(cond_args<T> a, cond_li
 {
   const uint32_t n = *lst.count;
   for (size_t q = gid(); q < n; q += size_t(gridDim.x) * BS) {
-    const uint32_t pos = lst.ent[q];
-    uint32_t id, c, m3_pos = pos;
-    if (a.storage_ijk) { id = pos; c = a.storage_ijk[pos]; if (a.sc_rank) m3_pos = a.sc_cell_start[c] + a.sc_rank[pos]; }
+    const uint32_t pos = lst.ent[2 * q], m3_pos = lst.ent[2 * q + 1];
+    uint32_t id, c;
+    if (a.storage_ijk) { id = pos; c = a.storage_ijk[pos]; }
     else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
     const T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id], kpa = UNI ? kpa_uniform : a.kpa[id], nn = T(a.n[id]);
     const cond_cell_fast<T> cc = a.pre[c];
