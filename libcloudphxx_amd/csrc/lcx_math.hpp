@@ -934,6 +934,18 @@ LCX_HD T advance_rw2_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt,
 // converged: |c_new - c| <= eps c, or the bracket is inside the tolerance.  The root it returns solves the same backward-Euler equation
 // to the same tolerance, eps = 2^-15 (config.hpp:39): it lies within that of the reference's answer (the midpoint of TOMS748's last
 // bracket), which is SURVEY 8a's bar for rw2 (rtol 1e-4), not bit for bit.  The strict arithmetic (the API default) keeps TOMS748.
+// the lean solvers' stopping rule (see lean2_loop): two successive iterates within the tolerance of each other are believed only when
+// the function value has at least halved on its side of the root (superlinear convergence gives orders of magnitude per step; a
+// secant that crawls along a step of f does not).  Double precision only: in single precision the function values next to the root
+// are rounding noise (RH - klv cancels to three digits of the 24-bit significand) and do not halve -- the float build's loop ran to its
+// iteration limit on that noise, its condensation launch 2.1 -> 6.1 ms -- and float's tolerance, 2^-7, is coarse enough for the plain rule.
+// (Tried: "or within an eighth of the tolerance" instead of the precision test -- the crawl's ratio can be 0.99, and 748 of 3e5 random
+// droplets of kappa = 1e-10 were off again.)
+template <class T> LCX_HD bool lean_converged(T d, T lim, T fc, T fs)
+{
+  if constexpr (sizeof(T) == 4) return d <= lim;
+  else return d <= lim && fabs(fc) <= T(0.5) * fabs(fs);
+}
 // (the lean solvers' early out of a clamped bracket, see lean2_head: kappa RH far above the rounding of rd2^(3/2) - rd3)
 template <class F> LCX_HD bool lean_clamped_sign_change(const F &f) { return (f.rd3 - f.rd3_1mk) * f.RH_eff > decltype(f.rd3)(1e-12) * f.rd3; }
 template <class T, class F>
@@ -971,7 +983,7 @@ LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond
       x1 = c; f1 = fc;
       const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
       r = c_new;
-      if ((fabs(c_new - c) <= eps * mn(fabs(c_new), fabs(c)) && fabs(fc) <= T(0.5) * fabs(fs)) || tol_reached(eps, x0, x1)) break;
+      if (lean_converged(T(fabs(c_new - c)), T(eps * mn(fabs(c_new), fabs(c))), fc, fs) || tol_reached(eps, x0, x1)) break;
       c = c_new;
     }
     if (!(r > mn(a, b) && r < mx(a, b))) r = x1;                                  // (never leave the reference's bracket)
@@ -1080,7 +1092,7 @@ LCX_HD bool lean2_loop(const F &f, T eps, unsigned budget, lean_state<T> &s, T &
     x1 = c; f1 = fc;
     const T c_new = x1 - f1 * dvd<FD>(T(x1 - x0), T(f1 - f0));
     r = c_new;
-    done = (fabs(c_new - c) <= eps * T(__builtin_fmin(fabs(c_new), fabs(c))) && fabs(fc) <= T(0.5) * fabs(fs)) ||
+    done = lean_converged(T(fabs(c_new - c)), T(eps * T(__builtin_fmin(fabs(c_new), fabs(c)))), fc, fs) ||
            fabs(x0 - x1) <= eps * T(__builtin_fmin(fabs(x0), fabs(x1)));
     c = c_new;
     if (done) break;
