@@ -1149,6 +1149,7 @@ struct Particles : IParticles {
         // the lean solver's list (cond_list): room for every droplet, 8 B each
         cond_list lst{nullptr, nullptr};
         bool listed = false;
+        launch_listed = nullptr;               // (a call that threw between the two launches must not leave its second half behind)
         if (!cond_toms && !dbg(LCX_DBG_COND_NO_LIST)) {
           cond_listed.alloc(2 * std::max<size_t>(cap, std::max<size_t>(nphys, npart)));
           lst = cond_list{cond_listed.p, defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE};
