@@ -540,6 +540,14 @@ def main():
                 roof["carries"] = "the scatter of the previous step's re-sort (k_scatter_sorted: %d B per SD), except in storage re-ordering steps" % carried
                 roof["achieved_with_carried"] = (cond_bytes_per_sd + carried) * n_local / (avg_ms * 1e-3) / 1e9
                 roof["frac_with_carried"] = roof["achieved_with_carried"] / HBM_PEAK_GBS
+            if not args.strict_fp and args.cond_solver == "lean" and world_out == 1 and not args.self_ring:
+                # (late round 5) the stage's time includes k_cond_lean_listed: the droplets whose bracket can hold several roots, solved
+                # with the reference's TOMS748 iterates -- how many of them the last step had
+                try:
+                    roof["listed_for_the_references_iterates"] = int(p1.state_u64("raw_cond_listed")[0])
+                    roof["listed_share"] = roof["listed_for_the_references_iterates"] / max(n_local, 1.)
+                except Exception:
+                    pass
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
             # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
             default_cfg = (world_out == 1 and n == 128 and not (args.nx or args.ny or args.nz) and args.sd_conc == 64 and args.real == "f64"

@@ -2066,6 +2066,11 @@ struct Particles : IParticles {
       unsigned long long tot = 0; for (auto x : h) tot += x;
       v.assign(1, tot);
     }
+    else if (s == "raw_cond_listed") {             // droplets that the last condensation substep handed to the reference's iterates (cond_list)
+      unsigned long long c = 0;
+      if (defer_cnt.p && defer_cnt.n >= size_t(DEFER_SHARDS * DEFER_CNT_STRIDE + 16)) c = d2h(defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE, 1)[0];
+      v.assign(1, c);
+    }
     else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "raw_ijk") { auto h = d2h(ijk.p, nphys); v.assign(h.begin(), h.end()); }
     else if (s == "raw_sorted_id") {               // the cell-sorted order as the last sort left it (the shuffled order of the next coalescence, mostly)

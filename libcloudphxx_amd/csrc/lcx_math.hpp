@@ -1008,7 +1008,7 @@ template <class T> struct lean_state { T x0, f0, x1, f1, c, a, b; };      // (x1
 // droplet that can evaporate down to its dry core within the step (the bracket's lower end is the dry radius, far below: a 0.8 um
 // droplet on a 5 nm core) has a root where it has shrunk to half its radius AND roots next to the core, where the Kelvin term takes
 // over; the growing counterpart is a bracket that spans more than a factor of four in radius in supersaturated air.  Each solver's
-// iterates pick one root; TOMS748's choice is the reference's.  0.1-0.3 % of the droplets of bench.py's boxes.
+// iterates pick one root; TOMS748's choice is the reference's.  0.05-0.08 % of the droplets of bench.py's settled boxes.
 template <class T, class F>
 LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, lean_state<T> &s, T &r, T &rd2, bool *suspicious = nullptr, bool ask = true)
 {
