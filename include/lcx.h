@@ -118,7 +118,7 @@ typedef struct {
                          *    advance_rw2_lean2_with): the ROOT of rw2' = rw2 + dt f(rw2') itself, within that tolerance of the reference's
                          *    answer -- which is the midpoint of TOMS748's last bracket, up to 1.5e-5 from the root it brackets.  A droplet
                          *    whose bracket can hold SEVERAL roots (one that can evaporate down to its dry core within the step, a bracket
-                         *    across more than a factor of four in radius in supersaturated air: 0.05-0.08 % of bench.py's boxes, roofline.listed_share) is solved with
+                         *    across more than a factor of four in radius in supersaturated air: about 0.1 % of bench.py's boxes) is solved with
                          *    TOMS748 as under 1, so that WHICH root it ends on is the reference's choice (k_cond_lean_listed).  Half the
                          *    kernel time of 1, what bench.py's headline runs */
   int reorder_every;    /* physical re-ordering of the super-droplet storage into the cell-sorted order (keeps the per-cell gathers

@@ -1209,7 +1209,7 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // SOLVER: 0 the lean solver in round 4's form, 1 in round 3's (the same bits, kept for the test that shows it), 2 TOMS748 -- the
 // reference's iterates on this kernel's growth-rate arithmetic (opts_init.cond_solver = 1), in the same storage-order walk
 // Round 5 (late): droplets whose bracket may hold SEVERAL roots (lcx_math.hpp lean2_head, `suspicious`) are not solved here: they
-// are listed (one atomic per wave that has any: 0.05-0.08 % of the droplets of bench.py's settled boxes, a tenth of a box whose aerosol is just
+// are listed (one atomic per wave that has any: about 0.1 % of the droplets of bench.py's settled boxes, a tenth of a box whose aerosol is just
 // activating) and k_cond_lean_listed takes them through TOMS748 -- the reference's iterates decide which root such a droplet ends on.
 // ent: two words per entry -- the kernel's own index of the droplet (storage slot, or position in the sorted order) and the position of
 // its change (what the carried scatter made of its rank: the rank buffer itself is the in-cell ranking's OUTPUT, and that ranking runs

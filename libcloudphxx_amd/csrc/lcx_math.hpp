@@ -1005,10 +1005,10 @@ LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond
 template <class T> struct lean_state { T x0, f0, x1, f1, c, a, b; };      // (x1, f1): the latest point, (x0, f0): the retained end (opposite sign)
 // suspicious (optional): set when the bracket may hold SEVERAL roots -- the caller then hands the droplet to the reference's own iterates
 // (k_cond_lean) and the function returns at once.  Seen at production size only (tests/test_hip_reverse_replay.py, 2^24 droplets): a
-// droplet that can evaporate down to its dry core within the step (the bracket's lower end is the dry radius, far below: a 0.8 um
-// droplet on a 5 nm core) has a root where it has shrunk to half its radius AND roots next to the core, where the Kelvin term takes
+// droplet that can evaporate down to its dry core within the step (the bracket reaches from beyond four dry radii to within four dry
+// radii of the core: a 0.8 um droplet on a 5 nm core) has a root where it has shrunk to half its radius AND roots next to the core, where the Kelvin term takes
 // over; the growing counterpart is a bracket that spans more than a factor of four in radius in supersaturated air.  Each solver's
-// iterates pick one root; TOMS748's choice is the reference's.  0.05-0.08 % of the droplets of bench.py's settled boxes.
+// iterates pick one root; TOMS748's choice is the reference's.  About 0.1 % of the droplets of bench.py's settled boxes.
 template <class T, class F>
 LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, lean_state<T> &s, T &r, T &rd2, bool *suspicious = nullptr, bool ask = true)
 {
@@ -1038,7 +1038,8 @@ LCX_HD bool lean2_head(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, le
   if (tol_reached(eps, a, b) && (a == a_un || lean_clamped_sign_change(f))) { r = (a + b) / 2; return true; }
   const bool grows = drw2 > 0;
   if (suspicious && ask) {      // (`ask`: a run-time switch beside the pointer -- a pointer that is selected at run time keeps the flag in memory)
-    const bool several = grows ? (f.RH_eff > T(1) && b > T(16) * rw2_old) : (a != a_un && rw2_old > T(16) * rd2);
+    // (evaporating: the bracket reaches from beyond four dry radii down to within four dry radii of the core -- clamped by it or not)
+    const bool several = grows ? (f.RH_eff > T(1) && b > T(16) * rw2_old) : (a < T(16) * rd2 && rw2_old > T(16) * rd2);
     *suspicious = several;
     if (several) return true;
   }

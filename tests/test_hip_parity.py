@@ -1125,7 +1125,7 @@ def test_brackets_that_may_hold_several_roots_take_the_references_iterates():
     from_lean, from_toms = prod == lean, prod == toms
     assert (from_lean | from_toms).all(), int((~(from_lean | from_toms)).sum())
     # (this box is made of such droplets -- fresh aerosol activating at RH 1.01, droplets of a micrometre on nanometre cores: most of it
-    # is listed; bench.py's settled boxes list 0.05-0.08 %)
+    # is listed; bench.py's settled boxes list about 0.1 %)
     assert (~from_lean).sum() > 100 and (~from_toms).sum() > 100, ((~from_lean).sum(), (~from_toms).sum())
     far = np.abs(lean / toms - 1.) > 1e-4
     assert from_toms[far].all(), int((~from_toms[far]).sum())
