@@ -115,6 +115,21 @@ __global__ void k_sync_multi(sync_jobs<T> J)
 // ---- exclusive scan of u32 (three launches: per-tile scan, scan of tile sums, add) ----
 constexpr int SCAN_TILE = 2048;         // 256 threads x 8 items, items interleaved for coalescing
 
+// Inclusive prefix sum over the 64 lanes of a wave in SIX vector instructions: Hillis-Steele inside each row of 16 lanes with the data
+// parallel primitives' row shifts (lanes without a source keep their value: `old` = 0 is added), then the last lane of rows 0 and 2
+// broadcast into rows 1 and 3, then lane 31 into the upper half (row_bcast:15 / row_bcast:31, GFX9).  The same sums as the shuffle
+// form below (integer addition), which costs a cross-lane LDS instruction, the lane test and the add per step: ~30 vector + 6 LDS
+// instructions -- an eighth of k_cellrank_bkt's.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v)
+{
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xf, 0xf, false));     // row_shr:1
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xf, 0xf, false));     // row_shr:2
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xf, 0xf, false));     // row_shr:4
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xf, 0xf, false));     // row_shr:8
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+  return v;
+}
 // block-wide exclusive prefix of one value per thread (wave shuffles + LDS across the 4 waves)
 constexpr int SCAN_MAX_WAVES = 16;      // block_exclusive_scan serves workgroups of up to 1024 threads (k_scan_sums)
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t &total, uint32_t *lds /* SCAN_MAX_WAVES entries */)
@@ -565,9 +580,7 @@ k_cellrank_bkt(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start,
     uint32_t v[4], tsum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { v[k] = bkt[4 * threadIdx.x + k]; tsum += v[k]; }     // (counters behind m are zero)
-    uint32_t incl = tsum;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane_id()) >= d) incl += t; }
+    const uint32_t incl = wave_inclusive_scan(tsum);
     if (lane_id() == WAVE - 1) wsum[wave_id()] = incl;
     __syncthreads();
     uint32_t run = incl - tsum;
@@ -706,9 +719,7 @@ k_cellsort_wave(const uint32_t *big_list, uint32_t n_big, const uint32_t *cell_s
       uint32_t loc[CPL], sum = 0;
 #pragma unroll
       for (int j = 0; j < CPL; ++j) { loc[j] = cb[lane * CPL + j]; sum += loc[j]; }
-      uint32_t incl = sum;
-#pragma unroll
-      for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane) >= d) incl += t; }
+      const uint32_t incl = wave_inclusive_scan(sum);
       uint32_t run = incl - sum;
       wave_sync();
 #pragma unroll
@@ -785,9 +796,7 @@ k_cellsort_wave_bkt(const uint32_t *big_list, uint32_t n_big, const uint32_t *ce
     uint32_t loc[CPL], sum = 0;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) { loc[j] = cb[lane * CPL + j]; sum += loc[j]; }      // (counters behind nb are zero)
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (int(lane) >= d) incl += t; }
+    const uint32_t incl = wave_inclusive_scan(sum);
     uint32_t run = incl - sum;
     wave_sync();
 #pragma unroll
