@@ -850,6 +850,8 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
 // two kernels through HBM 5.5 + 7..8.8 ms.  Dense waves of "hard" droplets pay the maximum over 64 of them, which costs
 // more than the idle lanes it removes.  The growth rate as a real (noinline) function instead of ~20 inlined copies
 // (80 KB of code): 16.3 ms against 8.6 -- the call ABI's register shuffling costs far more than the instruction cache gains.
+// (the lean solvers' early out of a clamped bracket, see lean2_head: kappa RH far above the rounding of rd2^(3/2) - rd3)
+template <class F> LCX_HD bool lean_clamped_sign_change(const F &f) { return (f.rd3 - f.rd3_1mk) * f.RH_eff > decltype(f.rd3)(1e-12) * f.rd3; }
 // cond_common.ipp:197-337 up to and including the first two root-finder steps.  Returns true when `result` is final.
 template <class T, class F>
 LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter, toms_carry<T> &k, T &result,
@@ -875,8 +877,10 @@ LCX_HD bool advance_rw2_head_with(const F &f, T rw2_old, T rd3, T dt, T eps, T c
     // Fast arithmetic: a bracket that already meets the root finder's tolerance (a droplet near equilibrium) is answered with its
     // midpoint WITHOUT the function value at its far end.  The reference evaluates f there first and then returns either that very
     // midpoint (toms748's entry check, toms748.hpp:296-305) or rw2_old + drw2 (no sign change) -- the same number, the midpoint of
-    // [rw2_old, rw2_old + 2 drw2], to the last bit or the one before it.  Not taken when the dry radius clamps the lower end.
-    if (a == a_un && tol_reached(eps, a, b)) { result = (a + b) / 2; return true; }
+    // [rw2_old, rw2_old + 2 drw2], to the last bit or the one before it.  Round 5: also when the dry radius clamps the lower end -- at
+    // the dry radius the water activity is zero, the droplet would grow there, the reference finds the sign change and returns this
+    // very midpoint (see lean2_head; near-dry particles of no hygroscopicity: 60 % of bench.py's coal-stress box).
+    if (tol_reached(eps, a, b) && (a == a_un || lean_clamped_sign_change(f))) { result = (a + b) / 2; return true; }
   }
   T fa, fb;
   // the reference takes f(rw2_old) == drw2 at the near end of the bracket (cond_common.ipp:296-305)
@@ -946,8 +950,6 @@ template <class T> LCX_HD bool lean_converged(T d, T lim, T fc, T fs)
   if constexpr (sizeof(T) == 4) return d <= lim;
   else return d <= lim && fabs(fc) <= T(0.5) * fabs(fs);
 }
-// (the lean solvers' early out of a clamped bracket, see lean2_head: kappa RH far above the rounding of rd2^(3/2) - rd3)
-template <class F> LCX_HD bool lean_clamped_sign_change(const F &f) { return (f.rd3 - f.rd3_1mk) * f.RH_eff > decltype(f.rd3)(1e-12) * f.rd3; }
 template <class T, class F>
 LCX_HD T advance_rw2_lean_with(const F &f, T rw2_old, T rd3, T dt, T eps, T cond_mlt, unsigned n_iter)
 {
