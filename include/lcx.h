@@ -181,6 +181,16 @@ enum lcx_dbg {
                                           unconverged droplets handed to the workgroup's lowest lanes through LDS; the same rw2 bit for bit, not faster) */
   LCX_DBG_COND_NO_LIST = 1 << 20,      /* cond_solver = 0: no list of droplets for the reference's iterates (brackets that may hold several roots, k_cond_lean /
                                         * k_cond_lean_listed): the lean solver takes every droplet, as in rounds 3-4 */
+  LCX_DBG_COND_WQ = 1 << 21,           /* cond_solver = 0, measured and not adopted (round 6): k_cond_lean_wq -- a wave walks several batches of 64 storage slots and keeps
+                                        * the droplets whose first loop trip has not converged on a queue of its own in LDS, taking them up again 64 at a time
+                                        * (the same rw2 bit for bit; dbg_cond_budget & 255 = batches per wave) -- instead of k_cond_lean with its budget */
+  LCX_DBG_COND_WQ_CAP128 = 1 << 22,    /* k_cond_lean_wq with a queue of 128 entries per wave (its trips always on full waves; four workgroups per CU) instead of 96 */
+  LCX_DBG_COND_WQ_PF = 1 << 23,        /* k_cond_lean_wq issues the next batch's slot-indexed loads before it computes the current batch */
+  LCX_DBG_COND_WQ_PF2 = 1 << 24,       /* ... and its cell-indexed loads as well (queue of 128 entries, three waves per SIMD) */
+  LCX_DBG_COND_BUDGET = 1 << 25,       /* cond_solver = 0, measured and not adopted (round 6): the first pass gives every droplet's loop a budget of two trips
+                                        * (dbg_cond_budget & 255: that many); a droplet that has not converged by then leaves the loop's state in a record and
+                                        * k_cond_lean_resume goes on with it (the same bits; dbg_cond_budget >> 8: records per part, tests) */
+  LCX_DBG_COND_PROBE = 1 << 26,        /* measurement only: k_cond_lean cut short at seven stages, launched ahead of the real kernel (k_cond_probe: instruction counts per part) */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };

@@ -204,7 +204,7 @@ struct Particles : IParticles {
   uint32_t *sid() const { join_rank(); return sorted_id.p + sort_base; }
   uint32_t *sijk() const { join_rank(); return sorted_ijk.p + sort_base; }
   uint32_t *rnk() const { join_rank(); return rank.p; }
-  DevBuf<uint8_t> mig, cond_pre, wave_flag; DevBuf<uint32_t> defer_cnt, wg_mig, cond_listed;
+  DevBuf<uint8_t> mig, cond_pre, wave_flag, cond_records; DevBuf<uint32_t> defer_cnt, wg_mig, cond_listed;
   const bool use_wave_flags = !dbg(LCX_DBG_NO_WAVE_FLAGS);
   void alloc_mig() { mig.alloc((cap + BS - 1) / BS * BS + 16); mig_ids[0].alloc(cap); mig_ids[1].alloc(cap); wg_mig.alloc(3 * (size_t(nblk(cap)) + 1)); }      // (+ the two offset arrays)
   DevBuf<uint64_t> sort_scratch;
@@ -1125,8 +1125,9 @@ struct Particles : IParticles {
       // ahead of the loop), hskpng_Tpr, and in fast arithmetic the droplet-independent set-up of the growth rate
       Range r(this, "hskpng_Tpr");
       // (the last 16 words: the counter of k_cond_lean's list of droplets for the reference's iterates, see cond_list -- cleared with the rest)
-      if (fast) { cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>)); defer_cnt.alloc(DEFER_SHARDS * DEFER_CNT_STRIDE + 16); }
-      const int n_defer_words = DEFER_SHARDS * DEFER_CNT_STRIDE + 16;
+      // (two sets of DEFER_SHARDS counters, 64 B apart: the list of droplets for the reference's iterates and the records of the first pass's budget, see cond_list -- cleared here)
+      if (fast) { cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>)); defer_cnt.alloc(2 * DEFER_SHARDS * DEFER_CNT_STRIDE); }
+      const int n_defer_words = 2 * DEFER_SHARDS * DEFER_CNT_STRIDE;
       hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(std::max(nblk(ncell), nblk(size_t(n_defer_words)))), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p,
                          Tk.p, RH.p, eta.p, dv.p, lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
                          fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr,
@@ -1150,10 +1151,23 @@ struct Particles : IParticles {
         cond_list lst{nullptr, nullptr};
         bool listed = false;
         launch_listed = nullptr;               // (a call that threw between the two launches must not leave its second half behind)
-        if (!cond_toms && !dbg(LCX_DBG_COND_NO_LIST)) {
-          cond_listed.alloc(2 * std::max<size_t>(cap, std::max<size_t>(nphys, npart)));
-          lst = cond_list{cond_listed.p, defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE};
-        }
+        // round 6: in DEFER_SHARDS parts (one counter each), and the first pass's loop with a budget of trips -- a droplet that needs more
+        // is listed as well (k_cond_lean).  list_parts(): the part's capacity for a launch of `blocks` workgroups of `per_block` droplets
+        auto list_parts = [&](size_t blocks, size_t per_block) {
+          const size_t shard_cap = nblk(blocks, DEFER_SHARDS) * per_block;
+          cond_listed.alloc(2 * size_t(DEFER_SHARDS) * shard_cap);
+          // (the budget: measured and not adopted -- the first pass 3.0 -> 2.75 ms, its second pass 0.26 ms beside the ranking: the step as before)
+          const unsigned budget = !dbg(LCX_DBG_COND_BUDGET) || dbg(LCX_DBG_COND_WQ) ? 100u : o.dbg_cond_budget > 0 && (o.dbg_cond_budget & 255) ? unsigned(o.dbg_cond_budget & 255) : 2u;
+          cond_list l{cond_listed.p, defer_cnt.p, shard_cap, budget, nullptr, nullptr, 0u};
+          if (budget < 100u) {
+            // records for 3 % of the droplets (bench.py's settled boxes leave 1 %; dbg_cond_budget >> 8: a test's own capacity per part)
+            l.rec_cap = o.dbg_cond_budget > 255 ? uint32_t(o.dbg_cond_budget >> 8) : uint32_t(std::max<size_t>(256, shard_cap * 3 / 100));
+            cond_records.alloc(size_t(DEFER_SHARDS) * l.rec_cap * sizeof(lean_record<T>));
+            l.rec = cond_records.p; l.rcount = defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE;
+          }
+          return l;
+        };
+        const bool want_list = !cond_toms && !dbg(LCX_DBG_COND_NO_LIST);
         cond_in_storage_order = cond_storage_order;
         if (cond_in_storage_order) {
           a.storage_ijk = ijk.p; a.xcd_group = xcd_group(nphys, ncell);
@@ -1172,19 +1186,55 @@ struct Particles : IParticles {
           // what a launch costs is the lanes that compute, not the instructions that issue; see k_cond_lean_fold)
           else if (dbg(LCX_DBG_COND_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (dbg(LCX_DBG_COND_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false>), gs, bl, 0, st, nphys, a, T(0));
-          else if (kpa_uniform) { hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value, lst); listed = lst.ent != nullptr; }
-          else { hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0), lst); listed = lst.ent != nullptr; }
+          else if (!dbg(LCX_DBG_COND_WQ)) {
+            if (dbg(LCX_DBG_COND_PROBE) && kpa_uniform) {      // (measurement only, see k_cond_probe)
+              hipLaunchKernelGGL((k_cond_probe<T, 0>), gs, bl, 0, st, nphys, a, kpa_value); hipLaunchKernelGGL((k_cond_probe<T, 1>), gs, bl, 0, st, nphys, a, kpa_value);
+              hipLaunchKernelGGL((k_cond_probe<T, 2>), gs, bl, 0, st, nphys, a, kpa_value); hipLaunchKernelGGL((k_cond_probe<T, 3>), gs, bl, 0, st, nphys, a, kpa_value);
+              hipLaunchKernelGGL((k_cond_probe<T, 4>), gs, bl, 0, st, nphys, a, kpa_value); hipLaunchKernelGGL((k_cond_probe<T, 5>), gs, bl, 0, st, nphys, a, kpa_value);
+              hipLaunchKernelGGL((k_cond_probe<T, 6>), gs, bl, 0, st, nphys, a, kpa_value);
+            }
+            if (want_list) lst = list_parts(gs.x, BS);
+            if (want_list && lst.budget == 2u) {                // (the production form: its two trips as straight-line code)
+              if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 0, 2>), gs, bl, 0, st, nphys, a, kpa_value, lst);
+              else hipLaunchKernelGGL((k_cond_lean<T, 15, false, 0, 2>), gs, bl, 0, st, nphys, a, T(0), lst);
+            }
+            else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value, lst);
+            else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0), lst);
+            listed = lst.ent != nullptr;
+          }
+          else {
+            // round 6: a wave walks n_batch batches of 64 slots and keeps the droplets whose first loop trip has not converged on a queue
+            // of its own in LDS (k_cond_lean_wq: the same bits).  dbg_cond_budget > 0: that many batches (tests, measurements)
+            const unsigned chunks = nblk(nphys);
+            unsigned nb = 8u;
+            while (nb > 1 && chunks / nb < 2048u) nb /= 2;           // (a small box: enough workgroups to fill the device first)
+            if (o.dbg_cond_budget > 0 && (o.dbg_cond_budget & 255)) nb = unsigned(o.dbg_cond_budget & 255);
+            a.xcd_group = std::max(1u, a.xcd_group / nb);
+            const dim3 gw((chunks + nb - 1) / nb);
+            if (want_list) { lst = list_parts(gw.x, size_t(BS) * nb); lst.budget = 100u; }      // (its queue takes the droplets that need more trips)
+            const T kv = kpa_uniform ? kpa_value : T(0);
+            launch_cond_lean_wq<T>(gw, st, wq_params<T>{nphys, a, kv, lst, nb}, kpa_uniform, dbg(LCX_DBG_COND_WQ_CAP128) ? 128 : 96, dbg(LCX_DBG_COND_WQ_PF2) ? 2 : dbg(LCX_DBG_COND_WQ_PF) ? 1 : 0);
+            listed = lst.ent != nullptr;
+          }
         }
         else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0));
-        else { hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
+        else { if (want_list) lst = list_parts(gr.x, BS); hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
         // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell
         // finish -- launched BEHIND the fork of the in-cell ranking below, so that its few thousand waves run next to the ranking's
         if (listed) {
           const bool uni = kpa_uniform && cond_in_storage_order;
           const T kv = uni ? kpa_value : T(0);
           launch_listed = [this, a, lst, uni, kv, bl]() {
-            if (uni) hipLaunchKernelGGL((k_cond_lean_listed<T, true>), dim3(2048), bl, 0, st, a, lst, kv);
-            else hipLaunchKernelGGL((k_cond_lean_listed<T, false>), dim3(2048), bl, 0, st, a, lst, kv);
+            // (the host does not know the counts: workgroups for 3 % of the droplets -- the settled boxes list 1 % -- at a droplet per lane,
+            // more droplets by the stride; a workgroup that finds nothing leaves at once)
+            const unsigned per_part = unsigned(std::min<size_t>(2048, std::max<size_t>(8, lst.shard_cap / 400 / BS + 1)));
+            if (lst.rec) {
+              const unsigned n_resume = DEFER_SHARDS * ((lst.rec_cap + BS - 1) / BS);
+              if (uni) hipLaunchKernelGGL((k_cond_lean_resume<T, true>), dim3(n_resume), bl, 0, st, a, lst, kv);
+              else hipLaunchKernelGGL((k_cond_lean_resume<T, false>), dim3(n_resume), bl, 0, st, a, lst, kv);
+            }
+            if (uni) hipLaunchKernelGGL((k_cond_lean_listed<T, true>), dim3(DEFER_SHARDS * per_part), bl, 0, st, a, lst, kv);
+            else hipLaunchKernelGGL((k_cond_lean_listed<T, false>), dim3(DEFER_SHARDS * per_part), bl, 0, st, a, lst, kv);
           };
         }
       }
@@ -2068,7 +2118,18 @@ struct Particles : IParticles {
     }
     else if (s == "raw_cond_listed") {             // droplets that the last condensation substep handed to the reference's iterates (cond_list)
       unsigned long long c = 0;
-      if (defer_cnt.p && defer_cnt.n >= size_t(DEFER_SHARDS * DEFER_CNT_STRIDE + 16)) c = d2h(defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE, 1)[0];
+      if (defer_cnt.p && defer_cnt.n >= size_t(DEFER_SHARDS * DEFER_CNT_STRIDE) && o.cond_solver == 0) {
+        auto h = d2h(defer_cnt.p, size_t(DEFER_SHARDS * DEFER_CNT_STRIDE));
+        for (int sh = 0; sh < DEFER_SHARDS; ++sh) c += h[size_t(sh) * DEFER_CNT_STRIDE];
+      }
+      v.assign(1, c);
+    }
+    else if (s == "raw_cond_resumed") {            // droplets whose loop the last condensation substep's first pass left to k_cond_lean_resume (its budget)
+      unsigned long long c = 0;
+      if (defer_cnt.p && defer_cnt.n >= size_t(2 * DEFER_SHARDS * DEFER_CNT_STRIDE) && o.cond_solver == 0) {
+        auto h = d2h(defer_cnt.p + DEFER_SHARDS * DEFER_CNT_STRIDE, size_t(DEFER_SHARDS * DEFER_CNT_STRIDE));
+        for (int sh = 0; sh < DEFER_SHARDS; ++sh) c += h[size_t(sh) * DEFER_CNT_STRIDE];
+      }
       v.assign(1, c);
     }
     else if (s == "raw_n") { auto h = d2h(A.n.p, nphys); v.assign(h.begin(), h.end()); }

@@ -11,35 +11,9 @@
 // for the condensation root finder).
 #pragma once
 #include "lcx_math.hpp"
+#include "lcx_cond_wq.hpp"
 
 namespace lcx {
-
-constexpr int BS = 256;                 // 4 waves per workgroup
-constexpr int WAVE = 64;
-
-// (BS, not blockDim.x: every kernel that calls gid() / gid_xcd() is launched with BS threads, and the run-time value is a vector load from
-// the dispatch packet with a full memory round trip ahead of the kernel's first own load -- one dependent level per wave, round 5)
-__device__ __forceinline__ size_t gid() { return size_t(blockIdx.x) * BS + threadIdx.x; }
-// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8; every XCD has its own 4 MiB L2).  gid_xcd hands each
-// XCD runs of XCD_GROUP consecutive workgroups of the walk instead of every 8th one, so that the gathers of neighbouring cells
-// (droplets that changed cell since the storage was last put in cell order sit in the neighbours' ranges) meet in ONE L2.
-// Measured on k_cond_fast, C3 (ms): plain order 7.60; groups of 4: 7.77, 16: 7.31, 64: 7.15, 128..1024: 7.11..7.13, 8192: 7.22, one
-// contiguous eighth per XCD: 7.33.  k_coal, k_move and k_scatter_sorted gain nothing (+-1 %; k_coal loses 17 % with eighths).
-// The run length follows the cells: xcd_group() = the workgroups of ~2048 cells (C3: 512 workgroups; C5, 512 SDs per cell: 4096).
-__host__ __device__ __forceinline__ unsigned xcd_group(size_t n_part, size_t n_cell)
-{
-  const size_t g = (n_part / (n_cell ? n_cell : 1) + 1) * 2048 / BS;
-  return unsigned(g < 64 ? 64 : g > 8192 ? 8192 : g);
-}
-__device__ __forceinline__ size_t gid_xcd(unsigned group)
-{
-  const unsigned W = 8u * group;
-  const unsigned b = blockIdx.x, w = b / W;
-  const unsigned t = (w + 1) * W <= gridDim.x ? w * W + (b % 8u) * group + (b % W) / 8u : b;      // (the ragged tail keeps its order)
-  return size_t(t) * BS + threadIdx.x;
-}
-__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (WAVE - 1); }
-__device__ __forceinline__ unsigned wave_id() { return threadIdx.x / WAVE; }
 
 // ============================================================================================
 // generic helpers
@@ -261,7 +235,7 @@ __global__ void k_init_dv(size_t n_cell, T *dv, int ny, int nz, T dx, T dy, T dz
 // housekeeping: cell index, sort
 // ============================================================================================
 struct grid_t { int nx, ny, nz, ndims; double dx, dy, dz; };
-constexpr uint32_t DEAD_CELL = 0xFFFFFFFFu;   // ijk of a super-droplet with n == 0 that has not been compacted away yet
+// (DEAD_CELL, the ijk of a super-droplet with n == 0 that has not been compacted away yet: lcx_cond_wq.hpp)
 
 // hskpng_ijk.ipp:159-200,33-82: size_t(double(x)/double(dx)), z fastest
 template <class T>
@@ -1017,22 +991,7 @@ __global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, cons
 // rw2, rd3, kpa, vt, n (gathers, near-coalesced while storage order ~ cell order), 8 cell fields
 // (wave broadcast).  Writes rw2 and the SD's contribution(s) to the 3rd wet moment into position-ordered
 // scratch (coalesced) for the order-preserving per-cell sum of k_cond_cellfinish.
-template <class T>
-struct cond_args {
-  const uint32_t *sorted_id, *sorted_ijk;
-  const n_t *n; const T *rd3, *kpa, *vt; T *rw2;
-  const T *rhod, *rv, *Tk, *eta, *RH, *lambda_D, *lambda_K;
-  T *m3_before, *m3_after;
-  T dt_sub, RH_max, eps, cond_mlt; unsigned n_iter; int first; size_t n_cell;
-  unsigned xcd_group;     // workgroups per XCD run (gid_xcd)
-  const T *ssp;           // turb_cond: SGS supersaturation perturbation of the SD added to the cell's RH (RH_sgs), else nullptr
-  const cond_cell_fast<T> *pre;   // fast arithmetic without turb_cond: the droplet-independent set-up, per cell (k_cond_cellpre)
-  const uint32_t *storage_ijk;    // k_cond_lean in storage order (see there), else nullptr
-  // the scatter of the re-sort that the end of the previous step left undone (k_scatter_sorted's two loads and two stores per droplet),
-  // carried by the storage-order condensation kernel, whose memory pipes idle while its vector ALU is the bottleneck; else sc_rank == nullptr
-  const uint32_t *sc_rank, *sc_cell_start; uint32_t *sc_sorted_id, *sc_sorted_ijk;
-  unsigned fold_cap;      // k_cond_lean_fold: slots of its LDS stage in use (<= FOLD_CAP; smaller only in tests, opts_init.dbg_cond_budget)
-};
+// (cond_args: lcx_cond_wq.hpp)
 template <class T>
 __global__ void k_cond_cellpre(size_t n_cell, const T *rhod, const T *rv, const T *Tk, const T *eta, const T *RH, const T *lambda_D,
                                const T *lambda_K, T RH_max, cond_cell_fast<T> *pre)
@@ -1143,7 +1102,7 @@ template <class T> __device__ __forceinline__ T rw2_to_rw3_signed(T x) { return 
 // The list is kept in DEFER_SHARDS parts, workgroup b appending to part b % DEFER_SHARDS with the part's own counter (one counter
 // for everybody saturates at ~90 appends per microsecond -- with a few per cent of stragglers nearly every wave appends, and the
 // first pass went from 7.8 to 25 ms); part s can hold every position of the workgroups that feed it, so it cannot overflow.
-constexpr int DEFER_SHARDS = 64, DEFER_CNT_STRIDE = 16;               // counters 64 B apart
+// (DEFER_SHARDS, DEFER_CNT_STRIDE: lcx_cond_wq.hpp)
 struct cond_defer { uint32_t *list, *count; size_t shard_cap; unsigned budget; };      // budget 0: no deferral (a single pass with the full budget)
 // one droplet; returns true when it was set aside for the second pass
 template <class T, int OPT, bool SECOND>
@@ -1225,9 +1184,11 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // its change (what the carried scatter made of its rank: the rank buffer itself is the in-cell ranking's OUTPUT, and that ranking runs
 // on its side stream next to k_cond_lean_listed); room for every droplet -- a list that could overflow would make WHO is listed depend
 // on the order in which the atomics are served; count: the entries
-struct cond_list { uint32_t *ent, *count; };
-template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0>
-__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0), cond_list lst = cond_list{nullptr, nullptr})
+// (struct cond_list: lcx_cond_wq.hpp)
+// BUDGET (SOLVER 0 with a list): loop trips of this pass as a compile-time number -- the trips are then straight-line code (a loop's
+// back edge copies the five reals of its state: 34 vector instructions per wave in the run-time form); 0: lst.budget at run time
+template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0, int BUDGET = 0>
+__global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0), cond_list lst = cond_list{nullptr, nullptr, 0, 0u, nullptr, nullptr, 0u})
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
   // attributes and the change (m3_after, storage-indexed; the per-cell finish gathers it through sorted_id) are read and written
@@ -1280,7 +1241,38 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     T r;
     if constexpr (SOLVER == 2) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     else if constexpr (SOLVER == 1) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
-    else r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, &several, lst.ent != nullptr);
+    else {
+      // (round 6) with records: the loop has a BUDGET of trips; a droplet that has not converged by then leaves the loop's state where it
+      // stands in a record and k_cond_lean_resume goes on with it (lean2_loop is resumable: the same bits) -- the wave no longer waits
+      // for its slowest droplet (cond_list)
+      lean_state<T> s;
+      T rd2 = 0;
+      const bool ask = lst.ent != nullptr, budgeted = lst.rec != nullptr;
+      if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2, &several, ask)) {
+        const unsigned budget = BUDGET > 0 ? unsigned(BUDGET) : budgeted ? lst.budget : a.n_iter;
+        bool done = lean2_loop(ff, a.eps, budget, s, r);
+        if (budgeted && !done) {
+          // (the lanes of this branch that go on: one atomic per wave that has any; `resumed` says that the record found room)
+          const unsigned long long bs = __ballot(true);
+          const int leader = __ffsll((long long)bs) - 1;
+          const unsigned shard = blockIdx.x % DEFER_SHARDS;
+          uint32_t base = 0;
+          if (int(lane_id()) == leader) base = atomicAdd(lst.rcount + shard * DEFER_CNT_STRIDE, uint32_t(__popcll(bs)));
+          base = __shfl(base, leader);
+          const uint32_t e = base + uint32_t(__popcll(bs & ((1ull << lane_id()) - 1ull)));
+          if (e < lst.rec_cap) {
+            lean_record<T> *rc = static_cast<lean_record<T> *>(lst.rec) + (size_t(shard) * lst.rec_cap + e);
+            const bool grows = s.b != rw2_old;            // (shrinking: b = rw2_old + 0, growing: a = max(rd2, rw2_old + 0), see lean2_head)
+            rc->v[0] = s.x0; rc->v[1] = s.f0; rc->v[2] = s.x1; rc->v[3] = s.f1; rc->v[4] = s.c;
+            rc->v[5] = grows ? s.b : s.a; rc->v[6] = grows ? -rd2 : rd2;
+            rc->idx = a.storage_ijk ? id : uint32_t(m3_pos); rc->m3_pos = uint32_t(m3_pos);
+            return;                                       // (its rw2 and its change: k_cond_lean_resume)
+          }
+          lean2_loop(ff, a.eps, a.n_iter - budget, s, r);      // (no room: on in its own lane)
+        }
+        r = lean2_tail(s, r, rd2);
+      }
+    }
     if (!several) {
       a.rw2[id] = r;
       // n (rw_new^3 - rw_old^3), the radii in the growth rate's own form rw2 * rsqrt(rw2) (its first evaluation has the old one already)
@@ -1292,11 +1284,12 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     if (bal) {
       const int leader = __ffsll((long long)bal) - 1;
       uint32_t base = 0;
-      if (int(lane_id()) == leader) base = atomicAdd(lst.count, uint32_t(__popcll(bal)));
+      const unsigned shard = blockIdx.x % DEFER_SHARDS;
+      if (int(lane_id()) == leader) base = atomicAdd(lst.count + shard * DEFER_CNT_STRIDE, uint32_t(__popcll(bal)));
       base = __shfl(base, leader);
       // (the kernel's own index of the droplet, from what is live anyway: the storage slot is `id`, the position in the sorted order `m3_pos`)
       if (several) {
-        const size_t q = 2 * size_t(base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull))));
+        const size_t q = 2 * (size_t(shard) * lst.shard_cap + base + uint32_t(__popcll(bal & ((1ull << lane_id()) - 1ull))));
         lst.ent[q] = a.storage_ijk ? id : uint32_t(m3_pos); lst.ent[q + 1] = uint32_t(m3_pos);
         return;                                                  // (its change: k_cond_lean_listed)
       }
@@ -1304,14 +1297,68 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
   }
   a.m3_after[m3_pos] = delta;
 }
+// MEASUREMENT ONLY (opts_init.dbg_flags & COND_PROBE): k_cond_lean<T, 15, true, 0> cut short at STAGE, launched ahead of the real kernel on
+// the same inputs and writing only the scratch m3_before -- the vector instructions that each part of the kernel issues, read off the
+// counters of consecutive stages (tools/pmc_steady.sh; profiles/r06_cond_stages.txt).  0: the two load levels and the stores; 1: + the set-up
+// and the near end's evaluation; 2: + the rest of the head (bracket, far end, first secant point); 3 / 4 / 5: + one / two / all loop trips; 6: +
+// the change of n rw^3 (the whole kernel but its list)
+template <class T, int STAGE>
+__global__ void __launch_bounds__(BS) k_cond_probe(size_t n_part, cond_args<T> a, T kpa_uniform)
+{
+  const size_t pos = gid_xcd(a.xcd_group); if (pos >= n_part) return;
+  const uint32_t id = uint32_t(pos), c = a.storage_ijk[pos];
+  uint32_t rk = 0;
+  if (a.sc_rank) rk = a.sc_rank[pos];
+  T rw2_old = a.rw2[pos], rd3 = a.rd3[pos], vt = a.vt[pos], kpa = kpa_uniform;
+  const n_t n_raw = a.n[pos];
+  asm volatile("" ::: "memory");
+  if (c == DEAD_CELL) return;
+  uint32_t cs = 0;
+  if (a.sc_rank) cs = a.sc_cell_start[c];
+  cond_cell_fast<T> cc = a.pre[c];
+  asm volatile("" ::: "memory");
+  const size_t m3_pos = a.sc_rank ? size_t(cs) + rk : pos;
+  T nn = T(n_raw);
+  asm volatile("" : "+v"(rw2_old), "+v"(rd3), "+v"(vt), "+v"(nn), "+v"(cc.Sc), "+v"(cc.Pr), "+v"(cc.lambda_D), "+v"(cc.lambda_K),
+               "+v"(cc.A), "+v"(cc.RH_eff), "+v"(cc.c1), "+v"(cc.c2_rho), "+v"(cc.RH_rho_w));
+  asm volatile("" : "+v"(cc.two_rho_eta));
+  T out = nn + rw2_old + rd3 + vt + cc.Sc + cc.Pr + cc.lambda_D + cc.lambda_K + cc.A + cc.RH_eff + cc.c1 + cc.c2_rho + cc.RH_rho_w + cc.two_rho_eta + T(id);
+  if constexpr (STAGE >= 1) {
+    out = nn;
+    if (!(rw2_old <= 0)) {
+      cond_fun_fast<T, 15> ff;
+      ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+      if constexpr (STAGE == 1) out = a.dt_sub * ff.drw2_dt(rw2_old);
+      else {
+        lean_state<T> s;
+        T r, rd2 = 0;
+        bool several = false;
+        if (!lean2_head(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, s, r, rd2, &several, true)) {
+          if constexpr (STAGE >= 3) {
+            lean2_loop(ff, a.eps, STAGE == 3 ? 1u : STAGE == 4 ? 2u : a.n_iter, s, r);
+            r = lean2_tail(s, r, rd2);
+          }
+        }
+        out = r;
+        if constexpr (STAGE >= 6) out = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+      }
+    }
+  }
+  a.m3_before[m3_pos] = out;
+}
+
 // the listed droplets of k_cond_lean through TOMS748 on the same growth-rate arithmetic (what k_cond_lean<T, 15, UNI, 2> computes for them,
 // bit for bit): a grid-stride walk over the list, a droplet per lane
 template <class T, bool UNI>
-__global__ void __launch_bounds__(BS) k_cond_lean_listed(cond_args<T> a, cond_list lst, T kpa_uniform)
+__device__ __forceinline__ void cond_lean_listed(const cond_args<T> &a, const cond_list &lst, T kpa_uniform, unsigned block, unsigned n_blocks)
 {
-  const uint32_t n = *lst.count;
-  for (size_t q = gid(); q < n; q += size_t(gridDim.x) * BS) {
-    const uint32_t pos = lst.ent[2 * q], m3_pos = lst.ent[2 * q + 1];
+  // workgroup b walks part b % DEFER_SHARDS with the stride of the workgroups that share it (the host does not know the counts):
+  // consecutive lanes take consecutive entries, and a wave's entries are the droplets of a few neighbouring waves of the first pass
+  const unsigned shard = block % DEFER_SHARDS;
+  const uint32_t n = lst.count[shard * DEFER_CNT_STRIDE];
+  const uint32_t *part = lst.ent + 2 * size_t(shard) * lst.shard_cap;
+  for (size_t q = size_t(block / DEFER_SHARDS) * BS + threadIdx.x; q < n; q += size_t(n_blocks / DEFER_SHARDS) * BS) {
+    const uint32_t pos = part[2 * q], m3_pos = part[2 * q + 1];
     uint32_t id, c;
     if (a.storage_ijk) { id = pos; c = a.storage_ijk[pos]; }
     else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
@@ -1324,6 +1371,47 @@ __global__ void __launch_bounds__(BS) k_cond_lean_listed(cond_args<T> a, cond_li
     a.m3_after[m3_pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
   }
 }
+
+// the records of k_cond_lean's first pass (droplets whose loop had not converged within its budget): the loop goes on where it stands,
+// a droplet per lane, consecutive lanes on consecutive records of a part -- the droplets of a few neighbouring waves of the first pass.
+// The droplet's attributes and its cell's constants are read again and set up with the same expressions: the same bits.
+template <class T, bool UNI>
+__device__ __forceinline__ void cond_lean_resume(const cond_args<T> &a, const cond_list &lst, T kpa_uniform, unsigned block, unsigned n_blocks)
+{
+  const unsigned shard = block % DEFER_SHARDS;
+  const uint32_t cnt = lst.rcount[shard * DEFER_CNT_STRIDE];
+  const uint32_t n = cnt < lst.rec_cap ? cnt : lst.rec_cap;
+  const lean_record<T> *part = static_cast<const lean_record<T> *>(lst.rec) + size_t(shard) * lst.rec_cap;
+  for (size_t q = size_t(block / DEFER_SHARDS) * BS + threadIdx.x; q < n; q += size_t(n_blocks / DEFER_SHARDS) * BS) {
+    const lean_record<T> rc = part[q];
+    const uint32_t pos = rc.idx, m3_pos = rc.m3_pos;
+    uint32_t id, c;
+    if (a.storage_ijk) { id = pos; c = a.storage_ijk[pos]; }
+    else { id = a.sorted_id[pos]; c = a.sorted_ijk[pos]; }
+    const T rw2_old = a.rw2[id], rd3 = a.rd3[id], vt = a.vt[id], kpa = UNI ? kpa_uniform : a.kpa[id], nn = T(a.n[id]);
+    const cond_cell_fast<T> cc = a.pre[c];
+    cond_fun_fast<T, 15> ff;
+    ff.setup_cell(cc, rw2_old, a.dt_sub, rd3, kpa, vt);
+    lean_state<T> s;
+    s.x0 = rc.v[0]; s.f0 = rc.v[1]; s.x1 = rc.v[2]; s.f1 = rc.v[3]; s.c = rc.v[4];
+    const T far = rc.v[5], rd2s = rc.v[6];
+    const bool grows = __builtin_signbit(rd2s);
+    const T rd2 = fabs(rd2s);
+    s.a = grows ? mx(rd2, rw2_old) : far; s.b = grows ? far : rw2_old;
+    T r = s.c;
+    lean2_loop(ff, a.eps, a.n_iter - lst.budget, s, r);
+    r = lean2_tail(s, r, rd2);
+    a.rw2[id] = r;
+    a.m3_after[m3_pos] = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+  }
+}
+
+// (Measured and dropped: both in ONE launch, the first workgroups on the records and the others on the list -- 0.49 ms beside the in-cell
+// ranking against 0.26 + 0.12 for the two launches.)
+template <class T, bool UNI>
+__global__ void __launch_bounds__(BS) k_cond_lean_listed(cond_args<T> a, cond_list lst, T kpa_uniform) { cond_lean_listed<T, UNI>(a, lst, kpa_uniform, blockIdx.x, gridDim.x); }
+template <class T, bool UNI>
+__global__ void __launch_bounds__(BS) k_cond_lean_resume(cond_args<T> a, cond_list lst, T kpa_uniform) { cond_lean_resume<T, UNI>(a, lst, kpa_uniform, blockIdx.x, gridDim.x); }
 
 // Round 5, measured and kept behind opts_init.dbg_flags & COND_FOLD: the lean kernel with its workgroup FOLDED behind the solver's first
 // loop trip.  Evaluations per droplet (below): 1 for the 7 % that take an early out, 3 for 72 % (near end, far end, the first secant point,

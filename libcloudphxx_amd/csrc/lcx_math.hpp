@@ -397,6 +397,33 @@ template <class T> LCX_HD T S_cr(T rd3, T kappa, T Tk)
   return a_w(rw3, rd3, kappa) * exp(kelvin_A(Tk) / T(cbrt(rw3)));
 }
 
+// Constant tables in a kernel that LOOPS over batches of droplets (k_cond_lean_wq).  Left alone, the compiler hoists the loop-invariant
+// scalar loads of every table of every inlined growth-rate evaluation in front of the loop and holds them in scalar registers through
+// it -- 66 of the 102 there are; the kernel's pointers then live in lanes of a vector register (v_readlane: vector issue slots).  A table
+// pointer that went through an empty asm statement (lcx_tab<true>) is a new value as far as the compiler can tell, so its loads stay inside
+// the loop's trip.  WHERE inside matters as much: a coefficient that is loaded in the basic block that uses it reaches the Horner step
+// through two v_mov_b32 and a v_fmac_f64; loaded in a DOMINATING block it is the scalar operand of a v_fma_f64 (measured: the kernel
+// issued 612 vector instructions per 64 droplets either way until its tables were loaded at the top of the trip -- lcx_tab_touch -- and
+// handed down to the evaluations as pointers, cond_fun_fast::t_expk / t_cbrt).
+#if defined(__HIP_DEVICE_COMPILE__)
+template <bool FRESH> __device__ __forceinline__ const double *lcx_tab(const double *p)
+{
+  if constexpr (FRESH) {
+    const double __attribute__((address_space(4))) *q = (const double __attribute__((address_space(4))) *)p;
+    asm volatile("" : "+s"(q));
+    return (const double *)q;
+  }
+  return p;
+}
+// the loads of c[0 .. N-1], here and now (later loads of the same addresses are these)
+template <int N> __device__ __forceinline__ void lcx_tab_touch(const double *c)
+{
+  static_assert(N == 5 || N == 14, "the tables of the growth rate");
+  if constexpr (N == 5) asm volatile("" :: "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]));
+  else asm volatile("" :: "s"(c[0]), "s"(c[1]), "s"(c[2]), "s"(c[3]), "s"(c[4]), "s"(c[5]), "s"(c[6]), "s"(c[7]), "s"(c[8]), "s"(c[9]), "s"(c[10]),
+                    "s"(c[11]), "s"(c[12]), "s"(c[13]));
+}
+#endif
 // ---- condensational growth: condensation/common/particles_impl_cond_common.ipp:80-338,
 //      maxwell-mason.hpp:15-47, ventil.hpp:16-80
 // Everything that does not depend on the trial radius is evaluated ONCE per super-droplet
@@ -572,10 +599,9 @@ __device__ __constant__ double lcx_expk_c[14] = {
   2.08767569878681e-09, 1.6059043836821613e-10, 2.755731922398589e-07, 2.505210838544172e-08, 2.48015873015873e-05, 2.7557319223985893e-06,
   1.3888888888888889e-03, 1.984126984126984e-04, 4.1666666666666664e-02, 8.333333333333333e-03, 1.6666666666666666e-01};
 #endif
-LCX_HD double exp_kelvin(double x)
-{
 #if defined(__HIP_DEVICE_COMPILE__)
-  const double *c = lcx_expk_c;
+__device__ __forceinline__ double exp_kelvin_c(double x, const double *c)         // (c: lcx_expk_c, or its image behind lcx_tab<true>)
+{
   const double k = __builtin_rint(x * c[0]);
   double r = __builtin_fma(-k, c[1], x);
   r = __builtin_fma(-k, c[2], r);
@@ -595,6 +621,12 @@ LCX_HD double exp_kelvin(double x)
   // 1 + r + r^2 (pe + r po)
   const double p = __builtin_fma(r2, __builtin_fma(po, r, pe), r) + 1.0;
   return __builtin_ldexp(p, int(k));
+}
+#endif
+LCX_HD double exp_kelvin(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return exp_kelvin_c(x, lcx_expk_c);
 #else
   return exp(x);
 #endif
@@ -631,9 +663,9 @@ LCX_HD float exp_reduced(float x) { return exp(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __constant__ double lcx_logl_c[14] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
                                                  1.0 / 3.0, 0.70710678118654752, 6.93147180369123816490e-01, 1.90821492927058770002e-10};
-LCX_HD double log_lean_core(double x)               // positive normal x is the caller's business
+template <bool FRESH = false> LCX_HD double log_lean_core(double x)               // positive normal x is the caller's business
 {
-  const double *c = lcx_logl_c;                      // (coefficients through the scalar cache, see exp_kelvin)
+  const double *c = lcx_tab<FRESH>(lcx_logl_c);                      // (coefficients through the scalar cache, see exp_kelvin)
   int e = __builtin_amdgcn_frexp_exp(x);
   double m = __builtin_amdgcn_frexp_mant(x);                     // [0.5, 1)
   if (m < c[11]) { m = m + m; e -= 1; }
@@ -733,7 +765,9 @@ __device__ __constant__ double lcx_cbrt1p_c[5] = {1. / 3, -1. / 9, 5. / 81, -10.
 template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the form the per-particle kernels and turb_cond use)
   static constexpr int fast_div = (OPT & 1) ? 2 : 1;      // the root finder may use refined reciprocals (t748 above)
   static constexpr bool trim = (OPT & 8) != 0 && sizeof(T) == 8;
+  static constexpr bool fresh = (OPT & 16) != 0;         // (a kernel that loops over batches of droplets: see lcx_tab)
   T rw2_old, dt, rd3, rd3_1mk, c_Re, Sc, Pr, lambda_D, lambda_K, A, RH_eff, c1, c2_rho, RH_rho_w;
+  const double *t_expk = nullptr, *t_cbrt = nullptr;     // (fresh: the tables' images that the kernel loaded at the top of its trip)
   LCX_HD void setup(const cond_fun<T> &f)
   {
     using c = cst<T>;
@@ -779,8 +813,8 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
       // cbrt_signed_core there.
 #if defined(__HIP_DEVICE_COMPILE__)
       const T xS = rw * Sc, xN = rw * Pr;                // (Sc, Pr hold c_Re Sc, c_Re Pr)
-      const double *q = lcx_cbrt1p_c;                  // (coefficients through the scalar cache, see exp_kelvin)
-      klv = exp_kelvin(A * irw);
+      const double *q = fresh ? t_cbrt : lcx_cbrt1p_c;  // (coefficients through the scalar cache, see exp_kelvin)
+      if constexpr (fresh) klv = exp_kelvin_c(A * irw, t_expk); else klv = exp_kelvin(A * irw);
       if (T(__builtin_fmax(fabs(xS), fabs(xN))) < T(0x1p-8)) {
         Sh = T(2) + xS * (T(q[0]) + xS * (T(q[1]) + xS * (T(q[2]) + xS * (T(q[3]) + xS * T(q[4])))));
         Nu = T(2) + xN * (T(q[0]) + xN * (T(q[1]) + xN * (T(q[2]) + xN * (T(q[3]) + xN * T(q[4])))));
@@ -789,7 +823,10 @@ template <class T, int OPT = 0> struct cond_fun_fast {      // (OPT = 0: the for
         T cS, cN;
         if (aS >= T(0.125) && aN >= T(0.125)) { cS = cbrt_seeded_core(aS); cN = cbrt_seeded_core(aN); }
         else { cS = cbrt_signed_core(aS); cN = cbrt_signed_core(aN); }      // (a droplet whose vt is flagged invalid, -1: see below)
-        const T m = (Re > T(1)) ? mx(T(1), T(pow_core(Re, T(.077)))) : T(1);
+        T m = T(1);
+        if (Re > T(1)) {
+          if constexpr (fresh) m = mx(T(1), T(exp_kelvin_c(T(.077) * log_lean_core<true>(Re), t_expk))); else m = mx(T(1), T(pow_core(Re, T(.077))));
+        }
         Sh = T(1) + cS * m; Nu = T(1) + cN * m;
       }
 #else

@@ -110,6 +110,12 @@ class dbg(enum.IntFlag):
     RANK_BY_COUNTING = 1 << 18
     COND_FOLD = 1 << 19
     COND_NO_LIST = 1 << 20
+    COND_WQ = 1 << 21
+    COND_WQ_CAP128 = 1 << 22
+    COND_WQ_PF = 1 << 23
+    COND_WQ_PF2 = 1 << 24
+    COND_BUDGET = 1 << 25
+    COND_PROBE = 1 << 26
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -1070,8 +1070,16 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
     # droplets in their own lanes: every droplet's numbers see the same operations in all of them)
     # (late round 5: the production kernel hands the droplets whose bracket may hold several roots to TOMS748, cond_list; the variants
     # compared HERE are kernels around the lean solver alone -- COND_NO_LIST in all of them; the list has its own test below)
+    # (round 6: COND_WQ is k_cond_lean_wq -- a wave walks several batches of 64 storage slots and keeps the droplets whose first loop
+    # trip has not converged on a queue of its own in LDS, taking them up again 64 at a time; dbg_cond_budget = the batches per wave (a box
+    # this small gets one by default: the queue then only empties at the wave's end), COND_WQ_CAP128 the longer queue, COND_WQ_PF / _PF2
+    # the next batch's loads issued ahead.  Measured, not adopted.  Every droplet's numbers see the same operations in all of them)
     FO, NL = int(lgrngn.dbg.COND_FOLD), int(lgrngn.dbg.COND_NO_LIST)
-    for flags, budget in ((0, 0), (int(lgrngn.dbg.KPA_ARRAY), 0), (int(lgrngn.dbg.COND_LEAN_R3), 0), (FO, 0), (FO | int(lgrngn.dbg.KPA_ARRAY), 0), (FO, 8)):
+    WQ, W128, KA = int(lgrngn.dbg.COND_WQ), int(lgrngn.dbg.COND_WQ_CAP128), int(lgrngn.dbg.KPA_ARRAY)
+    PF, PF2 = int(lgrngn.dbg.COND_WQ_PF), int(lgrngn.dbg.COND_WQ_PF2)
+    for flags, budget in ((0, 0), (KA, 0), (int(lgrngn.dbg.COND_LEAN_R3), 0), (FO, 0), (FO | KA, 0), (FO, 8),
+                          (WQ, 0), (WQ, 3), (WQ, 16), (WQ | KA, 5), (WQ | W128, 0), (WQ | W128, 7), (WQ | W128 | KA, 2),
+                          (WQ | PF, 4), (WQ | W128 | PF | KA, 3), (WQ | PF2, 5), (WQ | PF2 | KA, 2)):
         oi.dbg_flags = flags | NL
         oi.dbg_cond_budget = budget
         hip = h.hip_particles(oi)
@@ -1088,6 +1096,47 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
         for a_, b_ in zip(res[0][:4], res[k][:4]):
             assert np.array_equal(a_, b_), k
     assert np.abs(res[0][2] - rv).max() > 0
+
+
+@pytest.mark.parametrize("sd_conc,steps,reorder_every", [(64, 6, 3), (400, 3, 0)])
+def test_the_first_pass_budget_is_unobservable(sd_conc, steps, reorder_every):
+    """Round 6, measured and not adopted (dbg COND_BUDGET): k_cond_lean gives every droplet's loop a BUDGET of two trips; a droplet that has
+    not converged by then leaves the loop's state where it stands in a record (cond_list: 64 parts with a counter each, like the list of
+    droplets for the reference's iterates now) and k_cond_lean_resume -- a dense walk of those parts -- goes on with it: a wave of the first
+    pass does not wait for its slowest droplet.  A droplet's answer depends on neither the budget nor on who computes it: the same rw2,
+    th, rv and multiplicities bit for bit without a budget (the production kernel), with budgets of two (straight-line trips), one and
+    three trips (the run-time form of the loop), with room for only 4 records per part (dbg_cond_budget >> 8: the droplets that find
+    their part full carry on in their own lanes), over the sorted order, and through k_cond_lean_wq; full steps with coalescence, dead
+    slots and storage re-orderings."""
+    oi = h.box_opts(12, 10, 14, sd_conc, sstp_cond=2, strict_fp=False)
+    oi.reorder_every = reorder_every
+    fields = h.box_fields(oi)
+    res = []
+    BU, SO, WQ, KA = (int(lgrngn.dbg[k]) for k in ("COND_BUDGET", "COND_SORTED_ORDER", "COND_WQ", "KPA_ARRAY"))
+    for flags, budget in ((0, 0), (BU, 0), (BU, 1), (BU, 3), (BU, 2 | 4 << 8), (BU | KA, 0), (SO, 0), (SO | BU, 0), (WQ, 3)):
+        oi.dbg_flags = flags
+        oi.dbg_cond_budget = budget
+        hip = h.hip_particles(oi)
+        assert not hip.opts_init.strict_fp and hip.opts_init.cond_solver == 0
+        th, rv, rhod, C = fields
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        resumed = []
+        for _ in range(steps):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            resumed.append(int(hip.state_u64("raw_cond_resumed")[0]))
+            hip.step_async(opts)
+        res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part, resumed))
+    assert len(set(r_[4] for r_ in res)) == 1
+    for k in range(1, len(res)):
+        for a_, b_ in zip(res[0][:4], res[k][:4]):
+            assert np.array_equal(a_, b_), k
+    # (no budget, no records; a budget of one trip leaves more droplets behind than one of two, and that more than one of three; the
+    # counter also counts the droplets that found their part full)
+    assert sum(res[0][5]) == 0 and sum(res[2][5]) > sum(res[1][5]) > sum(res[3][5]) > 0, [sum(r_[5]) for r_ in res]
+    assert res[4][5] == res[1][5] and max(res[4][5]) > 64 * 4
+    print("records per substep (the step's last): two trips %s, one %s, three %s" % tuple(res[k][5][:3] for k in (1, 2, 3)))
 
 
 def test_brackets_that_may_hold_several_roots_take_the_references_iterates():
