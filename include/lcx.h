@@ -195,6 +195,21 @@ enum lcx_dbg {
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };
 
+/* lcx_get_state_u64("raw_mode") = { strict_fp, cond_solver, the kernel of the last condensation launch (below; 0: none yet), dbg_flags } as
+ * the OBJECT holds them: a test that claims the benchmarked or the default path reads them back instead of trusting what it meant to set */
+enum lcx_cond_kernel {
+  LCX_CK_STRICT = 1,                   /* k_cond<T, false>: strict_fp = 1 */
+  LCX_CK_FAST_PER_DROPLET_SETUP = 2,   /* k_cond<T, true>: fast arithmetic with turb_cond, or LCX_DBG_NO_COND_PRE */
+  LCX_CK_LEAN = 3,                     /* k_cond_lean over the storage order: cond_solver = 0, what bench.py's headline runs */
+  LCX_CK_LEAN_SORTED = 4,              /* ... over the sorted order (LCX_DBG_COND_SORTED_ORDER, or a droplet order that the storage does not have) */
+  LCX_CK_FOLD_TOMS748 = 5,             /* k_cond_lean_fold<.., 2>: cond_solver = 1, the API default */
+  LCX_CK_LEAN_TOMS748 = 6,             /* k_cond_lean<.., 2> (LCX_DBG_COND_NO_FOLD) */
+  LCX_CK_LEAN_TOMS748_SORTED = 7,
+  LCX_CK_TOMS748_TWO_PASS = 8,         /* k_cond_fast(_fold) (LCX_DBG_COND_TOMS_TWO_PASS) */
+  LCX_CK_LEAN_R3 = 9, LCX_CK_FOLD_LEAN = 10, LCX_CK_LEAN_WQ = 11,      /* LCX_DBG_COND_LEAN_R3, _COND_FOLD, _COND_WQ */
+  LCX_CK_PER_PARTICLE = 12             /* exact_sstp_cond: k_pp_cond_* */
+};
+
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */
 typedef struct {
   int adve, sedi, subs, cond, coal, src, rlx, rcyc, turb_adve, turb_cond, turb_coal, ice_nucl;

@@ -1176,6 +1176,8 @@ struct Particles : IParticles {
           const dim3 gs(nblk(nphys));
           // (cond_solver = 1: the workgroup folded behind TOMS748's head -- this kernel is bound by instruction issue at half-empty
           // waves, unlike the lean solver's; LCX_DBG_COND_NO_FOLD: the plain kernel, the same bits)
+          last_cond_kernel = cond_toms ? (dbg(LCX_DBG_COND_NO_FOLD) ? LCX_CK_LEAN_TOMS748 : LCX_CK_FOLD_TOMS748) : dbg(LCX_DBG_COND_LEAN_R3) ? LCX_CK_LEAN_R3 : dbg(LCX_DBG_COND_FOLD) ? LCX_CK_FOLD_LEAN
+                           : dbg(LCX_DBG_COND_WQ) ? LCX_CK_LEAN_WQ : LCX_CK_LEAN;
           if (cond_toms && !dbg(LCX_DBG_COND_NO_FOLD) && kpa_uniform) hipLaunchKernelGGL((k_cond_lean_fold<T, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
           else if (cond_toms && !dbg(LCX_DBG_COND_NO_FOLD)) hipLaunchKernelGGL((k_cond_lean_fold<T, false, 2>), gs, bl, 0, st, nphys, a, T(0));
           else if (cond_toms && kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 2>), gs, bl, 0, st, nphys, a, kpa_value);
@@ -1217,8 +1219,8 @@ struct Particles : IParticles {
             listed = lst.ent != nullptr;
           }
         }
-        else if (cond_toms) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0));
-        else { if (want_list) lst = list_parts(gr.x, BS); hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
+        else if (cond_toms) { last_cond_kernel = LCX_CK_LEAN_TOMS748_SORTED; hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0)); }
+        else { last_cond_kernel = LCX_CK_LEAN_SORTED; if (want_list) lst = list_parts(gr.x, BS); hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
         // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell
         // finish -- launched BEHIND the fork of the in-cell ranking below, so that its few thousand waves run next to the ranking's
         if (listed) {
@@ -1249,6 +1251,7 @@ struct Particles : IParticles {
         cond_defer df{rnk(), defer_cnt.p, size_t(nblk(nblk(npart), DEFER_SHARDS)) * BS, unsigned(budget)};
         if (size_t(DEFER_SHARDS) * df.shard_cap > cap) df.budget = 0;           // (tiny set-ups: the parts do not fit the scratch)
         const bool fold = !dbg(LCX_DBG_COND_NO_FOLD);                             // (test / measurement switch)
+        last_cond_kernel = LCX_CK_TOMS748_TWO_PASS;
         if (fold) hipLaunchKernelGGL((k_cond_fast_fold<T, 11>), gr, bl, 0, st, npart, a, df);
         else hipLaunchKernelGGL((k_cond_fast<T, 11, false>), gr, bl, 0, st, npart, a, df);
         if (df.budget) {
@@ -1256,8 +1259,8 @@ struct Particles : IParticles {
           hipLaunchKernelGGL((k_cond_fast<T, 11, true>), dim3(per_shard * DEFER_SHARDS), bl, 0, st, npart, a, df);
         }
       }
-      else if (o.strict_fp) hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a);
-      else hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a);
+      else if (o.strict_fp) { last_cond_kernel = LCX_CK_STRICT; hipLaunchKernelGGL((k_cond<T, false>), gr, bl, 0, st, npart, a); }
+      else { last_cond_kernel = LCX_CK_FAST_PER_DROPLET_SETUP; hipLaunchKernelGGL((k_cond<T, true>), gr, bl, 0, st, npart, a); }
     }
     if (carry_scatter) {                                      // the in-cell ranking, behind the kernel that scattered
       // (on its own stream when the list of crowded cells is on the host already, i.e. nothing in it waits for the device)
@@ -1291,6 +1294,7 @@ struct Particles : IParticles {
   // nothing set by the caller (set_particles), so that coalescence never mixes two values -- the condensation kernel then takes it as
   // a scalar.  (LCX_DBG_KPA_ARRAY: the array is read all the same.)
   bool kpa_uniform = false; T kpa_value = T(0);
+  int last_cond_kernel = 0;                  // (enum lcx_cond_kernel of the last condensation launch: "raw_mode")
   std::function<void()> launch_listed;       // (cond_substep: k_cond_lean_listed, queued behind the fork of the in-cell ranking)
   const bool cond_storage_order = !dbg(LCX_DBG_COND_SORTED_ORDER);      // (measurement switch: the positional form)
   bool cond_in_storage_order = false;
@@ -1323,6 +1327,7 @@ struct Particles : IParticles {
   void cond_perparticle(double RH_max, bool turb_cond)
   {
     if (!npart) return;
+    last_cond_kernel = LCX_CK_PER_PARTICLE;
     pp_args<T> a{};
     a.sorted_id = sid(); a.sorted_ijk = sijk();
     a.n = A.n.p; a.rd3 = A.rd3.p; a.kpa = A.kpa.p; a.vt = A.vt.p; a.rw2 = A.rw2.p;
@@ -2115,6 +2120,9 @@ struct Particles : IParticles {
       auto h = d2h(cnt.p, 64 * 8);
       unsigned long long tot = 0; for (auto x : h) tot += x;
       v.assign(1, tot);
+    }
+    else if (s == "raw_mode") {                    // what this object runs: strict_fp, cond_solver, the kernel of its last condensation launch (enum lcx_cond_kernel), dbg_flags
+      v = {(unsigned long long)(o.strict_fp ? 1 : 0), (unsigned long long)o.cond_solver, (unsigned long long)last_cond_kernel, (unsigned long long)o.dbg_flags};
     }
     else if (s == "raw_cond_listed") {             // droplets that the last condensation substep handed to the reference's iterates (cond_list)
       unsigned long long c = 0;

@@ -118,6 +118,23 @@ class dbg(enum.IntFlag):
     COND_PROBE = 1 << 26
 
 
+class cond_kernel(enum.IntEnum):
+    """enum lcx_cond_kernel (include/lcx.h): the kernel of an object's last condensation launch, particles_t.mode()"""
+    none = 0
+    strict = 1
+    fast_per_droplet_setup = 2
+    lean = 3
+    lean_sorted = 4
+    fold_toms748 = 5
+    lean_toms748 = 6
+    lean_toms748_sorted = 7
+    toms748_two_pass = 8
+    lean_r3 = 9
+    fold_lean = 10
+    lean_wq = 11
+    per_particle = 12
+
+
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8
     off = 0
     simple = 1
@@ -640,6 +657,12 @@ class particles_t:
         n = C.c_size_t()
         self._chk(self._f("timings")(self._h, names, ms, C.c_size_t(cap), C.byref(n)))
         return {names[i].decode(): ms[i] for i in range(n.value)}
+
+    def mode(self):
+        """what the OBJECT runs (lcx_get_state_u64 "raw_mode"): (strict_fp, cond_solver, cond_kernel of the last condensation launch,
+        dbg_flags) -- a test that claims the benchmarked or the default path asserts these instead of trusting what it meant to set"""
+        v = self.state_u64("raw_mode")
+        return bool(v[0]), int(v[1]), cond_kernel(int(v[2])), dbg(int(v[3]))
 
     def set_profiling(self, on):
         self._chk(self._f("set_profiling")(self._h, C.c_int(int(on))))

@@ -137,6 +137,21 @@ def hip_particles(opts_init, real_t=np.float64):
     return lgrngn.factory(lgrngn.backend_t.HIP, opts_init, real_t)
 
 
+def assert_mode(prt, strict_fp, cond_solver=None, kernel=None, no_dbg=()):
+    """What the OBJECT runs, read back from it (lcx_get_state_u64 "raw_mode"), not what the test meant to set: arithmetic, solver, the
+    kernel of its last condensation launch (lgrngn.cond_kernel names, one or several) and measurement switches that must be off.  Round 5's
+    production-size replay ran the strict kernels for most of the round because the suite pins the parity mode and nothing looked."""
+    sfp, solver, ck, flags = prt.mode()
+    assert sfp == bool(strict_fp), ("strict_fp", sfp)
+    if cond_solver is not None:
+        assert solver == cond_solver, ("cond_solver", solver)
+    if kernel is not None:
+        names = (kernel,) if isinstance(kernel, str) else tuple(kernel)
+        assert ck.name in names, ("condensation kernel", ck.name, names)
+    for name in no_dbg:
+        assert not flags & lgrngn.dbg[name], ("dbg_flags", flags)
+
+
 def oracle_rng_preview(prt, calls):
     """calls: list of (kind, length); returns list of arrays = what the oracle's engine will generate next."""
     kinds = (ctypes.c_int * len(calls))(*[k for k, _ in calls])

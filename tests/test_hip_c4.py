@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import bench
+import _harness as h
 from libcloudphxx_amd import lgrngn
 
 pytestmark = pytest.mark.gpu
@@ -21,6 +22,7 @@ def c4():
     try:
         oi = bench.make_opts_init(NX, NY, NZ, SD, 40., 1, 1, 44)
         oi.strict_fp = False
+        oi.cond_solver = 0             # (bench.py's headline: set here, read back from every slab in test_c4_steps)
         oi.dev_count = SLABS
         oi.n_sd_max = int(oi.n_sd_max * 1.1)
         prt = lgrngn.factory(lgrngn.backend_t.multi_HIP, oi)
@@ -92,6 +94,8 @@ def test_c4_steps(c4):
     o = lgrngn.opts_t()
     o.coal = o.adve = o.sedi = False
     prt.step_sync(o, th, rv, rhod, Cx, Cy, Cz)
+    for r in range(SLABS):             # (read back from every slab's object)
+        h.assert_mode(prt.slab(r), False, 0, ("lean", "lean_sorted"))
     prt.step_async(o)
     rv1, after = gathered(parts, 1), m3()
     np.testing.assert_allclose(rv1 - rv0, -(after - before) * 4. / 3 * np.pi * 1e3, rtol=1e-8, atol=1e-15)

@@ -337,6 +337,8 @@ def test_production_size_paths_vs_oracle(strict_fp):
     opts = lgrngn.opts_t()
     for it in range(2):
         (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        # (read back from the object: the arithmetic, the solver and the kernel that the parameter stands for; a replayed run walks the sorted order)
+        h.assert_mode(hip, oi.strict_fp, oi.cond_solver, ("strict",) if oi.strict_fp else ("fold_toms748", "lean_toms748_sorted") if toms else ("lean", "lean_sorted"))
         exact(hip.state_u64("n"), orc.state_u64("n"), "n")
         exact(hip.state_u64("ijk"), orc.state_u64("ijk"), "ijk")
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")

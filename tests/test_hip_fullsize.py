@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import bench
+import _harness as h
 from libcloudphxx_amd import lgrngn
 
 pytestmark = pytest.mark.gpu
@@ -17,6 +18,7 @@ def big(request):
     """strict_fp = False is exactly what bench.py runs (the benchmarked configuration is a tested configuration)"""
     oi = bench.make_opts_init(N, N, N, SD, 40., 1, 1, 44)
     oi.strict_fp = request.param
+    oi.cond_solver = 0                 # (bench.py's main sets both from its arguments; left alone they are whatever opts_init_t() starts from)
     fields = bench.make_fields(N, N, N, 0, N, np, np.float64)
     pr = lgrngn.factory(lgrngn.backend_t.HIP, oi)
     th, rv, rhod, Cx, Cy, Cz = fields
@@ -72,6 +74,8 @@ def test_full_step_properties(big):
     o = lgrngn.opts_t()
     o.coal = o.adve = o.sedi = False
     pr.step_sync(o, th, rv, rhod, Cx, Cy, Cz)
+    # (fast_fp: what bench.py's headline runs -- read back from the object)
+    h.assert_mode(pr, *((True, 0, "strict") if oi.strict_fp else (False, 0, ("lean", "lean_sorted"))))
     pr.step_async(o)
     after = m3()
     np.testing.assert_allclose(rv - rv0, -(after - before) * 4. / 3 * np.pi * 1e3, rtol=1e-8, atol=1e-15)
@@ -110,6 +114,7 @@ def test_production_shuffled_order_at_full_size():
     (hskpng_sort.ipp:28-47), for all 1.3e8 of them; the keys of consecutive steps differ (a fresh shuffle per step)."""
     oi = bench.make_opts_init(N, N, N, SD, 40., 1, 1, 44)
     oi.strict_fp = False
+    oi.cond_solver = 0
     oi.dbg_flags = int(lgrngn.dbg.TAG)                          # (lcx_rng_dump records what coalescence consumes)
     th, rv, rhod, Cx, Cy, Cz = bench.make_fields(N, N, N, 0, N, np, np.float64)
     pr = lgrngn.factory(lgrngn.backend_t.HIP, oi)
@@ -119,6 +124,7 @@ def test_production_shuffled_order_at_full_size():
     last_keys = None
     for it in range(4):
         pr.step_sync(opts, th, rv, rhod, Cx, Cy, Cz)
+        h.assert_mode(pr, False, 0, "lean", no_dbg=("NO_DEFERRED_SORT", "COND_SORTED_ORDER", "RANK_BY_COUNTING", "SHUFFLE_PHILOX"))
         order = pr.state_u64("raw_sorted_id").astype(np.int64)
         ijk = pr.state_u64("raw_ijk")
         alive = ijk != dead

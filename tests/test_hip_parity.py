@@ -603,6 +603,7 @@ def test_the_api_default_mode_keeps_the_strict_bars():
     opts = lgrngn.opts_t()
     for it in range(3):
         (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
+        h.assert_mode(hip, False, 1, ("fold_toms748", "lean_toms748_sorted"))      # (the default's kernels; a replayed run walks the sorted order)
         assert hip.n_part == orc.n_part
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
         exact(hip.state_u64("n"), orc.state_u64("n"), "n")

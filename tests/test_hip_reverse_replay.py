@@ -438,6 +438,10 @@ def test_reverse_replay_at_production_size(workload, cond_solver, free):
                                       free_bars=(5e-2, 5e-5, h.cond_bars(True)[2]) if cond_solver == 1 else (5e-2, 3e-4, h.cond_bars(False)[2]),
                                       free_field_bars=None if cond_solver == 1 else h.cond_bars(False)[:2])
         collisions += ncol
+        # (the benchmarked path, read back from the object: fast arithmetic, the solver asked for, the storage-order kernels, none of
+        # the switches that would take it off bench.py's path)
+        h.assert_mode(hip, False, cond_solver, "lean" if cond_solver == 0 else "fold_toms748",
+                      no_dbg=("NO_DEFERRED_SORT", "COND_SORTED_ORDER", "RANK_BY_COUNTING", "SHUFFLE_PHILOX", "EAGER_COMPACT", "COND_NO_LIST", "NO_COND_PRE"))
         assert hip.n_part == orc.n_part, it
         d, o = device_by_tag(hip), oracle_by_tag(orc)
         assert np.array_equal(d["tag"], o["tag"]), it
