@@ -61,6 +61,48 @@ def make_opts_init(nx, ny, nz, sd_conc, dx, sstp_cond, sstp_coal, seed, workload
     return oi
 
 
+def make_icicle_opts(nx=76, nz=76, sd_conc=64, sstp=10):
+    """BASELINE configs[1] (C2): the 2-D kinematic icicle set-up of the GMD 2015 paper -- 76 x 76 cells of 20 m, 64 super-droplets per cell,
+    ten condensation and ten coalescence substeps, the geometric kernel x 0.5, khvorostyanov_spherical terminal velocities, implicit
+    advection (ref models/kinematic_2D/src/opts_lgrngn.hpp:262,340-343, kin_cloud_2d_lgrngn.hpp:167-170, tests/paper_GMD_2015/fig_a/calc.cpp:36-39)"""
+    from libcloudphxx_amd import lgrngn
+    dx = 1500. / 75
+    oi = lgrngn.opts_init_t()
+    oi.nx, oi.ny, oi.nz = nx, 0, nz
+    oi.dx = oi.dz = dx
+    oi.dy = 1.
+    oi.x0, oi.z0 = dx / 2, dx / 2
+    oi.x1, oi.z1 = (nx - .5) * dx, (nz - .5) * dx
+    oi.y1 = 1.
+    oi.dt = 1.
+    oi.sd_conc = sd_conc
+    oi.n_sd_max = int(sd_conc * nx * nz * 1.2)
+    oi.dry_distros = {(.61, 0.): bimodal()}
+    oi.kernel = lgrngn.kernel_t.geometric
+    oi.kernel_parameters = [0.5]
+    oi.terminal_velocity = lgrngn.vt_t.khvorostyanov_spherical
+    oi.adve_scheme = lgrngn.as_t.implicit
+    oi.sstp_cond = oi.sstp_coal = sstp
+    return oi
+
+
+def make_icicle_fields(nx=76, nz=76, dtype=np.float32):
+    """th = 289 K, rv = 7.5e-3, rhod(z); the single-eddy stream function with w_max = 0.6 m/s (ref models/kinematic_2D/cases/
+    icmw8_case1.hpp:166-228): air rises through cloud base in one half of the domain in every step"""
+    dx = 1500. / 75
+    X, Z = nx * dx, nz * dx
+    z = (np.arange(nz) + .5) * dx
+    rhod = np.broadcast_to(1.2 * np.exp(-z / 8000.), (nx, nz)).astype(dtype).copy()
+    th = np.full((nx, nz), 289., dtype=dtype)
+    rv = np.full((nx, nz), 7.5e-3, dtype=dtype)
+    A = 0.6 * X / (2 * np.pi)
+    xe, ze = np.arange(nx + 1) * dx, np.arange(nz + 1) * dx
+    xc, zc = (np.arange(nx) + .5) * dx, (np.arange(nz) + .5) * dx
+    u = -A * np.pi / Z * np.cos(np.pi * zc[None, :] / Z) * np.cos(2 * np.pi * xe[:, None] / X)
+    w = A * 2 * np.pi / X * np.sin(np.pi * ze[None, :] / Z) * np.sin(2 * np.pi * xc[:, None] / X)
+    return th, rv, rhod, np.ascontiguousarray((u / dx / 1.2).astype(dtype)), np.ascontiguousarray((w / dx / 1.2).astype(dtype))
+
+
 def make_fields(nx_loc, ny, nz, x_off, nx_tot, xp, dtype):
     """th, rv, rhod and a smooth non-divergent-ish Courant field with |C| <= 0.3 for the slab of x-planes
     [x_off, x_off + nx_loc).  xp is numpy (CPU sample) or torch-on-device."""
@@ -164,6 +206,37 @@ def cpu_baseline(args):
                                         "sample": "the reference's thrust::omp backend, 64^3-class box, build container, BASELINE.md section 2"}}
 
 
+def c2_leg(lgrngn, torch, steps=60, warmup=10, real_t=np.float32, **change):
+    """BASELINE configs[1] timed: 76 x 76 cells x 64 super-droplets, sstp 10 / 10, float, icicle's call (th, rv as host arrays in every
+    step).  3.7e5 super-droplets and twenty substeps: what a step costs here is its launches and host waits, so both are counted"""
+    oi = make_icicle_opts()
+    for k, v in change.items():
+        setattr(oi, k, v)
+    th, rv, rhod, Cx, Cz = make_icicle_fields(dtype=real_t)
+    pr = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
+    pr.init(th, rv, rhod, Cx=Cx, Cz=Cz)
+    opts = lgrngn.opts_t()
+    for _ in range(warmup):
+        pr.step_sync(opts, th, rv)
+        pr.step_async(opts)
+    torch.cuda.synchronize()
+    l0 = pr.state_u64("raw_launches")
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(steps):
+        pr.step_sync(opts, th, rv)
+        pr.step_async(opts)
+        done += pr.n_part
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    l1 = pr.state_u64("raw_launches")
+    return {"value": done / dt_, "unit": "super-droplets/s", "ms_per_step": dt_ / steps * 1e3, "steps": steps,
+            "kernel_launches_per_step": float(l1[0] - l0[0]) / steps, "host_waits_per_step": float(l1[1] - l0[1]) / steps,
+            "super_droplets": int(done / steps), "dtype": "f32" if real_t == np.float32 else "f64",
+            "workload": "2-D kinematic icicle set-up (BASELINE configs[1]): 76 x 76 cells x 64 SD/cell, sstp_cond = sstp_coal = 10, geometric kernel x 0.5, "
+                        "khvorostyanov_spherical, implicit advection, the API's default arithmetic (cond_solver = 1), th and rv as host arrays in every step"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,7 +307,8 @@ def main():
                     help="which processes a step runs (opts_t.cond / coal / adve / sedi), as the reference's timing sweep does "
                          "(models/kinematic_2D/tests/paper_GMD_2015/fig_b/calc.cpp:49: a / ac / acc / accs): substeps timed in isolation; "
                          "the headline and every leg of the default line run all of them")
-    ap.add_argument("--no-extra-legs", action="store_true", help="skip the coal_stress and c5 legs of the default line")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the coal_stress, c5, c2, soak and activation legs of the default line")
+    ap.add_argument("--soak-steps", type=int, default=1000, help="steps of the default line's soak leg (the headline's configuration, long window)")
     ap.add_argument("--dbg", default="",
                     help="comma-separated names of opts_init.dbg_flags bits (libcloudphxx_amd.lgrngn.dbg: test / measurement switches, "
                          "e.g. NO_DEFERRED_SORT,COND_SORTED_ORDER,MULTI_SERIALIZE); the library reads no such switch from the environment")
@@ -493,7 +567,9 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         n_part_end = p1.n_part
-        cond_ms = p1.timings().get("cond") if not args.no_stage_timers else None
+        tm_ = p1.timings() if not args.no_stage_timers else {}
+        cond_ms = tm_.get("cond")
+        listed_ms_total = tm_.get("cond_listed")
         stage_ms = {}
         if not args.no_stage_timers and args.stage_steps > 0:
             p1.set_profiling(1)
@@ -505,6 +581,8 @@ def main():
             p1.set_profiling(0)
         if cond_ms is not None:
             stage_ms["cond"] = cond_ms                       # (the timed region's own)
+            if listed_ms_total is not None:
+                stage_ms["cond_listed"] = listed_ms_total
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -548,6 +626,10 @@ def main():
                     roof["listed_share"] = roof["listed_for_the_references_iterates"] / max(n_local, 1.)
                 except Exception:
                     pass
+                # (round 6) `avg_launch_ms` is k_cond_lean's launch alone; the listed droplets' kernel (k_cond_lean_listed, beside the in-cell
+                # ranking in the timed region) is a stage of its own
+                if "cond_listed" in stage_ms:
+                    roof["listed_ms"] = stage_ms["cond_listed"] / launches
             # HBM bytes and instruction counts per launch from the PMC passes of tools/profile_round.sh (FETCH_SIZE x 2 + WRITE_SIZE,
             # KiB; counters cannot be collected inside a timed run): reported only for the configuration they were measured on
             default_cfg = (world_out == 1 and n == 128 and not (args.nx or args.ny or args.nz) and args.sd_conc == 64 and args.real == "f64"
@@ -689,7 +771,10 @@ def main():
             gc.collect()
             torch.cuda.synchronize()
 
-            def run_leg(change, steps, host_arrays=False, collisions=False):
+            def run_leg(change, steps, host_arrays=False, collisions=False, forcing=None, listed=False):
+                """host_arrays: False (device arrays), True (all six as host arrays in every step: UWLCM's call), "thrv" (host arrays, th and
+                rv only in every step: icicle's call, kin_cloud_2d_lgrngn.hpp:242-246); forcing(it, tensors): the caller's own change of
+                its device arrays between two steps; listed: the share of droplets that the condensation kernel lists, sampled"""
                 keep = {k: getattr(oi, k) for k in change}
                 for k, v in change.items():
                     setattr(oi, k, v)
@@ -698,7 +783,17 @@ def main():
                     arrs = [t.cpu().numpy() for t in f] if host_arrays else [lgrngn.DeviceArray(t.data_ptr(), t.shape) for t in f]
                     pr = lgrngn.factory(lgrngn.backend_t.HIP, oi, real_t)
                     pr.init(arrs[0], arrs[1], arrs[2], Cx=arrs[3], Cy=arrs[4], Cz=arrs[5])
+                    if host_arrays == "thrv":
+                        arrs = arrs[:2]
+                    it_ = [0]
+
+                    def force():
+                        if forcing is not None:
+                            forcing(it_[0], f)
+                            torch.cuda.synchronize()
+                        it_[0] += 1
                     for _ in range(3):
+                        force()
                         pr.step_sync(opts, *arrs)
                         pr.step_async(opts)
                     # timed as the headline is: the condensation stage's two events per step and nothing else (level 2); the stage table
@@ -708,15 +803,29 @@ def main():
                     t0 = time.perf_counter()
                     done = 0
                     for _ in range(steps):
+                        force()
                         pr.step_sync(opts, *arrs)
                         pr.step_async(opts)
                         done += pr.n_part
                     torch.cuda.synchronize()
                     dt_ = time.perf_counter() - t0
-                    cond_ms_ = pr.timings().get("cond", 0.) / max(steps * args.sstp_cond, 1)
+                    tm2_ = pr.timings()
+                    cond_ms_ = tm2_.get("cond", 0.) / max(steps * args.sstp_cond, 1)
+                    listed_ms_ = tm2_.get("cond_listed", 0.) / max(steps * args.sstp_cond, 1)
+                    listed_share_ = None
+                    if listed:
+                        # (sampled behind the timed loop, a read-back per step: 16 more steps -- one period of the activation leg's forcing)
+                        sh_ = []
+                        for _ in range(16):
+                            force()
+                            pr.step_sync(opts, *arrs)
+                            sh_.append(int(pr.state_u64("raw_cond_listed")[0]) / max(pr.n_part, 1))
+                            pr.step_async(opts)
+                        listed_share_ = {"mean": float(np.mean(sh_)), "max": float(np.max(sh_)), "min": float(np.min(sh_))}
                     stage_steps_ = min(4, steps)
                     pr.set_profiling(1)
                     for _ in range(stage_steps_):
+                        force()
                         pr.step_sync(opts, *arrs)
                         pr.step_async(opts)
                     torch.cuda.synchronize()
@@ -729,6 +838,10 @@ def main():
                                         "frac": ach_ / HBM_PEAK_GBS if ach_ else None, "avg_launch_ms": cond_ms_,
                                         "algorithmic_bytes_per_sd": cond_bytes_per_sd},
                            "stage_ms_per_step": {k: v / stage_steps_ for k, v in st_.items()}}
+                    if listed:
+                        res["cond_ms"] = cond_ms_
+                        res["listed_ms"] = listed_ms_
+                        res["listed_share"] = listed_share_
                     if collisions:
                         # pairs that collided in the last step (the living super-droplets that carry coalescence's invalid terminal velocity);
                         # a collided pair writes back N + 3R bytes (n of the one, rw2, rd3, vt of the other)
@@ -764,6 +877,11 @@ def main():
                 out["host_arrays"] = run_leg({}, args.leg_steps, host_arrays=True)
                 out["host_arrays"]["arrays"] = arrays_note
                 out["host_arrays"]["extra_ms_per_step"] = out["host_arrays"]["ms_per_step"] - out["ms_per_step"]
+                # icicle's shape of the same call (round 6): th and rv only in every step (33.6 MB in, 33.6 MB out), the density and the
+                # Courant numbers at init
+                out["host_arrays_icicle"] = run_leg({}, args.leg_steps, host_arrays="thrv")
+                out["host_arrays_icicle"]["arrays"] = "th, rv as host (numpy) arrays in every step: %.1f MB in, %.1f MB out; rhod and the Courant numbers at init only (kin_cloud_2d_lgrngn.hpp:242-246)" % (
+                    2 * nx_tot * ny * nz * R / 1e6, 2 * nx_tot * ny * nz * R / 1e6)
                 if not args.strict_fp and args.cond_solver == "lean" and not args.no_toms_leg:
                     out["api_default_host_arrays"] = run_leg({"strict_fp": False, "cond_solver": 1}, args.leg_steps, host_arrays=True)
                     out["api_default_host_arrays"]["arrays"] = arrays_note
@@ -781,6 +899,19 @@ def main():
                                               "kernel": lgrngn.kernel_t.hall_davis_no_waals}, args.leg_steps, collisions=True)
                 out["coal_stress"]["spectrum"] = ("n(ln r) = 3 n0 (r/r0)^3 exp(-(r/r0)^3), r0 = 30.084 um, n0 = 2^23 m^-3, kappa = 1e-10 "
                                                  "(ref tests/python/physics/coalescence_golovin.py:31-44), kernel hall_davis_no_waals")
+                # (round 6) a LONG window of the headline's configuration: the box long settled, 15+ storage re-orderings in it
+                if args.soak_steps > 0:
+                    out["soak"] = run_leg({}, args.soak_steps, listed=True)
+                    out["soak"]["note"] = "the headline's options, %d steps behind 3 of warm-up on an object of its own" % args.soak_steps
+                # (round 6) aerosol that KEEPS ACTIVATING: the caller swings its vapour field by +-1 % with a period of 16 steps (what an
+                # updraft through cloud base does to the air that passes it; the stratocumulus box by itself settles within its first steps)
+                def swing(it, f):
+                    w = 2 * np.pi / 16.
+                    f[1].mul_(1. + 0.01 * (np.sin(w * (it + 1)) - np.sin(w * it)))
+                out["activation"] = run_leg({}, 4 * 16, forcing=swing, listed=True)
+                out["activation"]["forcing"] = "rv x (1 + 0.01 sin(2 pi step / 16)) applied by the caller between steps (device arrays)"
+                # BASELINE configs[1] (C2): the 2-D icicle set-up in its own arithmetic (float), th and rv as host arrays in every step
+                out["c2"] = c2_leg(lgrngn, torch)
                 # BASELINE configs[4] (C5): the headline spectrum x 512 per cell, 1.07e9 super-droplets on the one device (~210 GB);
                 # 17 steps behind 3 of warm-up: one storage re-ordering (every 16 steps where cells are crowded) falls into them
                 free_b, _tot_b = torch.cuda.mem_get_info()

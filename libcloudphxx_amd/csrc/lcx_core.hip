@@ -20,9 +20,17 @@
 #include <vector>
 #include <functional>
 
+#include <atomic>
 #include "../../include/lcx.h"
 #include "lcx_kernels.hpp"
 #include "lcx_pool.hpp"
+
+// every kernel launch of this translation unit and every host wait for a stream are COUNTED (lcx_get_state_u64 "raw_launches"): what a
+// step costs a thin slab or a 2-D set-up is its launches and its waits, not its bytes (bench.py's c2 leg reports both per step)
+namespace lcx { static std::atomic<unsigned long long> g_launches{0}, g_host_waits{0}; }
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...) \
+  do { lcx::g_launches.fetch_add(1, std::memory_order_relaxed); kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__); } while (0)
 
 namespace lcx {
 
@@ -356,9 +364,9 @@ struct Particles : IParticles {
     for (int e = 0; e < n_ext; ++e) s.ext[e] = a.ext[e].p;
     return s;
   }
-  void sync() { join_rank(); HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
+  void sync() { join_rank(); g_host_waits.fetch_add(1, std::memory_order_relaxed); HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
   // the end of step_cond: th and rv are written on `st`; a ranking on st_rank goes on while the host queues step_async
-  void sync_results_only() { HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
+  void sync_results_only() { g_host_waits.fetch_add(1, std::memory_order_relaxed); HIPCHK(hipStreamSynchronize(st)); hstage_busy = false; }
 
   // ---- profiling ranges (hipEvents on OUR stream) ----
   // profiling: 0 off; 1 every stage; 2 the condensation kernel's stage only -- two event records per step instead of fifty: every record
@@ -368,7 +376,7 @@ struct Particles : IParticles {
     Particles *self; const char *name; hipEvent_t a = nullptr, b = nullptr;
     Range(Particles *s, const char *nm) : self(s), name(nm)
     {
-      if (self->profiling == 1 || (self->profiling == 2 && !strcmp(nm, "cond"))) { a = self->prof_event(); b = self->prof_event(); (void)hipEventRecord(a, self->st); }
+      if (self->profiling == 1 || (self->profiling == 2 && (!strcmp(nm, "cond") || !strcmp(nm, "cond_listed")))) { a = self->prof_event(); b = self->prof_event(); (void)hipEventRecord(a, self->st); }
     }
     ~Range() { if (a) { (void)hipEventRecord(b, self->st); self->prof_events.push_back({std::string(name), {a, b}}); } }
   };
@@ -1227,9 +1235,9 @@ struct Particles : IParticles {
           const bool uni = kpa_uniform && cond_in_storage_order;
           const T kv = uni ? kpa_value : T(0);
           launch_listed = [this, a, lst, uni, kv, bl]() {
-            // (the host does not know the counts: workgroups for 3 % of the droplets -- the settled boxes list 1 % -- at a droplet per lane,
+            // (the host does not know the counts: workgroups for 1 % of the droplets -- the settled boxes list 0.1 %, a swinging one 1 % -- at a droplet per lane,
             // more droplets by the stride; a workgroup that finds nothing leaves at once)
-            const unsigned per_part = unsigned(std::min<size_t>(2048, std::max<size_t>(8, lst.shard_cap / 400 / BS + 1)));
+            const unsigned per_part = unsigned(std::min<size_t>(2048, std::max<size_t>(8, lst.shard_cap / 100 / BS + 1)));
             if (lst.rec) {
               const unsigned n_resume = DEFER_SHARDS * ((lst.rec_cap + BS - 1) / BS);
               if (uni) hipLaunchKernelGGL((k_cond_lean_resume<T, true>), dim3(n_resume), bl, 0, st, a, lst, kv);
@@ -1282,7 +1290,8 @@ struct Particles : IParticles {
         rank_pending = true;
       } else finish_deferred_sort(true);
     }
-    if (launch_listed) { Range r(this, "cond"); launch_listed(); launch_listed = nullptr; }
+    // ("cond_listed": a stage of its own since round 6 -- "cond" is the first pass's kernel alone, what the roofline prices)
+    if (launch_listed) { Range r(this, "cond_listed"); launch_listed(); launch_listed = nullptr; }
     {
       Range r(this, "cond_cellfinish");
       // (a kernel that carried the scatter has left each droplet's change at the droplet's place in the sorted order: no gather)
@@ -2120,6 +2129,9 @@ struct Particles : IParticles {
       auto h = d2h(cnt.p, 64 * 8);
       unsigned long long tot = 0; for (auto x : h) tot += x;
       v.assign(1, tot);
+    }
+    else if (s == "raw_launches") {                // kernel launches and host waits of the library in this process so far (the wq kernel's own launches not counted)
+      v = {g_launches.load(), g_host_waits.load()};
     }
     else if (s == "raw_mode") {                    // what this object runs: strict_fp, cond_solver, the kernel of its last condensation launch (enum lcx_cond_kernel), dbg_flags
       v = {(unsigned long long)(o.strict_fp ? 1 : 0), (unsigned long long)o.cond_solver, (unsigned long long)last_cond_kernel, (unsigned long long)o.dbg_flags};
