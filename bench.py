@@ -644,6 +644,7 @@ def main():
                         src = "profiles/" + os.path.basename(tf)
                         roof["traffic"] = t["hbm_bytes"]
                         roof["traffic_source"] = src
+                        roof["traffic_launches"] = (tj.get("_meta") or {}).get("launches", "launches 2-3 of a fresh box (a profile of rounds 1-5)")
                         # what the launch MOVES per super-droplet by the counters (the run's single hygroscopicity is a scalar: 8 of the
                         # 56 algorithmic bytes are not read) -- `frac_with_carried` prices 76 algorithmic bytes, not these
                         roof["bytes_moved_per_sd"] = t["hbm_bytes"] / n_local

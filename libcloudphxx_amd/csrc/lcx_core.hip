@@ -1111,12 +1111,12 @@ struct Particles : IParticles {
     HIPCHK(hipMemcpyAsync(sstp_tmp_th.p, th.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(sstp_tmp_rh.p, rhod.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
   }
-  void sstp_percell_step(int step)
+  // sstp_percell_step.ipp:7-48, as an argument of the substep's cell pass (k_cell_cond_pre)
+  sstp_fields<T> sstp_fused(int step)
   {
-    if (sstp_cond == 1) return;
-    T *scl[3] = {rv.p, th.p, rhod.p}, *tmp[3] = {sstp_tmp_rv.p, sstp_tmp_th.p, sstp_tmp_rh.p};
-    for (int ix = 0; ix < (var_rho ? 3 : 2); ++ix)
-      hipLaunchKernelGGL(k_sstp_step<T>, dim3(nblk(ncell)), dim3(BS), 0, st, ncell, step, T(sstp_cond), scl[ix], tmp[ix]);
+    sstp_fields<T> ss{0, step, T(sstp_cond), {rv.p, th.p, rhod.p}, {sstp_tmp_rv.p, sstp_tmp_th.p, sstp_tmp_rh.p}};
+    if (sstp_cond > 1) ss.n = var_rho ? 3 : 2;
+    return ss;
   }
   bool lean_storage_cond() const
   { return !o.strict_fp && !no_cond_pre && cond_storage_order && !cond_toms_two_pass() && !o.exact_sstp_cond; }
@@ -1139,7 +1139,7 @@ struct Particles : IParticles {
       hipLaunchKernelGGL(k_cell_cond_pre<T>, dim3(std::max(nblk(ncell), nblk(size_t(n_defer_words)))), dim3(BS), 0, st, ncell, th.p, rhod.p, rv.p, p.p,
                          Tk.p, RH.p, eta.p, dv.p, lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims, int(step == 0), T(RH_max),
                          fast ? reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p) : (cond_cell_fast<T> *)nullptr,
-                         fast ? defer_cnt.p : (uint32_t *)nullptr, fast ? n_defer_words : 0);
+                         fast ? defer_cnt.p : (uint32_t *)nullptr, fast ? n_defer_words : 0, sstp_fused(step));
       vtpre_valid = false;
     }
     if (npart) {
@@ -1933,7 +1933,7 @@ struct Particles : IParticles {
       if (!(sort_deferred && lean_storage_cond() && !opts.turb_cond && !(o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)))) hskpng_sort();
       if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) { hskpng_mfp(); cond_perparticle(opts.RH_max, opts.turb_cond); }
       else for (int step = 0; step < sstp_cond; ++step) {
-        sstp_percell_step(step);
+        // (the Eulerian fields' substep rides on the cell pass of cond_substep: sstp_fused)
         if (opts.turb_cond && nphys)                                                     // apply_perparticle_sgs_supersat.ipp
           hipLaunchKernelGGL(k_sgs_supersat<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, T(T(dt) / sstp_cond), A.ext[ix_dot_ssp].p, A.ext[ix_ssp].p);
         cond_substep(opts.RH_max, step, opts.turb_cond);                                 // (hskpng_mfp at substep 0 and hskpng_Tpr inside)

@@ -188,13 +188,25 @@ __global__ void k_cell_mfp(size_t n_cell, const T *Tk, const T *p, T *lambda_D, 
 // condensation substep's cell pass in one launch: (substep 0) the mean free paths from the temperature and pressure of the PREVIOUS
 // housekeeping, as the reference's hskpng_mfp placed ahead of the substep loop (particles_step.ipp:193-196) -- then hskpng_Tpr --
 // then (fast arithmetic) the droplet-independent set-up of the growth rate.  Same expressions as the three kernels it replaces.
+template <class T> struct sstp_fields { int n, step; T sstp; T *scl[3], *tmp[3]; };
 template <class T>
 __global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv, T *lambda_D, T *lambda_K,
                                 int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre,
-                                uint32_t *zero_words = nullptr, int n_zero_words = 0)
+                                uint32_t *zero_words = nullptr, int n_zero_words = 0, sstp_fields<T> ss = sstp_fields<T>{0, 0, T(1), {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}})
 {
   if (gid() < size_t(n_zero_words)) zero_words[gid()] = 0u;         // (the straggler counters of the condensation kernel that follows)
   const size_t c = gid(); if (c >= n_cell) return;
+  // (round 6) the substep's share of the Eulerian fields' change (sstp_percell_step.ipp:7-48: k_sstp_step's operations, per field) ahead of
+  // the cell's own pass over the same fields: two or three launches fewer per substep -- a 2-D set-up of ten substeps is a queue of
+  // five-microsecond kernels, and what it costs is their number (bench.py's c2 leg)
+  for (int f = 0; f < ss.n; ++f) {
+    T *scl = ss.scl[f], *tmp = ss.tmp[f];
+    if (ss.step == 0) {
+      const T d = scl[c] - tmp[c];
+      tmp[c] = d;
+      scl[c] = scl[c] - (ss.sstp - 1) * d / ss.sstp;
+    } else scl[c] = scl[c] + tmp[c] / ss.sstp;
+  }
   T lD, lK;
   if (do_mfp) { lD = lambda_D_of(Tk[c]); lK = lambda_K_of(Tk[c], p[c]); lambda_D[c] = lD; lambda_K[c] = lK; }
   else { lD = lambda_D[c]; lK = lambda_K[c]; }
@@ -208,7 +220,7 @@ __global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const
   if (ndims == 0) dv[c] = T(1) / rhod[c];
   if (pre) pre[c] = make_cond_cell_fast(rhod[c], rv[c], t, et, lD, lK, rh, RH_max);
 }
-// sstp_percell_step.ipp:7-48 for one field
+// sstp_percell_step.ipp:7-48 for one field (the fields of a substep as ONE argument of the cell pass: sstp_fields)
 template <class T>
 __global__ void k_sstp_step(size_t n_cell, int step, T sstp, T *scl, T *tmp)
 {

@@ -1,0 +1,11 @@
+"""one C2 run (bench.c2_leg) for a kernel trace:  rocprofv3 --kernel-trace --output-format csv -d out -- python3 tools/c2_trace.py [steps]"""
+import os
+import sys
+import json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from libcloudphxx_amd import lgrngn
+r = bench.c2_leg(lgrngn, torch, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+print(json.dumps(r))

@@ -28,7 +28,7 @@ try:
 except OSError:
     pass
 print()
-print("== PMC passes (python3 bench.py --steps 2 --warmup 1): per-launch averages of the steady-state launches")
+print("== PMC passes (python3 bench.py --steps 2 --warmup 18): per-launch averages of the last two launches = steps 19-20 of the box, its steady state")
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -69,4 +69,5 @@ print()
 print("== HBM traffic per launch (FETCH_SIZE*2 KiB + WRITE_SIZE KiB)")
 for k, t in traffic.items():
     print("%-48s read %.3f GB  write %.3f GB  total %.3f GB" % (k, t["read_bytes"] / 1e9, t["write_bytes"] / 1e9, t["hbm_bytes"] / 1e9))
+traffic["_meta"] = {"launches": "steady: the last two launches of every PMC pass, behind 18 warm-up steps (tools/profile_round.sh)"}
 json.dump(traffic, open(out + "/traffic.json", "w"), indent=1)
