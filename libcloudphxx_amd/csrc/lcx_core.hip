@@ -1204,9 +1204,13 @@ struct Particles : IParticles {
               hipLaunchKernelGGL((k_cond_probe<T, 6>), gs, bl, 0, st, nphys, a, kpa_value);
             }
             if (want_list) lst = list_parts(gs.x, BS);
-            if (want_list && lst.budget == 2u) {                // (the production form: its two trips as straight-line code)
+            if (lst.rec && lst.budget == 2u) {                  // (dbg COND_BUDGET: two trips as straight-line code)
               if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 0, 2>), gs, bl, 0, st, nphys, a, kpa_value, lst);
               else hipLaunchKernelGGL((k_cond_lean<T, 15, false, 0, 2>), gs, bl, 0, st, nphys, a, T(0), lst);
+            }
+            else if (lst.rec) {                                 // (any other budget: the run-time form of the loop)
+              if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true, 0, 0>), gs, bl, 0, st, nphys, a, kpa_value, lst);
+              else hipLaunchKernelGGL((k_cond_lean<T, 15, false, 0, 0>), gs, bl, 0, st, nphys, a, T(0), lst);
             }
             else if (kpa_uniform) hipLaunchKernelGGL((k_cond_lean<T, 15, true>), gs, bl, 0, st, nphys, a, kpa_value, lst);
             else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gs, bl, 0, st, nphys, a, T(0), lst);
@@ -1228,7 +1232,13 @@ struct Particles : IParticles {
           }
         }
         else if (cond_toms) { last_cond_kernel = LCX_CK_LEAN_TOMS748_SORTED; hipLaunchKernelGGL((k_cond_lean<T, 15, false, 2>), gr, bl, 0, st, npart, a, T(0)); }
-        else { last_cond_kernel = LCX_CK_LEAN_SORTED; if (want_list) lst = list_parts(gr.x, BS); hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst); listed = lst.ent != nullptr; }
+        else {
+          last_cond_kernel = LCX_CK_LEAN_SORTED;
+          if (want_list) lst = list_parts(gr.x, BS);
+          if (lst.rec) hipLaunchKernelGGL((k_cond_lean<T, 15, false, 0, 0>), gr, bl, 0, st, npart, a, T(0), lst);
+          else hipLaunchKernelGGL((k_cond_lean<T, 15, false>), gr, bl, 0, st, npart, a, T(0), lst);
+          listed = lst.ent != nullptr;
+        }
         // the listed droplets (brackets that may hold several roots): the reference's iterates, on the same stream ahead of the per-cell
         // finish -- launched BEHIND the fork of the in-cell ranking below, so that its few thousand waves run next to the ranking's
         if (listed) {

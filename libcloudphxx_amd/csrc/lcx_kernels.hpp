@@ -1197,9 +1197,11 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // on its side stream next to k_cond_lean_listed); room for every droplet -- a list that could overflow would make WHO is listed depend
 // on the order in which the atomics are served; count: the entries
 // (struct cond_list: lcx_cond_wq.hpp)
-// BUDGET (SOLVER 0 with a list): loop trips of this pass as a compile-time number -- the trips are then straight-line code (a loop's
-// back edge copies the five reals of its state: 34 vector instructions per wave in the run-time form); 0: lst.budget at run time
-template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0, int BUDGET = 0>
+// BUDGET (SOLVER 0 with records, dbg COND_BUDGET): loop trips of this pass as a compile-time number -- the trips are then straight-line
+// code (a loop's back edge copies the five reals of its state: 34 vector instructions per wave in the run-time form); 0: lst.budget at
+// run time; -1 (production): no budget, the solver as one call -- the kernel as round 5 had it (the budget's code costs the kernel 21
+// vector instructions per wave even where it never runs)
+template <class T, int OPT = 7, bool UNI = false, int SOLVER = 0, int BUDGET = -1>
 __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a, T kpa_uniform = T(0), cond_list lst = cond_list{nullptr, nullptr, 0, 0u, nullptr, nullptr, 0u})
 {
   // a.storage_ijk != nullptr: the droplets are taken in STORAGE order -- n_part is the storage extent, the cell comes from ijk, the
@@ -1253,6 +1255,7 @@ __global__ void __launch_bounds__(BS) k_cond_lean(size_t n_part, cond_args<T> a,
     T r;
     if constexpr (SOLVER == 2) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
     else if constexpr (SOLVER == 1) r = advance_rw2_lean_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+    else if constexpr (BUDGET < 0) r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, &several, lst.ent != nullptr);
     else {
       // (round 6) with records: the loop has a BUDGET of trips; a droplet that has not converged by then leaves the loop's state where it
       // stands in a record and k_cond_lean_resume goes on with it (lean2_loop is resumable: the same bits) -- the wave no longer waits
