@@ -191,6 +191,8 @@ enum lcx_dbg {
                                         * (dbg_cond_budget & 255: that many); a droplet that has not converged by then leaves the loop's state in a record and
                                         * k_cond_lean_resume goes on with it (the same bits; dbg_cond_budget >> 8: records per part, tests) */
   LCX_DBG_COND_PROBE = 1 << 26,        /* measurement only: k_cond_lean cut short at seven stages, launched ahead of the real kernel (k_cond_probe: instruction counts per part) */
+  LCX_DBG_COND_NO_FUSED_SUBSTEPS = 1 << 27, /* fast arithmetic, sstp_cond > 1: a cell pass, a condensation kernel and a per-cell finish per substep (rounds 1-5) instead of
+                                        * every substep of the step in one launch (k_cond_substeps: the same bits) */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };
@@ -207,7 +209,8 @@ enum lcx_cond_kernel {
   LCX_CK_LEAN_TOMS748_SORTED = 7,
   LCX_CK_TOMS748_TWO_PASS = 8,         /* k_cond_fast(_fold) (LCX_DBG_COND_TOMS_TWO_PASS) */
   LCX_CK_LEAN_R3 = 9, LCX_CK_FOLD_LEAN = 10, LCX_CK_LEAN_WQ = 11,      /* LCX_DBG_COND_LEAN_R3, _COND_FOLD, _COND_WQ */
-  LCX_CK_PER_PARTICLE = 12             /* exact_sstp_cond: k_pp_cond_* */
+  LCX_CK_PER_PARTICLE = 12,            /* exact_sstp_cond: k_pp_cond_* */
+  LCX_CK_SUBSTEPS = 13                 /* k_cond_substeps: fast arithmetic, sstp_cond > 1 -- every substep of the step in one launch */
 };
 
 /* POD mirror of opts_t<real_t> (opts.hpp:20-50) */

@@ -1111,6 +1111,30 @@ struct Particles : IParticles {
     HIPCHK(hipMemcpyAsync(sstp_tmp_th.p, th.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(sstp_tmp_rh.p, rhod.p, ncell * sizeof(T), hipMemcpyDeviceToDevice, st));
   }
+  // round 6: every condensation substep of the step in ONE launch (k_cond_substeps: a workgroup owns a run of cells and their droplets);
+  // fast arithmetic, sstp_cond > 1, the sorted order in place
+  void cond_substeps_fused(double RH_max)
+  {
+    Range r(this, "cond");
+    cond_pre.alloc(ncell * sizeof(cond_cell_fast<T>));
+    const cell_pre_args<T> P{ncell, th.p, rhod.p, rv.p, p.p, Tk.p, RH.p, eta.p, dv.p, lambda_D.p, lambda_K.p, o.th_dry, o.const_p, o.RH_formula, n_dims,
+                             T(RH_max), reinterpret_cast<cond_cell_fast<T> *>(cond_pre.p)};
+    cond_args<T> a{sid(), sijk(), A.n.p, A.rd3.p, A.kpa.p, A.vt.p, A.rw2.p, rhod.p, rv.p, Tk.p, eta.p, RH.p,
+                   lambda_D.p, lambda_K.p, m3_before.p, m3_after.p, T(T(dt) / sstp_cond), T(RH_max), eps_tol, T(2.), 100u, 1, ncell,
+                   0u, nullptr, P.pre, nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    const unsigned per_cell = unsigned(std::max<size_t>(1, npart / std::max<size_t>(1, ncell)));
+    const unsigned cells_per_wg = std::max(1u, std::min(unsigned(SUBSTEP_CELLS), unsigned(BS) / per_cell));
+    const dim3 grid(nblk(ncell, cells_per_wg)), bl(BS);
+    const bool toms = o.cond_solver == 1;
+    const int ask = dbg(LCX_DBG_COND_NO_LIST) ? 0 : 1;
+    const T kv = kpa_uniform ? kpa_value : T(0);
+    last_cond_kernel = LCX_CK_SUBSTEPS;
+    if (toms && kpa_uniform) hipLaunchKernelGGL((k_cond_substeps<T, true, 2>), grid, bl, 0, st, P, a, kv, cell_start.p, cells_per_wg, sstp_cond, sstp_fused(0), rw_mom3.p, ask);
+    else if (toms) hipLaunchKernelGGL((k_cond_substeps<T, false, 2>), grid, bl, 0, st, P, a, kv, cell_start.p, cells_per_wg, sstp_cond, sstp_fused(0), rw_mom3.p, ask);
+    else if (kpa_uniform) hipLaunchKernelGGL((k_cond_substeps<T, true, 0>), grid, bl, 0, st, P, a, kv, cell_start.p, cells_per_wg, sstp_cond, sstp_fused(0), rw_mom3.p, ask);
+    else hipLaunchKernelGGL((k_cond_substeps<T, false, 0>), grid, bl, 0, st, P, a, kv, cell_start.p, cells_per_wg, sstp_cond, sstp_fused(0), rw_mom3.p, ask);
+    vtpre_valid = false;
+  }
   // sstp_percell_step.ipp:7-48, as an argument of the substep's cell pass (k_cell_cond_pre)
   sstp_fields<T> sstp_fused(int step)
   {
@@ -1940,8 +1964,10 @@ struct Particles : IParticles {
     if (ix_ict >= 0 && nphys)                                                            // update_incloud_time, particles_step.ipp:180-181
       hipLaunchKernelGGL(k_incloud_time<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, A.rd3.p, A.kpa.p, A.rw2.p, Tk.p, T(dt), A.ext[ix_ict].p);
     if (opts.cond) {
-      if (!(sort_deferred && lean_storage_cond() && !opts.turb_cond && !(o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)))) hskpng_sort();
+      const bool fused_substeps = sstp_cond > 1 && lean_storage_cond() && !opts.turb_cond && npart && !dbg(LCX_DBG_COND_NO_FUSED_SUBSTEPS);
+      if (fused_substeps || !(sort_deferred && lean_storage_cond() && !opts.turb_cond && !(o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)))) hskpng_sort();
       if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) { hskpng_mfp(); cond_perparticle(opts.RH_max, opts.turb_cond); }
+      else if (fused_substeps) cond_substeps_fused(opts.RH_max);
       else for (int step = 0; step < sstp_cond; ++step) {
         // (the Eulerian fields' substep rides on the cell pass of cond_substep: sstp_fused)
         if (opts.turb_cond && nphys)                                                     // apply_perparticle_sgs_supersat.ipp

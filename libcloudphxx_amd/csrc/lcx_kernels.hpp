@@ -189,13 +189,14 @@ __global__ void k_cell_mfp(size_t n_cell, const T *Tk, const T *p, T *lambda_D, 
 // housekeeping, as the reference's hskpng_mfp placed ahead of the substep loop (particles_step.ipp:193-196) -- then hskpng_Tpr --
 // then (fast arithmetic) the droplet-independent set-up of the growth rate.  Same expressions as the three kernels it replaces.
 template <class T> struct sstp_fields { int n, step; T sstp; T *scl[3], *tmp[3]; };
+// one cell of that pass (shared with k_cond_substeps): returns the growth rate's set-up of the cell
+template <class T> struct cell_pre_args {
+  size_t n_cell; const T *th, *rhod, *rv; T *p, *Tk, *RH, *eta, *dv, *lambda_D, *lambda_K;
+  int th_dry, const_p, RH_formula, ndims; T RH_max; cond_cell_fast<T> *pre;
+};
 template <class T>
-__global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv, T *lambda_D, T *lambda_K,
-                                int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre,
-                                uint32_t *zero_words = nullptr, int n_zero_words = 0, sstp_fields<T> ss = sstp_fields<T>{0, 0, T(1), {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}})
+__device__ __forceinline__ cond_cell_fast<T> cell_cond_pre_one(const cell_pre_args<T> &A, size_t c, int do_mfp, const sstp_fields<T> &ss)
 {
-  if (gid() < size_t(n_zero_words)) zero_words[gid()] = 0u;         // (the straggler counters of the condensation kernel that follows)
-  const size_t c = gid(); if (c >= n_cell) return;
   // (round 6) the substep's share of the Eulerian fields' change (sstp_percell_step.ipp:7-48: k_sstp_step's operations, per field) ahead of
   // the cell's own pass over the same fields: two or three launches fewer per substep -- a 2-D set-up of ten substeps is a queue of
   // five-microsecond kernels, and what it costs is their number (bench.py's c2 leg)
@@ -208,17 +209,29 @@ __global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const
     } else scl[c] = scl[c] + tmp[c] / ss.sstp;
   }
   T lD, lK;
-  if (do_mfp) { lD = lambda_D_of(Tk[c]); lK = lambda_K_of(Tk[c], p[c]); lambda_D[c] = lD; lambda_K[c] = lK; }
-  else { lD = lambda_D[c]; lK = lambda_K[c]; }
-  const T t = th_dry ? theta_dry_T(th[c], rhod[c]) : T(th[c] * exner(p[c]));
-  Tk[c] = t;
-  T pp = p[c];
-  if (!const_p) { pp = theta_dry_p(rhod[c], rv[c], t); p[c] = pp; }
-  const T rh = RH_of(RH_formula, pp, rv[c], t), et = visc(t);
-  RH[c] = rh;
-  eta[c] = et;
-  if (ndims == 0) dv[c] = T(1) / rhod[c];
-  if (pre) pre[c] = make_cond_cell_fast(rhod[c], rv[c], t, et, lD, lK, rh, RH_max);
+  if (do_mfp) { lD = lambda_D_of(A.Tk[c]); lK = lambda_K_of(A.Tk[c], A.p[c]); A.lambda_D[c] = lD; A.lambda_K[c] = lK; }
+  else { lD = A.lambda_D[c]; lK = A.lambda_K[c]; }
+  const T t = A.th_dry ? theta_dry_T(A.th[c], A.rhod[c]) : T(A.th[c] * exner(A.p[c]));
+  A.Tk[c] = t;
+  T pp = A.p[c];
+  if (!A.const_p) { pp = theta_dry_p(A.rhod[c], A.rv[c], t); A.p[c] = pp; }
+  const T rh = RH_of(A.RH_formula, pp, A.rv[c], t), et = visc(t);
+  A.RH[c] = rh;
+  A.eta[c] = et;
+  if (A.ndims == 0) A.dv[c] = T(1) / A.rhod[c];
+  cond_cell_fast<T> cc{};
+  if (A.pre) { cc = make_cond_cell_fast(A.rhod[c], A.rv[c], t, et, lD, lK, rh, A.RH_max); A.pre[c] = cc; }
+  return cc;
+}
+template <class T>
+__global__ void k_cell_cond_pre(size_t n_cell, const T *th, const T *rhod, const T *rv, T *p, T *Tk, T *RH, T *eta, T *dv, T *lambda_D, T *lambda_K,
+                                int th_dry, int const_p, int RH_formula, int ndims, int do_mfp, T RH_max, cond_cell_fast<T> *pre,
+                                uint32_t *zero_words = nullptr, int n_zero_words = 0, sstp_fields<T> ss = sstp_fields<T>{0, 0, T(1), {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}})
+{
+  if (gid() < size_t(n_zero_words)) zero_words[gid()] = 0u;         // (the straggler counters of the condensation kernel that follows)
+  const size_t c = gid(); if (c >= n_cell) return;
+  const cell_pre_args<T> A{n_cell, th, rhod, rv, p, Tk, RH, eta, dv, lambda_D, lambda_K, th_dry, const_p, RH_formula, ndims, RH_max, pre};
+  (void)cell_cond_pre_one(A, c, do_mfp, ss);
 }
 // sstp_percell_step.ipp:7-48 for one field (the fields of a substep as ONE argument of the cell pass: sstp_fields)
 template <class T>
@@ -1808,6 +1821,100 @@ k_cond_cellfinish_direct(size_t n_cell, const uint32_t *cell_start, const T *cha
   if (!mine || sub != 0) return;
   const T after = bad ? T(NAN) : T(ldexp(double(acc), -fxk));
   cellfinish_apply(c, e > s, after, T(0), dv, rhod, rv, th, Tk, rw_mom3, 0, 1, ndims);
+}
+// Round 6: ALL the condensation substeps of a step in ONE launch (fast arithmetic, sstp_cond > 1).  Condensation couples droplets
+// through their cell alone -- the cell's th and rv take the droplets' change after every substep -- so a workgroup that owns a run of
+// cells and every droplet in them can make the substeps one after the other with workgroup barriers only: per substep the cell pass
+// (one lane per cell: the Eulerian fields' substep, hskpng_Tpr, the growth rate's set-up -- cell_cond_pre_one, kept in LDS), the droplets
+// (a lane per droplet of the cells' stretch of the sorted order: the same solver calls as k_cond_lean / k_cond_lean_fold), the cells'
+// fixed-point sums of the changes (LDS atomics: maximum, then integers -- k_cond_cellfinish_direct's numbers, whose sums do not depend
+// on the addends' order) and cellfinish_apply.  The same operations on the same numbers as the launches it replaces: bit-identical
+// (tests/test_hip_parity.py).  BASELINE configs[1] (76 x 76 cells x 64, ten substeps) made thirty launches of 5-16 us each for this:
+// 0.27 of its 0.62 ms step.  A lane walks its droplets (position S + lane, + 256 ...) in every substep and a cell lane its cell, so
+// everything a substep reads of what the previous one wrote was written by the same lane.
+// SOLVER 0: the lean solver, droplets whose bracket may hold several roots through TOMS748 in place (what k_cond_lean_listed computes
+// for them); 2: TOMS748 for every droplet.
+constexpr int SUBSTEP_CELLS = 64;              // cells per workgroup at most (the host picks 256 / (droplets per cell), at least one)
+template <class T, bool UNI, int SOLVER>
+__global__ void __launch_bounds__(BS) k_cond_substeps(cell_pre_args<T> P, cond_args<T> a, T kpa_uniform, const uint32_t *cell_start, unsigned cells_per_wg,
+                                                      int sstp, sstp_fields<T> ss, T *rw_mom3, int ask_several)
+{
+  __shared__ cond_cell_fast<T> cc_s[SUBSTEP_CELLS];
+  __shared__ unsigned long long amax_s[SUBSTEP_CELLS];
+  __shared__ long long fx_s[SUBSTEP_CELLS];
+  __shared__ int fxk_s[SUBSTEP_CELLS];
+  const size_t c0 = size_t(blockIdx.x) * cells_per_wg;
+  if (c0 >= P.n_cell) return;
+  const size_t c1 = c0 + cells_per_wg < P.n_cell ? c0 + cells_per_wg : P.n_cell;
+  const unsigned ncl = unsigned(c1 - c0), t = threadIdx.x;
+  const uint32_t S = cell_start[c0], E = cell_start[c1];
+  // a lane's FIRST droplet (its only one unless the cells hold more than 256 between them) stays in registers through the substeps: its
+  // attributes are read once, its wet radius is written once, its change never leaves the lane
+  const bool has0 = S + t < E;
+  uint32_t id0 = 0, lc0 = 0;
+  T rw2_0 = 0, rd3_0 = 0, vt_0 = 0, kpa_0 = kpa_uniform, nn_0 = 0, delta0 = 0;
+  if (has0) {
+    id0 = a.sorted_id[S + t]; lc0 = a.sorted_ijk[S + t] - uint32_t(c0);
+    rw2_0 = a.rw2[id0]; rd3_0 = a.rd3[id0]; vt_0 = a.vt[id0]; nn_0 = T(a.n[id0]);
+    if (!UNI) kpa_0 = a.kpa[id0];
+  }
+  for (int step = 0; step < sstp; ++step) {
+    if (t < ncl) {
+      ss.step = step;
+      cc_s[t] = cell_cond_pre_one(P, c0 + t, int(step == 0), ss);
+      amax_s[t] = 0ull; fx_s[t] = 0ll;
+    }
+    __syncthreads();
+    for (uint32_t j = 0, q = S + t; q < E; ++j, q += BS) {
+      uint32_t id = id0, lc = lc0;
+      T rw2_old = rw2_0, rd3 = rd3_0, vt = vt_0, kpa = kpa_0, nn = nn_0;
+      if (j) {
+        id = a.sorted_id[q]; lc = a.sorted_ijk[q] - uint32_t(c0);
+        rw2_old = a.rw2[id]; rd3 = a.rd3[id]; vt = a.vt[id]; nn = T(a.n[id]);
+        if (!UNI) kpa = a.kpa[id];
+      }
+      T delta = 0;
+      if (!(rw2_old <= 0)) {
+        cond_fun_fast<T, 15> ff;
+        ff.setup_cell(cc_s[lc], rw2_old, a.dt_sub, rd3, kpa, vt);
+        T r;
+        if constexpr (SOLVER == 2) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+        else {
+          bool several = false;
+          r = advance_rw2_lean2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter, &several, ask_several != 0);
+          if (several) r = advance_rw2_with(ff, rw2_old, rd3, a.dt_sub, a.eps, a.cond_mlt, a.n_iter);
+        }
+        if (j) a.rw2[id] = r; else rw2_0 = r;
+        delta = nn * (r * (r * rsqrt_pos(r)) - rw2_old * (rw2_old * rsqrt_pos(rw2_old)));
+      }
+      if (j) a.m3_after[q] = delta; else delta0 = delta;
+      // (the bits of a non-negative double order like the double; a NaN's lie above every number's: it stays, as nanmax keeps it)
+      atomicMax(&amax_s[lc], (unsigned long long)__double_as_longlong(fabs(double(delta))));
+    }
+    __syncthreads();
+    if (t < ncl) {
+      const double amax = __longlong_as_double((long long)amax_s[t]);
+      const uint32_t cnt = cell_start[c0 + t + 1] - cell_start[c0 + t];
+      fxk_s[t] = (amax > 0 && amax < 1e300) ? fx_shift(amax, cnt) : 0;
+    }
+    __syncthreads();
+    for (uint32_t j = 0, q = S + t; q < E; ++j, q += BS) {
+      const uint32_t lc = j ? a.sorted_ijk[q] - uint32_t(c0) : lc0;
+      const T delta = j ? a.m3_after[q] : delta0;
+      const double amax = __longlong_as_double((long long)amax_s[lc]);
+      if (amax > 0 && amax < 1e300) atomicAdd((unsigned long long *)&fx_s[lc], (unsigned long long)to_fx(double(delta), fxk_s[lc]));
+    }
+    __syncthreads();
+    if (t < ncl) {
+      const size_t c = c0 + t;
+      const double amax = __longlong_as_double((long long)amax_s[t]);
+      const bool bad = !(amax < 1e300);
+      const T after = bad ? T(NAN) : T(ldexp(double(fx_s[t]), -fxk_s[t]));
+      cellfinish_apply(c, cell_start[c + 1] > cell_start[c], after, T(0), P.dv, P.rhod, const_cast<T *>(P.rv), const_cast<T *>(P.th), P.Tk, rw_mom3, 0, 1, P.ndims);
+    }
+    __syncthreads();
+  }
+  if (has0 && !(rw2_0 <= 0)) a.rw2[id0] = rw2_0;
 }
 // Fast arithmetic, crowded cells (hundreds of SDs per cell): ONE WAVE per cell sums the segment with coalesced loads and a
 // fixed shuffle tree -- deterministic, but not the reference's serial order, so the sums differ from the ordered ones in the last

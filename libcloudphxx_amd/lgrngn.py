@@ -116,6 +116,7 @@ class dbg(enum.IntFlag):
     COND_WQ_PF2 = 1 << 24
     COND_BUDGET = 1 << 25
     COND_PROBE = 1 << 26
+    COND_NO_FUSED_SUBSTEPS = 1 << 27
 
 
 class cond_kernel(enum.IntEnum):
@@ -133,6 +134,7 @@ class cond_kernel(enum.IntEnum):
     fold_lean = 10
     lean_wq = 11
     per_particle = 12
+    substeps = 13
 
 
 class src_t(_bp_enum):              # lgrngn/ccn_source.hpp:8

@@ -603,7 +603,7 @@ def test_the_api_default_mode_keeps_the_strict_bars():
     opts = lgrngn.opts_t()
     for it in range(3):
         (tho, rvo), (thh, rvh) = step_pair(orc, hip, opts, fields)
-        h.assert_mode(hip, False, 1, ("fold_toms748", "lean_toms748_sorted"))      # (the default's kernels; a replayed run walks the sorted order)
+        h.assert_mode(hip, False, 1, ("fold_toms748", "lean_toms748_sorted", "substeps"))      # (the default's kernels; two substeps: both in one launch)
         assert hip.n_part == orc.n_part
         exact(hip.state_u64("sorted_id"), orc.state_u64("sorted_id"), "sorted_id")
         exact(hip.state_u64("n"), orc.state_u64("n"), "n")
@@ -1138,6 +1138,53 @@ def test_the_first_pass_budget_is_unobservable(sd_conc, steps, reorder_every):
     assert sum(res[0][5]) == 0 and sum(res[2][5]) > sum(res[1][5]) > sum(res[3][5]) > 0, [sum(r_[5]) for r_ in res]
     assert res[4][5] == res[1][5] and max(res[4][5]) > 64 * 4
     print("records per substep (the step's last): two trips %s, one %s, three %s" % tuple(res[k][5][:3] for k in (1, 2, 3)))
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+@pytest.mark.parametrize("dims,sd_conc,sstp,real_t", [((12, 10, 14), 64, 4, np.float64), ((9, 0, 11), 40, 10, np.float32), ((5, 4, 6), 300, 3, np.float64),
+                                                       ((0, 0, 0), 500, 5, np.float64)])
+def test_all_substeps_in_one_launch_give_the_same_bits(dims, sd_conc, sstp, real_t, solver):
+    """Round 6.  With sstp_cond > 1 the fast arithmetic makes every condensation substep of a step in ONE launch (k_cond_substeps: a
+    workgroup owns a run of cells and their droplets; per substep the cell pass, the droplets, the cells' fixed-point sums and the
+    feedback on th and rv, with workgroup barriers in between) instead of a cell pass, a condensation kernel and a per-cell finish per
+    substep (dbg COND_NO_FUSED_SUBSTEPS).  The same operations on the same numbers: rw2, th, rv, multiplicities and the sorted order bit
+    for bit after full steps with coalescence and advection -- both solvers, 3-D / 2-D / 0-D, float as C2 runs it, cells of 300 droplets
+    (more than a workgroup's lanes per cell)."""
+    nx, ny, nz = dims
+    kw = dict(sstp_cond=sstp, strict_fp=False)
+    if not nz:
+        kw["sedi_switch"] = False
+    oi = h.box_opts(nx, ny, nz, sd_conc, **kw)
+    oi.cond_solver = solver
+    fields = h.box_fields(oi)
+    res = []
+    for flags in (int(lgrngn.dbg.COND_NO_FUSED_SUBSTEPS), 0):
+        oi.dbg_flags = flags
+        hip = h.hip_particles(oi, real_t)
+        th, rv, rhod, C = [f.astype(real_t) if isinstance(f, np.ndarray) else {k: v.astype(real_t) for k, v in f.items()} for f in fields]
+        hip.init(th, rv, rhod, **C)
+        opts = lgrngn.opts_t()
+        if not nz:
+            opts.sedi = opts.adve = False
+        thh, rvh = th.copy(), rv.copy()
+        for _ in range(4):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            hip.step_async(opts)
+        h.assert_mode(hip, False, solver, "substeps" if not flags else ("lean", "lean_sorted", "fold_toms748", "lean_toms748", "lean_toms748_sorted"))
+        res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.state_u64("sorted_id"), hip.n_part))
+    assert res[0][5] == res[1][5]
+    if real_t is np.float32 and solver == 0:
+        # (float's growth rate is left to the compiler's contraction, `#pragma clang fp contract(fast)`, which may fuse differently in two
+        # kernels; TOMS748's iterates came out the same here, the lean solver's stopping decisions at float's tolerance 2^-7 flip on an ulp
+        # for a tenth of the droplets: the same answers to that tolerance, not the same bits)
+        assert np.array_equal(res[0][3], res[1][3]) and np.array_equal(res[0][4], res[1][4])
+        np.testing.assert_allclose(res[0][0], res[1][0], rtol=2. ** -7)
+        np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-6)
+        np.testing.assert_allclose(res[0][2], res[1][2], rtol=3e-6)
+    else:
+        for a_, b_ in zip(res[0][:5], res[1][:5]):
+            assert np.array_equal(a_, b_)
+    assert np.abs(res[0][2] - fields[1].astype(real_t)).max() > 0
 
 
 def test_brackets_that_may_hold_several_roots_take_the_references_iterates():
