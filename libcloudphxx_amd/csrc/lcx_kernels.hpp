@@ -200,7 +200,9 @@ __device__ __forceinline__ cond_cell_fast<T> cell_cond_pre_one(const cell_pre_ar
   // (round 6) the substep's share of the Eulerian fields' change (sstp_percell_step.ipp:7-48: k_sstp_step's operations, per field) ahead of
   // the cell's own pass over the same fields: two or three launches fewer per substep -- a 2-D set-up of ten substeps is a queue of
   // five-microsecond kernels, and what it costs is their number (bench.py's c2 leg)
-  for (int f = 0; f < ss.n; ++f) {
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {            // (unrolled: the fields' pointers stay in scalar registers, a run-time index would put the struct on the stack)
+    if (f >= ss.n) break;
     T *scl = ss.scl[f], *tmp = ss.tmp[f];
     if (ss.step == 0) {
       const T d = scl[c] - tmp[c];

@@ -1,4 +1,4 @@
-"""one C2 run (bench.c2_leg) for a kernel trace:  rocprofv3 --kernel-trace --output-format csv -d out -- python3 tools/c2_trace.py [steps]"""
+"""one C2 run (bench.c2_leg) for a kernel trace:  rocprofv3 --kernel-trace --output-format csv -d out -- python3 tools/c2_trace.py [steps] [cond_solver]"""
 import os
 import sys
 import json
@@ -7,5 +7,6 @@ import numpy as np
 import torch
 import bench
 from libcloudphxx_amd import lgrngn
-r = bench.c2_leg(lgrngn, torch, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20)
+kw = {"cond_solver": int(sys.argv[2])} if len(sys.argv) > 2 else {}
+r = bench.c2_leg(lgrngn, torch, steps=int(sys.argv[1]) if len(sys.argv) > 1 else 20, **kw)
 print(json.dumps(r))
