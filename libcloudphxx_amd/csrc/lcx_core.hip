@@ -1964,7 +1964,10 @@ struct Particles : IParticles {
     if (ix_ict >= 0 && nphys)                                                            // update_incloud_time, particles_step.ipp:180-181
       hipLaunchKernelGGL(k_incloud_time<T>, dim3(nblk(nphys)), dim3(BS), 0, st, nphys, ijk.p, A.rd3.p, A.kpa.p, A.rw2.p, Tk.p, T(dt), A.ext[ix_ict].p);
     if (opts.cond) {
-      const bool fused_substeps = sstp_cond > 1 && lean_storage_cond() && !opts.turb_cond && npart && !dbg(LCX_DBG_COND_NO_FUSED_SUBSTEPS);
+      // (a measurement switch that names one of the per-substep kernels gets that kernel)
+      constexpr unsigned per_substep_variants = LCX_DBG_COND_NO_FUSED_SUBSTEPS | LCX_DBG_COND_FOLD | LCX_DBG_COND_WQ | LCX_DBG_COND_BUDGET | LCX_DBG_COND_PROBE |
+                                                LCX_DBG_COND_LEAN_R3 | LCX_DBG_FINISH_STAGED | LCX_DBG_COND_NO_FOLD;
+      const bool fused_substeps = sstp_cond > 1 && lean_storage_cond() && !opts.turb_cond && npart && !(o.dbg_flags & per_substep_variants);
       if (fused_substeps || !(sort_deferred && lean_storage_cond() && !opts.turb_cond && !(o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)))) hskpng_sort();
       if (o.exact_sstp_cond && (sstp_cond > 1 || sstp_cond_act > 1)) { hskpng_mfp(); cond_perparticle(opts.RH_max, opts.turb_cond); }
       else if (fused_substeps) cond_substeps_fused(opts.RH_max);

@@ -1009,7 +1009,8 @@ def test_per_cell_finish_without_its_lds_stage_gives_the_same_bits(sd_conc, step
     fields = h.box_fields(oi)
     res = []
     for staged in (False, True):
-        oi.dbg_flags = int(lgrngn.dbg.FINISH_STAGED) if staged else 0
+        # (sstp_cond = 2: the per-substep launches in both, round 6's k_cond_substeps has a finish of its own)
+        oi.dbg_flags = int(lgrngn.dbg.FINISH_STAGED if staged else lgrngn.dbg.COND_NO_FUSED_SUBSTEPS)
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -1018,6 +1019,7 @@ def test_per_cell_finish_without_its_lds_stage_gives_the_same_bits(sd_conc, step
         for _ in range(steps):
             hip.step_sync(opts, thh, rvh, rhod, **C)
             hip.step_async(opts)
+        h.assert_mode(hip, False, None, ("lean", "lean_toms748"))
         res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n")))
     for a_, b_ in zip(res[0], res[1]):
         assert np.array_equal(a_, b_)
@@ -1035,7 +1037,8 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
     fields = h.box_fields(oi)
     res = []
     for positional in (False, True):
-        oi.dbg_flags = int(lgrngn.dbg.COND_SORTED_ORDER) if positional else 0
+        # (sstp_cond = 2: the per-substep storage-order kernel against the positional one; round 6's k_cond_substeps has its own test)
+        oi.dbg_flags = int(lgrngn.dbg.COND_SORTED_ORDER if positional else lgrngn.dbg.COND_NO_FUSED_SUBSTEPS)
         hip = h.hip_particles(oi)
         th, rv, rhod, C = fields
         hip.init(th, rv, rhod, **C)
@@ -1048,6 +1051,7 @@ def test_storage_order_condensation_is_bit_identical_to_the_positional_one(monke
         for _ in range(steps):
             hip.step_sync(opts, thh, rvh, rhod, **C)
             hip.step_async(opts)
+        h.assert_mode(hip, False, None, ("lean_sorted", "lean_toms748_sorted") if positional else ("lean", "lean_toms748"))
         res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part))
     assert res[0][4] == res[1][4] and res[0][4] < oi.nx * oi.ny * oi.nz * sd_conc      # (super-droplets were used up)
     for a_, b_ in zip(res[0][:4], res[1][:4]):
@@ -1078,7 +1082,11 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
     FO, NL = int(lgrngn.dbg.COND_FOLD), int(lgrngn.dbg.COND_NO_LIST)
     WQ, W128, KA = int(lgrngn.dbg.COND_WQ), int(lgrngn.dbg.COND_WQ_CAP128), int(lgrngn.dbg.KPA_ARRAY)
     PF, PF2 = int(lgrngn.dbg.COND_WQ_PF), int(lgrngn.dbg.COND_WQ_PF2)
-    for flags, budget in ((0, 0), (KA, 0), (int(lgrngn.dbg.COND_LEAN_R3), 0), (FO, 0), (FO | KA, 0), (FO, 8),
+    # (sstp_cond = 2: without a switch that names a per-substep kernel both substeps are k_cond_substeps' -- the first two variants; NF is
+    # the production kernel of sstp_cond = 1 launched per substep.  Every variant says which kernel it ran.)
+    NF, R3 = int(lgrngn.dbg.COND_NO_FUSED_SUBSTEPS), int(lgrngn.dbg.COND_LEAN_R3)
+    ran = {0: "substeps", KA: "substeps", NF: "lean", NF | KA: "lean", R3: "lean_r3"}
+    for flags, budget in ((NF, 0), (NF | KA, 0), (0, 0), (KA, 0), (R3, 0), (FO, 0), (FO | KA, 0), (FO, 8),
                           (WQ, 0), (WQ, 3), (WQ, 16), (WQ | KA, 5), (WQ | W128, 0), (WQ | W128, 7), (WQ | W128 | KA, 2),
                           (WQ | PF, 4), (WQ | W128 | PF | KA, 3), (WQ | PF2, 5), (WQ | PF2 | KA, 2)):
         oi.dbg_flags = flags | NL
@@ -1091,6 +1099,7 @@ def test_lean_kernel_round4_and_round3_solver_forms_give_the_same_bits(sd_conc, 
         for _ in range(steps):
             hip.step_sync(opts, thh, rvh, rhod, **C)
             hip.step_async(opts)
+        h.assert_mode(hip, False, 0, ran.get(flags, "fold_lean" if flags & FO else "lean_wq"))
         res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part))
     assert len(set(r_[4] for r_ in res)) == 1
     for k in range(1, len(res)):
@@ -1113,8 +1122,9 @@ def test_the_first_pass_budget_is_unobservable(sd_conc, steps, reorder_every):
     oi.reorder_every = reorder_every
     fields = h.box_fields(oi)
     res = []
-    BU, SO, WQ, KA = (int(lgrngn.dbg[k]) for k in ("COND_BUDGET", "COND_SORTED_ORDER", "COND_WQ", "KPA_ARRAY"))
-    for flags, budget in ((0, 0), (BU, 0), (BU, 1), (BU, 3), (BU, 2 | 4 << 8), (BU | KA, 0), (SO, 0), (SO | BU, 0), (WQ, 3)):
+    BU, SO, WQ, KA, NF = (int(lgrngn.dbg[k]) for k in ("COND_BUDGET", "COND_SORTED_ORDER", "COND_WQ", "KPA_ARRAY", "COND_NO_FUSED_SUBSTEPS"))
+    # (sstp_cond = 2: NF keeps the first variant on the per-substep production kernel -- without it both substeps are k_cond_substeps')
+    for flags, budget in ((NF, 0), (BU, 0), (BU, 1), (BU, 3), (BU, 2 | 4 << 8), (BU | KA, 0), (SO, 0), (SO | BU, 0), (WQ, 3), (0, 0)):
         oi.dbg_flags = flags
         oi.dbg_cond_budget = budget
         hip = h.hip_particles(oi)
@@ -1128,6 +1138,7 @@ def test_the_first_pass_budget_is_unobservable(sd_conc, steps, reorder_every):
             hip.step_sync(opts, thh, rvh, rhod, **C)
             resumed.append(int(hip.state_u64("raw_cond_resumed")[0]))
             hip.step_async(opts)
+        h.assert_mode(hip, False, 0, "substeps" if not flags else "lean_wq" if flags & WQ else "lean_sorted" if flags & SO else "lean")
         res.append((hip.get_attr("rw2"), thh, rvh, hip.state_u64("n"), hip.n_part, resumed))
     assert len(set(r_[4] for r_ in res)) == 1
     for k in range(1, len(res)):
