@@ -193,6 +193,8 @@ enum lcx_dbg {
   LCX_DBG_COND_PROBE = 1 << 26,        /* measurement only: k_cond_lean cut short at seven stages, launched ahead of the real kernel (k_cond_probe: instruction counts per part) */
   LCX_DBG_COND_NO_FUSED_SUBSTEPS = 1 << 27, /* fast arithmetic, sstp_cond > 1: a cell pass, a condensation kernel and a per-cell finish per substep (rounds 1-5) instead of
                                         * every substep of the step in one launch (k_cond_substeps: the same bits) */
+  LCX_DBG_VTERM_INVALID_OWN_PASS = 1 << 28, /* sstp_coal > 1: hskpng_vterm_invalid as a launch of its own between the substeps (rounds 1-5) instead of on the
+                                        * next substep's in-cell ranking (the same bits) */
   LCX_DBG_COND_TOMS_TWO_PASS = 1 << 15 /* cond_solver = 1 through round 2's kernels (k_cond_fast_fold + k_cond_fast over the sorted order, iteration budget and
                                         * straggler launch) instead of the storage-order kernel with TOMS748 in it */
 };

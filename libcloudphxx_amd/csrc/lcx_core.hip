@@ -822,6 +822,15 @@ struct Particles : IParticles {
         }
         const int crowded = npart / (ncell ? ncell : 1) > size_t(CELLRANK_MAX) / 2;
         if (every_cell_by_a_wave()) ;           // every cell is sorted in place below: nothing to rank and no buffer swap
+        else if (shuffle && !rs.un && !crowded && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING) && vt_fix_pending && nphys) {
+          // (between two coalescence substeps: hskpng_vterm_invalid rides on the ranking, see step_async)
+          const bool b77 = vtc.formula == LCX_VT_BEARD77 || vtc.formula == LCX_VT_BEARD77FAST;
+          const rank_vt_fix<T> fx{vtc, b77 ? (vtc.formula == LCX_VT_BEARD77FAST ? 2 : 1) : 0, o.strict_fp ? 0 : 1, Tk.p, p.p, rhod.p, eta.p, vt_0.p,
+                                  b77 ? vt_pre.p : nullptr, A.rw2.p, A.vt.p};
+          hipLaunchKernelGGL((k_cellrank_bkt<true, rank_vt_fix<T>>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs,
+                             rank_range{nullptr, nullptr, nullptr}, fx);
+          vt_fix_pending = false;
+        }
         else if (shuffle && !rs.un && !crowded && !shuffle_philox && (rs.s1 | rs.s2) && !dbg(LCX_DBG_RANK_BY_COUNTING)) hipLaunchKernelGGL(k_cellrank_bkt<>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, rank_range{nullptr, nullptr, nullptr});
         else if (shuffle && !rs.un && !crowded && !shuffle_philox) hipLaunchKernelGGL((k_cellrank<uint32_t, true>), dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
         else if (shuffle) hipLaunchKernelGGL(k_cellrank<uint64_t>, dim3(nblk(npart)), dim3(BS), 0, st, npart, sijk(), cell_start.p, sid(), rnk() + sort_base, rs, crowded, rank_range{nullptr, nullptr, nullptr});
@@ -1462,10 +1471,14 @@ struct Particles : IParticles {
   // ------------------------------------------------------------------------------------------
   // coalescence (coal.ipp:273-546)
   // ------------------------------------------------------------------------------------------
+  // the previous coalescence substep has left velocities invalid: the in-cell ranking of the next one refreshes them on its way
+  // (order_cells), or the pass of its own does where another ranking kernel runs
+  bool vt_fix_pending = false;
   void coal(double dt_sub, bool turb_coal = false)
   {
     if (!replay.empty()) ensure_compact();     // un[id] of a replayed CPU stream is indexed by the reference's (compact) ids
     hskpng_sort_helper(true);
+    if (vt_fix_pending) { vt_fix_pending = false; hskpng_vterm(true); }
     if (npart < 2) { if (npart) (void)rand_u01(npart); return; }
     Range r(this, "coal");
     const u01_src<T> rs = rand_u01(npart);
@@ -2011,7 +2024,8 @@ struct Particles : IParticles {
     if (opts.coal) {
       for (int step = 0; step < sstp_coal; ++step) {
         coal(dt / sstp_coal, opts.turb_coal);
-        if (step + 1 != sstp_coal) hskpng_vterm(true);
+        // (hskpng_vterm_invalid between the substeps: left to the next substep's ranking, which every droplet passes anyway)
+        if (step + 1 != sstp_coal) { if (dbg(LCX_DBG_VTERM_INVALID_OWN_PASS)) hskpng_vterm(true); else vt_fix_pending = true; }
       }
       if (pure_const_multi) {
         int flag = 0;

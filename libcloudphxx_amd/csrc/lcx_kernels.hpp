@@ -531,10 +531,13 @@ k_cellrank(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, con
 // alone and was bound by its waits; now it runs next to the per-cell finish and the terminal velocities (Particles::st_rank), whose waves
 // fill the barriers, and the vector ALU is what the three share.  Same order as k_cellrank<uint32_t, true> (the keys are unique).
 // A workgroup whose first or last cell reaches beyond the speculative window, or whose staged range exceeds the stage, ranks by counting.
-template <bool DUMMY = true>
+// EXTRA (round 6): something else that every droplet of the order needs before the kernel that consumes the ranking -- a coalescence
+// substep's pass over the invalid terminal velocities (rank_vt_fix below: one launch less per substep); nothing by default
+struct rank_no_extra { __device__ __forceinline__ void operator()(uint32_t, uint32_t) const {} };
+template <bool DUMMY = true, class EXTRA = rank_no_extra>
 __global__ void __launch_bounds__(BS)
 k_cellrank_bkt(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start, const uint32_t *in, uint32_t *out, rng_src r,
-               rank_range rg = rank_range{nullptr, nullptr, nullptr})
+               rank_range rg = rank_range{nullptr, nullptr, nullptr}, EXTRA extra = EXTRA())
 {
   using KEY = uint32_t;
   constexpr int CAP = cr_cap<KEY>;
@@ -558,6 +561,7 @@ k_cellrank_bkt(size_t n, const uint32_t *sorted_ijk, const uint32_t *cell_start,
   uint32_t id_e = 0;
   if (have_e) id_e = in[pe];
   if (active) { c = sorted_ijk[p]; id = in[p]; s = cell_start[c]; e = cell_start[c + 1]; }
+  if (active) extra(id, c);
 #pragma unroll
   for (int k = 0; k < CAP / BS; ++k) bkt[threadIdx.x + k * BS] = 0u;
   const KEY mine = active ? shuffle_un(id, r.s1, r.s2) : KEY(0);
@@ -1010,6 +1014,23 @@ __global__ void k_vterm(size_t n, int only_invalid, vt_cfg v, const T *rw2, cons
   if (c == DEAD_CELL) return;
   vt[i] = vt_eval(v, r2, Tk[c], p[c], rhod[c], eta[c], vt_0);
 }
+
+// hskpng_vterm_invalid for ONE droplet of the sorted order (k_vterm's / k_vterm_b77's expressions, whichever the run's formula takes), as
+// the EXTRA of the in-cell ranking that the next coalescence substep waits for anyway (sstp_coal > 1: a launch less per substep)
+// b77: 0 k_vterm's formulas (vt_eval), 1 beard77 / 2 beard77fast through the cells' prepared part; fast: opts_init.strict_fp == 0
+template <class T> struct rank_vt_fix {
+  vt_cfg v; int b77, fast; const T *Tk, *p, *rhod, *eta, *vt_0; const beard77_cell<T> *pre; const T *rw2; T *vt;
+  __device__ __forceinline__ void operator()(uint32_t id, uint32_t c) const
+  {
+    const T r2 = rw2[id];
+    if (!(r2 > T(0)) || !(vt[id] == T(-1)) || c == DEAD_CELL) return;
+    T out = T(0);
+    if (b77 == 0) out = vt_eval(v, r2, Tk[c], p[c], rhod[c], eta[c], vt_0);
+    else if (b77 == 1) { if (fast) vterm_b77_one<T, true, false>(v, r2, c, pre, vt_0, out); else vterm_b77_one<T, false, false>(v, r2, c, pre, vt_0, out); }
+    else { if (fast) vterm_b77_one<T, true, true>(v, r2, c, pre, vt_0, out); else vterm_b77_one<T, false, true>(v, r2, c, pre, vt_0, out); }
+    vt[id] = out;
+  }
+};
 
 // ============================================================================================
 // condensation (percell/particles_impl_cond.ipp:13-139 + moms.ipp:277-350 + update_th_rv.ipp:74-191)

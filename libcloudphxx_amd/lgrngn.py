@@ -117,6 +117,7 @@ class dbg(enum.IntFlag):
     COND_BUDGET = 1 << 25
     COND_PROBE = 1 << 26
     COND_NO_FUSED_SUBSTEPS = 1 << 27
+    VTERM_INVALID_OWN_PASS = 1 << 28
 
 
 class cond_kernel(enum.IntEnum):

@@ -1198,6 +1198,57 @@ def test_all_substeps_in_one_launch_give_the_same_bits(dims, sd_conc, sstp, real
     assert np.abs(res[0][2] - fields[1].astype(real_t)).max() > 0
 
 
+@pytest.mark.parametrize("dims,sd_conc,sstp,real_t,vt,kernel", [
+    ((9, 0, 11), 64, 10, np.float32, "khvorostyanov_spherical", "geometric"),       # C2's shape
+    ((7, 6, 8), 64, 4, np.float64, "beard77fast", "hall_davis_no_waals"),
+    ((6, 5, 4), 40, 3, np.float64, "beard77", "geometric"),
+    ((5, 4, 6), 120, 2, np.float64, "beard76", "Long"),
+    ((4, 3, 4), 300, 3, np.float64, "beard77fast", "geometric"),                    # crowded cells: another ranking kernel, the pass of its own
+])
+@pytest.mark.parametrize("strict", [False, True])
+def test_invalid_velocities_refreshed_by_the_next_substeps_ranking(dims, sd_conc, sstp, real_t, vt, kernel, strict):
+    """Round 6.  Between two coalescence substeps the reference refreshes the terminal velocities that the collisions have invalidated
+    (hskpng_vterm_invalid, particles_step.ipp:389-391).  Here the in-cell ranking of the NEXT substep does it on its way -- every droplet
+    of the order passes that kernel, and the coalescence kernel behind it is the first reader (k_cellrank_bkt's EXTRA; dbg
+    VTERM_INVALID_OWN_PASS keeps the launch of its own): one launch less per substep, the same multiplicities, radii, velocities and
+    order bit for bit after full steps on drizzle that collides -- both arithmetics, every velocity formula's path, float as C2 runs it;
+    where another ranking kernel runs (crowded cells) the pass of its own stays."""
+    nx, ny, nz = dims
+    oi = h.box_opts(nx, ny, nz, sd_conc, sstp_coal=sstp, sstp_cond=2, strict_fp=strict)
+    oi.terminal_velocity = getattr(lgrngn.vt_t, vt)
+    oi.kernel = getattr(lgrngn.kernel_t, kernel)
+    fields = h.box_fields(oi)
+    res = []
+    for flags in (int(lgrngn.dbg.VTERM_INVALID_OWN_PASS), 0):
+        oi.dbg_flags = flags
+        hip = h.hip_particles(oi, real_t)
+        th, rv, rhod, C = [f.astype(real_t) if isinstance(f, np.ndarray) else {k: v.astype(real_t) for k, v in f.items()} for f in fields]
+        hip.init(th, rv, rhod, **C)
+        rw2 = hip.get_attr("rw2")
+        rw2[::5] = (70e-6) ** 2                                  # drizzle among the aerosol: pairs collide in every substep
+        rw2[1::11] = (25e-6) ** 2
+        hip.set_particles(hip.state_u64("n"), hip.get_attr("rd3"), rw2, hip.get_attr("kappa"), np.full(rw2.size, -1.),
+                          hip.get_attr("x"), hip.get_attr("y"), hip.get_attr("z"))
+        opts = lgrngn.opts_t()
+        thh, rvh = th.copy(), rv.copy()
+        n0 = hip.state_u64("n").sum()
+        launches = []
+        for _ in range(3):
+            hip.step_sync(opts, thh, rvh, rhod, **C)
+            l0 = int(hip.state_u64("raw_launches")[0])
+            hip.step_async(opts)
+            launches.append(int(hip.state_u64("raw_launches")[0]) - l0)
+        res.append((hip.state_u64("n"), hip.get_attr("rw2"), hip.get_attr("rd3"), hip.state_real("vt"), hip.state_u64("sorted_id"), thh, rvh, hip.n_part, n0,
+                    launches))
+    assert res[0][7] == res[1][7]
+    assert res[0][0].sum() < res[0][8]                           # (multiplicity was used up: collisions happened)
+    for a_, b_ in zip(res[0][:7], res[1][:7]):
+        assert np.array_equal(a_, b_)
+    # (a launch less per substep boundary where the bucket ranking runs; the same launches where it does not)
+    saved = [a_ - b_ for a_, b_ in zip(res[0][9], res[1][9])]
+    assert saved == [sstp - 1 if sd_conc <= 128 else 0] * 3, (res[0][9], res[1][9])
+
+
 def test_brackets_that_may_hold_several_roots_take_the_references_iterates():
     """Late round 5.  A droplet that can evaporate down to its dry core within the step (a 0.8 um droplet on a 5 nm core in subsaturated
     air: a root where it has shrunk to half its radius, and roots next to the core where the Kelvin term takes over), or whose bracket
